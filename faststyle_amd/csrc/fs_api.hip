@@ -1,0 +1,324 @@
+// extern "C" surface of libfaststyle_hip.so (include/faststyle_hip.h).
+#include "../../include/faststyle_hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+
+#include "fs_tnet.h"
+#include "fs_vgg.h"
+
+struct fs_ctx {
+    int device;
+    hipStream_t stream;
+    // cached layouts (recomputed when the shape changes)
+    fs::TnetLayout tnet;
+    bool tnet_valid;
+};
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" {
+
+const char* fs_last_error(void) { return g_err; }
+const char* fs_version(void) { return "faststyle_hip 0.1 (gfx950, fp32 MFMA)"; }
+
+int fs_ctx_create(int device, void* hip_stream, fs_ctx** out) {
+    if (!out) return fail(-1, "fs_ctx_create: out is null");
+    if (hipSetDevice(device) != hipSuccess) return fail(-2, "fs_ctx_create: hipSetDevice(%d) failed", device);
+    fs_ctx* c = new fs_ctx();
+    c->device = device;
+    c->stream = (hipStream_t)hip_stream;
+    c->tnet_valid = false;
+    *out = c;
+    return 0;
+}
+void fs_ctx_destroy(fs_ctx* ctx) { delete ctx; }
+int fs_ctx_set_stream(fs_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(-1, "null ctx");
+    ctx->stream = (hipStream_t)hip_stream;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ transform net
+int fs_tnet_param_info(int idx, const char** name, int* offset, int* ndim, int dims[4]) {
+    if (idx < 0 || idx >= 48) return fail(-1, "fs_tnet_param_info: index %d out of range", idx);
+    const fs::ParamInfo& p = fs::param_table()[idx];
+    if (name) *name = p.name;
+    if (offset) *offset = p.offset;
+    if (ndim) *ndim = p.ndim;
+    if (dims) memcpy(dims, p.dims, sizeof(int) * 4);
+    return 0;
+}
+
+int fs_tnet_out_shape(int H, int W, int* Ho, int* Wo) {
+    if (H < 41 || W < 41) return fail(-1, "fs_tnet_out_shape: REFLECT padding by 40 needs H,W >= 41 (got %dx%d)", H, W);
+    auto f = [](int s) { return 4 * (fs::cdiv(fs::cdiv(s + 80, 2), 2) - 20); };
+    if (Ho) *Ho = f(H);
+    if (Wo) *Wo = f(W);
+    return 0;
+}
+
+static const fs::TnetLayout* get_layout(fs_ctx* ctx, int N, int H, int W) {
+    if (!ctx->tnet_valid || ctx->tnet.N != N || ctx->tnet.H != H || ctx->tnet.W != W) {
+        fs::tnet_layout(N, H, W, &ctx->tnet);
+        ctx->tnet_valid = true;
+    }
+    return &ctx->tnet;
+}
+
+size_t fs_tnet_workspace_bytes(int N, int H, int W, int flags) {
+    (void)flags;
+    if (N < 1 || H < 41 || W < 41) return 0;
+    fs::TnetLayout L;
+    fs::tnet_layout(N, H, W, &L);
+    return L.total_floats * sizeof(float);
+}
+
+int fs_tnet_forward(fs_ctx* ctx, const float* params, const float* x, int N, int H, int W, float* y, void* ws,
+                    size_t ws_bytes, int flags) {
+    (void)flags;
+    if (!ctx || !params || !x || !y || !ws) return fail(-1, "fs_tnet_forward: null argument");
+    if (N < 1 || H < 41 || W < 41) return fail(-2, "fs_tnet_forward: need N>=1 and H,W>=41 (got %d,%d,%d)", N, H, W);
+    const fs::TnetLayout* L = get_layout(ctx, N, H, W);
+    if (ws_bytes < L->total_floats * sizeof(float))
+        return fail(-3, "fs_tnet_forward: workspace too small (%zu < %zu bytes)", ws_bytes, L->total_floats * sizeof(float));
+    const int rc = fs::tnet_forward(*L, params, x, y, (float*)ws, ctx->stream);
+    return rc ? fail(rc, "fs_tnet_forward: launch failed (%d)", rc) : 0;
+}
+
+int fs_tnet_backward(fs_ctx* ctx, const float* params, const float* x, const float* dy, int N, int H, int W, float* grads,
+                     void* ws, size_t ws_bytes) {
+    if (!ctx || !params || !x || !dy || !grads || !ws) return fail(-1, "fs_tnet_backward: null argument");
+    if (N < 1 || H < 41 || W < 41) return fail(-2, "fs_tnet_backward: need N>=1 and H,W>=41");
+    const fs::TnetLayout* L = get_layout(ctx, N, H, W);
+    if (ws_bytes < L->total_floats * sizeof(float)) return fail(-3, "fs_tnet_backward: workspace too small");
+    const int rc = fs::tnet_backward(*L, params, x, dy, grads, (float*)ws, ctx->stream);
+    return rc ? fail(rc, "fs_tnet_backward: launch failed (%d)", rc) : 0;
+}
+
+// ------------------------------------------------------------------------------ VGG / losses
+size_t fs_vgg_prepared_floats(void) { return fs::vgg_prepared_floats(); }
+
+int fs_vgg_prepare(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], float* prepared) {
+    if (!ctx || !w || !prepared) return fail(-1, "fs_vgg_prepare: null argument");
+    const int rc = fs::vgg_prepare(w, prepared, ctx->stream);
+    return rc ? fail(rc, "fs_vgg_prepare failed (%d)", rc) : 0;
+}
+
+static int check_cfg(const fs_loss_cfg* cfg) {
+    if (!cfg) return fail(-1, "null loss cfg");
+    if (cfg->n_content < 0 || cfg->n_content > 4 || cfg->n_style < 0 || cfg->n_style > 4)
+        return fail(-2, "loss cfg: at most 4 content and 4 style layers");
+    for (int i = 0; i < cfg->n_content; ++i)
+        if (cfg->content_layer[i] < 0 || cfg->content_layer[i] >= FS_VGG_NLAYERS) return fail(-2, "bad content layer");
+    for (int i = 0; i < cfg->n_style; ++i)
+        if (cfg->style_layer[i] < 0 || cfg->style_layer[i] >= FS_VGG_NLAYERS) return fail(-2, "bad style layer");
+    return 0;
+}
+
+size_t fs_perceptual_workspace_bytes(int N, int H, int W, const fs_loss_cfg* cfg) {
+    if (check_cfg(cfg) || N < 1 || H < 1 || W < 1) return 0;
+    fs::VggLayout L;
+    fs::vgg_layout(N, H, W, *cfg, true, &L);
+    return L.total_floats * sizeof(float);
+}
+
+int fs_perceptual_loss(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
+                       const float* prepared, const fs_loss_cfg* cfg, const float* y, const float* content, int N, int H,
+                       int W, float* losses, float* dy, void* ws, size_t ws_bytes) {
+    if (!ctx || !w || !b || !prepared || !y || !content || !losses || !dy || !ws)
+        return fail(-1, "fs_perceptual_loss: null argument");
+    if (int rc = check_cfg(cfg)) return rc;
+    for (int i = 0; i < cfg->n_style; ++i)
+        if (!cfg->target_gram[i]) return fail(-2, "fs_perceptual_loss: target_gram[%d] is null", i);
+    fs::VggLayout L;
+    fs::vgg_layout(N, H, W, *cfg, true, &L);
+    if (ws_bytes < L.total_floats * sizeof(float)) return fail(-3, "fs_perceptual_loss: workspace too small");
+    const int rc = fs::perceptual_loss(L, w, b, prepared, *cfg, y, content, losses, dy, (float*)ws, ctx->stream);
+    return rc ? fail(rc, "fs_perceptual_loss: launch failed (%d)", rc) : 0;
+}
+
+size_t fs_style_targets_workspace_bytes(int H, int W) {
+    fs_loss_cfg cfg{};
+    cfg.n_style = 4;
+    cfg.style_layer[0] = 1;
+    cfg.style_layer[1] = 3;
+    cfg.style_layer[2] = 6;
+    cfg.style_layer[3] = 9;
+    fs::VggLayout L;
+    fs::vgg_layout(1, H, W, cfg, false, &L);
+    return L.total_floats * sizeof(float);
+}
+
+int fs_style_targets(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
+                     const fs_loss_cfg* cfg, const float* style_img, int H, int W, float* const grams[4], void* ws,
+                     size_t ws_bytes) {
+    if (!ctx || !w || !b || !style_img || !grams || !ws) return fail(-1, "fs_style_targets: null argument");
+    if (int rc = check_cfg(cfg)) return rc;
+    if (ws_bytes < fs_style_targets_workspace_bytes(H, W)) return fail(-3, "fs_style_targets: workspace too small");
+    fs::VggLayout L;
+    fs_loss_cfg c2 = *cfg;
+    c2.n_content = 0;
+    // worst-case layout (all layers) so the size matches fs_style_targets_workspace_bytes
+    fs_loss_cfg full{};
+    full.n_style = 4;
+    full.style_layer[0] = 1;
+    full.style_layer[1] = 3;
+    full.style_layer[2] = 6;
+    full.style_layer[3] = 9;
+    fs::vgg_layout(1, H, W, full, false, &L);
+    const int rc = fs::style_targets(L, w, b, c2, style_img, grams, (float*)ws, ctx->stream);
+    return rc ? fail(rc, "fs_style_targets: launch failed (%d)", rc) : 0;
+}
+
+int fs_adam_tf_step(fs_ctx* ctx, float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                    float beta2, float eps, long long t) {
+    if (!ctx || !p || !g || !m || !v) return fail(-1, "fs_adam_tf_step: null argument");
+    if (t < 1) return fail(-2, "fs_adam_tf_step: t is the 1-based step count");
+    const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)t)) / (1.0 - std::pow((double)beta1, (double)t));
+    return fs::adam_tf(p, g, m, v, n, (float)lr_t, beta1, beta2, eps, ctx->stream);
+}
+
+// ------------------------------------------------------------------------------ single ops
+static void resolve_pads(int H, int W, int KH, int KW, int stride, int mode, int refl, int src_mode, int* Ho, int* Wo,
+                         int* pt, int* pl) {
+    int vh = H, vw = W;
+    if (src_mode == FS_SRC_REFLECT) {
+        vh += 2 * refl;
+        vw += 2 * refl;
+    }
+    if (mode == FS_PAD_SAME) {
+        *Ho = fs::cdiv(vh, stride);
+        *Wo = fs::cdiv(vw, stride);
+        int th = (*Ho - 1) * stride + KH - vh, tw = (*Wo - 1) * stride + KW - vw;
+        *pt = th > 0 ? th / 2 : 0;
+        *pl = tw > 0 ? tw / 2 : 0;
+    } else if (mode == FS_PAD_VALID) {
+        *Ho = (vh - KH) / stride + 1;
+        *Wo = (vw - KW) / stride + 1;
+        *pt = *pl = 0;
+    }
+}
+
+static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
+    if (!d) return fail(-1, "null conv desc");
+    if (d->pad_mode != FS_PAD_EXPLICIT)
+        resolve_pads(d->H, d->W, d->KH, d->KW, d->stride, d->pad_mode, d->refl, d->src_mode, &d->Ho, &d->Wo, &d->pad_t,
+                     &d->pad_l);
+    if (d->Cin != 3 && (d->Cin % 4)) return fail(-2, "fs_conv2d: Cin must be 3 or a multiple of 4 (got %d)", d->Cin);
+    if (d->shuffle && (d->Cout % 4)) return fail(-2, "fs_conv2d: pixel-shuffle needs Cout %% 4 == 0");
+    if (d->Ho < 1 || d->Wo < 1) return fail(-2, "fs_conv2d: empty output");
+    *a = fs::ConvArgs{};
+    a->x = d->x;
+    a->w = d->w;
+    a->y = d->y;
+    a->N = d->N;
+    a->H = d->H;
+    a->W = d->W;
+    a->Cin = d->Cin;
+    a->Ho = d->Ho;
+    a->Wo = d->Wo;
+    a->Cout = d->Cout;
+    a->KH = d->KH;
+    a->KW = d->KW;
+    a->stride = d->stride;
+    a->pad_t = d->pad_t;
+    a->pad_l = d->pad_l;
+    a->src_mode = d->src_mode;
+    a->refl = d->refl;
+    a->in_a = d->in_a;
+    a->in_b = d->in_b;
+    a->in_nstride = d->in_per_sample ? d->Cin : 0;
+    a->in_relu = d->in_relu;
+    a->bias = d->bias;
+    a->out_relu = d->out_relu;
+    a->shuffle = d->shuffle;
+    a->stats = d->stats;
+    a->add_src = d->add_src;
+    a->add_pad = d->add_pad;
+    a->w_nstride = d->w_nstride;
+    a->p = fs::conv_plan(*a);
+    return 0;
+}
+
+int fs_conv2d_plan(fs_conv_desc* d, int* tiles_per_image) {
+    fs::ConvArgs a;
+    if (int rc = fill_conv(d, &a)) return rc;
+    if (tiles_per_image) *tiles_per_image = a.p.tiles_y * a.p.tiles_x;
+    return 0;
+}
+
+int fs_conv2d_fwd(fs_ctx* ctx, fs_conv_desc* d) {
+    if (!ctx) return fail(-1, "null ctx");
+    fs::ConvArgs a;
+    if (int rc = fill_conv(d, &a)) return rc;
+    if (!a.x || !a.w || !a.y) return fail(-1, "fs_conv2d_fwd: null tensor");
+    const int rc = fs::conv_launch(a, ctx->stream);
+    return rc ? fail(rc, "fs_conv2d_fwd: launch failed (%d)", rc) : 0;
+}
+
+int fs_instnorm_finalize(fs_ctx* ctx, const float* stats, int N, int tiles, int C, int groups, const float* gamma,
+                         const float* beta, float eps, float* mean, float* rstd, float* a, float* b) {
+    if (!ctx || !stats || !gamma || !beta || !mean || !rstd || !a || !b) return fail(-1, "fs_instnorm_finalize: null argument");
+    return fs::in_finalize(stats, N, tiles, C, groups, gamma, beta, eps, mean, rstd, a, b, ctx->stream);
+}
+
+static int fill_wgrad(fs_wgrad_desc* d, fs::WgradArgs* a) {
+    if (!d) return fail(-1, "null wgrad desc");
+    if (d->pad_mode != FS_PAD_EXPLICIT)
+        resolve_pads(d->H, d->W, d->KH, d->KW, d->stride, d->pad_mode, d->refl, d->src_mode, &d->Ho, &d->Wo, &d->pad_t,
+                     &d->pad_l);
+    if (d->Cin > 128 && (d->Cin % 128)) return fail(-2, "fs_conv2d_wgrad: Cin > 128 must be a multiple of 128");
+    *a = fs::WgradArgs{};
+    a->x = d->x;
+    a->dy = d->dy;
+    a->N = d->N;
+    a->H = d->H;
+    a->W = d->W;
+    a->Cin = d->Cin;
+    a->Ho = d->Ho;
+    a->Wo = d->Wo;
+    a->Cout = d->Cout;
+    a->KH = d->KH;
+    a->KW = d->KW;
+    a->stride = d->stride;
+    a->pad_t = d->pad_t;
+    a->pad_l = d->pad_l;
+    a->src_mode = d->src_mode;
+    a->refl = d->refl;
+    a->in_a = d->in_a;
+    a->in_b = d->in_b;
+    a->in_nstride = d->in_per_sample ? d->Cin : 0;
+    a->in_relu = d->in_relu;
+    a->per_sample = d->per_sample;
+    a->p = fs::wgrad_plan(*a);
+    return 0;
+}
+
+size_t fs_conv2d_wgrad_workspace_bytes(fs_wgrad_desc* d) {
+    fs::WgradArgs a;
+    if (fill_wgrad(d, &a)) return 0;
+    return (size_t)(a.per_sample ? a.N : 1) * a.p.n_wg * a.p.K * a.Cout * sizeof(float);
+}
+
+int fs_conv2d_wgrad(fs_ctx* ctx, fs_wgrad_desc* d, void* ws, size_t ws_bytes) {
+    if (!ctx || !ws) return fail(-1, "fs_conv2d_wgrad: null argument");
+    fs::WgradArgs a;
+    if (int rc = fill_wgrad(d, &a)) return rc;
+    const size_t need = (size_t)(a.per_sample ? a.N : 1) * a.p.n_wg * a.p.K * a.Cout * sizeof(float);
+    if (ws_bytes < need) return fail(-3, "fs_conv2d_wgrad: workspace too small");
+    a.slabs = (float*)ws;
+    int rc = fs::wgrad_launch(a, ctx->stream);
+    if (rc) return fail(rc, "fs_conv2d_wgrad: launch failed (%d)", rc);
+    return fs::reduce_slabs(a.slabs, a.per_sample ? a.N : 1, a.p.n_wg, (size_t)a.p.K * a.Cout, d->scale, d->dw, ctx->stream);
+}
+
+}  // extern "C"

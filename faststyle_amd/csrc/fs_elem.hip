@@ -1,0 +1,553 @@
+// HBM-bound elementwise / reduction kernels of the hot path (all NHWC fp32, channel innermost so a
+// wave reads whole 256-byte pixel rows):
+//   instance-norm statistics finalize (Chan merge of the conv epilogue's per-tile partials),
+//   residual add, scaled tanh, instance-norm backward, max-pool, ReLU/pool gradient routing,
+//   loss reductions, slab reduction, TF-style Adam, filter re-layouts.
+#include "fs_kernels.h"
+
+namespace fs {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Sum over the 256 threads of a block; result valid in every thread.  `sh` needs 4 floats.
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ---------------------------------------------------------------- instance-norm finalize
+// stats: [N][T][Cv][3] = {mean, M2, count} per conv tile, Cv = groups*C (groups=4 for the
+// pixel-shuffled resize-conv whose 4 phases hold the same real channel).
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float* stats, int T, int C, int groups, const float* gamma,
+                                                          const float* beta, float eps, float* mean, float* rstd,
+                                                          float* oa, float* ob) {
+    __shared__ double sc[256], sm[256], sq[256];
+    const int n = blockIdx.x, cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 16 + cl;
+    const int Cv = C * groups;
+    double cnt = 0, mu = 0, m2 = 0;
+    if (c < C) {
+        for (int i = tl; i < T * groups; i += 16) {
+            const int t = i / groups, q = i - t * groups;
+            const float* st = stats + (((size_t)n * T + t) * Cv + q * C + c) * 3;
+            const double cb = st[2], mb = st[0], qb = st[1];
+            if (cb > 0) {
+                const double nn = cnt + cb, d = mb - mu;
+                mu += d * cb / nn;
+                m2 += qb + d * d * cnt * cb / nn;
+                cnt = nn;
+            }
+        }
+    }
+    sc[threadIdx.x] = cnt;
+    sm[threadIdx.x] = mu;
+    sq[threadIdx.x] = m2;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+        for (int j = 1; j < 16; ++j) {
+            const double cb = sc[j * 16 + cl], mb = sm[j * 16 + cl], qb = sq[j * 16 + cl];
+            if (cb > 0) {
+                const double nn = cnt + cb, d = mb - mu;
+                mu += d * cb / nn;
+                m2 += qb + d * d * cnt * cb / nn;
+                cnt = nn;
+            }
+        }
+        const float var = (float)(m2 / cnt);
+        const float r = 1.0f / sqrtf(var + eps);
+        const float fm = (float)mu;
+        const float a = gamma[c] * r;
+        mean[n * C + c] = fm;
+        rstd[n * C + c] = r;
+        oa[n * C + c] = a;
+        ob[n * C + c] = beta[c] - fm * a;
+    }
+}
+
+int in_finalize(const float* stats, int N, int T, int C, int groups, const float* gamma, const float* beta, float eps,
+                float* mean, float* rstd, float* a, float* b, hipStream_t s) {
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(N, cdiv(C, 16)), dim3(256), 0, s, stats, T, C, groups, gamma, beta, eps,
+                       mean, rstd, a, b);
+    return 0;
+}
+
+// ---------------------------------------------------------------- residual add / tanh
+// out[n,y,x,c] = z*a+b + T(skip[n,y+2,x+2,c]),  T = optional affine+ReLU (block 0 reads the raw
+// initconv_2 output).  reference im_transf_net.py:268-274
+__global__ __launch_bounds__(256) void apply_res_kernel(const float* z, const float* a, const float* b, const float* skip,
+                                                        const float* sa, const float* sb, int skip_relu, float* out,
+                                                        int H, int W, int C, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t pix = i / C;
+        const int x = (int)(pix % W);
+        pix /= W;
+        const int y = (int)(pix % H);
+        const int n = (int)(pix / H);
+        float sk = skip[(((size_t)n * (H + 4) + y + 2) * (W + 4) + x + 2) * C + c];
+        if (sa) sk = fmaf(sk, sa[n * C + c], sb[n * C + c]);
+        if (skip_relu) sk = fmaxf(sk, 0.f);
+        out[i] = fmaf(z[i], a[n * C + c], b[n * C + c]) + sk;
+    }
+}
+
+int apply_res(const float* z, const float* a, const float* b, const float* skip, const float* sa, const float* sb,
+              int skip_relu, float* out, int N, int H, int W, int C, hipStream_t s) {
+    const size_t total = (size_t)N * H * W * C;
+    hipLaunchKernelGGL(apply_res_kernel, dim3((unsigned)min((size_t)2048, (total + 255) / 256)), dim3(256), 0, s, z, a, b,
+                       skip, sa, sb, skip_relu, out, H, W, C, total);
+    return 0;
+}
+
+// y = (255*tanh(a z + b) + 255)/2   reference im_transf_net.py:202-215
+__global__ __launch_bounds__(256) void apply_tanh_kernel(const float* z, const float* a, const float* b, float* y, int HW,
+                                                         int C, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int n = (int)(i / ((size_t)HW * C));
+        const float v = fmaf(z[i], a[n * C + c], b[n * C + c]);
+        y[i] = (255.0f * tanhf(v) + 255.0f) / 2.0f;
+    }
+}
+
+int apply_tanh(const float* z, const float* a, const float* b, float* y, int N, int HW, int C, hipStream_t s) {
+    const size_t total = (size_t)N * HW * C;
+    hipLaunchKernelGGL(apply_tanh_kernel, dim3((unsigned)min((size_t)2048, (total + 255) / 256)), dim3(256), 0, s, z, a, b,
+                       y, HW, C, total);
+    return 0;
+}
+
+// ---------------------------------------------------------------- slab reduction
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs, int n_wg, size_t count, float scale,
+                                                           float* out) {
+    const size_t g = blockIdx.y;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        const float* p = slabs + g * n_wg * count + i;
+        float acc = 0.f;
+        for (int w = 0; w < n_wg; ++w) acc += p[(size_t)w * count];
+        out[g * count + i] = acc * scale;
+    }
+}
+
+int reduce_slabs(const float* slabs, int groups, int n_wg, size_t count, float scale, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)min((size_t)1024, (count + 255) / 256), groups), dim3(256), 0, s,
+                       slabs, n_wg, count, scale, out);
+    return 0;
+}
+
+// ---------------------------------------------------------------- instance-norm backward
+__device__ __forceinline__ float in_bwd_g(float gin, float z, float a, float b, int mode) {
+    const float v = fmaf(z, a, b);
+    if (mode == 1) return v > 0.f ? gin : 0.f;
+    if (mode == 2) {
+        const float t = tanhf(v);
+        return gin * 127.5f * (1.f - t * t);
+    }
+    return gin;
+}
+
+// partial[n][chunk][C][2] = sums over the chunk's pixels of {g, g*xhat}
+__global__ __launch_bounds__(256) void in_bwd_partial_kernel(const float* gin, const float* z, const float* mean,
+                                                             const float* rstd, const float* a, const float* b, int mode,
+                                                             float* partial, int HW, int C, int chunk_px) {
+    __shared__ float sh[512];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int rows = 256 / C > 0 ? 256 / C : 1;
+    const int c = threadIdx.x % C, row = threadIdx.x / C;
+    float s1 = 0.f, s2 = 0.f;
+    if (row < rows && C <= 256) {
+        const float mu = mean[n * C + c], r = rstd[n * C + c], ca = a[n * C + c], cb = b[n * C + c];
+        const int p0 = chunk * chunk_px, p1 = min(HW, p0 + chunk_px);
+        for (int p = p0 + row; p < p1; p += rows) {
+            const size_t i = ((size_t)n * HW + p) * C + c;
+            const float zz = z[i];
+            const float g = in_bwd_g(gin[i], zz, ca, cb, mode);
+            s1 += g;
+            s2 += g * ((zz - mu) * r);
+        }
+    }
+    sh[threadIdx.x] = s1;
+    sh[256 + threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int r2 = 0; r2 < rows; ++r2) {
+            t1 += sh[r2 * C + threadIdx.x];
+            t2 += sh[256 + r2 * C + threadIdx.x];
+        }
+        float* o = partial + (((size_t)n * gridDim.x + chunk) * C + threadIdx.x) * 2;
+        o[0] = t1;
+        o[1] = t2;
+    }
+}
+
+// S[n][c][2] = sum over chunks; dgamma[c] = sum_n S2, dbeta[c] = sum_n S1
+__global__ __launch_bounds__(256) void in_bwd_final_kernel(const float* partial, int N, int chunks, int C, float* S,
+                                                           float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float g1 = 0.f, g2 = 0.f;
+    for (int n = 0; n < N; ++n) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int k = 0; k < chunks; ++k) {
+            const float* p = partial + (((size_t)n * chunks + k) * C + c) * 2;
+            t1 += p[0];
+            t2 += p[1];
+        }
+        S[(n * C + c) * 2] = t1;
+        S[(n * C + c) * 2 + 1] = t2;
+        g1 += t1;
+        g2 += t2;
+    }
+    dbeta[c] = g1;
+    dgamma[c] = g2;
+}
+
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* gin, const float* z, const float* mean,
+                                                           const float* rstd, const float* a, const float* b, int mode,
+                                                           const float* S, float* dz, int HW, int C, size_t total) {
+    const float inv = 1.0f / (float)HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int n = (int)(i / ((size_t)HW * C));
+        const int k = n * C + c;
+        const float zz = z[i];
+        const float g = in_bwd_g(gin[i], zz, a[k], b[k], mode);
+        const float xh = (zz - mean[k]) * rstd[k];
+        dz[i] = a[k] * (g - S[2 * k] * inv - xh * S[2 * k + 1] * inv);
+    }
+}
+
+// scratch: N*chunks*C*2 + N*C*2 floats
+int in_bwd(const float* gin, const float* z, const float* mean, const float* rstd, const float* a, const float* b, int mode,
+           float* dz, float* dgamma, float* dbeta, float* scratch, int N, int HW, int C, hipStream_t s) {
+    if (C > 256) return -1;
+    int chunks = cdiv(HW, 2048);
+    if (chunks > 256) chunks = 256;
+    const int chunk_px = cdiv(HW, chunks);
+    chunks = cdiv(HW, chunk_px);
+    float* partial = scratch;
+    float* S = scratch + (size_t)N * chunks * C * 2;
+    hipLaunchKernelGGL(in_bwd_partial_kernel, dim3(chunks, N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, partial, HW,
+                       C, chunk_px);
+    hipLaunchKernelGGL(in_bwd_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, partial, N, chunks, C, S, dgamma, dbeta);
+    const size_t total = (size_t)N * HW * C;
+    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0, s, gin, z,
+                       mean, rstd, a, b, mode, S, dz, HW, C, total);
+    return 0;
+}
+size_t in_bwd_scratch_floats(int N, int HW, int C) { return (size_t)N * 256 * C * 2 + (size_t)N * C * 2; }
+
+// ---------------------------------------------------------------- VGG: max-pool + gradient routing
+// tf.nn.max_pool 2x2/2 SAME (reference libs/vgg16.py:63-67): out = ceil(in/2), padded cells never win.
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* x, float* y, int H, int W, int C, int Ho, int Wo,
+                                                      size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t pix = i / C;
+        const int ox = (int)(pix % Wo);
+        pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const int n = (int)(pix / Ho);
+        const float* base = x + ((size_t)n * H * W) * C + c;
+        const int y0 = 2 * oy, x0 = 2 * ox;
+        float m = base[((size_t)y0 * W + x0) * C];
+        if (x0 + 1 < W) m = fmaxf(m, base[((size_t)y0 * W + x0 + 1) * C]);
+        if (y0 + 1 < H) {
+            m = fmaxf(m, base[((size_t)(y0 + 1) * W + x0) * C]);
+            if (x0 + 1 < W) m = fmaxf(m, base[((size_t)(y0 + 1) * W + x0 + 1) * C]);
+        }
+        y[i] = m;
+    }
+}
+
+int maxpool(const float* x, float* y, int N, int H, int W, int C, hipStream_t s) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const size_t total = (size_t)N * Ho * Wo * C;
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0, s, x, y, H, W,
+                       C, Ho, Wo, total);
+    return 0;
+}
+
+// d_pre[n,y,x,c] = (route(d_above) + d_tap) * (out > 0)
+//   pooled=0: d_above has the shape of `out`;   pooled=1: d_above is the gradient of max_pool(out)
+//   and goes to the FIRST maximum of each window (TF MaxPoolGrad).  d_above / d_tap may be null.
+__global__ __launch_bounds__(256) void vgg_bwd_route_kernel(const float* out, const float* d_above, const float* d_tap,
+                                                            int pooled, float* d_pre, int H, int W, int C, size_t total) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const float v = out[i];
+        float g = d_tap ? d_tap[i] : 0.f;
+        if (d_above) {
+            if (!pooled) {
+                g += d_above[i];
+            } else {
+                const int c = (int)(i % C);
+                size_t pix = i / C;
+                const int x = (int)(pix % W);
+                pix /= W;
+                const int y = (int)(pix % H);
+                const int n = (int)(pix / H);
+                const int y0 = y & ~1, x0 = x & ~1;
+                const float* base = out + ((size_t)n * H * W) * C + c;
+                const int me = (y - y0) * 2 + (x - x0);
+                bool win = true;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int yy = y0 + (e >> 1), xx = x0 + (e & 1);
+                    if (e == me || yy >= H || xx >= W) continue;
+                    const float o = base[((size_t)yy * W + xx) * C];
+                    if (e < me ? o >= v : o > v) win = false;
+                }
+                if (win) g += d_above[(((size_t)n * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c];
+            }
+        }
+        d_pre[i] = v > 0.f ? g : 0.f;
+    }
+}
+
+int vgg_bwd_route(const float* out, const float* d_above, const float* d_tap, int pooled, float* d_pre, int N, int H, int W,
+                  int C, hipStream_t s) {
+    const size_t total = (size_t)N * H * W * C;
+    hipLaunchKernelGGL(vgg_bwd_route_kernel, dim3((unsigned)min((size_t)8192, (total + 255) / 256)), dim3(256), 0, s, out,
+                       d_above, d_tap, pooled, d_pre, H, W, C, total);
+    return 0;
+}
+
+// ---------------------------------------------------------------- losses
+// partial[b] = sum (x - t)^2 over the block's elements; grad = gscale*(x - t) (optional).
+// t index = i % t_period (style targets broadcast over the batch; reference losses.py:61-64).
+__global__ __launch_bounds__(256) void sqdiff_kernel(const float* x, const float* t, size_t t_period, size_t total,
+                                                     float gscale, float* grad, float* partial) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const float d = x[i] - t[i % t_period];
+        acc = fmaf(d, d, acc);
+        if (grad) grad[i] = gscale * d;
+    }
+    const float tot = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// out[0] (+)= scale * sum(partial[0..n))  -- single block, fixed order
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* partial, int n, float scale, float* out,
+                                                           int accumulate) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    const float tot = block_sum(acc, sh);
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + scale * tot;
+}
+
+// loss_out (+)= lscale*sum((x-t)^2);  grad = gscale*(x-t).  scratch: >= 1024 floats.
+int sqdiff_loss(const float* x, const float* t, size_t t_period, size_t total, float lscale, float gscale, float* grad,
+                float* loss_out, int accumulate, float* scratch, hipStream_t s) {
+    const int blocks = (int)min((size_t)1024, (total + 255) / 256);
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(blocks), dim3(256), 0, s, x, t, t_period, total, gscale, grad, scratch);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, scratch, blocks, lscale, loss_out, accumulate);
+    return 0;
+}
+
+// TV loss (reference losses.py:70-97): sum of squared forward differences along H and W, and
+// its gradient scaled by gscale, ACCUMULATED into grad (grad += gscale * dTV/dx) when grad != null.
+__global__ __launch_bounds__(256) void tv_kernel(const float* x, int H, int W, int C, size_t total, float gscale,
+                                                 float* grad, float* partial) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        size_t pix = i / C;
+        const int xx = (int)(pix % W);
+        pix /= W;
+        const int yy = (int)(pix % H);
+        const float v = x[i];
+        float g = 0.f;
+        if (yy + 1 < H) {
+            const float d = v - x[i + (size_t)W * C];
+            acc = fmaf(d, d, acc);
+            g += 2.f * d;
+        }
+        if (yy > 0) g -= 2.f * (x[i - (size_t)W * C] - v);
+        if (xx + 1 < W) {
+            const float d = v - x[i + C];
+            acc = fmaf(d, d, acc);
+            g += 2.f * d;
+        }
+        if (xx > 0) g -= 2.f * (x[i - C] - v);
+        if (grad) grad[i] += gscale * g;
+    }
+    const float tot = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+int tv_loss(const float* x, int N, int H, int W, int C, float lscale, float gscale, float* grad, float* loss_out,
+            float* scratch, hipStream_t s) {
+    const size_t total = (size_t)N * H * W * C;
+    const int blocks = (int)min((size_t)1024, (total + 255) / 256);
+    hipLaunchKernelGGL(tv_kernel, dim3(blocks), dim3(256), 0, s, x, H, W, C, total, gscale, grad, scratch);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, scratch, blocks, lscale, loss_out, 0);
+    return 0;
+}
+
+// out = alpha * (x - t[i % period])     (style: S = coef*(G - Gt), the filter of the Gram backward)
+__global__ __launch_bounds__(256) void axpby_kernel(const float* x, const float* y, float a, float b, float* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+
+int axpby(const float* x, const float* y, float a, float b, float* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)min((size_t)4096, (n + 255) / 256)), dim3(256), 0, s, x, y, a, b, out, n);
+    return 0;
+}
+
+// ---------------------------------------------------------------- TF-style Adam
+// tf.train.AdamOptimizer (reference train.py:203): theta -= lr_t * m / (sqrt(v) + eps), with
+// lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the host -- epsilon outside the bias correction.
+__global__ __launch_bounds__(256) void adam_tf_kernel(float* p, const float* g, float* m, float* v, size_t n, float lr_t,
+                                                      float b1, float b2, float eps) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+int adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)min((size_t)2048, (n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr_t,
+                       b1, b2, eps);
+    return 0;
+}
+
+// ---------------------------------------------------------------- filter re-layouts
+// dgrad filter of a stride-1/2 conv: out[kh,kw,co,ci] = w[KH-1-kh, KW-1-kw, ci, co]
+__global__ __launch_bounds__(256) void wt_flip_transpose_kernel(const float* w, float* out, int KH, int KW, int Ci, int Co) {
+    const int total = KH * KW * Ci * Co;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int ci = i % Ci;
+        int r = i / Ci;
+        const int co = r % Co;
+        r /= Co;
+        const int kw = r % KW, kh = r / KW;
+        out[i] = w[(((KH - 1 - kh) * KW + (KW - 1 - kw)) * Ci + ci) * Co + co];
+    }
+}
+
+int wt_flip_transpose(const float* w, float* out, int KH, int KW, int Ci, int Co, hipStream_t s) {
+    hipLaunchKernelGGL(wt_flip_transpose_kernel, dim3(cdiv(KH * KW * Ci * Co, 256)), dim3(256), 0, s, w, out, KH, KW, Ci, Co);
+    return 0;
+}
+
+// Phase-collapsed resize-conv (reference im_transf_net.py:122-155: NEAREST x4 then 3x3 stride-2
+// SAME == per output parity (a,b) a 2x2-tap conv on the low-res input):
+//   weff[dy,dx,ci,(a*2+b)*Co+co] = sum_{kh in R(a,dy), kw in R(b,dx)} w[kh,kw,ci,co]
+//   R(0,0)={0,1,2}  R(0,1)={}  R(1,0)={0,1}  R(1,1)={2}
+__device__ __forceinline__ bool up_in_R(int a, int d, int k) {
+    if (a == 0) return d == 0;
+    return d == 0 ? k < 2 : k == 2;
+}
+__global__ __launch_bounds__(256) void wt_upconv_fwd_kernel(const float* w, float* weff, int Ci, int Co) {
+    const int total = 4 * Ci * 4 * Co;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int j = i % (4 * Co);
+        int r = i / (4 * Co);
+        const int ci = r % Ci;
+        const int tap = r / Ci;
+        const int dy = tap >> 1, dx = tap & 1;
+        const int q = j / Co, co = j % Co, a = q >> 1, b = q & 1;
+        float acc = 0.f;
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw)
+                if (up_in_R(a, dy, kh) && up_in_R(b, dx, kw)) acc += w[((kh * 3 + kw) * Ci + ci) * Co + co];
+        weff[i] = acc;
+    }
+}
+
+// its dgrad as a 3x3 stride-2 conv over dY (pad 1 before):  v[t,s,co,ci], t,s in {0,1,2} <-> {-1,0,1}
+//   row sets: t=0 -> {2}, t=1 -> {0,1,2}, t=2 -> {0,1}
+__device__ __forceinline__ bool up_in_V(int t, int k) { return t == 0 ? k == 2 : (t == 1 ? true : k < 2); }
+__global__ __launch_bounds__(256) void wt_upconv_dgrad_kernel(const float* w, float* v, int Ci, int Co) {
+    const int total = 9 * Co * Ci;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int ci = i % Ci;
+        int r = i / Ci;
+        const int co = r % Co;
+        const int tap = r / Co;
+        const int t = tap / 3, s2 = tap % 3;
+        float acc = 0.f;
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw)
+                if (up_in_V(t, kh) && up_in_V(s2, kw)) acc += w[((kh * 3 + kw) * Ci + ci) * Co + co];
+        v[i] = acc;
+    }
+}
+
+// fold the collapsed filter gradient back:  dw[kh,kw,ci,co] = sum over (a,dy)∋kh,(b,dx)∋kw of dweff
+__global__ __launch_bounds__(256) void wt_upconv_wgrad_fold_kernel(const float* dweff, float* dw, int Ci, int Co) {
+    const int total = 9 * Ci * Co;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int co = i % Co;
+        int r = i / Co;
+        const int ci = r % Ci;
+        const int tap = r / Ci;
+        const int kh = tap / 3, kw = tap % 3;
+        float acc = 0.f;
+        for (int a = 0; a < 2; ++a)
+            for (int dy = 0; dy < 2; ++dy)
+                for (int b = 0; b < 2; ++b)
+                    for (int dx = 0; dx < 2; ++dx)
+                        if (up_in_R(a, dy, kh) && up_in_R(b, dx, kw))
+                            acc += dweff[(((dy * 2 + dx) * Ci + ci) * 4 + (a * 2 + b)) * Co + co];
+        dw[i] = acc;
+    }
+}
+
+int wt_upconv_fwd(const float* w, float* weff, int Ci, int Co, hipStream_t s) {
+    hipLaunchKernelGGL(wt_upconv_fwd_kernel, dim3(cdiv(16 * Ci * Co, 256)), dim3(256), 0, s, w, weff, Ci, Co);
+    return 0;
+}
+int wt_upconv_dgrad(const float* w, float* v, int Ci, int Co, hipStream_t s) {
+    hipLaunchKernelGGL(wt_upconv_dgrad_kernel, dim3(cdiv(9 * Ci * Co, 256)), dim3(256), 0, s, w, v, Ci, Co);
+    return 0;
+}
+int wt_upconv_wgrad_fold(const float* dweff, float* dw, int Ci, int Co, hipStream_t s) {
+    hipLaunchKernelGGL(wt_upconv_wgrad_fold_kernel, dim3(cdiv(9 * Ci * Co, 256)), dim3(256), 0, s, dweff, dw, Ci, Co);
+    return 0;
+}
+
+}  // namespace fs
+
+namespace fs {
+// on-load affine of the VGG input: images - [123.68,116.779,103.939] (reference libs/vgg16.py:41-42)
+__global__ void vgg_consts_kernel(float* ab) {
+    if (threadIdx.x == 0) {
+        ab[0] = ab[1] = ab[2] = 1.0f;
+        ab[3] = 0.f;
+        ab[4] = -123.68f;
+        ab[5] = -116.779f;
+        ab[6] = -103.939f;
+        ab[7] = 0.f;
+    }
+}
+int vgg_consts(float* ab, hipStream_t s) {
+    hipLaunchKernelGGL(vgg_consts_kernel, dim3(1), dim3(64), 0, s, ab);
+    return 0;
+}
+// losses = {total, content, style, beta*tv}   (reference train.py:184)
+__global__ void loss_total_kernel(float* l) {
+    if (threadIdx.x == 0) l[0] = l[1] + l[2] + l[3];
+}
+int loss_total(float* losses, hipStream_t s) {
+    hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, s, losses);
+    return 0;
+}
+}  // namespace fs

@@ -1,0 +1,113 @@
+// Internal declarations shared by the HIP translation units of libfaststyle_hip.so.
+// (The public C ABI is include/faststyle_hip.h; nothing here is exported.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace fs {
+
+// How a conv reads its (virtual) input image.  Padding outside the virtual image is zero.
+enum SrcMode {
+    SRC_PLAIN = 0,    // virtual image == tensor
+    SRC_REFLECT = 1,  // virtual image = tensor mirrored by `refl` px on H and W (tf.pad REFLECT)
+    SRC_DILATE2 = 2,  // virtual[2i] = tensor[i], odd positions zero (dgrad of a stride-2 conv)
+    SRC_UP4 = 3,      // virtual[i] = tensor[i/4] (as-written NEAREST x4 upsample; wgrad only)
+};
+
+struct ConvPlan {
+    int variant;  // 0: 32x32x2 MFMA, 64 couts/WG; 1: 32x32x2, 32 couts/WG; 2: 16x16x4, 16 couts/WG
+    int BN;       // output channels per workgroup
+    int flat;     // Cin==3: K runs over (kw,ci) contiguously per kernel row
+    int CC;       // input channels staged per chunk
+    int LG;       // k-extent of one tap group (CC, or roundup(KW*Cin) when flat)
+    int S;        // LDS floats per patch pixel
+    int TH, TW, tiles_y, tiles_x;
+    int PH, PW;   // staged patch extent
+    int lds_bytes;
+};
+
+struct ConvArgs {
+    const float* x;  // [N,H,W,Cin]
+    const float* w;  // [KH*KW, Cin, Cout] (HWIO); + n*w_nstride for per-sample weights
+    float* y;        // [N,Ho,Wo,Cout], or [N,2Ho,2Wo,Cout/4] when shuffle
+    int N, H, W, Cin;
+    int Ho, Wo, Cout;
+    int KH, KW, stride, pad_t, pad_l;
+    int src_mode, refl;
+    const float* in_a;  // optional on-load affine: v = x*in_a[n*in_nstride+c] + in_b[...]
+    const float* in_b;
+    int in_nstride;     // 0 -> per-channel only
+    int in_relu;
+    const float* bias;  // optional [Cout]
+    int out_relu;
+    int shuffle;           // 2x2 pixel-shuffle store (phase-collapsed resize-conv)
+    float* stats;          // optional per-tile {mean, M2, count} partials [N*tiles][Cout][3]
+    const float* add_src;  // optional residual [N,Ho-2*add_pad,Wo-2*add_pad,Cout] added in the interior
+    int add_pad;
+    long long w_nstride;
+    ConvPlan p;
+};
+
+struct WgradPlan {
+    int TH, TW, tiles_y, tiles_x, PH, PW, S;
+    int K;        // KH*KW*Cin
+    int KB;       // k-blocks of 32 (ceil)
+    int NB;       // cout blocks of 32 (ceil)
+    int n_wg;     // workgroups per sample-group (each strides over the tile list)
+    int lds_bytes;
+};
+
+struct WgradArgs {
+    const float* x;   // conv input  [N,H,W,Cin]  (virtual via src_mode)
+    const float* dy;  // conv output gradient [N,Ho,Wo,Cout]
+    float* slabs;     // partial sums [groups][n_wg][K][Cout]; groups = N when per_sample else 1
+    int N, H, W, Cin, Ho, Wo, Cout;
+    int KH, KW, stride, pad_t, pad_l;
+    int src_mode, refl;
+    const float* in_a;
+    const float* in_b;
+    int in_nstride, in_relu;
+    int per_sample;   // 1: Gram-style, one result per n; 0: summed over the batch
+    int dy_unshuffle; // dy is [N,2Ho,2Wo,Cout/4]; read it as the 2x2 pixel-unshuffled [N,Ho,Wo,Cout]
+    WgradPlan p;
+};
+
+ConvPlan conv_plan(const ConvArgs& a);
+int conv_launch(const ConvArgs& a, hipStream_t s);
+WgradPlan wgrad_plan(const WgradArgs& a);
+int wgrad_launch(const WgradArgs& a, hipStream_t s);
+
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace fs
+
+namespace fs {
+// ---- fs_elem.hip ----
+int in_finalize(const float* stats, int N, int T, int C, int groups, const float* gamma, const float* beta, float eps,
+                float* mean, float* rstd, float* a, float* b, hipStream_t s);
+int apply_res(const float* z, const float* a, const float* b, const float* skip, const float* sa, const float* sb,
+              int skip_relu, float* out, int N, int H, int W, int C, hipStream_t s);
+int apply_tanh(const float* z, const float* a, const float* b, float* y, int N, int HW, int C, hipStream_t s);
+int reduce_slabs(const float* slabs, int groups, int n_wg, size_t count, float scale, float* out, hipStream_t s);
+int in_bwd(const float* gin, const float* z, const float* mean, const float* rstd, const float* a, const float* b, int mode,
+           float* dz, float* dgamma, float* dbeta, float* scratch, int N, int HW, int C, hipStream_t s);
+size_t in_bwd_scratch_floats(int N, int HW, int C);
+int maxpool(const float* x, float* y, int N, int H, int W, int C, hipStream_t s);
+int vgg_bwd_route(const float* out, const float* d_above, const float* d_tap, int pooled, float* d_pre, int N, int H, int W,
+                  int C, hipStream_t s);
+int sqdiff_loss(const float* x, const float* t, size_t t_period, size_t total, float lscale, float gscale, float* grad,
+                float* loss_out, int accumulate, float* scratch, hipStream_t s);
+int tv_loss(const float* x, int N, int H, int W, int C, float lscale, float gscale, float* grad, float* loss_out,
+            float* scratch, hipStream_t s);
+int axpby(const float* x, const float* y, float a, float b, float* out, size_t n, hipStream_t s);
+int adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s);
+int wt_flip_transpose(const float* w, float* out, int KH, int KW, int Ci, int Co, hipStream_t s);
+int wt_upconv_fwd(const float* w, float* weff, int Ci, int Co, hipStream_t s);
+int wt_upconv_dgrad(const float* w, float* v, int Ci, int Co, hipStream_t s);
+int wt_upconv_wgrad_fold(const float* dweff, float* dw, int Ci, int Co, hipStream_t s);
+}  // namespace fs

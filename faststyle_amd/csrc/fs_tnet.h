@@ -1,0 +1,48 @@
+// Transform-net host orchestration (layout + launch sequences); see fs_tnet.hip.
+#pragma once
+#include "fs_kernels.h"
+
+#include <cstdio>
+
+namespace fs {
+
+struct ParamInfo {
+    char name[48];
+    int offset, count, ndim, dims[4];
+};
+const ParamInfo* param_table();  // 48 entries, checkpoint key order
+
+// One conv + instance-norm unit of the net.
+struct Unit {
+    int kind;  // 0: conv, 1: phase-collapsed resize-conv (2x2 taps, pixel-shuffle store)
+    int K, stride, Cin, Cout;
+    int Cc;            // channels the conv kernel produces (4*Cout for kind 1)
+    int Hsrc, Wsrc;    // tensor the conv kernel reads (the unpadded image for initconv_0)
+    int Hin, Win;      // conv input extent (after reflect padding)
+    int Hc, Wc;        // conv kernel output extent
+    int Hout, Wout;    // unit output extent (2x Hc for kind 1)
+    int pad_t, pad_l, src_mode, refl;
+    int w_off, g_off, b_off;  // offsets into the flat parameter buffer
+    size_t z, stats, mean, rstd, a, b;  // workspace offsets (floats)
+    int tiles;
+    ConvPlan plan;
+    WgradPlan wplan;
+};
+
+struct TnetLayout {
+    int N, H, W, Hy, Wy;
+    Unit u[16];
+    size_t h[5];      // residual block outputs
+    size_t weff[2];   // collapsed resize-conv filters
+    size_t fwd_floats;
+    size_t g[3], dz, wT, dweff, inbwd, slabs;  // backward scratch
+    size_t total_floats;
+};
+
+void tnet_layout(int N, int H, int W, TnetLayout* L);
+WgradArgs unit_wgrad_args(const Unit& u, int N);
+int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s);
+int tnet_backward(const TnetLayout& L, const float* params, const float* x, const float* dy, float* grads, float* ws,
+                  hipStream_t s);
+
+}  // namespace fs

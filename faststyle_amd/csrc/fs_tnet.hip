@@ -1,0 +1,418 @@
+// Host orchestration of the image-transform net (reference im_transf_net.py:14-75) on top of
+// the kernels in fs_conv.hip / fs_wgrad.hip / fs_elem.hip: workspace layout, the forward launch
+// sequence (16 convs, each followed by the statistics finalize; normalisation+ReLU folded into
+// the consumer's load) and the hand-derived backward sequence.  No allocation, no sync.
+#include "fs_tnet.h"
+
+#include <cstring>
+
+namespace fs {
+
+// ---------------------------------------------------------------- parameter table (sorted keys)
+static ParamInfo g_params[48];
+static bool g_params_ready = false;
+
+static void add_param(int& idx, int& off, const char* layer, const char* leaf, int nd, int d0, int d1, int d2, int d3) {
+    ParamInfo& p = g_params[idx++];
+    snprintf(p.name, sizeof(p.name), "%s/%s", layer, leaf);
+    p.offset = off;
+    p.ndim = nd;
+    p.dims[0] = d0;
+    p.dims[1] = d1;
+    p.dims[2] = d2;
+    p.dims[3] = d3;
+    int n = 1;
+    for (int i = 0; i < nd; ++i) n *= p.dims[i];
+    p.count = n;
+    off += n;
+}
+
+const ParamInfo* param_table() {
+    if (g_params_ready) return g_params;
+    int idx = 0, off = 0;
+    const int ic[3][3] = {{9, 3, 16}, {3, 16, 32}, {3, 32, 64}};
+    for (int i = 0; i < 3; ++i) {
+        char l[32];
+        snprintf(l, sizeof(l), "initconv_%d", i);
+        add_param(idx, off, l, "INscale", 1, ic[i][2], 1, 1, 1);
+        add_param(idx, off, l, "INshift", 1, ic[i][2], 1, 1, 1);
+        add_param(idx, off, l, "W", 4, ic[i][0], ic[i][0], ic[i][1], ic[i][2]);
+    }
+    for (int i = 0; i < 5; ++i) {
+        char l[32];
+        snprintf(l, sizeof(l), "resblock_%d", i);
+        add_param(idx, off, l, "INscale1", 1, 64, 1, 1, 1);
+        add_param(idx, off, l, "INscale2", 1, 64, 1, 1, 1);
+        add_param(idx, off, l, "INshift1", 1, 64, 1, 1, 1);
+        add_param(idx, off, l, "INshift2", 1, 64, 1, 1, 1);
+        add_param(idx, off, l, "W1", 4, 3, 3, 64, 64);
+        add_param(idx, off, l, "W2", 4, 3, 3, 64, 64);
+    }
+    const int uc[3][3] = {{3, 64, 32}, {3, 32, 16}, {9, 16, 3}};
+    for (int i = 0; i < 3; ++i) {
+        char l[32];
+        snprintf(l, sizeof(l), "upsample_%d", i);
+        add_param(idx, off, l, "INscale", 1, uc[i][2], 1, 1, 1);
+        add_param(idx, off, l, "INshift", 1, uc[i][2], 1, 1, 1);
+        add_param(idx, off, l, "W", 4, uc[i][0], uc[i][0], uc[i][1], uc[i][2]);
+    }
+    g_params_ready = true;
+    return g_params;
+}
+
+static int find_param(const char* name) {
+    const ParamInfo* t = param_table();
+    for (int i = 0; i < 48; ++i)
+        if (!strcmp(t[i].name, name)) return t[i].offset;
+    return -1;
+}
+
+static void same_pads(int size, int k, int s, int* out, int* before) {
+    *out = cdiv(size, s);
+    int tot = (*out - 1) * s + k - size;
+    if (tot < 0) tot = 0;
+    *before = tot / 2;
+}
+
+// ---------------------------------------------------------------- layout
+struct Bump {
+    size_t off = 0;
+    size_t take(size_t floats) {
+        const size_t o = off;
+        off += (floats + 63) & ~(size_t)63;  // 256-byte granules
+        return o;
+    }
+};
+
+static ConvArgs unit_args(const Unit& u, int N) {
+    ConvArgs a{};
+    a.N = N;
+    a.H = u.Hsrc;
+    a.W = u.Wsrc;
+    a.Cin = u.Cin;
+    a.Ho = u.Hc;
+    a.Wo = u.Wc;
+    a.Cout = u.Cc;
+    a.KH = a.KW = u.K;
+    a.stride = u.stride;
+    a.pad_t = u.pad_t;
+    a.pad_l = u.pad_l;
+    a.src_mode = u.src_mode;
+    a.refl = u.refl;
+    a.shuffle = u.kind == 1;
+    return a;
+}
+
+void tnet_layout(int N, int H, int W, TnetLayout* L) {
+    memset(L, 0, sizeof(*L));
+    L->N = N;
+    L->H = H;
+    L->W = W;
+    Bump b;
+    int h = H + 80, w = W + 80;  // after reflect_pad(40)   im_transf_net.py:34
+    int ui = 0;
+    auto conv_unit = [&](const char* layer, const char* wleaf, const char* gleaf, const char* bleaf, int K, int stride,
+                         int Cin, int Cout, int valid, int hin, int win) -> Unit& {
+        Unit& u = L->u[ui++];
+        char nm[64];
+        snprintf(nm, sizeof(nm), "%s/%s", layer, wleaf);
+        u.w_off = find_param(nm);
+        snprintf(nm, sizeof(nm), "%s/%s", layer, gleaf);
+        u.g_off = find_param(nm);
+        snprintf(nm, sizeof(nm), "%s/%s", layer, bleaf);
+        u.b_off = find_param(nm);
+        u.kind = 0;
+        u.K = K;
+        u.stride = stride;
+        u.Cin = Cin;
+        u.Cout = u.Cc = Cout;
+        u.Hin = u.Hsrc = hin;
+        u.Win = u.Wsrc = win;
+        if (valid) {
+            u.Hc = hin - K + 1;
+            u.Wc = win - K + 1;
+            u.pad_t = u.pad_l = 0;
+        } else {
+            same_pads(hin, K, stride, &u.Hc, &u.pad_t);
+            same_pads(win, K, stride, &u.Wc, &u.pad_l);
+        }
+        u.Hout = u.Hc;
+        u.Wout = u.Wc;
+        return u;
+    };
+    {  // initconv_0: reflect pad fused into the load
+        Unit& u = conv_unit("initconv_0", "W", "INscale", "INshift", 9, 1, 3, 16, 0, h, w);
+        u.src_mode = SRC_REFLECT;
+        u.refl = 40;
+        u.Hsrc = H;
+        u.Wsrc = W;
+        same_pads(h, 9, 1, &u.Hc, &u.pad_t);
+        same_pads(w, 9, 1, &u.Wc, &u.pad_l);
+        u.Hout = u.Hc;
+        u.Wout = u.Wc;
+    }
+    {
+        Unit& u = conv_unit("initconv_1", "W", "INscale", "INshift", 3, 2, 16, 32, 0, h, w);
+        h = u.Hout;
+        w = u.Wout;
+    }
+    {
+        Unit& u = conv_unit("initconv_2", "W", "INscale", "INshift", 3, 2, 32, 64, 0, h, w);
+        h = u.Hout;
+        w = u.Wout;
+    }
+    for (int k = 0; k < 5; ++k) {
+        char l[32];
+        snprintf(l, sizeof(l), "resblock_%d", k);
+        conv_unit(l, "W1", "INscale1", "INshift1", 3, 1, 64, 64, 1, h, w);
+        conv_unit(l, "W2", "INscale2", "INshift2", 3, 1, 64, 64, 1, h - 2, w - 2);
+        h -= 4;
+        w -= 4;
+    }
+    for (int k = 0; k < 2; ++k) {  // phase-collapsed resize-conv: 2x2 taps, 4*Cout virtual channels
+        char l[32];
+        snprintf(l, sizeof(l), "upsample_%d", k);
+        const int Cin = k == 0 ? 64 : 32, Cout = k == 0 ? 32 : 16;
+        Unit& u = conv_unit(l, "W", "INscale", "INshift", 3, 1, Cin, Cout, 0, h, w);
+        u.kind = 1;
+        u.K = 2;
+        u.Cc = 4 * Cout;
+        u.Hc = h;
+        u.Wc = w;
+        u.pad_t = u.pad_l = 0;
+        u.Hout = 2 * h;
+        u.Wout = 2 * w;
+        h = u.Hout;
+        w = u.Wout;
+    }
+    conv_unit("upsample_2", "W", "INscale", "INshift", 9, 1, 16, 3, 0, h, w);
+    L->Hy = h;
+    L->Wy = w;
+
+    size_t max_act = 0, max_slab = 0, max_inbwd = 0;
+    for (int i = 0; i < 16; ++i) {
+        Unit& u = L->u[i];
+        ConvArgs a = unit_args(u, N);
+        u.plan = conv_plan(a);
+        u.tiles = u.plan.tiles_y * u.plan.tiles_x;
+        const size_t act = (size_t)N * u.Hout * u.Wout * u.Cout;
+        u.z = b.take(act);
+        u.stats = b.take((size_t)N * u.tiles * u.Cc * 3);
+        u.mean = b.take((size_t)N * u.Cout);
+        u.rstd = b.take((size_t)N * u.Cout);
+        u.a = b.take((size_t)N * u.Cout);
+        u.b = b.take((size_t)N * u.Cout);
+        if (act > max_act) max_act = act;
+        const size_t ib = in_bwd_scratch_floats(N, u.Hout * u.Wout, u.Cout);
+        if (ib > max_inbwd) max_inbwd = ib;
+    }
+    for (int k = 0; k < 5; ++k) {
+        const Unit& u2 = L->u[3 + 2 * k + 1];
+        L->h[k] = b.take((size_t)N * u2.Hout * u2.Wout * 64);
+    }
+    L->weff[0] = b.take(4 * 64 * 128);
+    L->weff[1] = b.take(4 * 32 * 64);
+    L->fwd_floats = b.off;
+    // ---- backward scratch ----
+    for (int k = 0; k < 3; ++k) L->g[k] = b.take(max_act);
+    L->dz = b.take(max_act);
+    L->wT = b.take(81 * 16 * 3 > 9 * 64 * 64 ? 81 * 16 * 3 : 9 * 64 * 64);
+    L->dweff = b.take(4 * 64 * 128);
+    L->inbwd = b.take(max_inbwd);
+    for (int i = 0; i < 16; ++i) {
+        Unit& u = L->u[i];
+        WgradArgs wa = unit_wgrad_args(u, N);
+        u.wplan = wgrad_plan(wa);
+        const size_t sl = (size_t)u.wplan.n_wg * u.wplan.K * wa.Cout;
+        if (sl > max_slab) max_slab = sl;
+    }
+    L->slabs = b.take(max_slab);
+    L->total_floats = b.off;
+}
+
+WgradArgs unit_wgrad_args(const Unit& u, int N) {
+    WgradArgs a{};
+    a.N = N;
+    a.H = u.Hsrc;
+    a.W = u.Wsrc;
+    a.Cin = u.Cin;
+    a.Ho = u.Hc;
+    a.Wo = u.Wc;
+    a.Cout = u.Cc;
+    a.KH = a.KW = u.K;
+    a.stride = u.stride;
+    a.pad_t = u.pad_t;
+    a.pad_l = u.pad_l;
+    a.src_mode = u.src_mode;
+    a.refl = u.refl;
+    a.dy_unshuffle = u.kind == 1;
+    return a;
+}
+
+// ---------------------------------------------------------------- forward
+#define FS_TRY(x)            \
+    do {                     \
+        int rc_ = (x);       \
+        if (rc_) return rc_; \
+    } while (0)
+
+int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s) {
+    const int N = L.N;
+    // collapsed resize-conv filters (weights may have changed since the last call: training)
+    FS_TRY(wt_upconv_fwd(params + L.u[13].w_off, ws + L.weff[0], 64, 32, s));
+    FS_TRY(wt_upconv_fwd(params + L.u[14].w_off, ws + L.weff[1], 32, 16, s));
+    const float* src = x;
+    const float* src_a = nullptr;
+    const float* src_b = nullptr;
+    for (int i = 0; i < 16; ++i) {
+        const Unit& u = L.u[i];
+        ConvArgs a = unit_args(u, N);
+        a.p = u.plan;
+        a.x = src;
+        a.in_a = src_a;
+        a.in_b = src_b;
+        a.in_nstride = src_a ? u.Cin : 0;
+        a.in_relu = src_a ? 1 : 0;
+        a.w = u.kind == 1 ? ws + L.weff[i - 13] : params + u.w_off;
+        a.y = ws + u.z;
+        a.stats = ws + u.stats;
+        FS_TRY(conv_launch(a, s));
+        FS_TRY(in_finalize(ws + u.stats, N, u.tiles, u.Cout, u.kind == 1 ? 4 : 1, params + u.g_off, params + u.b_off, 1e-3f,
+                           ws + u.mean, ws + u.rstd, ws + u.a, ws + u.b, s));
+        // what the next conv reads
+        src = ws + u.z;
+        src_a = ws + u.a;
+        src_b = ws + u.b;
+        if (i >= 4 && i <= 12 && ((i - 3) & 1)) {  // second conv of a residual block -> materialise h_k
+            const int k = (i - 4) / 2;
+            const float* skip;
+            const float *sa = nullptr, *sb = nullptr;
+            if (k == 0) {
+                skip = ws + L.u[2].z;
+                sa = ws + L.u[2].a;
+                sb = ws + L.u[2].b;
+            } else {
+                skip = ws + L.h[k - 1];
+            }
+            FS_TRY(apply_res(ws + u.z, ws + u.a, ws + u.b, skip, sa, sb, k == 0, ws + L.h[k], N, u.Hout, u.Wout, 64, s));
+            src = ws + L.h[k];
+            src_a = src_b = nullptr;
+        }
+    }
+    const Unit& u = L.u[15];
+    return apply_tanh(ws + u.z, ws + u.a, ws + u.b, y, N, u.Hout * u.Wout, 3, s);
+}
+
+// ---------------------------------------------------------------- backward
+// dgrad helper: d(input of unit u) from dz (gradient of u's raw conv output)
+static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, const float* dz, float* dst,
+                      const float* add_src, float* ws, hipStream_t s) {
+    const int N = L.N;
+    ConvArgs a{};
+    a.N = N;
+    a.x = dz;
+    a.y = dst;
+    a.w = ws + L.wT;
+    a.add_src = add_src;
+    a.add_pad = add_src ? 2 : 0;
+    if (u.kind == 1) {  // resize-conv: 3x3 stride-2 conv over dY, pad 1 before
+        FS_TRY(wt_upconv_dgrad(params + u.w_off, ws + L.wT, u.Cin, u.Cout, s));
+        a.H = u.Hout;
+        a.W = u.Wout;
+        a.Cin = u.Cout;
+        a.Ho = u.Hin;
+        a.Wo = u.Win;
+        a.Cout = u.Cin;
+        a.KH = a.KW = 3;
+        a.stride = 2;
+        a.pad_t = a.pad_l = 1;
+        a.src_mode = SRC_PLAIN;
+    } else {
+        FS_TRY(wt_flip_transpose(params + u.w_off, ws + L.wT, u.K, u.K, u.Cin, u.Cout, s));
+        a.H = u.Hout;
+        a.W = u.Wout;
+        a.Cin = u.Cout;
+        a.Ho = u.Hin;
+        a.Wo = u.Win;
+        a.Cout = u.Cin;
+        a.KH = a.KW = u.K;
+        a.stride = 1;
+        a.pad_t = u.K - 1 - u.pad_t;
+        a.pad_l = u.K - 1 - u.pad_l;
+        a.src_mode = u.stride == 2 ? SRC_DILATE2 : SRC_PLAIN;
+    }
+    a.p = conv_plan(a);
+    return conv_launch(a, s);
+}
+
+static int unit_wgrad(const TnetLayout& L, const Unit& u, const float* xin, const float* xa, const float* xb,
+                      const float* dz, float* grads, float* ws, hipStream_t s) {
+    WgradArgs a = unit_wgrad_args(u, L.N);
+    a.p = u.wplan;
+    a.x = xin;
+    a.in_a = xa;
+    a.in_b = xb;
+    a.in_nstride = xa ? u.Cin : 0;
+    a.in_relu = xa ? 1 : 0;
+    a.dy = dz;
+    a.slabs = ws + L.slabs;
+    FS_TRY(wgrad_launch(a, s));
+    const size_t count = (size_t)a.p.K * a.Cout;
+    if (u.kind == 1) {
+        FS_TRY(reduce_slabs(ws + L.slabs, 1, a.p.n_wg, count, 1.0f, ws + L.dweff, s));
+        return wt_upconv_wgrad_fold(ws + L.dweff, grads + u.w_off, u.Cin, u.Cout, s);
+    }
+    return reduce_slabs(ws + L.slabs, 1, a.p.n_wg, count, 1.0f, grads + u.w_off, s);
+}
+
+int tnet_backward(const TnetLayout& L, const float* params, const float* x, const float* dy, float* grads, float* ws,
+                  hipStream_t s) {
+    const int N = L.N;
+    const float* g = dy;         // gradient wrt the current unit's output activation (or h_k)
+    const float* res_g = nullptr;  // d h_k, kept alive until the block's first conv adds it to its dgrad
+    float* dz = ws + L.dz;
+    for (int i = 15; i >= 0; --i) {
+        const Unit& u = L.u[i];
+        const bool res2 = i >= 4 && i <= 12 && ((i - 3) & 1);       // second conv of a block (no activation)
+        const bool res1 = i >= 3 && i <= 11 && ((i - 3) & 1) == 0;  // first conv of a block
+        if (res2) res_g = g;
+        const int mode = i == 15 ? 2 : (res2 ? 0 : 1);
+        FS_TRY(in_bwd(g, ws + u.z, ws + u.mean, ws + u.rstd, ws + u.a, ws + u.b, mode, dz, grads + u.g_off, grads + u.b_off,
+                      ws + L.inbwd, N, u.Hout * u.Wout, u.Cout, s));
+        // the tensor this unit's conv consumed
+        const float* xin;
+        const float *xa = nullptr, *xb = nullptr;
+        if (i == 0) {
+            xin = x;
+        } else if (i >= 3 && i <= 13 && ((i - 3) & 1) == 0) {  // first conv of block k, or upsample_0 (k=5)
+            const int k = (i - 3) / 2;
+            if (k == 0) {
+                xin = ws + L.u[2].z;
+                xa = ws + L.u[2].a;
+                xb = ws + L.u[2].b;
+            } else {
+                xin = ws + L.h[k - 1];
+            }
+        } else {
+            xin = ws + L.u[i - 1].z;
+            xa = ws + L.u[i - 1].a;
+            xb = ws + L.u[i - 1].b;
+        }
+        FS_TRY(unit_wgrad(L, u, xin, xa, xb, dz, grads, ws, s));
+        if (i == 0) break;
+        float* dst = nullptr;
+        for (int k = 0; k < 3; ++k) {
+            float* cand = ws + L.g[k];
+            if (cand != g && cand != res_g) {
+                dst = cand;
+                break;
+            }
+        }
+        FS_TRY(unit_dgrad(L, u, params, dz, dst, res1 ? res_g : nullptr, ws, s));
+        if (res1) res_g = nullptr;
+        g = dst;
+    }
+    return 0;
+}
+
+}  // namespace fs

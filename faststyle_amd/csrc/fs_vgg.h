@@ -1,0 +1,32 @@
+// VGG16 feature extractor + Gram + perceptual losses: host orchestration (see fs_vgg.hip).
+#pragma once
+#include "../../include/faststyle_hip.h"
+#include "fs_kernels.h"
+
+namespace fs {
+
+struct VggLayout {
+    int N;        // samples that carry gradient (the transform-net outputs)
+    int NB;       // samples pushed through the shared layers (2N when content targets ride along)
+    int H, W;
+    int lmax;     // last conv layer evaluated
+    int cmax;     // last layer the content half is needed for (-1: none)
+    int Hl[FS_VGG_NLAYERS], Wl[FS_VGG_NLAYERS];
+    size_t xin, ab, act[FS_VGG_NLAYERS], pool[3];
+    size_t gram[4], sm[4], slabs;
+    size_t d_pre, d_in[2], d_tap, d_tap2, scratch;
+    size_t total_floats;
+};
+
+size_t vgg_prepared_floats();
+int vgg_prepare(const float* const w[FS_VGG_NLAYERS], float* prepared, hipStream_t s);
+void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, VggLayout* L);
+int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
+                    const float* prepared, const fs_loss_cfg& cfg, const float* y, const float* content, float* losses,
+                    float* dy, float* ws, hipStream_t s);
+int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
+                  const fs_loss_cfg& cfg, const float* img, float* const grams[4], float* ws, hipStream_t s);
+int vgg_consts(float* ab, hipStream_t s);
+int loss_total(float* losses, hipStream_t s);
+
+}  // namespace fs

@@ -1,0 +1,273 @@
+// VGG16 feature extraction (reference libs/vgg16.py:36-220), Gram matrices (utils.py:66-83),
+// content/style/TV losses (losses.py:12-97) and the gradient of their sum wrt the VGG input
+// (the VGG half of train.py:203's gradient graph; VGG itself is frozen, train.py:198-199).
+//
+// Launch sequence of one fs_perceptual_loss call:
+//   [y ; content] -> conv1_1 .. conv(cmax)        one 2N batch through the shared layers
+//   y only        -> .. conv(lmax)
+//   per style layer: G = F^T F/(hwc) (fs_wgrad per-sample 1x1), loss + S = coef*(G-Gt)
+//   per content layer: loss + tap gradient
+//   backward lmax..0: route (pool argmax, ReLU mask, + tap gradients incl. dF = F*S as a 1x1 conv
+//   with per-sample filters) -> 3x3 dgrad conv with the pre-flipped filters -> ... -> dy (+ beta*dTV)
+#include "fs_vgg.h"
+
+#include <cstring>
+
+namespace fs {
+
+static const int kCin[FS_VGG_NLAYERS] = {3, 64, 64, 128, 128, 256, 256, 256, 512, 512};
+static const int kCout[FS_VGG_NLAYERS] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512};
+static inline bool pool_after(int l) { return l == 1 || l == 3 || l == 6; }
+static inline int pool_index(int l) { return l == 1 ? 0 : (l == 3 ? 1 : 2); }
+
+#define FS_TRY(x)            \
+    do {                     \
+        int rc_ = (x);       \
+        if (rc_) return rc_; \
+    } while (0)
+
+size_t vgg_prepared_floats() {
+    size_t n = 0;
+    for (int l = 0; l < FS_VGG_NLAYERS; ++l) n += ((size_t)9 * kCin[l] * kCout[l] + 63) & ~(size_t)63;
+    return n;
+}
+static size_t prepared_offset(int l) {
+    size_t n = 0;
+    for (int i = 0; i < l; ++i) n += ((size_t)9 * kCin[i] * kCout[i] + 63) & ~(size_t)63;
+    return n;
+}
+
+int vgg_prepare(const float* const w[FS_VGG_NLAYERS], float* prepared, hipStream_t s) {
+    for (int l = 0; l < FS_VGG_NLAYERS; ++l)
+        FS_TRY(wt_flip_transpose(w[l], prepared + prepared_offset(l), 3, 3, kCin[l], kCout[l], s));
+    return 0;
+}
+
+struct Bump2 {
+    size_t off = 0;
+    size_t take(size_t floats) {
+        const size_t o = off;
+        off += (floats + 63) & ~(size_t)63;
+        return o;
+    }
+};
+
+static WgradArgs gram_args(int N, int H, int W, int C) {
+    WgradArgs a{};
+    a.N = N;
+    a.H = a.Ho = H;
+    a.W = a.Wo = W;
+    a.Cin = a.Cout = C;
+    a.KH = a.KW = 1;
+    a.stride = 1;
+    a.per_sample = 1;
+    return a;
+}
+
+void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, VggLayout* L) {
+    memset(L, 0, sizeof(*L));
+    L->N = N;
+    L->H = H;
+    L->W = W;
+    int lmax = 0, cmax = -1;
+    for (int i = 0; i < cfg.n_style; ++i)
+        if (cfg.style_layer[i] > lmax) lmax = cfg.style_layer[i];
+    for (int i = 0; i < cfg.n_content; ++i) {
+        if (cfg.content_layer[i] > lmax) lmax = cfg.content_layer[i];
+        if (cfg.content_layer[i] > cmax) cmax = cfg.content_layer[i];
+    }
+    if (!with_content) cmax = -1;
+    L->lmax = lmax;
+    L->cmax = cmax;
+    L->NB = cmax >= 0 ? 2 * N : N;
+    Bump2 b;
+    L->xin = b.take((size_t)L->NB * H * W * 3);
+    L->ab = b.take(8);
+    int h = H, w = W;
+    size_t max_act = 0, max_slab = 0;
+    for (int l = 0; l <= lmax; ++l) {
+        L->Hl[l] = h;
+        L->Wl[l] = w;
+        const int nb = l <= cmax ? L->NB : N;
+        L->act[l] = b.take((size_t)nb * h * w * kCout[l]);
+        const size_t grad_act = (size_t)N * h * w * kCout[l];
+        if (grad_act > max_act) max_act = grad_act;
+        if (pool_after(l) && l < lmax) {
+            h = (h + 1) / 2;
+            w = (w + 1) / 2;
+            L->pool[pool_index(l)] = b.take((size_t)nb * h * w * kCout[l]);
+        }
+    }
+    for (int i = 0; i < cfg.n_style; ++i) {
+        const int l = cfg.style_layer[i], C = kCout[l];
+        L->gram[i] = b.take((size_t)N * C * C);
+        L->sm[i] = b.take((size_t)N * C * C);
+        WgradArgs ga = gram_args(N, L->Hl[l], L->Wl[l], C);
+        const WgradPlan p = wgrad_plan(ga);
+        const size_t sl = (size_t)N * p.n_wg * C * C;
+        if (sl > max_slab) max_slab = sl;
+    }
+    L->slabs = b.take(max_slab);
+    L->d_pre = b.take(max_act);
+    L->d_in[0] = b.take(max_act);
+    L->d_in[1] = b.take(max_act);
+    L->d_tap = b.take(max_act);
+    L->d_tap2 = b.take(max_act);
+    L->scratch = b.take(2048);
+    L->total_floats = b.off;
+}
+
+static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, const float* bias, const float* ab, float* y,
+                    hipStream_t s) {
+    ConvArgs a{};
+    a.x = x;
+    a.w = w;
+    a.y = y;
+    a.N = N;
+    a.H = a.Ho = H;
+    a.W = a.Wo = W;
+    a.Cin = kCin[l];
+    a.Cout = kCout[l];
+    a.KH = a.KW = 3;
+    a.stride = 1;
+    a.pad_t = a.pad_l = 1;
+    a.bias = bias;
+    a.out_relu = 1;
+    if (l == 0) {  // images - mean folded into the load (padding stays zero, as in TF)
+        a.in_a = ab;
+        a.in_b = ab + 4;
+    }
+    a.p = conv_plan(a);
+    return conv_launch(a, s);
+}
+
+// forward through layers [0..lmax]; samples [0,N) go all the way, [N,NB) stop after cmax
+static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
+                       float* ws, hipStream_t s) {
+    FS_TRY(vgg_consts(ws + L.ab, s));
+    const float* src = ws + L.xin;
+    for (int l = 0; l <= L.lmax; ++l) {
+        const int nb = l <= L.cmax ? L.NB : L.N;
+        FS_TRY(vgg_conv(src, nb, L.Hl[l], L.Wl[l], l, w[l], b[l], ws + L.ab, ws + L.act[l], s));
+        src = ws + L.act[l];
+        if (pool_after(l) && l < L.lmax) {
+            FS_TRY(maxpool(ws + L.act[l], ws + L.pool[pool_index(l)], nb, L.Hl[l], L.Wl[l], kCout[l], s));
+            src = ws + L.pool[pool_index(l)];
+        }
+    }
+    return 0;
+}
+
+static int gram_forward(const VggLayout& L, int l, const float* F, float* G, float* ws, hipStream_t s) {
+    const int C = kCout[l], H = L.Hl[l], W = L.Wl[l];
+    WgradArgs ga = gram_args(L.N, H, W, C);
+    ga.x = F;
+    ga.dy = F;
+    ga.slabs = ws + L.slabs;
+    ga.p = wgrad_plan(ga);
+    FS_TRY(wgrad_launch(ga, s));
+    return reduce_slabs(ws + L.slabs, L.N, ga.p.n_wg, (size_t)C * C, 1.0f / ((float)H * W * C), G, s);
+}
+
+int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
+                  const fs_loss_cfg& cfg, const float* img, float* const grams[4], float* ws, hipStream_t s) {
+    if (hipMemcpyAsync(ws + L.xin, img, (size_t)L.H * L.W * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return -10;
+    VggLayout L2 = L;
+    int lmax = 0;
+    for (int i = 0; i < cfg.n_style; ++i)
+        if (cfg.style_layer[i] > lmax) lmax = cfg.style_layer[i];
+    L2.lmax = lmax;
+    FS_TRY(vgg_forward(L2, w, b, ws, s));
+    for (int i = 0; i < cfg.n_style; ++i) FS_TRY(gram_forward(L2, cfg.style_layer[i], ws + L2.act[cfg.style_layer[i]], grams[i], ws, s));
+    return 0;
+}
+
+int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
+                    const float* prepared, const fs_loss_cfg& cfg, const float* y, const float* content, float* losses,
+                    float* dy, float* ws, hipStream_t s) {
+    const int N = L.N;
+    const size_t img = (size_t)N * L.H * L.W * 3;
+    if (hipMemcpyAsync(ws + L.xin, y, img * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -10;
+    if (L.cmax >= 0 &&
+        hipMemcpyAsync(ws + L.xin + img, content, img * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return -10;
+    if (hipMemsetAsync(losses, 0, 4 * sizeof(float), s) != hipSuccess) return -10;
+    FS_TRY(vgg_forward(L, w, b, ws, s));
+
+    // ---- losses ----
+    for (int i = 0; i < cfg.n_style; ++i) {
+        const int l = cfg.style_layer[i], C = kCout[l];
+        const float hwc = (float)L.Hl[l] * L.Wl[l] * C;
+        FS_TRY(gram_forward(L, l, ws + L.act[l], ws + L.gram[i], ws, s));
+        // loss += w * sum (G-Gt)^2 / c^2 ;  S = 4w/(c^2 hwc) (G - Gt)   (dF = F S, G symmetric)
+        const float wgt = cfg.style_weight[i];
+        FS_TRY(sqdiff_loss(ws + L.gram[i], cfg.target_gram[i], (size_t)C * C, (size_t)N * C * C, wgt / ((float)C * C),
+                           4.0f * wgt / ((float)C * C * hwc), ws + L.sm[i], losses + 2, 1, ws + L.scratch, s));
+    }
+
+    // ---- backward ----
+    const float* d_above = nullptr;
+    int di = 0;
+    for (int l = L.lmax; l >= 0; --l) {
+        const int C = kCout[l], H = L.Hl[l], W = L.Wl[l];
+        const size_t act_n = (size_t)N * H * W * C;  // the y half
+        // tap gradient of this layer (content first, then the style term accumulates through add_src)
+        const float* tap = nullptr;
+        for (int i = 0; i < cfg.n_content; ++i)
+            if (cfg.content_layer[i] == l) {
+                const float hwc = (float)H * W * C;
+                const float wgt = cfg.content_weight[i];
+                // reference losses.py:32-37: w * sum_{b,h,w,c} (phi(Y)-phi_t)^2 / (h*w*c)
+                FS_TRY(sqdiff_loss(ws + L.act[l], ws + L.act[l] + act_n, act_n, act_n, wgt / hwc, 2.0f * wgt / hwc,
+                                   ws + L.d_tap, losses + 1, 1, ws + L.scratch, s));
+                tap = ws + L.d_tap;
+            }
+        for (int i = 0; i < cfg.n_style; ++i)
+            if (cfg.style_layer[i] == l) {
+                ConvArgs a{};
+                a.x = ws + L.act[l];
+                a.w = ws + L.sm[i];
+                a.w_nstride = (long long)C * C;
+                a.N = N;
+                a.H = a.Ho = H;
+                a.W = a.Wo = W;
+                a.Cin = a.Cout = C;
+                a.KH = a.KW = 1;
+                a.stride = 1;
+                a.add_src = tap;
+                a.add_pad = 0;
+                float* dst = tap == ws + L.d_tap ? ws + L.d_tap2 : ws + L.d_tap;
+                a.y = dst;
+                a.p = conv_plan(a);
+                FS_TRY(conv_launch(a, s));
+                tap = dst;
+            }
+        if (!d_above && !tap) continue;  // nothing flows into this layer (cannot happen for lmax)
+        const bool pooled = d_above && pool_after(l);
+        FS_TRY(vgg_bwd_route(ws + L.act[l], d_above, tap, pooled ? 1 : 0, ws + L.d_pre, N, H, W, C, s));
+        // input gradient of conv l
+        ConvArgs a{};
+        a.x = ws + L.d_pre;
+        a.w = prepared + prepared_offset(l);
+        a.N = N;
+        a.H = a.Ho = H;
+        a.W = a.Wo = W;
+        a.Cin = C;
+        a.Cout = kCin[l];
+        a.KH = a.KW = 3;
+        a.stride = 1;
+        a.pad_t = a.pad_l = 1;
+        a.y = l == 0 ? dy : ws + L.d_in[di];
+        a.p = conv_plan(a);
+        FS_TRY(conv_launch(a, s));
+        d_above = ws + L.d_in[di];
+        di ^= 1;
+    }
+    // TV term on y itself (reference losses.py:70-97, train.py:183-184); beta defaults to 0
+    if (cfg.beta != 0.0f)
+        FS_TRY(tv_loss(y, N, L.H, L.W, 3, cfg.beta, cfg.beta, dy, losses + 3, ws + L.scratch, s));
+    return loss_total(losses, s);
+}
+
+}  // namespace fs

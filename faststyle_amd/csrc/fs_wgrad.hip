@@ -1,0 +1,260 @@
+// Pixel-reduction contractions on the fp32 matrix cores:
+//   * filter gradients of the transform-net convs,  dW[k,co] = sum_p X[p+tap(k), ci(k)] * dY[p,co]
+//     (the adjoint of tf.nn.conv2d wrt its filter, reference im_transf_net.py:115 / train.py:203);
+//   * the per-sample Gram matrices  G = F^T F  (reference utils.py:76-82) as the 1x1 case with
+//     X == dY == F and one result per sample.
+//
+// MFMA mapping (v_mfma_f32_32x32x2_f32): the instruction's K dimension is a PAIR OF PIXELS, its
+// M dimension 32 consecutive k = (tap, ci) and its N dimension 32 output channels.  A workgroup
+// owns a 128(k) x 128(co) block of the result (wave w: k-block w, up to four co-blocks = 64
+// accumulator registers), walks a strided list of pixel tiles, stages each tile's input patch as
+// [pixel][C+1] and its dY tile as [pixel][128] in LDS, and finally writes ONE partial slab;
+// fs::reduce_slabs sums the slabs in a fixed order (deterministic, no atomics).
+#include "fs_kernels.h"
+
+#include <cstdlib>
+
+namespace fs {
+
+__device__ __forceinline__ bool wsrc_coord(int mode, int refl, int v, int n_src, int& s) {
+    if (mode == SRC_PLAIN) {
+        s = v;
+        return v >= 0 && v < n_src;
+    } else if (mode == SRC_REFLECT) {
+        if (v < 0 || v >= n_src + 2 * refl) return false;
+        s = v - refl;
+        if (s < 0) s = -s;
+        if (s >= n_src) s = 2 * (n_src - 1) - s;
+        return true;
+    } else if (mode == SRC_DILATE2) {
+        if (v < 0 || (v & 1)) return false;
+        s = v >> 1;
+        return s < n_src;
+    } else {
+        if (v < 0) return false;
+        s = v >> 2;
+        return s < n_src;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const WgradPlan& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 31, kq = lane >> 5;
+    const int cogroups = cdiv(p.NB, 4);
+    const int kbg = blockIdx.y / cogroups, nbg = blockIdx.y % cogroups;
+    const int kb = kbg * 4 + wave;          // this wave's k-block
+    const int nbw = min(4, p.NB - nbg * 4);  // co-blocks of this workgroup
+    const int DP = nbw * 32;                 // dY LDS pitch
+    const int co_g0 = nbg * 128;
+    // staged input-channel window
+    const int CS = p.S - 1;
+    const int cA = a.Cin <= 128 ? 0 : (kbg * 128) % a.Cin;
+    const int S = p.S, PW = p.PW, PH = p.PH;
+    const int patch_floats = (PH * PW * S + 4 + 3) & ~3;
+    float* patch = smem;
+    float* dyl = smem + patch_floats;
+
+    // A-operand base of this lane: k -> (tap, ci)
+    const int k = kb * 32 + lm;
+    const bool kvalid = kb < p.KB && k < p.K;
+    int abase = PH * PW * S;  // zero slack
+    int amul = 0;
+    if (kvalid) {
+        const int tap = k / a.Cin, ci = k - tap * a.Cin;
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+        abase = (kh * PW + kw) * S + (ci - cA);
+        amul = 1;
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int nsel = a.per_sample ? 1 : a.N;
+    const int total = nsel * tiles;
+    const bool has_ab = a.in_a != nullptr;
+    const bool xvec = (a.Cin & 3) == 0;
+    const int Cr = a.dy_unshuffle ? a.Cout >> 2 : a.Cout;
+
+    bool first = true;
+    for (int t = blockIdx.x; t < total; t += p.n_wg) {
+        const int n = a.per_sample ? (int)blockIdx.z : t / tiles;
+        const int tr = t % tiles;
+        const int ty0 = (tr / p.tiles_x) * p.TH, tx0 = (tr % p.tiles_x) * p.TW;
+        const int vy0 = ty0 * a.stride - a.pad_t, vx0 = tx0 * a.stride - a.pad_l;
+        const float* xn = a.x + (size_t)n * a.H * a.W * a.Cin;
+        const float* ia = has_ab ? a.in_a + (size_t)n * a.in_nstride : nullptr;
+        const float* ib = has_ab ? a.in_b + (size_t)n * a.in_nstride : nullptr;
+        if (!first) __syncthreads();
+        first = false;
+        // ---- stage x patch ----
+        if (xvec) {
+            const int c4n = CS >> 2;
+            for (int e = tid; e < PH * PW * c4n; e += 256) {
+                const int pix = e / c4n, c4 = e - pix * c4n;
+                const int py = pix / PW, px = pix - py * PW;
+                int sy, sx;
+                const bool ok = wsrc_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) &&
+                                wsrc_coord(a.src_mode, a.refl, vx0 + px, a.W, sx);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) {
+                    const int c = cA + c4 * 4;
+                    v = *reinterpret_cast<const float4*>(xn + ((size_t)sy * a.W + sx) * a.Cin + c);
+                    if (has_ab) {
+                        const float4 va = *reinterpret_cast<const float4*>(ia + c);
+                        const float4 vb = *reinterpret_cast<const float4*>(ib + c);
+                        v.x = fmaf(v.x, va.x, vb.x);
+                        v.y = fmaf(v.y, va.y, vb.y);
+                        v.z = fmaf(v.z, va.z, vb.z);
+                        v.w = fmaf(v.w, va.w, vb.w);
+                    }
+                    if (a.in_relu) {
+                        v.x = fmaxf(v.x, 0.f);
+                        v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f);
+                        v.w = fmaxf(v.w, 0.f);
+                    }
+                }
+                float* d = patch + pix * S + c4 * 4;
+                d[0] = v.x;
+                d[1] = v.y;
+                d[2] = v.z;
+                d[3] = v.w;
+            }
+        } else {
+            for (int e = tid; e < PH * PW * CS; e += 256) {
+                const int pix = e / CS, c = e - pix * CS;
+                const int py = pix / PW, px = pix - py * PW;
+                int sy, sx;
+                const bool ok = wsrc_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) &&
+                                wsrc_coord(a.src_mode, a.refl, vx0 + px, a.W, sx);
+                float v = 0.f;
+                if (ok) {
+                    v = xn[((size_t)sy * a.W + sx) * a.Cin + cA + c];
+                    if (has_ab) v = fmaf(v, ia[cA + c], ib[cA + c]);
+                    if (a.in_relu) v = fmaxf(v, 0.f);
+                }
+                patch[pix * S + c] = v;
+            }
+        }
+        if (tid < 4) patch[PH * PW * S + tid] = 0.f;
+        // ---- stage dY tile [TH*TW][DP] (zero outside the image / beyond Cout) ----
+        {
+            const int j4n = DP >> 2;
+            const bool vec = (Cr & 3) == 0;
+            for (int e = tid; e < p.TH * p.TW * j4n; e += 256) {
+                const int pix = e / j4n, j4 = e - pix * j4n;
+                const int py = pix / p.TW, px = pix - py * p.TW;
+                const int oy = ty0 + py, ox = tx0 + px;
+                const int co = co_g0 + j4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (oy < a.Ho && ox < a.Wo && co < a.Cout) {
+                    const float* src;
+                    if (a.dy_unshuffle) {
+                        const int q = co / Cr, cr = co - q * Cr;
+                        src = a.dy + (((size_t)n * 2 * a.Ho + 2 * oy + (q >> 1)) * (2 * a.Wo) + 2 * ox + (q & 1)) * Cr + cr;
+                    } else {
+                        src = a.dy + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+                    }
+                    if (vec && co + 3 < a.Cout) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v.x = src[0];
+                        if (co + 1 < a.Cout) v.y = src[1];
+                        if (co + 2 < a.Cout) v.z = src[2];
+                        if (co + 3 < a.Cout) v.w = src[3];
+                    }
+                }
+                *reinterpret_cast<float4*>(dyl + pix * DP + j4 * 4) = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA sweep over pixel pairs ----
+        if (kb < p.KB) {
+            for (int py = 0; py < p.TH; ++py) {
+                const int rowA = py * a.stride * PW;
+#pragma unroll 2
+                for (int px0 = 0; px0 < p.TW; px0 += 2) {
+                    const int px = px0 + kq;
+                    const float av = patch[abase + amul * ((rowA + px * a.stride) * S)];
+                    const float* pb = dyl + (py * p.TW + px) * DP + lm;
+                    float bv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bv[j] = j < nbw ? pb[j * 32] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < nbw) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- write this workgroup's partial slab ----
+    if (kb < p.KB) {
+        float* slab = a.slabs + ((size_t)blockIdx.z * p.n_wg + blockIdx.x) * (size_t)p.K * a.Cout;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= nbw) continue;
+            const int co = co_g0 + j * 32 + lm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (kk < p.K && co < a.Cout) slab[(size_t)kk * a.Cout + co] = acc[j][r];
+            }
+        }
+    }
+}
+
+static int env_int2(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+WgradPlan wgrad_plan(const WgradArgs& a) {
+    WgradPlan p{};
+    p.K = a.KH * a.KW * a.Cin;
+    p.KB = cdiv(p.K, 32);
+    p.NB = cdiv(a.Cout, 32);
+    // pixel tile: 128 pixels, even width
+    int tw = a.Wo >= 16 ? 16 : ((a.Wo + 1) & ~1);
+    tw = cdiv(cdiv(a.Wo, cdiv(a.Wo, tw)), 2) * 2;
+    int th = 128 / tw;
+    if (th > a.Ho) th = a.Ho;
+    th = cdiv(a.Ho, cdiv(a.Ho, th));
+    p.TH = th;
+    p.TW = tw;
+    p.tiles_y = cdiv(a.Ho, th);
+    p.tiles_x = cdiv(a.Wo, tw);
+    p.PH = (th - 1) * a.stride + a.KH;
+    p.PW = (tw - 1) * a.stride + a.KW;
+    const int CS = a.Cin <= 128 ? a.Cin : 128;
+    p.S = CS + 1;
+    const int DP = 32 * (p.NB < 4 ? p.NB : 4);
+    p.lds_bytes = 4 * (((p.PH * p.PW * p.S + 4 + 3) & ~3) + th * tw * DP);
+    const int total = (a.per_sample ? 1 : a.N) * p.tiles_y * p.tiles_x;
+    const int groups = cdiv(p.KB, 4) * cdiv(p.NB, 4) * (a.per_sample ? a.N : 1);
+    int want = env_int2("FS_WGRAD_WGS", 1024) / groups;  // aim for ~1024 workgroups in flight
+    if (want < 1) want = 1;
+    p.n_wg = total < want ? total : want;
+    return p;
+}
+
+int wgrad_launch(const WgradArgs& a, hipStream_t s) {
+    const WgradPlan& p = a.p;
+    if (a.Cin > 128 && a.Cin % 128) return -1;
+    if (p.lds_bytes > 160 * 1024) return -2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)p.n_wg, (unsigned)(cdiv(p.KB, 4) * cdiv(p.NB, 4)), (unsigned)(a.per_sample ? a.N : 1));
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), (size_t)p.lds_bytes, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace fs

@@ -1,0 +1,301 @@
+"""Thin Python driver over the C ABI: owns a context, workspaces and the pointer plumbing.
+
+Device memory, streams and (in ``parallel.py``) ``torch.distributed`` come from PyTorch-ROCm --
+plumbing only; every FLOP of the path runs in libfaststyle_hip.so.  The memory provider is
+injectable (``mem``) so the parity tests can drive the very same code with host arrays against
+the kernel emulator build; the product always uses ``TorchMem`` on a ROCm device.
+"""
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib as L
+
+
+class TorchMem(object):
+    """Device tensors from PyTorch-ROCm on the current HIP stream."""
+
+    def __init__(self, device="cuda:0"):
+        import torch
+        if not torch.cuda.is_available():
+            raise L.FaststyleError("no ROCm/HIP device visible: the faststyle engine has no CPU path")
+        self.torch = torch
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+
+    def empty(self, shape):
+        return self.torch.empty(tuple(int(s) for s in shape), dtype=self.torch.float32, device=self.device)
+
+    def zeros(self, shape):
+        return self.torch.zeros(tuple(int(s) for s in shape), dtype=self.torch.float32, device=self.device)
+
+    def from_numpy(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy()
+
+    def ptr(self, t):
+        if t is None:
+            return None
+        assert t.is_contiguous() and t.dtype == self.torch.float32 and t.is_cuda
+        return t.data_ptr()
+
+    def stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def device_index(self):
+        return self.device.index or 0
+
+    def view(self, t, offset, shape):
+        n = int(np.prod(shape))
+        return t.view(-1)[offset:offset + n].view(*shape)
+
+
+def default_loss_cfg():
+    """train.py:52-70 defaults: content conv3_3 x1.0; style conv1_2/2_2/3_3/4_3 x5.0."""
+    return dict(content_layers=["conv3_3"], content_weights=[1.0],
+                style_layers=["conv1_2", "conv2_2", "conv3_3", "conv4_3"], style_weights=[5.0] * 4, beta=0.0)
+
+
+class Engine(object):
+    def __init__(self, mem=None, lib=None):
+        self.lib = lib if lib is not None else L.load()
+        self.mem = mem if mem is not None else TorchMem()
+        ctx = ctypes.c_void_p()
+        L.check(self.lib, self.lib.fs_ctx_create(self.mem.device_index(), ctypes.c_void_p(self.mem.stream()),
+                                                 ctypes.byref(ctx)), "fs_ctx_create")
+        self.ctx = ctx
+        self._tnet_ws = {}
+        self._perc_ws = {}
+        self._keep = []
+
+    def close(self):
+        if self.ctx:
+            self.lib.fs_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def _sync_stream(self):
+        self.lib.fs_ctx_set_stream(self.ctx, ctypes.c_void_p(self.mem.stream()))
+
+    # ------------------------------------------------------------------ parameters
+    def param_table(self):
+        """[(name, offset, shape)] of the 48 tensors in the flat parameter buffer (ckpt order)."""
+        out = []
+        for i in range(L.FS_TNET_NTENSORS):
+            name = ctypes.c_char_p()
+            off = ctypes.c_int()
+            nd = ctypes.c_int()
+            dims = (ctypes.c_int * 4)()
+            L.check(self.lib, self.lib.fs_tnet_param_info(i, ctypes.byref(name), ctypes.byref(off), ctypes.byref(nd),
+                                                          ctypes.byref(dims)), "fs_tnet_param_info")
+            out.append((name.value.decode(), off.value, tuple(dims[k] for k in range(nd.value))))
+        return out
+
+    def flatten_params(self, tensors, scope="img_t_net/"):
+        """dict name->ndarray (checkpoint names) -> flat float32 vector in table order."""
+        flat = np.empty(L.FS_TNET_NPARAMS, dtype=np.float32)
+        for name, off, shape in self.param_table():
+            a = tensors.get(scope + name, tensors.get(name))
+            if a is None:
+                raise L.FaststyleError("checkpoint lacks tensor %s%s" % (scope, name))
+            if tuple(a.shape) != shape:
+                raise L.FaststyleError("tensor %s has shape %s, expected %s (wrong --upsample_method?)"
+                                       % (name, a.shape, shape))
+            flat[off:off + a.size] = np.asarray(a, dtype=np.float32).ravel()
+        return flat
+
+    def unflatten_params(self, flat, scope="img_t_net/"):
+        flat = np.asarray(flat)
+        return OrderedDict((scope + name, flat[off:off + int(np.prod(shape))].reshape(shape).copy())
+                           for name, off, shape in self.param_table())
+
+    # ------------------------------------------------------------------ transform net
+    def tnet_out_shape(self, H, W):
+        ho, wo = ctypes.c_int(), ctypes.c_int()
+        L.check(self.lib, self.lib.fs_tnet_out_shape(H, W, ctypes.byref(ho), ctypes.byref(wo)), "fs_tnet_out_shape")
+        return ho.value, wo.value
+
+    def _tnet_workspace(self, N, H, W):
+        key = (N, H, W)
+        if key not in self._tnet_ws:
+            nbytes = self.lib.fs_tnet_workspace_bytes(N, H, W, L.FS_FLAG_SAVE_FOR_BWD)
+            if nbytes == 0:
+                raise L.FaststyleError("bad transform-net shape %s" % (key,))
+            self._tnet_ws = {key: (self.mem.empty((nbytes // 4,)), nbytes)}   # keep only the latest shape
+        return self._tnet_ws[key]
+
+    def tnet_forward(self, params, x, save_for_bwd=False):
+        """create_net(x, 'resize'): x [N,H,W,3] float32 RGB 0..255 -> y [N,Ho,Wo,3]."""
+        self._sync_stream()
+        N, H, W, C = (int(s) for s in x.shape)
+        assert C == 3
+        Ho, Wo = self.tnet_out_shape(H, W)
+        ws, nbytes = self._tnet_workspace(N, H, W)
+        y = self.mem.empty((N, Ho, Wo, 3))
+        p = self.mem.ptr
+        L.check(self.lib, self.lib.fs_tnet_forward(self.ctx, p(params), p(x), N, H, W, p(y), p(ws), nbytes,
+                                                   L.FS_FLAG_SAVE_FOR_BWD if save_for_bwd else 0), "fs_tnet_forward")
+        return y
+
+    def tnet_backward(self, params, x, dy, grads=None):
+        """Gradient of the 48 tensors given dL/dy; must follow tnet_forward(save_for_bwd=True)."""
+        self._sync_stream()
+        N, H, W, _ = (int(s) for s in x.shape)
+        ws, nbytes = self._tnet_workspace(N, H, W)
+        if grads is None:
+            grads = self.mem.empty((L.FS_TNET_NPARAMS,))
+        p = self.mem.ptr
+        L.check(self.lib, self.lib.fs_tnet_backward(self.ctx, p(params), p(x), p(dy), N, H, W, p(grads), p(ws), nbytes),
+                "fs_tnet_backward")
+        return grads
+
+    # ------------------------------------------------------------------ VGG / losses
+    def vgg_load(self, weights):
+        """weights: mapping in the npz convention of vgg16.load_weights (vgg16.py:257-266):
+        'conv1_1_W' [3,3,3,64], 'conv1_1_b' [64], ...  Keeps device copies + dgrad re-layout."""
+        self._sync_stream()
+        self.vgg_w, self.vgg_b = [], []
+        for i, n in enumerate(L.VGG_LAYER_NAMES):
+            w = np.asarray(weights[n + "_W"], dtype=np.float32)
+            b = np.asarray(weights[n + "_b"], dtype=np.float32)
+            if w.shape != (3, 3, L.VGG_CIN[i], L.VGG_COUT[i]) or b.shape != (L.VGG_COUT[i],):
+                raise L.FaststyleError("VGG weight %s has shape %s" % (n, w.shape))
+            self.vgg_w.append(self.mem.from_numpy(w))
+            self.vgg_b.append(self.mem.from_numpy(b))
+        self._wp = (ctypes.c_void_p * L.FS_VGG_NLAYERS)(*[self.mem.ptr(t) for t in self.vgg_w])
+        self._bp = (ctypes.c_void_p * L.FS_VGG_NLAYERS)(*[self.mem.ptr(t) for t in self.vgg_b])
+        self.vgg_prepared = self.mem.empty((self.lib.fs_vgg_prepared_floats(),))
+        L.check(self.lib, self.lib.fs_vgg_prepare(self.ctx, ctypes.byref(self._wp), self.mem.ptr(self.vgg_prepared)),
+                "fs_vgg_prepare")
+
+    def _cfg(self, cfg, target_grams=None):
+        c = L.fs_loss_cfg()
+        c.n_content = len(cfg["content_layers"])
+        for i, (n, w) in enumerate(zip(cfg["content_layers"], cfg["content_weights"])):
+            c.content_layer[i] = L.VGG_LAYER_NAMES.index(n)
+            c.content_weight[i] = w
+        c.n_style = len(cfg["style_layers"])
+        for i, (n, w) in enumerate(zip(cfg["style_layers"], cfg["style_weights"])):
+            c.style_layer[i] = L.VGG_LAYER_NAMES.index(n)
+            c.style_weight[i] = w
+            if target_grams is not None:
+                c.target_gram[i] = self.mem.ptr(target_grams[i])
+        c.beta = cfg.get("beta", 0.0)
+        return c
+
+    def style_targets(self, style_img, cfg):
+        """utils.get_grams on the style image (train.py:144-151): list of [1,C,C] device tensors."""
+        self._sync_stream()
+        _, H, W, _ = (int(s) for s in style_img.shape)
+        c = self._cfg(cfg)
+        grams = [self.mem.empty((1, L.VGG_COUT[c.style_layer[i]], L.VGG_COUT[c.style_layer[i]]))
+                 for i in range(c.n_style)]
+        gp = (ctypes.c_void_p * 4)(*([self.mem.ptr(g) for g in grams] + [None] * (4 - len(grams))))
+        nbytes = self.lib.fs_style_targets_workspace_bytes(H, W)
+        ws = self.mem.empty((nbytes // 4,))
+        L.check(self.lib, self.lib.fs_style_targets(self.ctx, ctypes.byref(self._wp), ctypes.byref(self._bp), ctypes.byref(c),
+                                                    self.mem.ptr(style_img), H, W, ctypes.byref(gp), self.mem.ptr(ws), nbytes),
+                "fs_style_targets")
+        return grams
+
+    def perceptual_loss(self, y, content, target_grams, cfg):
+        """loss = content + style + beta*tv (train.py:164-184) and dL/dy.
+        Returns (losses[4] device tensor {loss, content, style, beta*tv}, dy)."""
+        self._sync_stream()
+        N, H, W, _ = (int(s) for s in y.shape)
+        c = self._cfg(cfg, target_grams)
+        key = (N, H, W, tuple(cfg["content_layers"]), tuple(cfg["style_layers"]))
+        if key not in self._perc_ws:
+            nbytes = self.lib.fs_perceptual_workspace_bytes(N, H, W, ctypes.byref(c))
+            self._perc_ws = {key: (self.mem.empty((nbytes // 4,)), nbytes)}
+        ws, nbytes = self._perc_ws[key]
+        losses = self.mem.empty((4,))
+        dy = self.mem.empty((N, H, W, 3))
+        p = self.mem.ptr
+        L.check(self.lib, self.lib.fs_perceptual_loss(self.ctx, ctypes.byref(self._wp), ctypes.byref(self._bp),
+                                                      p(self.vgg_prepared), ctypes.byref(c), p(y), p(content), N, H, W,
+                                                      p(losses), p(dy), p(ws), nbytes), "fs_perceptual_loss")
+        return losses, dy
+
+    def adam_tf_step(self, p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+        """tf.train.AdamOptimizer(lr) update (train.py:203), in place; t = 1-based step."""
+        self._sync_stream()
+        P = self.mem.ptr
+        L.check(self.lib, self.lib.fs_adam_tf_step(self.ctx, P(p), P(g), P(m), P(v), int(np.prod(p.shape)), lr, beta1,
+                                                   beta2, eps, t), "fs_adam_tf_step")
+
+    # ------------------------------------------------------------------ single ops (tests)
+    def conv2d(self, x, w, stride=1, padding="SAME", **kw):
+        self._sync_stream()
+        d = L.fs_conv_desc()
+        N, H, W, Cin = (int(s) for s in x.shape)
+        KH, KW, _, Cout = (int(s) for s in w.shape[-4:])
+        d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride = N, H, W, Cin, Cout, KH, KW, stride
+        if isinstance(padding, str):
+            d.pad_mode = L.FS_PAD_SAME if padding == "SAME" else L.FS_PAD_VALID
+        else:
+            d.pad_mode = L.FS_PAD_EXPLICIT
+            d.pad_t, d.pad_l, d.Ho, d.Wo = padding
+        d.src_mode = kw.get("src_mode", 0)
+        d.refl = kw.get("refl", 0)
+        p = self.mem.ptr
+        d.x, d.w = p(x), p(w)
+        for k in ("in_a", "in_b", "bias", "add_src"):
+            setattr(d, k, p(kw.get(k)))
+        d.in_per_sample = int(kw.get("in_per_sample", 0))
+        d.in_relu = int(kw.get("in_relu", 0))
+        d.out_relu = int(kw.get("out_relu", 0))
+        d.shuffle = int(kw.get("shuffle", 0))
+        d.add_pad = int(kw.get("add_pad", 0))
+        d.w_nstride = int(kw.get("w_nstride", 0))
+        tiles = ctypes.c_int()
+        L.check(self.lib, self.lib.fs_conv2d_plan(ctypes.byref(d), ctypes.byref(tiles)), "fs_conv2d_plan")
+        if d.shuffle:
+            y = self.mem.empty((N, 2 * d.Ho, 2 * d.Wo, Cout // 4))
+        else:
+            y = self.mem.empty((N, d.Ho, d.Wo, Cout))
+        d.y = p(y)
+        stats = None
+        if kw.get("want_stats"):
+            stats = self.mem.empty((N, tiles.value, Cout, 3))
+            d.stats = p(stats)
+        L.check(self.lib, self.lib.fs_conv2d_fwd(self.ctx, ctypes.byref(d)), "fs_conv2d_fwd")
+        return (y, stats, tiles.value) if kw.get("want_stats") else y
+
+    def instnorm_finalize(self, stats, tiles, C, groups, gamma, beta, eps=1e-3):
+        self._sync_stream()
+        N = int(stats.shape[0])
+        out = [self.mem.empty((N, C)) for _ in range(4)]
+        p = self.mem.ptr
+        L.check(self.lib, self.lib.fs_instnorm_finalize(self.ctx, p(stats), N, tiles, C, groups, p(gamma), p(beta), eps,
+                                                        *[p(o) for o in out]), "fs_instnorm_finalize")
+        return out  # mean, rstd, a, b
+
+    def conv2d_wgrad(self, x, dy, k, stride=1, padding="SAME", per_sample=False, scale=1.0, **kw):
+        self._sync_stream()
+        d = L.fs_wgrad_desc()
+        N, H, W, Cin = (int(s) for s in x.shape)
+        Cout = int(dy.shape[-1])
+        d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride = N, H, W, Cin, Cout, k, k, stride
+        if isinstance(padding, str):
+            d.pad_mode = L.FS_PAD_SAME if padding == "SAME" else L.FS_PAD_VALID
+        else:
+            d.pad_mode = L.FS_PAD_EXPLICIT
+            d.pad_t, d.pad_l, d.Ho, d.Wo = padding
+        d.src_mode = kw.get("src_mode", 0)
+        d.refl = kw.get("refl", 0)
+        p = self.mem.ptr
+        d.x, d.dy = p(x), p(dy)
+        d.in_a, d.in_b = p(kw.get("in_a")), p(kw.get("in_b"))
+        d.in_per_sample = int(kw.get("in_per_sample", 0))
+        d.in_relu = int(kw.get("in_relu", 0))
+        d.per_sample = int(per_sample)
+        d.scale = scale
+        dw = self.mem.empty((N, Cin, Cout) if per_sample else (k, k, Cin, Cout))
+        d.dw = p(dw)
+        nbytes = self.lib.fs_conv2d_wgrad_workspace_bytes(ctypes.byref(d))
+        ws = self.mem.empty((max(nbytes // 4, 1),))
+        L.check(self.lib, self.lib.fs_conv2d_wgrad(self.ctx, ctypes.byref(d), p(ws), nbytes), "fs_conv2d_wgrad")
+        return dw

@@ -1,0 +1,146 @@
+/* libfaststyle_hip.so -- C ABI of the MI355X (gfx950) fast-style-transfer hot path.
+ *
+ * The reference (ghwatson/faststyle) has no FFI of its own: every FLOP of the path is a stock
+ * TensorFlow-1 op called from Python.  This header is the boundary a maintainer binds instead
+ * (ctypes stub: INTEGRATION.md / faststyle_amd/_lib.py); each entry point names the reference
+ * call site it replaces (file:line relative to the reference repo).
+ *
+ * Conventions
+ *   - every call returns 0 on success, a negative code on error; fs_last_error() (thread-local)
+ *     holds the message;
+ *   - the caller owns ALL tensor memory (device pointers: hipMalloc / torch data_ptr()); the
+ *     library never allocates or frees it; scratch comes from fs_*_workspace_bytes() + a
+ *     caller-provided workspace;
+ *   - every launch is asynchronous on the ctx stream, no hidden synchronisation, no allocation
+ *     after fs_ctx_create (hipGraph-capturable);
+ *   - a ctx is not thread-safe; distinct ctxs are independent;
+ *   - tensors are NHWC fp32, filters HWIO fp32 (TensorFlow layout).
+ */
+#ifndef FASTSTYLE_HIP_H
+#define FASTSTYLE_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fs_ctx fs_ctx;
+
+int fs_ctx_create(int device, void* hip_stream, fs_ctx** out);
+void fs_ctx_destroy(fs_ctx* ctx);
+int fs_ctx_set_stream(fs_ctx* ctx, void* hip_stream);
+const char* fs_last_error(void);
+const char* fs_version(void);
+
+/* ---- image-transform net: reference im_transf_net.py:14-75 (create_net) ------------------ */
+#define FS_TNET_NPARAMS 424102 /* 48 fp32 tensors, sorted-key (= checkpoint) order */
+#define FS_TNET_NTENSORS 48
+#define FS_FLAG_SAVE_FOR_BWD 1 /* keep every intermediate the backward pass needs */
+
+/* name / offset (floats) / shape of the idx-th parameter tensor in the flat buffer; the order is
+ * the key order of the TF bundle (models/<style>_final.ckpt.index), without the "img_t_net/" scope. */
+int fs_tnet_param_info(int idx, const char** name, int* offset, int* ndim, int dims[4]);
+/* im_transf_net.py:14-75: output size of create_net for an HxW input. */
+int fs_tnet_out_shape(int H, int W, int* Ho, int* Wo);
+size_t fs_tnet_workspace_bytes(int N, int H, int W, int flags);
+/* y[N,Ho,Wo,3] = create_net(x[N,H,W,3], 'resize') with the 48 tensors in params[FS_TNET_NPARAMS].
+ * Replaces sess.run(Y, {X: img}) at stylize_image.py:75 and the forward half of train.py:256-275. */
+int fs_tnet_forward(fs_ctx* ctx, const float* params, const float* x, int N, int H, int W, float* y, void* ws,
+                    size_t ws_bytes, int flags);
+/* grads[FS_TNET_NPARAMS] = d loss / d params given dy = d loss / d y; `ws` must be the workspace a
+ * fs_tnet_forward(..., FS_FLAG_SAVE_FOR_BWD) call on the same inputs just filled.  Replaces the
+ * transform-net half of AdamOptimizer.minimize's gradient graph (train.py:203). */
+int fs_tnet_backward(fs_ctx* ctx, const float* params, const float* x, const float* dy, int N, int H, int W, float* grads,
+                     void* ws, size_t ws_bytes);
+
+/* ---- VGG16 + Gram + losses: reference libs/vgg16.py:36-220, utils.py:66-83, losses.py ------ */
+#define FS_VGG_NLAYERS 10 /* conv1_1 .. conv4_3 (conv5_x is never fetched: train.py:55-59) */
+/* floats needed for the dgrad re-layout of the 10 frozen filters */
+size_t fs_vgg_prepared_floats(void);
+/* w[i], b[i]: conv1_1,conv1_2,conv2_1,...,conv4_3 in the npz convention of vgg16.load_weights
+ * (vgg16.py:257-266: HWIO [3,3,Cin,Cout] kernels, [Cout] biases).  Fills `prepared` with the
+ * flipped/transposed filters the input-gradient convs use (VGG is frozen: train.py:198-199). */
+int fs_vgg_prepare(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], float* prepared);
+
+typedef struct {
+    int n_content;              /* content layers (default 1: conv3_3, train.py:52-55) */
+    int content_layer[4];       /* layer index 0..9 */
+    float content_weight[4];
+    int n_style;                /* style layers (default conv1_2,conv2_2,conv3_3,conv4_3) */
+    int style_layer[4];
+    float style_weight[4];
+    const float* target_gram[4]; /* [C,C] of the style image, broadcast over the batch (losses.py:63) */
+    float beta;                 /* TV weight (train.py:88-93) */
+} fs_loss_cfg;
+
+size_t fs_perceptual_workspace_bytes(int N, int H, int W, const fs_loss_cfg* cfg);
+/* One evaluation of loss = content + style + beta*tv (train.py:164-184) AND its gradient wrt y:
+ *   y[N,H,W,3]        transform-net output fed to VGG directly (train.py:164-165)
+ *   content[N,H,W,3]  the raw batch whose VGG features are the content targets (train.py:250-251)
+ *   losses[4]         device floats: {loss, content_loss, style_loss, beta*tv_loss}
+ *   dy[N,H,W,3]       d loss / d y  (VGG filter gradients are never formed) */
+int fs_perceptual_loss(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
+                       const float* prepared, const fs_loss_cfg* cfg, const float* y, const float* content, int N, int H,
+                       int W, float* losses, float* dy, void* ws, size_t ws_bytes);
+/* utils.get_grams on the style image (train.py:144-151): grams[i] = [C_i,C_i] for cfg->style_layer[i]. */
+size_t fs_style_targets_workspace_bytes(int H, int W);
+int fs_style_targets(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
+                     const fs_loss_cfg* cfg, const float* style_img, int H, int W, float* const grams[4], void* ws,
+                     size_t ws_bytes);
+
+/* ---- optimiser: tf.train.AdamOptimizer (train.py:203), TF1 epsilon placement ---------------- */
+int fs_adam_tf_step(fs_ctx* ctx, float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                    float beta2, float eps, long long t /* 1-based step */);
+
+/* ---- single ops (used by the parity tests; same kernels the composite calls launch) --------- */
+#define FS_PAD_SAME 0
+#define FS_PAD_VALID 1
+#define FS_PAD_EXPLICIT 2
+#define FS_SRC_PLAIN 0
+#define FS_SRC_REFLECT 1
+#define FS_SRC_DILATE2 2
+typedef struct {
+    const float* x;      /* [N,H,W,Cin] */
+    const float* w;      /* [KH,KW,Cin,Cout] */
+    float* y;            /* [N,Ho,Wo,Cout] */
+    int N, H, W, Cin, Cout, KH, KW, stride;
+    int pad_mode, pad_t, pad_l, Ho, Wo; /* Ho/Wo/pad_* are inputs only with FS_PAD_EXPLICIT */
+    int src_mode, refl;
+    const float* in_a;   /* optional producer instance-norm folded into the load: relu(x*a+b) */
+    const float* in_b;
+    int in_per_sample;   /* in_a/in_b are [N,Cin] (else [Cin]) */
+    int in_relu;
+    const float* bias;   /* optional [Cout] */
+    int out_relu;
+    int shuffle;         /* 2x2 pixel-shuffle store: y is [N,2Ho,2Wo,Cout/4] */
+    float* stats;        /* optional per-tile instance-norm partials, see fs_conv2d_stats_floats */
+    const float* add_src;
+    int add_pad;
+    long long w_nstride; /* per-sample filter stride in floats (0: shared) */
+} fs_conv_desc;
+/* tf.nn.conv2d (im_transf_net.py:115, vgg16.py:47) on the matrix cores. */
+int fs_conv2d_fwd(fs_ctx* ctx, fs_conv_desc* d);
+/* resolves Ho/Wo/pads and returns the per-image tile count the launch will use */
+int fs_conv2d_plan(fs_conv_desc* d, int* tiles_per_image);
+/* tf.nn.moments + normalisation constants (im_transf_net.py:238-245) from the conv epilogue's
+ * per-tile partials: mean,rstd,a,b are [N,C];  a = gamma*rstd, b = beta - mean*a. */
+int fs_instnorm_finalize(fs_ctx* ctx, const float* stats, int N, int tiles, int C, int groups, const float* gamma,
+                         const float* beta, float eps, float* mean, float* rstd, float* a, float* b);
+typedef struct {
+    const float* x;
+    const float* dy;
+    float* dw;           /* [KH,KW,Cin,Cout], or [N,Cin,Cout] when per_sample */
+    int N, H, W, Cin, Cout, KH, KW, stride, pad_mode, pad_t, pad_l, Ho, Wo, src_mode, refl;
+    const float* in_a;
+    const float* in_b;
+    int in_per_sample, in_relu;
+    int per_sample;
+    float scale;
+} fs_wgrad_desc;
+size_t fs_conv2d_wgrad_workspace_bytes(fs_wgrad_desc* d);
+/* tf.nn.conv2d_backprop_filter; with per_sample and KH=KW=1, x==dy it is utils.get_grams. */
+int fs_conv2d_wgrad(fs_ctx* ctx, fs_wgrad_desc* d, void* ws, size_t ws_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

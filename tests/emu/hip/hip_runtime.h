@@ -1,0 +1,280 @@
+// TEST INFRASTRUCTURE ONLY -- a fiber-based CPU emulator of the small slice of the HIP
+// programming model the faststyle kernels use, so that the *unmodified* kernel sources in
+// faststyle_amd/csrc can be compiled with a host compiler (`clang++ -I tests/emu`) and
+// their index/tile/fragment logic exercised by `pytest -m "not gpu"` in a container that
+// has no GPU.  It is never part of the product: the shipped library is built by hipcc for
+// gfx950 against the real <hip/hip_runtime.h>, and faststyle_amd/_lib.py refuses to load
+// anything else.
+//
+// Model: one workgroup = blockDim.x cooperative fibers (ucontext) on one OS thread; a
+// fiber runs until it reaches __syncthreads() or a wave-level operation (MFMA, shuffle),
+// then yields.  Fibers are resumed in lane order, so a missing barrier shows up
+// deterministically as a stale read.  Workgroups of a launch are spread over OS threads.
+// MFMA lane layouts follow /opt/skills/guides/cdna_hip_programming.md §3:
+//   32x32x2 f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D col=l&31,
+//                row=(r&3)+8*(r>>2)+4*(l>>5);
+//   16x16x4 f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D col=l&15, row=4*(l>>4)+r.
+// Results are k-ordered fmaf chains, bit-identical to the hardware instruction.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local   /* one workgroup at a time per OS thread */
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "emulator"; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : 1; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+enum { hipMemcpyHostToDevice = 1 };
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+
+namespace fsemu {
+
+struct Idx { unsigned x, y, z; };
+enum State { RUN = 0, WAIT_WAVE, WAIT_BLOCK, DONE };
+
+struct Wave {
+    float a[2][64], b[2][64];
+    float sh[2][64];
+    unsigned arrived = 0, gen = 0;
+};
+
+struct Fiber {
+    ucontext_t ctx;
+    Idx tid;
+    int lane, wave;
+    State st;
+    unsigned wait_gen;
+    unsigned mfma_seq, shfl_seq;
+};
+
+struct Block {
+    ucontext_t sched;
+    std::vector<Fiber> fibers;
+    std::vector<Wave> waves;
+    std::vector<char*> stacks;
+    char* smem = nullptr;
+    size_t smem_cap = 0;
+    unsigned arrived = 0, gen = 0, nthreads = 0;
+    Idx bid, bdim, gdim;
+    Fiber* cur = nullptr;
+    const std::function<void()>* body = nullptr;
+    ~Block() { for (char* s : stacks) free(s); free(smem); }
+};
+
+static const size_t kStack = 256 * 1024;
+inline Block*& tls_block() { static thread_local Block* b = nullptr; return b; }
+inline Block& blk() { return *tls_block(); }
+
+inline void yield_to_sched() { Block& b = blk(); swapcontext(&b.cur->ctx, &b.sched); }
+
+inline void trampoline() {
+    Block& b = blk();
+    (*b.body)();
+    b.cur->st = DONE;
+    swapcontext(&b.cur->ctx, &b.sched);
+}
+
+inline void block_sync() {
+    Block& b = blk();
+    Fiber* f = b.cur;
+    unsigned g = b.gen;
+    if (++b.arrived == b.nthreads) { b.arrived = 0; b.gen++; return; }
+    f->st = WAIT_BLOCK; f->wait_gen = g;
+    yield_to_sched();
+}
+
+inline void wave_sync() {
+    Block& b = blk();
+    Fiber* f = b.cur;
+    Wave& w = b.waves[f->wave];
+    unsigned g = w.gen;
+    if (++w.arrived == 64) { w.arrived = 0; w.gen++; return; }
+    f->st = WAIT_WAVE; f->wait_gen = g;
+    yield_to_sched();
+}
+
+inline void run_block(Block& b, const std::function<void()>& body, Idx bid, Idx bdim, Idx gdim, size_t smem) {
+    tls_block() = &b;
+    unsigned nt = bdim.x * bdim.y * bdim.z;
+    if (nt % 64) { fprintf(stderr, "fsemu: blockDim must be a multiple of 64\n"); abort(); }
+    b.nthreads = nt; b.bid = bid; b.bdim = bdim; b.gdim = gdim; b.body = &body;
+    b.arrived = 0;
+    if (b.fibers.size() < nt) {
+        b.fibers.resize(nt);
+        while (b.stacks.size() < nt) b.stacks.push_back((char*)aligned_alloc(64, kStack));
+    }
+    b.waves.assign(nt / 64, Wave());
+    if (smem + 64 > b.smem_cap) { free(b.smem); b.smem_cap = smem + 64; b.smem = (char*)aligned_alloc(64, (b.smem_cap + 63) / 64 * 64); }
+    memset(b.smem, 0xCD, smem);   // poison: reading unwritten LDS shows up as garbage
+    for (unsigned t = 0; t < nt; ++t) {
+        Fiber& f = b.fibers[t];
+        f.tid = Idx{t % bdim.x, (t / bdim.x) % bdim.y, t / (bdim.x * bdim.y)};
+        f.lane = t % 64; f.wave = t / 64; f.st = RUN; f.mfma_seq = f.shfl_seq = 0;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = b.stacks[t];
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+    unsigned done = 0;
+    while (done < nt) {
+        bool progressed = false;
+        for (unsigned wv = 0; wv < nt / 64; ++wv) {
+            bool wave_prog = true;
+            while (wave_prog) {
+                wave_prog = false;
+                for (unsigned l = 0; l < 64; ++l) {
+                    Fiber& f = b.fibers[wv * 64 + l];
+                    if (f.st == DONE) continue;
+                    if (f.st == WAIT_BLOCK) { if (b.gen == f.wait_gen) continue; f.st = RUN; }
+                    if (f.st == WAIT_WAVE) { if (b.waves[wv].gen == f.wait_gen) continue; f.st = RUN; }
+                    b.cur = &f;
+                    swapcontext(&b.sched, &f.ctx);
+                    wave_prog = progressed = true;
+                    if (f.st == DONE) ++done;
+                }
+            }
+        }
+        if (!progressed && done < nt) { fprintf(stderr, "fsemu: deadlock (divergent barrier?)\n"); abort(); }
+    }
+}
+
+template <class F>
+inline void launch(F&& body, dim3 grid, dim3 block, size_t smem) {
+    std::function<void()> fn = body;
+    size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    unsigned nthr = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), nblocks);
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        Block* b = new Block();
+        for (;;) {
+            size_t i = next.fetch_add(1);
+            if (i >= nblocks) break;
+            Idx bid{(unsigned)(i % grid.x), (unsigned)((i / grid.x) % grid.y), (unsigned)(i / ((size_t)grid.x * grid.y))};
+            run_block(*b, fn, bid, Idx{block.x, block.y, block.z}, Idx{grid.x, grid.y, grid.z}, smem);
+        }
+        delete b;
+    };
+    if (nthr <= 1) { worker(); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthr; ++t) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+}
+
+inline Idx& tid() { return blk().cur->tid; }
+inline Idx& bid() { return blk().bid; }
+inline Idx& bdim() { return blk().bdim; }
+inline Idx& gdim() { return blk().gdim; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+    Block& bk = blk(); Fiber* f = bk.cur; Wave& w = bk.waves[f->wave];
+    int s = f->mfma_seq++ & 1, l = f->lane;
+    w.a[s][l] = a; w.b[s][l] = b;
+    wave_sync();
+    int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) acc = fmaf(w.a[s][i + 32 * k], w.b[s][j + 32 * k], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
+inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
+    Block& bk = blk(); Fiber* f = bk.cur; Wave& w = bk.waves[f->wave];
+    int s = f->mfma_seq++ & 1, l = f->lane;
+    w.a[s][l] = a; w.b[s][l] = b;
+    wave_sync();
+    int j = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int i = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(w.a[s][i + 16 * k], w.b[s][j + 16 * k], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
+inline float shfl_idx(float v, int src) {
+    Block& bk = blk(); Fiber* f = bk.cur; Wave& w = bk.waves[f->wave];
+    int s = f->shfl_seq++ & 1;
+    w.sh[s][f->lane] = v;
+    wave_sync();
+    return w.sh[s][src & 63];
+}
+
+}  // namespace fsemu
+
+#define threadIdx (fsemu::tid())
+#define blockIdx (fsemu::bid())
+#define blockDim (fsemu::bdim())
+#define gridDim (fsemu::gdim())
+#define __syncthreads() fsemu::block_sync()
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(fsemu::blk().smem);
+
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) fsemu::mfma_32x32x2((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) fsemu::mfma_16x16x4((a), (b), (c))
+
+static inline float __shfl_xor(float v, int mask, int width = 64) { (void)width; return fsemu::shfl_idx(v, fsemu::blk().cur->lane ^ mask); }
+static inline float __shfl_down(float v, int d, int width = 64) { (void)width; int l = fsemu::blk().cur->lane; return fsemu::shfl_idx(v, l + d > 63 ? l : l + d); }
+static inline float __shfl(float v, int src, int width = 64) { (void)width; return fsemu::shfl_idx(v, src); }
+static inline float atomicAdd(float* p, float v) {
+    static std::atomic_flag lk = ATOMIC_FLAG_INIT;
+    while (lk.test_and_set(std::memory_order_acquire)) {}
+    float o = *p; *p = o + v;
+    lk.clear(std::memory_order_release);
+    return o;
+}
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+using std::max;
+using std::min;
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+template <class T>
+static inline hipError_t hipFuncSetAttribute(T, hipFuncAttribute, int) { return hipSuccess; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...)                        \
+    do {                                                                                   \
+        (void)(stream);                                                                    \
+        fsemu::launch([=]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block), (smem));    \
+    } while (0)
