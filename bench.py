@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""Headline benchmark of the faststyle hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one full train.py loop body (reference train.py:245-275) on a synthetic 256x256 batch
+of 4 images per GPU (the reference's --batch_size 4; global batch 4N, 32 at N=8 = BASELINE.json's
+"256x256 b32"): content-target VGG pass, transform-net forward, VGG16+Gram+losses, full backward,
+one RCCL all-reduce (SUM) of the 424,102 gradients, TF-Adam.  fp32 end to end (the reference's
+dtype); every convolution / Gram contraction runs on the fp32 matrix cores.
+
+Prints ONE JSON line on rank 0 (contract: see the task statement); extra keys:
+  roofline      dominant kernel (conv_igemm<32,2,2>, the VGG16 / residual 3x3 convs): algorithmic
+                FLOP / HIP-event time, measured live on the launch stream during the timed steps
+  cpu_baseline  the numpy oracle (a port of the reference path; TF1 itself cannot be installed)
+                timed on this box's host cores on a bounded sample, rank 0 / N=1 only
+  stylize_720p_fps  config[1]: im_transf_net forward on a 720p frame, batch 1, fp32
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# SURVEY.md §8d algorithmic work (FLOP = 2*MAC, convs/Grams only), per image at 256x256
+GFLOP_PER_IMG_AS_WRITTEN = 121.94
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=4)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stylize", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(n_images, size):
+    """Oracle (numpy float32 port of the reference path, as-written algorithm) train-step rate."""
+    from oracle import perceptual, tnet            # allowed here: the CPU-baseline leg only
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    rng = np.random.default_rng(1)
+    P = tnet.init_params(0)
+    Wv = perceptual.synthetic_vgg_weights(3)
+    style = rng.uniform(0, 255, (1, 128, 128, 3)).astype(np.float32)
+    tg = perceptual.target_grams(style, Wv, ("conv1_2", "conv2_2", "conv3_3", "conv4_3"))
+    t0 = time.perf_counter()
+    for _ in range(n_images):
+        x = rng.uniform(0, 255, (1, size, size, 3)).astype(np.float32)
+        perceptual.train_step(P, x, tg, Wv)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_images / dt, 4), "unit": "images/sec", "cores": int(threads), "kind": "port",
+            "sample": "%d train steps of 1x%dx%dx3 (fwd+bwd, no Adam), numpy/OpenBLAS float32 oracle of the "
+                      "reference path; host has %d logical cores" % (n_images, size, size, os.cpu_count() or 0)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from faststyle_amd import engine, im_transf_net, trainer, utils, vgg16
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    eng = engine.Engine(engine.TorchMem("cuda:%d" % local))
+
+    B, S = args.batch_per_gpu, args.size
+    params = eng.flatten_params(im_transf_net.initial_variables(seed=0), scope="")
+    npz = os.path.join(ROOT, "libs", "vgg16_weights.npz")
+    real_vgg = os.path.exists(npz)
+    vgg_w = vgg16.load_weights(npz) if real_vgg else vgg16.synthetic_weights(seed=3)
+    style = utils.imread(os.path.join(ROOT, "style_images", "starry_night_crop.jpg")).astype(np.float32)[None]
+    tr = trainer.Trainer(eng, params, vgg_w, style, learn_rate=1e-3, dist=dist if world > 1 else None)
+
+    # synthetic COCO: uniform [0,255) float32 batches, pre-generated on the device, fresh per step
+    g = torch.Generator(device="cuda")
+    g.manual_seed(100 + rank)
+    pool = [torch.rand((B, S, S, 3), device="cuda", generator=g) * 255.0 for _ in range(8)]
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        tr.step(pool[i % len(pool)])
+    sync()
+    eng.lib.fs_profile_begin(eng.ctx)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = tr.step(pool[(args.warmup + i) % len(pool)])
+    sync()
+    elapsed = time.perf_counter() - t0
+    import ctypes
+    prof = (ctypes.c_double * 12)()
+    eng.lib.fs_profile_end(eng.ctx, ctypes.byref(prof))
+    loss_val = float(losses[0].item())
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # config[1]: 720p stylize, batch 1 per GPU, independent frames (no collective)
+    fps = None
+    if not args.no_stylize:
+        from faststyle_amd import ckpt
+        W = ckpt.load_checkpoint(os.path.join(ROOT, "models", "starry_final.ckpt"))
+        flat = eng.mem.from_numpy(eng.flatten_params(W))
+        frame = torch.rand((1, 720, 1280, 3), device="cuda", generator=g) * 255.0
+        for _ in range(3):
+            eng.tnet_forward(flat, frame)
+        sync()
+        t1 = time.perf_counter()
+        iters = 20
+        for _ in range(iters):
+            eng.tnet_forward(flat, frame)
+        sync()
+        dt = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        fps = world * iters / dt
+
+    if rank == 0:
+        n_img = args.steps * B * world
+        value = n_img / elapsed
+        fam = [[prof[f * 3 + k] for k in range(3)] for f in range(4)]
+        dom = fam[0]
+        achieved = dom[1] / (dom[2] * 1e-3) / 1e12 if dom[2] > 0 else 0.0
+        mfma_flops = sum(f[1] for f in fam)
+        mfma_ms = sum(f[2] for f in fam)
+        out = {
+            "metric": "images/sec train-step 256x256 (global batch 4/GPU x N; b32 at N=8)",
+            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (uniform[0,255) images; %s VGG16 weights; random-init transform net)"
+                    % ("real" if real_vgg else "synthetic He-normal"),
+            "config": {"workload": "train.py step: 256x256, batch %d/GPU, VGG16 conv1_2/2_2/3_3/4_3 Gram style loss + "
+                                   "conv3_3 content loss, resize-conv transform net, TF-Adam" % B,
+                       "global_batch": B * world, "image_size": [S, S], "parallelism": "dp%d" % world,
+                       "style_image": "starry_night_crop.jpg 640x938"},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel<32,2,2> (fp32 MFMA implicit-GEMM conv)",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": round(dom[0] / args.steps, 1),
+                         "avg_launch_us": round(1e3 * dom[2] / dom[0], 2) if dom[0] else None,
+                         "all_mfma_kernels_tflops": round(mfma_flops / (mfma_ms * 1e-3) / 1e12, 2) if mfma_ms else None,
+                         "mfma_kernel_ms_per_step": round(mfma_ms / args.steps, 3)},
+            "step_tflops_as_written": round(GFLOP_PER_IMG_AS_WRITTEN * value / 1e3, 2),
+            "step_frac_of_f32_mfma_peak": round(GFLOP_PER_IMG_AS_WRITTEN * value / 1e3 / world / PEAK_F32_MFMA_TFLOPS, 4),
+            "final_loss": loss_val,
+        }
+        if fps is not None:
+            out["stylize_720p_fps"] = round(fps, 2)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_images, S)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

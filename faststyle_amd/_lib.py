@@ -64,6 +64,8 @@ PROTOTYPES = {
     "fs_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
     "fs_last_error": (c_char_p, []),
     "fs_version": (c_char_p, []),
+    "fs_profile_begin": (c_int, [c_void_p]),
+    "fs_profile_end": (c_int, [c_void_p, POINTER(ctypes.c_double * 12)]),
     "fs_tnet_param_info": (c_int, [c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int), POINTER(c_int * 4)]),
     "fs_tnet_out_shape": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "fs_tnet_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -83,6 +85,9 @@ PROTOTYPES = {
     "fs_conv2d_plan": (c_int, [POINTER(fs_conv_desc), POINTER(c_int)]),
     "fs_instnorm_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fs_instnorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "fs_instnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fs_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(fs_wgrad_desc)]),
     "fs_conv2d_wgrad": (c_int, [c_void_p, POINTER(fs_wgrad_desc), c_void_p, c_size_t]),
 }

@@ -47,6 +47,24 @@ int fs_ctx_set_stream(fs_ctx* ctx, void* hip_stream) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------ profiling hook
+static fs::Profiler g_prof;
+int fs_profile_begin(fs_ctx* ctx) {
+    if (!ctx) return fail(-1, "null ctx");
+    g_prof.reset();
+    fs::Profiler::current() = &g_prof;
+    return 0;
+}
+int fs_profile_end(fs_ctx* ctx, double out[12]) {
+    if (!ctx || !out) return fail(-1, "fs_profile_end: null argument");
+    fs::Profiler::current() = nullptr;
+    double tmp[fs::Profiler::kFamilies][3];
+    if (g_prof.collect(tmp)) return fail(-4, "fs_profile_end: event query failed");
+    memcpy(out, tmp, sizeof(tmp));
+    g_prof.reset();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ transform net
 int fs_tnet_param_info(int idx, const char** name, int* offset, int* ndim, int dims[4]) {
     if (idx < 0 || idx >= 48) return fail(-1, "fs_tnet_param_info: index %d out of range", idx);
@@ -269,6 +287,18 @@ int fs_instnorm_finalize(fs_ctx* ctx, const float* stats, int N, int tiles, int 
                          const float* beta, float eps, float* mean, float* rstd, float* a, float* b) {
     if (!ctx || !stats || !gamma || !beta || !mean || !rstd || !a || !b) return fail(-1, "fs_instnorm_finalize: null argument");
     return fs::in_finalize(stats, N, tiles, C, groups, gamma, beta, eps, mean, rstd, a, b, ctx->stream);
+}
+
+size_t fs_instnorm_bwd_workspace_bytes(int N, int HW, int C) { return fs::in_bwd_scratch_floats(N, HW, C) * sizeof(float); }
+
+int fs_instnorm_bwd(fs_ctx* ctx, const float* gin, const float* z, const float* mean, const float* rstd, const float* a,
+                    const float* b, int mode, int N, int HW, int C, float* dz, float* dgamma, float* dbeta, void* ws,
+                    size_t ws_bytes) {
+    if (!ctx || !gin || !z || !mean || !rstd || !a || !b || !dz || !dgamma || !dbeta || !ws)
+        return fail(-1, "fs_instnorm_bwd: null argument");
+    if (C > 256) return fail(-2, "fs_instnorm_bwd: C <= 256");
+    if (ws_bytes < fs_instnorm_bwd_workspace_bytes(N, HW, C)) return fail(-3, "fs_instnorm_bwd: workspace too small");
+    return fs::in_bwd(gin, z, mean, rstd, a, b, mode, dz, dgamma, dbeta, (float*)ws, N, HW, C, ctx->stream);
 }
 
 static int fill_wgrad(fs_wgrad_desc* d, fs::WgradArgs* a) {

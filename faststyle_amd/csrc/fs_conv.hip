@@ -333,6 +333,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // -------------------------------------------------------------------------------------- host
+Profiler*& Profiler::current() {
+    static thread_local Profiler* p = nullptr;
+    return p;
+}
+void Profiler::begin(int fam, double flops, hipStream_t s) {
+    if (n == cap) {
+        const int ncap = cap ? cap * 2 : 1024;
+        Rec* nr = (Rec*)realloc(recs, sizeof(Rec) * ncap);
+        if (!nr) return;
+        recs = nr;
+        for (int i = cap; i < ncap; ++i) {
+            (void)hipEventCreate(&recs[i].a);
+            (void)hipEventCreate(&recs[i].b);
+        }
+        cap = ncap;
+    }
+    recs[n].fam = fam;
+    recs[n].flops = flops;
+    (void)hipEventRecord(recs[n].a, s);
+}
+void Profiler::end(hipStream_t s) {
+    if (n < cap) (void)hipEventRecord(recs[n++].b, s);
+}
+int Profiler::collect(double out[kFamilies][3]) {
+    for (int f = 0; f < kFamilies; ++f) out[f][0] = out[f][1] = out[f][2] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (hipEventSynchronize(recs[i].b) != hipSuccess) return -1;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, recs[i].a, recs[i].b) != hipSuccess) return -1;
+        out[recs[i].fam][0] += 1;
+        out[recs[i].fam][1] += recs[i].flops;
+        out[recs[i].fam][2] += ms;
+    }
+    return 0;
+}
+void Profiler::reset() { n = 0; }
+Profiler::~Profiler() {
+    for (int i = 0; i < cap; ++i) {
+        (void)hipEventDestroy(recs[i].a);
+        (void)hipEventDestroy(recs[i].b);
+    }
+    free(recs);
+}
+
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -415,12 +459,20 @@ int conv_launch(const ConvArgs& a, hipStream_t s) {
     if (p.CC <= 0 || (!p.flat && (a.Cin % 4 || a.Cin % p.CC))) return -1;
     if (p.lds_bytes > 64 * 1024) return -2;
     dim3 grid((unsigned)(a.N * p.tiles_y * p.tiles_x), (unsigned)cdiv(a.Cout, p.BN));
+    Profiler* prof = Profiler::current();
+    if (prof) {
+        // algorithmic FLOPs: 2*M*K*N with the true extents; a zero-dilated dgrad only does 1/4 useful work
+        double fl = 2.0 * a.N * a.Ho * a.Wo * (double)a.KH * a.KW * a.Cin * a.Cout;
+        if (a.src_mode == SRC_DILATE2) fl *= 0.25;
+        prof->begin(p.variant, fl, s);
+    }
     if (p.variant == 0)
         hipLaunchKernelGGL((conv_igemm_kernel<32, 2, 2>), grid, dim3(256), (size_t)p.lds_bytes, s, a);
     else if (p.variant == 1)
         hipLaunchKernelGGL((conv_igemm_kernel<32, 2, 1>), grid, dim3(256), (size_t)p.lds_bytes, s, a);
     else
         hipLaunchKernelGGL((conv_igemm_kernel<16, 4, 1>), grid, dim3(256), (size_t)p.lds_bytes, s, a);
+    if (prof) prof->end(s);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -111,3 +111,20 @@ int wt_upconv_fwd(const float* w, float* weff, int Ci, int Co, hipStream_t s);
 int wt_upconv_dgrad(const float* w, float* v, int Ci, int Co, hipStream_t s);
 int wt_upconv_wgrad_fold(const float* dweff, float* dw, int Ci, int Co, hipStream_t s);
 }  // namespace fs
+
+namespace fs {
+// Optional HIP-event profiler around the MFMA kernels (bench.py's roofline leg): per kernel
+// family it accumulates launches, algorithmic FLOPs and the event-measured duration.
+struct Profiler {
+    static const int kFamilies = 4;  // conv variants 0..2, wgrad/gram 3
+    struct Rec { hipEvent_t a, b; int fam; double flops; };
+    Rec* recs = nullptr;
+    int n = 0, cap = 0;
+    static Profiler*& current();
+    void begin(int fam, double flops, hipStream_t s);
+    void end(hipStream_t s);
+    int collect(double out[kFamilies][3]);  // {launches, flops, ms}; synchronises on the events
+    void reset();
+    ~Profiler();
+};
+}  // namespace fs

@@ -253,7 +253,10 @@ int wgrad_launch(const WgradArgs& a, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid((unsigned)p.n_wg, (unsigned)(cdiv(p.KB, 4) * cdiv(p.NB, 4)), (unsigned)(a.per_sample ? a.N : 1));
+    Profiler* prof = Profiler::current();
+    if (prof) prof->begin(3, 2.0 * a.N * a.Ho * a.Wo * (double)p.K * a.Cout, s);
     hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), (size_t)p.lds_bytes, s, a);
+    if (prof) prof->end(s);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

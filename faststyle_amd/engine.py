@@ -205,6 +205,10 @@ class Engine(object):
         Returns (losses[4] device tensor {loss, content, style, beta*tv}, dy)."""
         self._sync_stream()
         N, H, W, _ = (int(s) for s in y.shape)
+        if tuple(content.shape) != tuple(y.shape):
+            # the reference feeds VGG(batch) into placeholders shaped like VGG(Y) (train.py:171-176, 250-254)
+            raise L.FaststyleError("content batch %s and net output %s differ: training sizes must be multiples "
+                                   "of 4 (create_net maps H -> 4*ceil(ceil((H+80)/2)/2)-80)" % (tuple(content.shape), tuple(y.shape)))
         c = self._cfg(cfg, target_grams)
         key = (N, H, W, tuple(cfg["content_layers"]), tuple(cfg["style_layers"]))
         if key not in self._perc_ws:
@@ -272,6 +276,18 @@ class Engine(object):
         L.check(self.lib, self.lib.fs_instnorm_finalize(self.ctx, p(stats), N, tiles, C, groups, p(gamma), p(beta), eps,
                                                         *[p(o) for o in out]), "fs_instnorm_finalize")
         return out  # mean, rstd, a, b
+
+    def instnorm_bwd(self, gin, z, mean, rstd, a, b, mode):
+        self._sync_stream()
+        N, H, W, C = (int(s) for s in z.shape)
+        dz = self.mem.empty(z.shape)
+        dg, db = self.mem.empty((C,)), self.mem.empty((C,))
+        nbytes = self.lib.fs_instnorm_bwd_workspace_bytes(N, H * W, C)
+        ws = self.mem.empty((nbytes // 4,))
+        p = self.mem.ptr
+        L.check(self.lib, self.lib.fs_instnorm_bwd(self.ctx, p(gin), p(z), p(mean), p(rstd), p(a), p(b), mode, N, H * W, C,
+                                                   p(dz), p(dg), p(db), p(ws), nbytes), "fs_instnorm_bwd")
+        return dz, dg, db
 
     def conv2d_wgrad(self, x, dy, k, stride=1, padding="SAME", per_sample=False, scale=1.0, **kw):
         self._sync_stream()

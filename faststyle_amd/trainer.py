@@ -1,0 +1,48 @@
+"""The train.py loop body (reference train.py:245-275) on the HIP engine, data-parallel ready.
+
+One step = content-target pass + transform-net forward + VGG/Gram/loss forward + full backward
+(all inside libfaststyle_hip.so) + ONE gradient all-reduce (SUM, RCCL over xGMI through
+torch.distributed) + TF-style Adam.  Losses are batch-SUMMED in the reference (losses.py:32,63)
+and instance norm is per sample, so SUM-reducing per-rank gradients of local batches reproduces
+the single-process gradient of the global batch exactly (up to fp32 summation order).
+"""
+import numpy as np
+
+from . import engine as _engine
+
+
+class Trainer(object):
+    def __init__(self, eng, params_flat, vgg_weights, style_img, cfg=None, learn_rate=1e-3, dist=None):
+        """params_flat: np.float32 [424102] (ckpt order); style_img: np [1,Hs,Ws,3] RGB 0..255;
+        dist: None or an initialised torch.distributed module (backend nccl == RCCL)."""
+        self.eng = eng
+        self.cfg = cfg or _engine.default_loss_cfg()
+        self.lr = learn_rate
+        self.dist = dist
+        mem = eng.mem
+        self.params = mem.from_numpy(np.asarray(params_flat, np.float32))
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self.params, src=0)            # identical init on every rank
+        self.grads = mem.zeros(self.params.shape)
+        self.m = mem.zeros(self.params.shape)
+        self.v = mem.zeros(self.params.shape)
+        self.global_step = 0
+        eng.vgg_load(vgg_weights)
+        # train.py:144-151: target Grams of the style image, computed once
+        self.target_grams = eng.style_targets(mem.from_numpy(style_img), self.cfg)
+
+    def step(self, batch):
+        """batch: device tensor [B,H,W,3] float32 RGB 0..255 (train.py:158-160).
+        Returns the device tensor {loss, content, style, beta*tv} of the LOCAL batch."""
+        e = self.eng
+        y = e.tnet_forward(self.params, batch, save_for_bwd=True)
+        losses, dy = e.perceptual_loss(y, batch, self.target_grams, self.cfg)
+        e.tnet_backward(self.params, batch, dy, grads=self.grads)
+        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
+            self.dist.all_reduce(self.grads, op=self.dist.ReduceOp.SUM)   # 1,696,408 B, once per step
+        self.global_step += 1
+        e.adam_tf_step(self.params, self.grads, self.m, self.v, self.global_step, lr=self.lr)
+        return losses
+
+    def params_numpy(self):
+        return self.eng.mem.to_numpy(self.params).copy()

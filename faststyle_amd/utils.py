@@ -1,0 +1,40 @@
+"""Image I/O wrappers with the reference's conventions (reference utils.py:14-52), on PIL.
+
+The reference uses OpenCV 3.1: imread -> BGR->RGB uint8; imwrite of float32 rounds + saturates
+to uint8 and writes JPEG quality 95, 4:2:0 chroma.  imresize: INTER_CUBIC up / INTER_AREA down;
+PIL's BICUBIC / BOX are the closest filters (exact OpenCV resampling parity is unpinned:
+SURVEY.md §2 row 9).
+"""
+import os
+
+import numpy as np
+from PIL import Image
+
+
+def imread(path):
+    """utils.imread (utils.py:14-22): RGB uint8 [H,W,3]."""
+    return np.asarray(Image.open(path).convert("RGB"))
+
+
+def imresize(img, scale):
+    """utils.imresize (utils.py:25-40): cubic for scale>1, area for scale<1, identity at 1."""
+    if scale == 1.0:
+        return img
+    h, w = img.shape[:2]
+    size = (int(round(w * scale)), int(round(h * scale)))
+    resample = Image.BICUBIC if scale > 1.0 else Image.BOX
+    return np.asarray(Image.fromarray(np.asarray(img, np.uint8)).resize(size, resample))
+
+
+def imwrite(path, img):
+    """utils.imwrite (utils.py:43-52): float RGB image -> round/saturate u8 -> file
+    (JPEG q95 4:2:0 like cv2.imwrite's defaults)."""
+    u8 = np.clip(np.rint(np.asarray(img, np.float64)), 0, 255).astype(np.uint8)
+    d = os.path.dirname(path)
+    if d and not os.path.isdir(d):
+        os.makedirs(d)
+    ext = os.path.splitext(path)[1].lower()
+    if ext in (".jpg", ".jpeg"):
+        Image.fromarray(u8).save(path, format="JPEG", quality=95, subsampling="4:2:0")
+    else:
+        Image.fromarray(u8).save(path)

@@ -31,6 +31,12 @@ int fs_ctx_set_stream(fs_ctx* ctx, void* hip_stream);
 const char* fs_last_error(void);
 const char* fs_version(void);
 
+/* ---- measurement hook (bench.py): HIP events around every MFMA-kernel launch on the ctx stream.
+ * out[f*3+{0,1,2}] = {launches, algorithmic FLOPs, milliseconds} for kernel family f:
+ * 0 conv_igemm<32,2,2>, 1 conv_igemm<32,2,1>, 2 conv_igemm<16,4,1>, 3 conv_wgrad (incl. Gram). */
+int fs_profile_begin(fs_ctx* ctx);
+int fs_profile_end(fs_ctx* ctx, double out[12]);
+
 /* ---- image-transform net: reference im_transf_net.py:14-75 (create_net) ------------------ */
 #define FS_TNET_NPARAMS 424102 /* 48 fp32 tensors, sorted-key (= checkpoint) order */
 #define FS_TNET_NTENSORS 48
@@ -125,6 +131,12 @@ int fs_conv2d_plan(fs_conv_desc* d, int* tiles_per_image);
  * per-tile partials: mean,rstd,a,b are [N,C];  a = gamma*rstd, b = beta - mean*a. */
 int fs_instnorm_finalize(fs_ctx* ctx, const float* stats, int N, int tiles, int C, int groups, const float* gamma,
                          const float* beta, float eps, float* mean, float* rstd, float* a, float* b);
+/* Backward of activation(inst_norm(z)) (im_transf_net.py:218-247 adjoint): gin = dL/d(activation
+ * output); mode 0: no activation, 1: ReLU, 2: scaled tanh.  dz = dL/dz, dgamma/dbeta = [C]. */
+size_t fs_instnorm_bwd_workspace_bytes(int N, int HW, int C);
+int fs_instnorm_bwd(fs_ctx* ctx, const float* gin, const float* z, const float* mean, const float* rstd, const float* a,
+                    const float* b, int mode, int N, int HW, int C, float* dz, float* dgamma, float* dbeta, void* ws,
+                    size_t ws_bytes);
 typedef struct {
     const float* x;
     const float* dy;

@@ -1,0 +1,144 @@
+"""Single-op parity of the HIP kernels against the numpy oracle (float32 tolerance 2e-5 of
+the tensor's max magnitude: the kernels are exact-fp32 fmaf chains, only the summation order
+differs).  `emu` ids run the same kernel sources on the CPU emulator; `hip` ids need the GPU."""
+import numpy as np
+import pytest
+
+from oracle import nnops, perceptual
+from tests.backends import engine_params, get_engine
+
+TOL = 2e-5
+
+
+def rel(got, want):
+    return np.abs(np.asarray(got, np.float64) - want).max() / (np.abs(want).max() + 1e-30)
+
+
+@pytest.fixture(params=engine_params())
+def eng(request):
+    return get_engine(request.param)
+
+
+def up(e, a):
+    return e.mem.from_numpy(a)
+
+
+def down(e, t):
+    return e.mem.to_numpy(t)
+
+
+CONV_CASES = [
+    # name, x shape, w shape, stride, padding
+    ("res3x3", (1, 12, 14, 64), (3, 3, 64, 64), 1, "VALID"),
+    ("s2_odd", (2, 11, 13, 16), (3, 3, 16, 32), 2, "SAME"),
+    ("s2_even", (1, 12, 16, 32), (3, 3, 32, 64), 2, "SAME"),
+    ("final9x9", (1, 20, 24, 16), (9, 9, 16, 3), 1, "SAME"),
+    ("vgg128", (1, 9, 10, 128), (3, 3, 128, 128), 1, "SAME"),
+    ("vgg_first", (2, 16, 20, 3), (3, 3, 3, 64), 1, "SAME"),
+    ("one_by_one", (1, 7, 9, 64), (1, 1, 64, 64), 1, "SAME"),
+    ("ragged_1px", (1, 3, 1, 16), (3, 3, 16, 16), 1, "SAME"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_matches_oracle(eng, case):
+    _, xs, ws, stride, padding = case
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(xs).astype(np.float32)
+    w = (rng.standard_normal(ws) * 0.1).astype(np.float32)
+    y = down(eng, eng.conv2d(up(eng, x), up(eng, w), stride, padding))
+    want = nnops.conv2d(x.astype(np.float64), w.astype(np.float64), stride, padding)
+    assert y.shape == want.shape
+    assert rel(y, want) < TOL
+
+
+def test_conv_reflect_pad_fused(eng):
+    rng = np.random.default_rng(2)
+    x = rng.uniform(0, 255, (1, 45, 50, 3)).astype(np.float32)
+    w = (rng.standard_normal((9, 9, 3, 16)) * 0.1).astype(np.float32)
+    y = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME", src_mode=1, refl=40))
+    want = nnops.conv2d(nnops.reflect_pad(x.astype(np.float64), 40), w.astype(np.float64), 1, "SAME")
+    assert rel(y, want) < TOL
+
+
+def test_conv_producer_instnorm_folded_into_load_and_stats(eng):
+    """conv epilogue statistics + finalize == tf.nn.moments (im_transf_net.py:238-245), and a
+    consumer conv that applies relu(a*z+b) on load == conv(relu(inst_norm(z)))."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 23, 19, 16)).astype(np.float32) + 0.7
+    w1 = (rng.standard_normal((3, 3, 16, 32)) * 0.2).astype(np.float32)
+    w2 = (rng.standard_normal((3, 3, 32, 64)) * 0.1).astype(np.float32)
+    gamma = (1 + 0.3 * rng.standard_normal(32)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(32)).astype(np.float32)
+    z, stats, tiles = eng.conv2d(up(eng, x), up(eng, w1), 1, "SAME", want_stats=True)
+    mean, rstd, a, b = eng.instnorm_finalize(stats, tiles, 32, 1, up(eng, gamma), up(eng, beta))
+    y = down(eng, eng.conv2d(z, up(eng, w2), 2, "SAME", in_a=a, in_b=b, in_per_sample=1, in_relu=1))
+    z64 = nnops.conv2d(x.astype(np.float64), w1.astype(np.float64), 1, "SAME")
+    n64, (xhat, rs, _) = nnops.inst_norm(z64, gamma.astype(np.float64), beta.astype(np.float64))
+    assert rel(down(eng, mean), z64.mean(axis=(1, 2))) < TOL
+    assert rel(down(eng, rstd), rs[:, 0, 0, :]) < TOL
+    want = nnops.conv2d(nnops.relu(n64), w2.astype(np.float64), 2, "SAME")
+    assert rel(y, want) < 5e-5
+
+
+def test_phase_collapsed_resize_conv_equals_as_written(eng):
+    """NEAREST x4 + conv3x3 stride 2 SAME (im_transf_net.py:122-155) == 2x2-tap conv with the
+    pre-summed filters + pixel shuffle.  The oracle keeps the as-written form."""
+    from tests import wt
+    rng = np.random.default_rng(4)
+    for (h, w_, ci, co) in [(5, 7, 64, 32), (9, 6, 32, 16)]:
+        x = rng.standard_normal((2, h, w_, ci)).astype(np.float32)
+        w = rng.standard_normal((3, 3, ci, co)).astype(np.float32)
+        weff = wt.upconv_weff(w)
+        y = down(eng, eng.conv2d(up(eng, x), up(eng, weff), 1, (0, 0, h, w_), shuffle=1))
+        want = nnops.conv2d(nnops.resize_nearest(x.astype(np.float64), 4), w.astype(np.float64), 2, "SAME")
+        assert y.shape == want.shape == (2, 2 * h, 2 * w_, co)
+        assert rel(y, want) < TOL
+
+
+@pytest.mark.parametrize("stride,h,w_", [(1, 10, 12), (2, 11, 14), (2, 12, 13)])
+def test_dgrad_through_forward_kernel(eng, stride, h, w_):
+    """Input gradient = the forward kernel on flipped/transposed filters (zero-dilated dY for
+    stride 2), incl. the asymmetric SAME padding of even/odd sizes."""
+    rng = np.random.default_rng(5)
+    ci, co, k = 32, 64, 3
+    w = (rng.standard_normal((k, k, ci, co)) * 0.1).astype(np.float32)
+    Ho, pt, _ = nnops.same_pads(h, k, stride)
+    Wo, pl, _ = nnops.same_pads(w_, k, stride)
+    dy = rng.standard_normal((2, Ho, Wo, co)).astype(np.float32)
+    wT = np.ascontiguousarray(w[::-1, ::-1].transpose(0, 1, 3, 2))
+    dx = down(eng, eng.conv2d(up(eng, dy), up(eng, wT), 1, (k - 1 - pt, k - 1 - pl, h, w_),
+                              src_mode=2 if stride == 2 else 0))
+    want = nnops.conv2d_bwd_input(dy.astype(np.float64), w.astype(np.float64), (h, w_), stride, "SAME")
+    assert rel(dx, want) < TOL
+
+
+WGRAD_CASES = [("res", (2, 12, 14, 64), 64, 3, 1, "VALID", 0), ("s2", (2, 13, 11, 16), 32, 3, 2, "SAME", 0),
+               ("first_reflect", (1, 45, 43, 3), 16, 9, 1, "SAME", 1), ("final", (1, 14, 18, 16), 3, 9, 1, "SAME", 0)]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_wgrad_matches_oracle(eng, case):
+    _, xs, co, k, stride, padding, reflect = case
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal(xs).astype(np.float32)
+    xv = nnops.reflect_pad(x, 40) if reflect else x
+    want_y = nnops.conv2d(xv.astype(np.float64), np.zeros((k, k, xs[3], co)), stride, padding)
+    dy = rng.standard_normal(want_y.shape).astype(np.float32)
+    dw = down(eng, eng.conv2d_wgrad(up(eng, x), up(eng, dy), k, stride, padding,
+                                    src_mode=1 if reflect else 0, refl=40 if reflect else 0))
+    want = nnops.conv2d_bwd_filter(xv.astype(np.float64), dy.astype(np.float64), k, stride, padding)
+    assert rel(dw, want) < TOL
+
+
+@pytest.mark.parametrize("hw,c", [((16, 12), 64), ((9, 7), 128), ((5, 6), 512)])
+def test_gram_is_symmetric_psd_and_matches_oracle(eng, hw, c):
+    rng = np.random.default_rng(7)
+    f = np.abs(rng.standard_normal((2,) + hw + (c,))).astype(np.float32)
+    ft = up(eng, f)
+    g = down(eng, eng.conv2d_wgrad(ft, ft, 1, 1, "SAME", per_sample=True, scale=1.0 / (hw[0] * hw[1] * c)))
+    want = perceptual.gram(f.astype(np.float64))
+    assert rel(g, want) < TOL
+    assert np.abs(g - g.transpose(0, 2, 1)).max() <= 1e-6 * np.abs(g).max()
+    ev = np.linalg.eigvalsh(g[0].astype(np.float64))
+    assert ev.min() > -1e-5 * ev.max()

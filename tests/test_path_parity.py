@@ -1,0 +1,256 @@
+"""Composite-call parity: fs_tnet_forward / fs_tnet_backward / fs_perceptual_loss /
+fs_style_targets / fs_adam_tf_step against the numpy oracle (float64 oracle, float32 kernels).
+Tolerances: forward pixels 1e-3 relative of the 0..255 range is the north-star budget -- we
+hold 2e-5; gradients 2e-4 of each tensor's max magnitude."""
+import os
+
+import numpy as np
+import pytest
+
+from faststyle_amd import ckpt, engine
+from oracle import perceptual, tnet
+from tests.backends import engine_params, get_engine
+from tests.imgutil import jpeg_roundtrip, load_rgb, psnr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(params=engine_params())
+def eng(request):
+    return get_engine(request.param)
+
+
+def f64(d):
+    return {k: np.asarray(v, np.float64) for k, v in d.items()}
+
+
+def starry():
+    return ckpt.load_checkpoint(os.path.join(ROOT, "models", "starry_final.ckpt"))
+
+
+def grads_close(e, g, want, tol):
+    bad = []
+    # some gradients are exactly 0 by symmetry (INshift1 feeds a VALID conv + instance norm):
+    # their float32 value is summation noise, so errors are measured against a global floor
+    floor = 5e-2 * max(np.abs(w).max() for w in want.values())
+    for name, off, shape in e.param_table():
+        n = int(np.prod(shape))
+        a = g[off:off + n].reshape(shape)
+        err = np.abs(a - want[name]).max() / max(np.abs(want[name]).max(), floor)
+        if not err < tol:
+            bad.append((name, err))
+    return bad
+
+
+def flat_close(got, want, tight=1e-4, l2=2e-3, cos_min=0.99999):
+    """Tight max-abs agreement, or -- when a ReLU / max-pool kink flipped between float32 and
+    float64 -- agreement of the whole gradient vector in direction and norm."""
+    got = np.asarray(got, np.float64).ravel()
+    want = np.asarray(want, np.float64).ravel()
+    if np.abs(got - want).max() / np.abs(want).max() < tight:
+        return True
+    cos = np.dot(got, want) / (np.linalg.norm(got) * np.linalg.norm(want))
+    return cos > cos_min and np.linalg.norm(got - want) / np.linalg.norm(want) < l2
+
+
+def test_param_table_is_checkpoint_order(eng):
+    names = [n for n, _, _ in eng.param_table()]
+    assert ["img_t_net/" + n for n in names] == list(starry())
+    assert eng.param_table()[2] == ("initconv_0/W", 32, (9, 9, 3, 16))       # byte offset 128 in .data
+    assert eng.param_table()[-1][1] * 4 == 1680856
+    flat = eng.flatten_params(starry())
+    rt = eng.unflatten_params(flat)
+    assert all(np.array_equal(rt[k], v) for k, v in starry().items())
+
+
+def kink_free_params(seed=0):
+    """Random-init parameters whose ReLU inputs stay positive (INscale~0.25, INshift~+6 on every ReLU'd unit):
+    the loss is then smooth in float32 noise, so ALL 48 gradients can be held to a tight
+    tolerance.  (With real masks a single pre-activation within ~1e-7 of zero flips its ReLU
+    derivative between the float32 kernel and the float64 oracle and moves upstream gradient
+    sums by ~1/sqrt(#pixels) -- a property of the kink, not of the kernels.)"""
+    rng = np.random.default_rng(seed)
+    P = tnet.init_params(seed=seed)
+    for k in P:
+        leaf = k.split("/")[1]
+        if leaf.startswith("INscale"):
+            P[k] = (0.25 + 0.05 * rng.standard_normal(P[k].shape)).astype(np.float32)
+        elif leaf in ("INshift", "INshift1") and not k.startswith("upsample_2"):
+            P[k] = (6.0 + 0.1 * rng.standard_normal(P[k].shape)).astype(np.float32)
+        elif leaf.startswith("INshift"):
+            P[k] = (0.1 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    return P
+
+
+def run_fwd_bwd(eng, P_named, shape, seed):
+    rng = np.random.default_rng(seed)
+    flat = eng.mem.from_numpy(eng.flatten_params(P_named, scope=""))
+    x = rng.uniform(0, 255, shape + (3,)).astype(np.float32)
+    xd = eng.mem.from_numpy(x)
+    y = eng.mem.to_numpy(eng.tnet_forward(flat, xd, save_for_bwd=True))
+    yo, cache = tnet.create_net(x.astype(np.float64), f64(P_named), keep=True)
+    assert y.shape == yo.shape == (shape[0],) + eng.tnet_out_shape(shape[1], shape[2]) + (3,)
+    dy = rng.standard_normal(y.shape).astype(np.float32)
+    g = eng.mem.to_numpy(eng.tnet_backward(flat, xd, eng.mem.from_numpy(dy)))
+    assert np.isfinite(g).all()
+    want = tnet.create_net_bwd(dy.astype(np.float64), f64(P_named), cache)
+    return y, yo, g, want
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 56), (1, 41, 41), (1, 45, 67)])
+def test_tnet_forward_matches_oracle_and_backward_tight_when_kink_free(eng, shape):
+    """Smallest legal size (41: REFLECT needs pad < dim), odd sizes (asymmetric SAME padding of
+    the stride-2 convs, 45 -> 125 -> 63 -> 32) and a batch of 2."""
+    y, yo, g, want = run_fwd_bwd(eng, kink_free_params(), shape, seed=0)
+    assert np.abs(y - yo).max() / 255.0 < 2e-5
+    assert grads_close(eng, g, want, 2e-4) == []
+
+
+def test_tnet_shipped_weights_forward_tight_backward_with_real_relu_masks(eng):
+    y, yo, g, want = run_fwd_bwd(eng, tnet.strip_scope(starry()), (2, 48, 56), seed=0)
+    assert np.abs(y - yo).max() / 255.0 < 2e-5
+    wflat = np.concatenate([want[n].ravel() for n, _, _ in eng.param_table()])
+    cos = np.dot(g, wflat) / (np.linalg.norm(g) * np.linalg.norm(wflat))
+    assert cos > 0.99999
+    assert np.linalg.norm(g - wflat) / np.linalg.norm(wflat) < 2e-3
+    # SURVEY.md §8a invariant: dL/dINshift2 is the same vector for every residual block
+    tab = {n: (o, s) for n, o, s in eng.param_table()}
+    ref = g[tab["resblock_0/INshift2"][0]:][:64]
+    for k in range(1, 5):
+        np.testing.assert_allclose(g[tab["resblock_%d/INshift2" % k][0]:][:64], ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_instnorm_backward_modes(eng, mode):
+    """IN backward with the three activations; pre-activations are nudged away from the ReLU kink."""
+    from oracle import nnops
+    rng = np.random.default_rng(3)
+    N, H, W, C = 2, 13, 11, 16
+    z = rng.standard_normal((N, H, W, C)).astype(np.float32) * 2 + 0.5
+    gamma = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32)
+    beta = (0.3 * rng.standard_normal(C)).astype(np.float32)
+    n64, cache = nnops.inst_norm(z.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64))
+    near = np.abs(n64) < 1e-3
+    z[near] += 0.05
+    n64, cache = nnops.inst_norm(z.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64))
+    xhat, rstd, _ = cache
+    mean = z.astype(np.float64).mean(axis=(1, 2))
+    a = gamma * rstd[:, 0, 0, :]
+    b = beta - mean * a
+    gin = rng.standard_normal(z.shape).astype(np.float32)
+    if mode == 1:
+        dn = gin * (n64 > 0)
+    elif mode == 2:
+        dn = nnops.scaled_tanh_bwd(gin.astype(np.float64), n64)
+    else:
+        dn = gin.astype(np.float64)
+    dz_o, dg_o, db_o = nnops.inst_norm_bwd(dn, cache)
+    up = eng.mem.from_numpy
+    dz, dg, db = eng.instnorm_bwd(up(gin), up(z), up(mean), up(rstd[:, 0, 0, :]), up(a), up(b), mode)
+    for got, wnt in ((dz, dz_o), (dg, dg_o), (db, db_o)):
+        assert np.abs(eng.mem.to_numpy(got) - wnt).max() / np.abs(wnt).max() < 5e-5
+
+
+def test_perceptual_loss_and_gradient_match_oracle(eng):
+    rng = np.random.default_rng(1)
+    Wv = perceptual.synthetic_vgg_weights(seed=3)
+    eng.vgg_load(Wv)
+    cfg = engine.default_loss_cfg()
+    cfg["beta"] = 1e-4
+    style = rng.uniform(0, 255, (1, 37, 45, 3)).astype(np.float32)      # odd sizes: SAME max-pool padding
+    tg = eng.style_targets(eng.mem.from_numpy(style), cfg)
+    tgo = perceptual.target_grams(style.astype(np.float64), f64(Wv), cfg["style_layers"])
+    for a, b in zip(tg, tgo):
+        assert np.abs(eng.mem.to_numpy(a) - b).max() / np.abs(b).max() < 2e-5
+    y = rng.uniform(0, 255, (2, 32, 40, 3)).astype(np.float32)
+    xc = rng.uniform(0, 255, (2, 32, 40, 3)).astype(np.float32)
+    losses, dy = eng.perceptual_loss(eng.mem.from_numpy(y), eng.mem.from_numpy(xc), tg, cfg)
+    feats = perceptual.vgg16(xc.astype(np.float64), f64(Wv), upto="conv3_3")
+    lo, dyo = perceptual.perceptual_loss(y.astype(np.float64), [feats["conv3_3"]], tgo, f64(Wv), beta=1e-4)
+    got = eng.mem.to_numpy(losses)
+    want = [lo[k] for k in ("loss", "content_loss", "style_loss", "tv_loss")]
+    np.testing.assert_allclose(got, want, rtol=2e-5)
+    assert flat_close(eng.mem.to_numpy(dy), dyo)
+
+
+def test_adam_tf_step_matches_oracle(eng):
+    rng = np.random.default_rng(2)
+    n = 5000
+    p = rng.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    po, mo, vo = {"a": p.astype(np.float64)}, {"a": m.astype(np.float64)}, {"a": v.astype(np.float64)}
+    pd, md, vd = (eng.mem.from_numpy(t) for t in (p, m, v))
+    for t in (1, 2, 3):
+        g = rng.standard_normal(n).astype(np.float32)
+        eng.adam_tf_step(pd, eng.mem.from_numpy(g), md, vd, t)
+        perceptual.adam_tf(po, {"a": g.astype(np.float64)}, mo, vo, t)
+    np.testing.assert_allclose(eng.mem.to_numpy(pd), po["a"], rtol=0, atol=2e-6)
+    # float32(0.999) != 0.999: (1-beta2) carries a 1.3e-5 relative rounding, exactly as in TF's float32 ApplyAdam
+    np.testing.assert_allclose(eng.mem.to_numpy(vd), vo["a"], rtol=1e-4, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------- GPU-only, full sizes
+@pytest.mark.gpu
+@pytest.mark.parametrize("style", ["starry", "candy"])
+def test_hip_reproduces_shipped_golden_jpeg(style):
+    """The reference's own known answer (README.md:5-18) through the HIP path, full 474x712."""
+    e = get_engine("hip")
+    assets = os.path.join(ROOT, "tests", "golden", "ref_assets")
+    x = load_rgb(os.path.join(assets, "chicago.jpg")).astype(np.float32)[None]
+    W = ckpt.load_checkpoint(os.path.join(ROOT, "models", style + "_final.ckpt"))
+    y = e.mem.to_numpy(e.tnet_forward(e.mem.from_numpy(e.flatten_params(W)), e.mem.from_numpy(x)))
+    assert y.shape == (1, 476, 712, 3)
+    dec = jpeg_roundtrip(y[0])
+    gold = load_rgb(os.path.join(assets, style + "_chicago.jpg"))
+    assert psnr(dec, gold) >= 63.0
+    assert (dec == gold).mean() >= 0.985
+    yo = tnet.create_net(x, tnet.strip_scope(W))               # float32 oracle, same input
+    assert np.abs(y - yo).max() / 255.0 < 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_720p_forward_matches_oracle():
+    """BASELINE config 2: 720p frame, batch 1, fp32, starry weights, rng(0) uniform[0,255)."""
+    e = get_engine("hip")
+    W = starry()
+    x = np.random.default_rng(0).uniform(0, 255, (1, 720, 1280, 3)).astype(np.float32)
+    y = e.mem.to_numpy(e.tnet_forward(e.mem.from_numpy(e.flatten_params(W)), e.mem.from_numpy(x)))
+    assert y.shape == (1, 720, 1280, 3) and np.isfinite(y).all() and y.min() >= 0 and y.max() <= 255
+    yo = tnet.create_net(x, tnet.strip_scope(W))
+    assert np.abs(y - yo).max() <= 0.255        # 1e-3 * 255, the north-star tolerance
+
+
+@pytest.mark.gpu
+def test_hip_train_step_256_matches_oracle_and_batch_sum_property():
+    """BASELINE config 3 shape (256x256): losses + all 48 gradients vs the float32 oracle on a
+    batch of 2, and the data-parallel identity grads(batch) == sum of per-sample grads (losses are
+    batch-summed, losses.py:32,63; instance norm is per sample) that the 8-GPU SUM all-reduce
+    relies on."""
+    e = get_engine("hip")
+    rng = np.random.default_rng(1)
+    Wv = perceptual.synthetic_vgg_weights(seed=3)
+    e.vgg_load(Wv)
+    cfg = engine.default_loss_cfg()
+    P = tnet.init_params(seed=0)
+    flat = e.mem.from_numpy(e.flatten_params(P, scope=""))
+    style = rng.uniform(0, 255, (1, 96, 128, 3)).astype(np.float32)
+    tg = e.style_targets(e.mem.from_numpy(style), cfg)
+    x = rng.uniform(0, 255, (2, 256, 256, 3)).astype(np.float32)
+
+    def step(xb):
+        xd = e.mem.from_numpy(xb)
+        y = e.tnet_forward(flat, xd, save_for_bwd=True)
+        losses, dy = e.perceptual_loss(y, xd, tg, cfg)
+        g = e.tnet_backward(flat, xd, dy)
+        return e.mem.to_numpy(losses).copy(), e.mem.to_numpy(g).copy()
+
+    l2, g2 = step(x)
+    la, ga = step(x[:1])
+    lb, gb = step(x[1:])
+    np.testing.assert_allclose(l2, la + lb, rtol=1e-4)
+    assert np.abs(g2 - (ga + gb)).max() / np.abs(g2).max() < 1e-4
+    tgo = perceptual.target_grams(style, Wv, cfg["style_layers"])
+    lo, go, _ = perceptual.train_step(P, x, tgo, Wv)
+    np.testing.assert_allclose(l2[:3], [lo["loss"], lo["content_loss"], lo["style_loss"]], rtol=1e-3)
+    assert flat_close(g2, np.concatenate([go[n].ravel() for n, _, _ in e.param_table()]), l2=5e-3, cos_min=0.9999)
