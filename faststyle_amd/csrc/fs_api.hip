@@ -55,7 +55,7 @@ int fs_profile_begin(fs_ctx* ctx) {
     fs::Profiler::current() = &g_prof;
     return 0;
 }
-int fs_profile_end(fs_ctx* ctx, double out[12]) {
+int fs_profile_end(fs_ctx* ctx, double out[18]) {
     if (!ctx || !out) return fail(-1, "fs_profile_end: null argument");
     fs::Profiler::current() = nullptr;
     double tmp[fs::Profiler::kFamilies][3];

@@ -406,21 +406,19 @@ static void plan_tile(int Ho, int Wo, int KH, int KW, int stride, int max_px, in
     *TW = btw;
 }
 
-ConvPlan conv_plan(const ConvArgs& a) {
+// variant -> (MFMA tile, m-tiles per wave, n-tiles per wave); pixels per workgroup = 4*WM*MT
+static const int kVarMT[5] = {32, 32, 16, 32, 32};
+static const int kVarWM[5] = {2, 2, 4, 1, 1};
+static const int kVarWN[5] = {2, 1, 1, 2, 1};
+
+static void plan_variant(const ConvArgs& a, int variant, ConvPlan* out) {
     ConvPlan p{};
     p.flat = a.Cin == 3;
-    if (a.Cout > 32) {
-        p.variant = 0;
-        p.BN = 64;
-    } else if (a.Cout > 16) {
-        p.variant = 1;
-        p.BN = 32;
-    } else {
-        p.variant = 2;
-        p.BN = 16;
-    }
-    const int kstep = p.variant == 2 ? 4 : 2;
-    plan_tile(a.Ho, a.Wo, a.KH, a.KW, a.stride, 256, &p.TH, &p.TW);
+    p.variant = variant;
+    p.BN = kVarMT[variant] * kVarWN[variant];
+    const int max_px = 4 * kVarWM[variant] * kVarMT[variant];
+    const int kstep = kVarMT[variant] == 16 ? 4 : 2;
+    plan_tile(a.Ho, a.Wo, a.KH, a.KW, a.stride, max_px, &p.TH, &p.TW);
     p.tiles_y = cdiv(a.Ho, p.TH);
     p.tiles_x = cdiv(a.Wo, p.TW);
     p.PH = (p.TH - 1) * a.stride + a.KH;
@@ -451,6 +449,26 @@ ConvPlan conv_plan(const ConvArgs& a) {
         p.lds_bytes = chosen_bytes;
     }
     if (p.lds_bytes < 4 * 5 * p.BN) p.lds_bytes = 4 * 5 * p.BN;  // stats scratch
+    *out = p;
+}
+
+ConvPlan conv_plan(const ConvArgs& a) {
+    ConvPlan p;
+    if (a.Cout <= 16) {
+        plan_variant(a, 2, &p);
+        return p;
+    }
+    // widest tile first; halve the workgroup tile while the launch cannot fill the chip
+    // (256 CUs x >= 2 workgroups), e.g. VGG conv4_x at batch 4 or the 64-channel residual convs
+    const int min_wgs = env_int("FS_CONV_MIN_WGS", 512);
+    const int order_wide[3] = {0, 3, 4}, order_narrow[2] = {1, 4};
+    const int* order = a.Cout > 32 ? order_wide : order_narrow;
+    const int n = a.Cout > 32 ? 3 : 2;
+    for (int i = 0; i < n; ++i) {
+        plan_variant(a, order[i], &p);
+        const long wgs = (long)a.N * p.tiles_y * p.tiles_x * cdiv(a.Cout, p.BN);
+        if (wgs >= min_wgs) break;
+    }
     return p;
 }
 
@@ -464,14 +482,18 @@ int conv_launch(const ConvArgs& a, hipStream_t s) {
         // algorithmic FLOPs: 2*M*K*N with the true extents; a zero-dilated dgrad only does 1/4 useful work
         double fl = 2.0 * a.N * a.Ho * a.Wo * (double)a.KH * a.KW * a.Cin * a.Cout;
         if (a.src_mode == SRC_DILATE2) fl *= 0.25;
-        prof->begin(p.variant, fl, s);
+        prof->begin(p.variant < 3 ? p.variant : p.variant + 1, fl, s);
     }
     if (p.variant == 0)
         hipLaunchKernelGGL((conv_igemm_kernel<32, 2, 2>), grid, dim3(256), (size_t)p.lds_bytes, s, a);
     else if (p.variant == 1)
         hipLaunchKernelGGL((conv_igemm_kernel<32, 2, 1>), grid, dim3(256), (size_t)p.lds_bytes, s, a);
-    else
+    else if (p.variant == 2)
         hipLaunchKernelGGL((conv_igemm_kernel<16, 4, 1>), grid, dim3(256), (size_t)p.lds_bytes, s, a);
+    else if (p.variant == 3)
+        hipLaunchKernelGGL((conv_igemm_kernel<32, 1, 2>), grid, dim3(256), (size_t)p.lds_bytes, s, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<32, 1, 1>), grid, dim3(256), (size_t)p.lds_bytes, s, a);
     if (prof) prof->end(s);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -131,7 +131,15 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs, i
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
         const float* p = slabs + g * n_wg * count + i;
         float acc = 0.f;
-        for (int w = 0; w < n_wg; ++w) acc += p[(size_t)w * count];
+        int w = 0;
+        for (; w + 8 <= n_wg; w += 8) {  // 8 independent loads in flight, summed in slab order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(w + u) * count];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; w < n_wg; ++w) acc += p[(size_t)w * count];
         out[g * count + i] = acc * scale;
     }
 }
@@ -188,26 +196,42 @@ __global__ __launch_bounds__(256) void in_bwd_partial_kernel(const float* gin, c
     }
 }
 
-// S[n][c][2] = sum over chunks; dgamma[c] = sum_n S2, dbeta[c] = sum_n S1
+// S[n][c][2] = sum over chunks; dgamma[c] = sum_n S2, dbeta[c] = sum_n S1.
+// One block per 16 channels: 16 lanes per channel stride over the chunk list, fixed-order combine.
 __global__ __launch_bounds__(256) void in_bwd_final_kernel(const float* partial, int N, int chunks, int C, float* S,
                                                            float* dgamma, float* dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float sh[512];
+    const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float g1 = 0.f, g2 = 0.f;
     for (int n = 0; n < N; ++n) {
         float t1 = 0.f, t2 = 0.f;
-        for (int k = 0; k < chunks; ++k) {
-            const float* p = partial + (((size_t)n * chunks + k) * C + c) * 2;
-            t1 += p[0];
-            t2 += p[1];
+        if (c < C)
+            for (int k = tl; k < chunks; k += 16) {
+                const float* p = partial + (((size_t)n * chunks + k) * C + c) * 2;
+                t1 += p[0];
+                t2 += p[1];
+            }
+        __syncthreads();
+        sh[threadIdx.x] = t1;
+        sh[256 + threadIdx.x] = t2;
+        __syncthreads();
+        if (tl == 0 && c < C) {
+            float u1 = 0.f, u2 = 0.f;
+            for (int j = 0; j < 16; ++j) {
+                u1 += sh[j * 16 + cl];
+                u2 += sh[256 + j * 16 + cl];
+            }
+            S[(n * C + c) * 2] = u1;
+            S[(n * C + c) * 2 + 1] = u2;
+            g1 += u1;
+            g2 += u2;
         }
-        S[(n * C + c) * 2] = t1;
-        S[(n * C + c) * 2 + 1] = t2;
-        g1 += t1;
-        g2 += t2;
     }
-    dbeta[c] = g1;
-    dgamma[c] = g2;
+    if (tl == 0 && c < C) {
+        dbeta[c] = g1;
+        dgamma[c] = g2;
+    }
 }
 
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* gin, const float* z, const float* mean,
@@ -229,21 +253,21 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* gin, con
 int in_bwd(const float* gin, const float* z, const float* mean, const float* rstd, const float* a, const float* b, int mode,
            float* dz, float* dgamma, float* dbeta, float* scratch, int N, int HW, int C, hipStream_t s) {
     if (C > 256) return -1;
-    int chunks = cdiv(HW, 2048);
-    if (chunks > 256) chunks = 256;
-    const int chunk_px = cdiv(HW, chunks);
-    chunks = cdiv(HW, chunk_px);
+    // enough blocks to cover the HBM latency: ~2k blocks of >= 64 pixels
+    int chunk_px = cdiv(HW * N, 2048);
+    if (chunk_px < 64) chunk_px = 64;
+    const int chunks = cdiv(HW, chunk_px);
     float* partial = scratch;
     float* S = scratch + (size_t)N * chunks * C * 2;
     hipLaunchKernelGGL(in_bwd_partial_kernel, dim3(chunks, N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, partial, HW,
                        C, chunk_px);
-    hipLaunchKernelGGL(in_bwd_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, partial, N, chunks, C, S, dgamma, dbeta);
+    hipLaunchKernelGGL(in_bwd_final_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partial, N, chunks, C, S, dgamma, dbeta);
     const size_t total = (size_t)N * HW * C;
     hipLaunchKernelGGL(in_bwd_apply_kernel, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0, s, gin, z,
                        mean, rstd, a, b, mode, S, dz, HW, C, total);
     return 0;
 }
-size_t in_bwd_scratch_floats(int N, int HW, int C) { return (size_t)N * 256 * C * 2 + (size_t)N * C * 2; }
+size_t in_bwd_scratch_floats(int N, int HW, int C) { return (size_t)N * cdiv(HW, 64) * C * 2 + (size_t)N * C * 2; }
 
 // ---------------------------------------------------------------- VGG: max-pool + gradient routing
 // tf.nn.max_pool 2x2/2 SAME (reference libs/vgg16.py:63-67): out = ceil(in/2), padded cells never win.

@@ -20,7 +20,7 @@ enum SrcMode {
 };
 
 struct ConvPlan {
-    int variant;  // 0: 32x32x2 MFMA, 64 couts/WG; 1: 32x32x2, 32 couts/WG; 2: 16x16x4, 16 couts/WG
+    int variant;  // conv_igemm_kernel<MT,WM,WN>: 0 <32,2,2>  1 <32,2,1>  2 <16,4,1>  3 <32,1,2>  4 <32,1,1>
     int BN;       // output channels per workgroup
     int flat;     // Cin==3: K runs over (kw,ci) contiguously per kernel row
     int CC;       // input channels staged per chunk
@@ -58,6 +58,7 @@ struct WgradPlan {
     int K;        // KH*KW*Cin
     int KB;       // k-blocks of 32 (ceil)
     int NB;       // cout blocks of 32 (ceil)
+    int KWV;      // k-blocks per wave (1, 2 or 4); a wave owns KWV x (4/KWV) MFMA tiles
     int n_wg;     // workgroups per sample-group (each strides over the tile list)
     int lds_bytes;
 };
@@ -116,7 +117,7 @@ namespace fs {
 // Optional HIP-event profiler around the MFMA kernels (bench.py's roofline leg): per kernel
 // family it accumulates launches, algorithmic FLOPs and the event-measured duration.
 struct Profiler {
-    static const int kFamilies = 4;  // conv variants 0..2, wgrad/gram 3
+    static const int kFamilies = 6;  // conv variants 0..2, wgrad/gram 3, conv variants 3..4 -> 4..5
     struct Rec { hipEvent_t a, b; int fam; double flops; };
     Rec* recs = nullptr;
     int n = 0, cap = 0;

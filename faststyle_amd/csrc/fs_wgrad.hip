@@ -5,11 +5,13 @@
 //     X == dY == F and one result per sample.
 //
 // MFMA mapping (v_mfma_f32_32x32x2_f32): the instruction's K dimension is a PAIR OF PIXELS, its
-// M dimension 32 consecutive k = (tap, ci) and its N dimension 32 output channels.  A workgroup
-// owns a 128(k) x 128(co) block of the result (wave w: k-block w, up to four co-blocks = 64
-// accumulator registers), walks a strided list of pixel tiles, stages each tile's input patch as
-// [pixel][C+1] and its dY tile as [pixel][128] in LDS, and finally writes ONE partial slab;
-// fs::reduce_slabs sums the slabs in a fixed order (deterministic, no atomics).
+// M dimension 32 consecutive k = (tap, ci) and its N dimension 32 output channels.  A wave owns
+// KWV k-blocks x (4/KWV) co-blocks of the result (64 accumulator registers); KWV is 1 for wide
+// outputs (Gram, 128+ channels), 2 for 64 channels, 4 for <= 32 channels, so the four waves of a
+// workgroup always cover 16 MFMA tiles per staged pixel tile.  A workgroup walks a strided list
+// of pixel tiles, stages each tile's input patch as [pixel][C+1] and its dY tile as [pixel][DP] in
+// LDS, and finally writes ONE partial slab; fs::reduce_slabs sums the slabs in a fixed order
+// (deterministic, no atomics).
 #include "fs_kernels.h"
 
 #include <cstdlib>
@@ -37,17 +39,19 @@ __device__ __forceinline__ bool wsrc_coord(int mode, int refl, int v, int n_src,
     }
 }
 
+template <int KWV>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int NWV = 4 / KWV;
     HIP_DYNAMIC_SHARED(float, smem)
     const WgradPlan& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lm = lane & 31, kq = lane >> 5;
-    const int cogroups = cdiv(p.NB, 4);
+    const int cogroups = cdiv(p.NB, NWV);
     const int kbg = blockIdx.y / cogroups, nbg = blockIdx.y % cogroups;
-    const int kb = kbg * 4 + wave;          // this wave's k-block
-    const int nbw = min(4, p.NB - nbg * 4);  // co-blocks of this workgroup
-    const int DP = nbw * 32;                 // dY LDS pitch
-    const int co_g0 = nbg * 128;
+    const int kb0 = (kbg * 4 + wave) * KWV;           // this wave's first k-block
+    const int nbw = min(NWV, p.NB - nbg * NWV);       // co-blocks of this workgroup
+    const int DP = nbw * 32;                          // dY LDS pitch
+    const int co_g0 = nbg * NWV * 32;
     // staged input-channel window
     const int CS = p.S - 1;
     const int cA = a.Cin <= 128 ? 0 : (kbg * 128) % a.Cin;
@@ -56,23 +60,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     float* patch = smem;
     float* dyl = smem + patch_floats;
 
-    // A-operand base of this lane: k -> (tap, ci)
-    const int k = kb * 32 + lm;
-    const bool kvalid = kb < p.KB && k < p.K;
-    int abase = PH * PW * S;  // zero slack
-    int amul = 0;
-    if (kvalid) {
-        const int tap = k / a.Cin, ci = k - tap * a.Cin;
-        const int kh = tap / a.KW, kw = tap - kh * a.KW;
-        abase = (kh * PW + kw) * S + (ci - cA);
-        amul = 1;
+    // A-operand base of this lane per owned k-block: k -> (tap, ci)
+    int abase[KWV], amul[KWV];
+#pragma unroll
+    for (int q = 0; q < KWV; ++q) {
+        const int k = (kb0 + q) * 32 + lm;
+        abase[q] = PH * PW * S;  // zero slack
+        amul[q] = 0;
+        if (kb0 + q < p.KB && k < p.K) {
+            const int tap = k / a.Cin, ci = k - tap * a.Cin;
+            const int kh = tap / a.KW, kw = tap - kh * a.KW;
+            abase[q] = (kh * PW + kw) * S + (ci - cA);
+            amul[q] = 1;
+        }
     }
 
-    f32x16 acc[4];
+    f32x16 acc[KWV][NWV];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int q = 0; q < KWV; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int j = 0; j < NWV; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][j][r] = 0.f;
 
     const int tiles = p.tiles_y * p.tiles_x;
     const int nsel = a.per_sample ? 1 : a.N;
@@ -175,35 +184,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
         __syncthreads();
         // ---- MFMA sweep over pixel pairs ----
-        if (kb < p.KB) {
+        if (kb0 < p.KB) {
             for (int py = 0; py < p.TH; ++py) {
                 const int rowA = py * a.stride * PW;
 #pragma unroll 2
                 for (int px0 = 0; px0 < p.TW; px0 += 2) {
                     const int px = px0 + kq;
-                    const float av = patch[abase + amul * ((rowA + px * a.stride) * S)];
+                    const int poff = (rowA + px * a.stride) * S;
+                    float av[KWV], bv[NWV];
+#pragma unroll
+                    for (int q = 0; q < KWV; ++q) av[q] = patch[abase[q] + amul[q] * poff];
                     const float* pb = dyl + (py * p.TW + px) * DP + lm;
-                    float bv[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bv[j] = j < nbw ? pb[j * 32] : 0.f;
+                    for (int j = 0; j < NWV; ++j) bv[j] = j < nbw ? pb[j * 32] : 0.f;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < nbw) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[j], 0, 0, 0);
+                    for (int q = 0; q < KWV; ++q)
+#pragma unroll
+                        for (int j = 0; j < NWV; ++j)
+                            if (j < nbw) acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[j], acc[q][j], 0, 0, 0);
                 }
             }
         }
     }
     // ---- write this workgroup's partial slab ----
-    if (kb < p.KB) {
-        float* slab = a.slabs + ((size_t)blockIdx.z * p.n_wg + blockIdx.x) * (size_t)p.K * a.Cout;
+    float* slab = a.slabs + ((size_t)blockIdx.z * p.n_wg + blockIdx.x) * (size_t)p.K * a.Cout;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+    for (int q = 0; q < KWV; ++q) {
+        if (kb0 + q >= p.KB) continue;
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) {
             if (j >= nbw) continue;
             const int co = co_g0 + j * 32 + lm;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kk = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (kk < p.K && co < a.Cout) slab[(size_t)kk * a.Cout + co] = acc[j][r];
+                const int kk = (kb0 + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (kk < p.K && co < a.Cout) slab[(size_t)kk * a.Cout + co] = acc[q][j][r];
             }
         }
     }
@@ -219,10 +234,15 @@ WgradPlan wgrad_plan(const WgradArgs& a) {
     p.K = a.KH * a.KW * a.Cin;
     p.KB = cdiv(p.K, 32);
     p.NB = cdiv(a.Cout, 32);
-    // pixel tile: 128 pixels, even width
+    p.KWV = (p.NB >= 4 || a.Cin > 128) ? 1 : (p.NB >= 2 ? 2 : 4);
+    const int NWV = 4 / p.KWV;
+    // pixel tile: 128 pixels (256 when the staged tensors are narrow), even width
+    const int CS = a.Cin <= 128 ? a.Cin : 128;
+    const int DP = 32 * (p.NB < NWV ? p.NB : NWV);
+    const int max_px = (CS + DP <= 64) ? 256 : 128;
     int tw = a.Wo >= 16 ? 16 : ((a.Wo + 1) & ~1);
     tw = cdiv(cdiv(a.Wo, cdiv(a.Wo, tw)), 2) * 2;
-    int th = 128 / tw;
+    int th = max_px / tw;
     if (th > a.Ho) th = a.Ho;
     th = cdiv(a.Ho, cdiv(a.Ho, th));
     p.TH = th;
@@ -231,31 +251,41 @@ WgradPlan wgrad_plan(const WgradArgs& a) {
     p.tiles_x = cdiv(a.Wo, tw);
     p.PH = (th - 1) * a.stride + a.KH;
     p.PW = (tw - 1) * a.stride + a.KW;
-    const int CS = a.Cin <= 128 ? a.Cin : 128;
     p.S = CS + 1;
-    const int DP = 32 * (p.NB < 4 ? p.NB : 4);
     p.lds_bytes = 4 * (((p.PH * p.PW * p.S + 4 + 3) & ~3) + th * tw * DP);
     const int total = (a.per_sample ? 1 : a.N) * p.tiles_y * p.tiles_x;
-    const int groups = cdiv(p.KB, 4) * cdiv(p.NB, 4) * (a.per_sample ? a.N : 1);
-    int want = env_int2("FS_WGRAD_WGS", 1024) / groups;  // aim for ~1024 workgroups in flight
+    const int groups = cdiv(p.KB, 4 * p.KWV) * cdiv(p.NB, NWV) * (a.per_sample ? a.N : 1);
+    int want = env_int2("FS_WGRAD_WGS", 512) / groups;  // aim for ~2 workgroups per CU in flight
     if (want < 1) want = 1;
     p.n_wg = total < want ? total : want;
     return p;
+}
+
+template <int KWV>
+static void launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KWV>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_kernel<KWV>), grid, dim3(256), (size_t)a.p.lds_bytes, s, a);
 }
 
 int wgrad_launch(const WgradArgs& a, hipStream_t s) {
     const WgradPlan& p = a.p;
     if (a.Cin > 128 && a.Cin % 128) return -1;
     if (p.lds_bytes > 160 * 1024) return -2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    dim3 grid((unsigned)p.n_wg, (unsigned)(cdiv(p.KB, 4) * cdiv(p.NB, 4)), (unsigned)(a.per_sample ? a.N : 1));
+    const int NWV = 4 / p.KWV;
+    dim3 grid((unsigned)p.n_wg, (unsigned)(cdiv(p.KB, 4 * p.KWV) * cdiv(p.NB, NWV)), (unsigned)(a.per_sample ? a.N : 1));
     Profiler* prof = Profiler::current();
     if (prof) prof->begin(3, 2.0 * a.N * a.Ho * a.Wo * (double)p.K * a.Cout, s);
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), (size_t)p.lds_bytes, s, a);
+    if (p.KWV == 1)
+        launch_wgrad<1>(a, grid, s);
+    else if (p.KWV == 2)
+        launch_wgrad<2>(a, grid, s);
+    else
+        launch_wgrad<4>(a, grid, s);
     if (prof) prof->end(s);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Drop-in for the reference's stylize_image.py (same flags, same messages, same file formats):
+loads a TF bundle-V2 checkpoint of the image-transform net and filters one image -- on the
+MI355X through libfaststyle_hip.so instead of a TF1 session (reference stylize_image.py:19-82).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def setup_parser():
+    """Options for command-line input (reference stylize_image.py:19-43)."""
+    parser = argparse.ArgumentParser(description="""Use a trained fast style
+                                     transfer model to filter an input
+                                     image, and save to an output image.""")
+    parser.add_argument('--input_img_path',
+                        help='Input content image that will be stylized.')
+    parser.add_argument('--output_img_path',
+                        help='Desired output image path.',
+                        default='./results/styled.jpg')
+    parser.add_argument('--model_path',
+                        default='./models/starry_final.ckpt',
+                        help='Path to .ckpt for the trained model.')
+    parser.add_argument('--content_target_resize',
+                        help="""Resize input content image. Useful if having
+                        OOM issues.""",
+                        default=1.0,
+                        type=float)
+    parser.add_argument('--upsample_method',
+                        help="""The upsample method that was used to construct
+                        the model being loaded. Note that if the wrong one is
+                        chosen an error will occur.""",
+                        choices=['resize', 'deconv'],
+                        default='resize')
+    return parser
+
+
+def main(argv=None):
+    args = setup_parser().parse_args(argv)
+    from faststyle_amd import ckpt, engine, utils
+    from faststyle_amd.im_transf_net import create_net
+
+    # Read + preprocess input image (stylize_image.py:57-60).
+    img = utils.imread(args.input_img_path)
+    img = utils.imresize(img, args.content_target_resize)
+    img_4d = img[np.newaxis, :].astype(np.float32)
+
+    eng = engine.Engine()                 # fails loudly without the HIP library / a GPU
+    print('Loading up model...')
+    variables = eng.mem.from_numpy(eng.flatten_params(ckpt.load_checkpoint(args.model_path)))
+    print('Evaluating...')
+    Y = create_net(eng.mem.from_numpy(img_4d), args.upsample_method, variables=variables, engine=eng)
+    img_out = eng.mem.to_numpy(Y)
+
+    print('Saving image.')
+    utils.imwrite(args.output_img_path, np.squeeze(img_out))
+    print('Done.')
+
+
+if __name__ == '__main__':
+    main()

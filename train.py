@@ -1,0 +1,249 @@
+#!/usr/bin/env python
+"""Drop-in for the reference's train.py (same flags, checkpoint names, logging cadence):
+trains the image-transform net against the VGG16 perceptual loss -- every FLOP in
+libfaststyle_hip.so on MI355X, optionally data-parallel (one process per GPU, launched with
+``python -m torch.distributed.run --nproc-per-node N train.py ...``; ``--batch_size`` is then the
+per-GPU batch and gradients are SUM-all-reduced once per step over RCCL).
+
+Differences from the reference that are forced by the environment and stated, not hidden:
+  * ``--train_dir`` may be a directory of JPEG/PNG files (decoded with PIL, bicubic-resized to
+    ``--preprocess_size``, shuffled with a ``--num_pipe_buffer`` buffer) or the literal
+    ``synthetic`` (uniform [0,255) images, MS-COCO train2014 count 82,783 per epoch); the
+    TFRecord queue pipeline (reference datapipe.py) is a "next" row;
+  * TensorBoard event files are replaced by ``summaries/train/<run_name>/scalars.jsonl`` with the
+    same four scalars at the same steps (reference train.py:185-189, 260-272).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def setup_parser():
+    """Used to interface with the command-line (reference train.py:23-105)."""
+    parser = argparse.ArgumentParser(
+                description='Train a style transfer net.')
+    parser.add_argument('--train_dir',
+                        help='Directory of TFRecords training data.')
+    parser.add_argument('--model_name',
+                        help='Name of model being trained.')
+    parser.add_argument('--style_img_path',
+                        default='./style_images/starry_night_crop.jpg',
+                        help='Path to style target image.')
+    parser.add_argument('--learn_rate',
+                        help='Learning rate for Adam optimizer.',
+                        default=1e-3, type=float)
+    parser.add_argument('--batch_size',
+                        help='Batch size for training.',
+                        default=4, type=int)
+    parser.add_argument('--n_epochs',
+                        help='Number of training epochs.',
+                        default=2, type=int)
+    parser.add_argument('--preprocess_size',
+                        help="""Dimensions to resize training images to before passing
+                        them into the image transformation network.""",
+                        default=[256, 256], nargs=2, type=int)
+    parser.add_argument('--run_name',
+                        help="""Name of log directory within the Tensoboard
+                        directory (./summaries). If not set, will use
+                        --model_name to create a unique directory.""",
+                        default=None)
+    parser.add_argument('--loss_content_layers',
+                        help='Names of layers to define content loss.',
+                        nargs='*',
+                        default=['conv3_3'])
+    parser.add_argument('--loss_style_layers',
+                        help='Names of layers to define style loss.',
+                        nargs='*',
+                        default=['conv1_2', 'conv2_2', 'conv3_3', 'conv4_3'])
+    parser.add_argument('--content_weights',
+                        help="""Weights that multiply the content loss
+                        terms.""",
+                        nargs='*',
+                        default=[1.0],
+                        type=float)
+    parser.add_argument('--style_weights',
+                        help="""Weights that multiply the style loss terms.""",
+                        nargs='*',
+                        default=[5.0, 5.0, 5.0, 5.0],
+                        type=float)
+    parser.add_argument('--num_steps_ckpt',
+                        help="""Save a checkpoint everytime this number of
+                        steps passes in training.""",
+                        default=1000,
+                        type=int)
+    parser.add_argument('--num_pipe_buffer',
+                        help="""Number of images loaded into RAM in pipeline.
+                        The larger, the better the shuffling, but the more RAM
+                        filled, and a slower startup.""",
+                        default=4000,
+                        type=int)
+    parser.add_argument('--num_steps_break',
+                        help="""Max on number of steps. Training ends when
+                        either num_epochs or this is reached (whichever comes
+                        first).""",
+                        default=-1,
+                        type=int)
+    parser.add_argument('--beta',
+                        help="""TV regularization weight. If using deconv for
+                        --upsample_method, try 1.e-4 for starters. Otherwise,
+                        this is not needed.""",
+                        default=0.0,
+                        type=float)
+    parser.add_argument('--style_target_resize',
+                        help="""Scale factor to apply to the style target image.
+                        Can change the dominant stylistic features.""",
+                        default=1.0, type=float)
+    parser.add_argument('--upsample_method',
+                        help="""Either deconvolution as in the original paper,
+                        or the resize convolution method. The latter seems
+                        superior and does not require TV regularization through
+                        beta.""",
+                        choices=['deconv', 'resize'],
+                        default='resize')
+    return parser
+
+
+COCO_TRAIN2014 = 82783
+
+
+def batcher(train_dir, batch_size, resize, n_epochs, buffer_size, seed, rank, world):
+    """Yields float32 [B,H,W,3] RGB 0..255 numpy batches until n_epochs are exhausted
+    (role of reference datapipe.batcher, datapipe.py:55-78: decode -> bicubic resize ->
+    shuffle buffer -> batches; the trailing partial batch is dropped like shuffle_batch does)."""
+    rng = np.random.default_rng(seed + rank)
+    H, W = resize
+    if train_dir == "synthetic":
+        per_rank = COCO_TRAIN2014 * n_epochs // world
+        for _ in range(per_rank // batch_size):
+            yield rng.uniform(0, 255, (batch_size, H, W, 3)).astype(np.float32)
+        return
+    from PIL import Image
+    files = sorted(os.path.join(train_dir, f) for f in os.listdir(train_dir)
+                   if f.lower().endswith((".jpg", ".jpeg", ".png")))
+    if not files:
+        raise SystemExit("no images under --train_dir %s" % train_dir)
+    files = files[rank::world]
+    buf = []
+
+    def load(path):
+        im = Image.open(path).convert("RGB").resize((W, H), Image.BICUBIC)
+        return np.asarray(im, dtype=np.float32)
+
+    def drain(min_keep):
+        while len(buf) > min_keep and len(buf) >= batch_size:
+            idx = rng.choice(len(buf), batch_size, replace=False)
+            out = np.stack([buf[i] for i in idx])
+            for i in sorted(idx, reverse=True):
+                buf.pop(i)
+            yield out
+
+    for _ in range(n_epochs):
+        for f in files:
+            buf.append(load(f))
+            if len(buf) >= buffer_size + 3 * batch_size:
+                for b in drain(buffer_size):
+                    yield b
+    for b in drain(0):
+        yield b
+
+
+def main(args):
+    import torch
+    import torch.distributed as dist
+    from faststyle_amd import ckpt, engine, im_transf_net, trainer, utils, vgg16
+
+    if args.upsample_method != 'resize':
+        raise SystemExit("--upsample_method deconv is not built on the HIP path yet (SURVEY.md §8f)")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    eng = engine.Engine(engine.TorchMem("cuda:%d" % local))
+
+    # Load in style image that will define the model (train.py:135-137).
+    style_img = utils.imread(args.style_img_path)
+    style_img = utils.imresize(style_img, args.style_target_resize)
+    style_img = style_img[np.newaxis, :].astype(np.float32)
+
+    cfg = dict(content_layers=args.loss_content_layers, content_weights=args.content_weights,
+               style_layers=args.loss_style_layers, style_weights=args.style_weights, beta=args.beta)
+    if rank == 0:
+        print('Precomputing target style layers.')
+    vgg_w = vgg16.load_weights('libs/vgg16_weights.npz')          # train.py:148, 239 (path relative to CWD)
+    params = eng.flatten_params(im_transf_net.initial_variables(seed=0), scope="")
+    tr = trainer.Trainer(eng, params, vgg_w, style_img, cfg, learn_rate=args.learn_rate,
+                         dist=dist if world > 1 else None)
+
+    # Setup subdirectory for this run's logs (train.py:207-217).
+    run_name = args.run_name
+    if rank == 0:
+        if not os.path.exists('./summaries/train/'):
+            os.makedirs('./summaries/train/')
+        if run_name is None:
+            current_dirs = [name for name in os.listdir('./summaries/train/')
+                            if os.path.isdir('./summaries/train/' + name)]
+            name = args.model_name + '0'
+            count = 0
+            while name in current_dirs:
+                count += 1
+                name = args.model_name + '{}'.format(count)
+            run_name = name
+        for d in ('./training', './models', './summaries/train/' + run_name):
+            if not os.path.exists(d):
+                os.makedirs(d)
+        log = open('./summaries/train/' + run_name + '/scalars.jsonl', 'a')
+
+    def save(prefix, full):
+        tensors = eng.unflatten_params(tr.params_numpy())
+        if full:   # saver = tf.train.Saver(): all variables incl. Adam slots and global_step (train.py:224)
+            for k, v in eng.unflatten_params(eng.mem.to_numpy(tr.m)).items():
+                tensors[k + "/Adam"] = v
+            for k, v in eng.unflatten_params(eng.mem.to_numpy(tr.v)).items():
+                tensors[k + "/Adam_1"] = v
+            tensors["global_step"] = np.array(tr.global_step, dtype=np.int64)
+        ckpt.save_checkpoint(prefix, tensors)
+
+    if rank == 0:
+        print('Starting training...')
+    try:
+        for batch in batcher(args.train_dir, args.batch_size, args.preprocess_size, args.n_epochs,
+                             args.num_pipe_buffer, 1234, rank, world):
+            current_step = tr.global_step
+            if rank == 0 and current_step % args.num_steps_ckpt == 0:
+                # Save a checkpoint (train.py:256-259), incl. step 0
+                save('training/' + args.model_name + '.ckpt-%d' % current_step, full=True)
+            losses = tr.step(eng.mem.from_numpy(batch))
+            if current_step % args.num_steps_ckpt == 0 or current_step % 10 == 0:
+                if world > 1:
+                    dist.all_reduce(losses, op=dist.ReduceOp.SUM)     # losses are batch-summed (losses.py:32,63)
+                lv = [float(v) for v in eng.mem.to_numpy(losses)]
+                if rank == 0:
+                    log.write(json.dumps({"step": current_step, "loss": lv[0], "content_loss": lv[1],
+                                          "style_loss": lv[2], "tv_loss": lv[3]}) + "\n")
+                    log.flush()
+                    print(current_step, lv[0])
+            if current_step == args.num_steps_break:
+                print('Done training.')
+                break
+        else:
+            if rank == 0:
+                print('Done training.')
+    finally:
+        # Save the model (the image transformation network) for later usage (train.py:283-286)
+        if rank == 0:
+            save('models/' + args.model_name + '_final.ckpt', full=False)
+        if world > 1:
+            dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    parser = setup_parser()
+    main(parser.parse_args())
