@@ -68,7 +68,7 @@ struct Frag<16> {
     __device__ static __forceinline__ int row(int r, int lane) { return 4 * (lane >> 4) + r; }
 };
 
-template <int MT, int WM, int WN>
+template <int MT, int WM, int WN, bool FLAT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     typedef Frag<MT> F;
     typedef typename F::acc_t acc_t;
@@ -107,59 +107,226 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < NACC; ++r) acc[m][nn][r] = 0.f;
 
-    const int G = p.flat ? a.KH : a.KH * a.KW;
-    const int nchunks = p.flat ? 1 : a.Cin / CC;
+    const int G = FLAT ? a.KH : a.KH * a.KW;
+    const int nchunks = FLAT ? 1 : a.Cin / CC;
     const float* wbase = a.w + (size_t)n * a.w_nstride;
     const float* xn = a.x + (size_t)n * a.H * a.W * a.Cin;
     const int vy0 = ty0 * a.stride - a.pad_t, vx0 = tx0 * a.stride - a.pad_l;
     const bool has_ab = a.in_a != nullptr;
     const float* ia = has_ab ? a.in_a + (size_t)n * a.in_nstride : nullptr;
     const float* ib = has_ab ? a.in_b + (size_t)n * a.in_nstride : nullptr;
+    const int buf_floats = patch_floats + G * LG * BN;  // one (patch, filter) stage
+    constexpr int J4N = BN >> 2;                        // float4 per filter row
 
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int ci0 = chunk * CC;
-        if (chunk) __syncthreads();
-        // ---- stage the input patch (virtual image -> LDS [pixel][S]) ----
-        if (p.flat) {
-            for (int pix = tid; pix < PH * PW; pix += 256) {
-                const int py = pix / PW, px = pix - py * PW;
-                int sy, sx;
-                const bool ok = src_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) &&
-                                src_coord(a.src_mode, a.refl, vx0 + px, a.W, sx);
-                float v[3] = {0.f, 0.f, 0.f};
-                if (ok) {
-                    const float* src = xn + ((size_t)sy * a.W + sx) * 3;
+    // MFMA sweep over the taps x channels of one staged chunk.
+    // Fast path: the (tap, k) loop is flattened into groups of two k-steps and software-pipelined
+    // through two register sets: the LDS reads of group q+1 are issued before the MFMAs of group q,
+    // so a wave never waits on ds_read latency inside a chunk (B advances linearly through the
+    // staged filter; A's tap offset is tracked with scalar counters).
+    auto sweep = [&](const float* patch, const float* wl) {
+        if constexpr (!FLAT && MT == 32) {  // LG is 4, 8, 16 or 32: a whole number of 2-k-step groups
+            const int gpt = LG / (2 * KSTEP);
+            const int ngroups = G * gpt;
+            const float* pb = wl + laneB;
+            int kh = 0, kw = 0, kkg = 0, qload = 0;
+            float a0[2][WM], b0[2][WN], a1[2][WM], b1[2][WN];
+            auto load = [&](float (&av)[2][WM], float (&bv)[2][WN]) {
+                const int aoff = (kh * PW + kw) * S + kkg * 2 * KSTEP;
+                const float* pa = patch + aoff;
+                const float* pq = pb + qload * 2 * KSTEP * BN;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float t = src[c];
-                        if (has_ab) t = fmaf(t, ia[c], ib[c]);
-                        if (a.in_relu) t = fmaxf(t, 0.f);
-                        v[c] = t;
+                for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                    for (int m = 0; m < WM; ++m) av[u][m] = pa[laneA[m] + u * KSTEP];
+#pragma unroll
+                    for (int nn = 0; nn < WN; ++nn) bv[u][nn] = pq[u * KSTEP * BN + nn * MT];
+                }
+                ++qload;
+                if (++kkg == gpt) {
+                    kkg = 0;
+                    if (++kw == a.KW) {
+                        kw = 0;
+                        ++kh;
                     }
                 }
-                patch[pix * 3 + 0] = v[0];
-                patch[pix * 3 + 1] = v[1];
-                patch[pix * 3 + 2] = v[2];
+            };
+            auto mma = [&](float (&av)[2][WM], float (&bv)[2][WN]) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int m = 0; m < WM; ++m)
+#pragma unroll
+                        for (int nn = 0; nn < WN; ++nn) acc[m][nn] = F::mma(av[u][m], bv[u][nn], acc[m][nn]);
+            };
+            load(a0, b0);
+            int q = 0;
+            for (; q + 2 <= ngroups; q += 2) {
+                load(a1, b1);
+                mma(a0, b0);
+                if (q + 2 < ngroups) load(a0, b0);
+                mma(a1, b1);
             }
+            if (q < ngroups) mma(a0, b0);
         } else {
-            const int c4n = CC >> 2;
-            for (int e = tid; e < PH * PW * c4n; e += 256) {
-                const int pix = e / c4n, c4 = e - pix * c4n;
+        for (int g = 0; g < G; ++g) {
+            const int aoff = FLAT ? g * PW * S : ((g / a.KW) * PW + (g % a.KW)) * S;
+            const float* pa = patch + aoff;
+            const float* pb = wl + g * LG * BN + laneB;
+            for (int kk = 0; kk < LG; kk += KSTEP) {
+                float av[WM], bv[WN];
+#pragma unroll
+                for (int m = 0; m < WM; ++m) av[m] = pa[laneA[m] + kk];
+#pragma unroll
+                for (int nn = 0; nn < WN; ++nn) bv[nn] = pb[kk * BN + nn * MT];
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < WN; ++nn) acc[m][nn] = F::mma(av[m], bv[nn], acc[m][nn]);
+            }
+        }
+        }
+    };
+
+    if constexpr (FLAT) {
+        // ---- Cin == 3: one chunk, K runs over (kw,ci) contiguously per kernel row ----
+        float* patch = smem;
+        float* wl = smem + patch_floats;
+        for (int pix = tid; pix < PH * PW; pix += 256) {
+            const int py = pix / PW, px = pix - py * PW;
+            int sy, sx;
+            const bool ok = src_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) &&
+                            src_coord(a.src_mode, a.refl, vx0 + px, a.W, sx);
+            float v[3] = {0.f, 0.f, 0.f};
+            if (ok) {
+                const float* src = xn + ((size_t)sy * a.W + sx) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float t = src[c];
+                    if (has_ab) t = fmaf(t, ia[c], ib[c]);
+                    if (a.in_relu) t = fmaxf(t, 0.f);
+                    v[c] = t;
+                }
+            }
+            patch[pix * 3 + 0] = v[0];
+            patch[pix * 3 + 1] = v[1];
+            patch[pix * 3 + 2] = v[2];
+        }
+        if (tid < 8) patch[PH * PW * S + tid] = 0.f;  // slack read by the zero-weight k padding
+        const bool vec = (a.Cout & 3) == 0;
+        for (int e = tid; e < G * LG * J4N; e += 256) {
+            const int k = e / J4N, j4 = e - k * J4N;
+            const int g = k / LG, r = k - g * LG;
+            const int co = co0 + j4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < a.KW * a.Cin) {
+                const float* src = wbase + ((size_t)g * a.KW * a.Cin + r) * a.Cout + co;
+                if (vec && co + 3 < a.Cout) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (co + 0 < a.Cout) v.x = src[0];
+                    if (co + 1 < a.Cout) v.y = src[1];
+                    if (co + 2 < a.Cout) v.z = src[2];
+                    if (co + 3 < a.Cout) v.w = src[3];
+                }
+            }
+            *reinterpret_cast<float4*>(wl + e * 4) = v;
+        }
+        __syncthreads();
+        sweep(patch, wl);
+    } else {
+        // ---- software pipeline over input-channel chunks: two LDS stages; the next chunk's global
+        // loads are issued BEFORE the MFMA sweep of the current one and committed to the other stage
+        // after it (one barrier per chunk) ----
+        constexpr int PMAX = 6, WMAX = 6;  // float4 elements per thread and chunk (plan guarantees the bound)
+        const int c4n = CC >> 2;
+        const int c4sh = c4n == 1 ? 0 : (c4n == 2 ? 1 : (c4n == 4 ? 2 : 3));
+        const int lgsh = c4sh + 2;  // log2(CC)
+        const int ne_p = PH * PW * c4n, ne_w = G * LG * J4N;
+        float* abl = smem + 2 * buf_floats;  // [2][Cin] on-load affine
+        if (has_ab)
+            for (int c = tid; c < a.Cin; c += 256) {
+                abl[c] = ia[c];
+                abl[a.Cin + c] = ib[c];
+            }
+        int goff[PMAX];  // >=0: source offset (floats) of this thread's i-th patch element; -1: zero pad; -2: none
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i) {
+            const int e = tid + i * 256;
+            goff[i] = -2;
+            if (e < ne_p) {
+                const int pix = e >> c4sh, c4 = e & (c4n - 1);
                 const int py = pix / PW, px = pix - py * PW;
                 int sy, sx;
                 const bool ok = src_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) &&
                                 src_coord(a.src_mode, a.refl, vx0 + px, a.W, sx);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) {
-                    const int c = ci0 + c4 * 4;
-                    v = *reinterpret_cast<const float4*>(xn + ((size_t)sy * a.W + sx) * a.Cin + c);
+                goff[i] = ok ? (sy * a.W + sx) * a.Cin + c4 * 4 : -1;
+            }
+        }
+        float4 pv[PMAX], wv[WMAX];
+        const bool vec = (a.Cout & 3) == 0;
+        const bool wfast = vec && co0 + BN <= a.Cout;  // whole filter rows in range: precomputed offsets
+        int woff[WMAX];
+#pragma unroll
+        for (int i = 0; i < WMAX; ++i) {
+            const int e = tid + i * 256;
+            woff[i] = -1;
+            if (e < ne_w) {
+                const int k = e / J4N, j4 = e - k * J4N;
+                woff[i] = ((k >> lgsh) * a.Cin + (k & (CC - 1))) * a.Cout + co0 + j4 * 4;
+            }
+        }
+        auto issue = [&](int chunk) {
+            const int ci0 = chunk * CC;
+#pragma unroll
+            for (int i = 0; i < PMAX; ++i) {
+                pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (goff[i] >= 0) pv[i] = *reinterpret_cast<const float4*>(xn + goff[i] + ci0);
+            }
+            if (wfast) {
+                const float* wc = wbase + (size_t)ci0 * a.Cout;
+#pragma unroll
+                for (int i = 0; i < WMAX; ++i) {
+                    wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (woff[i] >= 0) wv[i] = *reinterpret_cast<const float4*>(wc + woff[i]);
+                }
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < WMAX; ++i) {
+                const int e = tid + i * 256;
+                wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < ne_w) {
+                    const int k = e / J4N, j4 = e - k * J4N;
+                    const int g = k >> lgsh, r = k & (CC - 1);
+                    const int co = co0 + j4 * 4;
+                    const float* src = wbase + ((size_t)g * a.Cin + ci0 + r) * a.Cout + co;
+                    if (vec && co + 3 < a.Cout) {
+                        wv[i] = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (co + 0 < a.Cout) wv[i].x = src[0];
+                        if (co + 1 < a.Cout) wv[i].y = src[1];
+                        if (co + 2 < a.Cout) wv[i].z = src[2];
+                        if (co + 3 < a.Cout) wv[i].w = src[3];
+                    }
+                }
+            }
+        };
+        auto commit = [&](int chunk, float* patch, float* wl) {
+            const int ci0 = chunk * CC;
+#pragma unroll
+            for (int i = 0; i < PMAX; ++i) {
+                if (goff[i] == -2) continue;
+                const int e = tid + i * 256;
+                const int pix = e >> c4sh, c4 = e & (c4n - 1);
+                float4 v = pv[i];
+                if (goff[i] >= 0) {
                     if (has_ab) {
-                        const float4 va = *reinterpret_cast<const float4*>(ia + c);
-                        const float4 vb = *reinterpret_cast<const float4*>(ib + c);
-                        v.x = fmaf(v.x, va.x, vb.x);
-                        v.y = fmaf(v.y, va.y, vb.y);
-                        v.z = fmaf(v.z, va.z, vb.z);
-                        v.w = fmaf(v.w, va.w, vb.w);
+                        const float* pa_ = abl + ci0 + c4 * 4;
+                        const float* pb_ = pa_ + a.Cin;
+                        v.x = fmaf(v.x, pa_[0], pb_[0]);
+                        v.y = fmaf(v.y, pa_[1], pb_[1]);
+                        v.z = fmaf(v.z, pa_[2], pb_[2]);
+                        v.w = fmaf(v.w, pa_[3], pb_[3]);
                     }
                     if (a.in_relu) {
                         v.x = fmaxf(v.x, 0.f);
@@ -174,66 +341,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 d[2] = v.z;
                 d[3] = v.w;
             }
-        }
-        if (tid < 8) patch[PH * PW * S + tid] = 0.f;  // slack read by the zero-weight k padding
-        // ---- stage the filter slice [G*LG][BN] ----
-        {
-            const int j4n = BN >> 2;
-            const int rows = G * LG;
-            const bool vec = (a.Cout & 3) == 0;
-            for (int e = tid; e < rows * j4n; e += 256) {
-                const int k = e / j4n, j4 = e - k * j4n;
-                const int g = k / LG, r = k - g * LG;
-                const int co = co0 + j4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                bool rowok;
-                size_t grow;
-                if (p.flat) {
-                    rowok = r < a.KW * a.Cin;
-                    grow = (size_t)g * a.KW * a.Cin + r;
-                } else {
-                    rowok = true;
-                    grow = (size_t)g * a.Cin + ci0 + r;
-                }
-                if (rowok) {
-                    const float* src = wbase + grow * a.Cout + co;
-                    if (vec && co + 3 < a.Cout) {
-                        v = *reinterpret_cast<const float4*>(src);
-                    } else {
-                        if (co + 0 < a.Cout) v.x = src[0];
-                        if (co + 1 < a.Cout) v.y = src[1];
-                        if (co + 2 < a.Cout) v.z = src[2];
-                        if (co + 3 < a.Cout) v.w = src[3];
-                    }
-                }
-                *reinterpret_cast<float4*>(wl + k * BN + j4 * 4) = v;
+#pragma unroll
+            for (int i = 0; i < WMAX; ++i) {
+                const int e = tid + i * 256;
+                if (e < ne_w) *reinterpret_cast<float4*>(wl + e * 4) = wv[i];
             }
-        }
+        };
+        issue(0);
+        __syncthreads();  // abl visible
+        commit(0, smem, smem + patch_floats);
         __syncthreads();
-        // ---- MFMA sweep over taps x channels of this chunk ----
-        for (int g = 0; g < G; ++g) {
-            const int aoff = p.flat ? g * PW * S : ((g / a.KW) * PW + (g % a.KW)) * S;
-            const float* pa = patch + aoff;
-            const float* pb = wl + g * LG * BN + laneB;
-#pragma unroll 4
-            for (int kk = 0; kk < LG; kk += KSTEP) {
-                float av[WM], bv[WN];
-#pragma unroll
-                for (int m = 0; m < WM; ++m) av[m] = pa[laneA[m] + kk];
-#pragma unroll
-                for (int nn = 0; nn < WN; ++nn) bv[nn] = pb[kk * BN + nn * MT];
-#pragma unroll
-                for (int m = 0; m < WM; ++m)
-#pragma unroll
-                    for (int nn = 0; nn < WN; ++nn) acc[m][nn] = F::mma(av[m], bv[nn], acc[m][nn]);
-            }
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            float* cur = smem + (chunk & 1) * buf_floats;
+            float* nxt = smem + ((chunk + 1) & 1) * buf_floats;
+            const bool more = chunk + 1 < nchunks;
+            if (more) issue(chunk + 1);
+            sweep(cur, cur + patch_floats);
+            if (more) commit(chunk + 1, nxt, nxt + patch_floats);
+            __syncthreads();
         }
     }
 
     // ---- epilogue ----
     const int th_valid = min(p.TH, a.Ho - ty0), tw_valid = min(p.TW, a.Wo - tx0);
     // validity + coordinates of the rows this lane holds
-    // (row index within the workgroup tile: t = (wave*WM+m)*MT + F::row(r,lane))
+    // (row index within the workgroup tile: t = (wave*WM+m)*MT + F::row(r,lane));
+    // t / TW through a float reciprocal: exact for these small integers, 3 VALU instead of ~25
+    const float inv_tw = 1.0f / (float)p.TW;
     if (a.stats) {
         float s1[WN];
 #pragma unroll
@@ -243,7 +377,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < NACC; ++r) {
                 const int t = (wave * WM + m) * MT + F::row(r, lane);
-                const int py = t / p.TW, px = t - py * p.TW;
+                const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
                 const bool ok = t < tile_px && py < th_valid && px < tw_valid;
 #pragma unroll
                 for (int nn = 0; nn < WN; ++nn) s1[nn] += ok ? acc[m][nn][r] : 0.f;
@@ -274,7 +408,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < NACC; ++r) {
                 const int t = (wave * WM + m) * MT + F::row(r, lane);
-                const int py = t / p.TW, px = t - py * p.TW;
+                const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
                 const bool ok = t < tile_px && py < th_valid && px < tw_valid;
 #pragma unroll
                 for (int nn = 0; nn < WN; ++nn) {
@@ -299,35 +433,48 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
     }
 
+    // store: per-image base pointers are 64-bit scalars, everything per element is 32-bit
     const int Cr = a.shuffle ? a.Cout >> 2 : a.Cout;
+    float* yn = a.y + (size_t)n * a.Ho * a.Wo * a.Cout;
+    const int ap = a.add_pad;
+    const int aW = a.Wo - 2 * ap;
+    const float* asn = a.add_src ? a.add_src + (size_t)n * (a.Ho - 2 * ap) * aW * a.Cout : nullptr;
+    int cof[WN], qa[WN], qb[WN];  // per n-tile: channel offset inside a pixel, pixel-shuffle phase
+    float bs[WN];
+    bool cok[WN];
+#pragma unroll
+    for (int nn = 0; nn < WN; ++nn) {
+        const int co = co0 + nn * MT + lm;
+        cok[nn] = co < a.Cout;
+        const int q = a.shuffle ? co / Cr : 0;
+        cof[nn] = a.shuffle ? co - q * Cr : co;
+        qa[nn] = q >> 1;
+        qb[nn] = q & 1;
+        bs[nn] = (a.bias && cok[nn]) ? a.bias[co] : 0.f;
+    }
 #pragma unroll
     for (int m = 0; m < WM; ++m)
 #pragma unroll
         for (int r = 0; r < NACC; ++r) {
             const int t = (wave * WM + m) * MT + F::row(r, lane);
-            const int py = t / p.TW, px = t - py * p.TW;
+            const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
             if (!(t < tile_px && py < th_valid && px < tw_valid)) continue;
             const int oy = ty0 + py, ox = tx0 + px;
+            const bool inner = asn && oy >= ap && oy < a.Ho - ap && ox >= ap && ox < a.Wo - ap;
+            const int aoff = ((oy - ap) * aW + (ox - ap)) * a.Cout;
+            const int poff = (oy * a.Wo + ox) * a.Cout;
 #pragma unroll
             for (int nn = 0; nn < WN; ++nn) {
-                const int co = co0 + nn * MT + lm;
-                if (co >= a.Cout) continue;
-                float v = acc[m][nn][r];
-                if (a.bias) v += a.bias[co];
+                if (!cok[nn]) continue;
+                float v = acc[m][nn][r] + bs[nn];
                 if (a.out_relu) v = fmaxf(v, 0.f);
-                if (a.add_src) {
-                    const int ap = a.add_pad;
-                    if (oy >= ap && oy < a.Ho - ap && ox >= ap && ox < a.Wo - ap)
-                        v += a.add_src[(((size_t)n * (a.Ho - 2 * ap) + (oy - ap)) * (a.Wo - 2 * ap) + (ox - ap)) * a.Cout + co];
-                }
-                size_t o;
-                if (a.shuffle) {
-                    const int q = co / Cr, cr = co - q * Cr;
-                    o = (((size_t)n * 2 * a.Ho + 2 * oy + (q >> 1)) * (2 * a.Wo) + 2 * ox + (q & 1)) * Cr + cr;
-                } else {
-                    o = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
-                }
-                a.y[o] = v;
+                if (inner) v += asn[aoff + cof[nn]];
+                int o;
+                if (a.shuffle)
+                    o = ((2 * oy + qa[nn]) * (2 * a.Wo) + 2 * ox + qb[nn]) * Cr + cof[nn];
+                else
+                    o = poff + cof[nn];
+                yn[o] = v;
             }
         }
 }
@@ -418,26 +565,31 @@ static void plan_variant(const ConvArgs& a, int variant, ConvPlan* out) {
     p.BN = kVarMT[variant] * kVarWN[variant];
     const int max_px = 4 * kVarWM[variant] * kVarMT[variant];
     const int kstep = kVarMT[variant] == 16 ? 4 : 2;
-    plan_tile(a.Ho, a.Wo, a.KH, a.KW, a.stride, max_px, &p.TH, &p.TW);
-    p.tiles_y = cdiv(a.Ho, p.TH);
-    p.tiles_x = cdiv(a.Wo, p.TW);
-    p.PH = (p.TH - 1) * a.stride + a.KH;
-    p.PW = (p.TW - 1) * a.stride + a.KW;
-    const int budget = env_int("FS_CONV_LDS_KB", 40) * 1024;
-    if (p.flat) {
-        p.CC = 3;
-        p.S = 3;
-        p.LG = cdiv(a.KW * 3, kstep) * kstep;
-        const int G = a.KH;
-        p.lds_bytes = 4 * (((p.PH * p.PW * p.S + 8 + 3) & ~3) + G * p.LG * p.BN);
-    } else {
+    const int budget = env_int("FS_CONV_LDS_KB", 36) * 1024;  // per pipeline stage (two stages + affine table)
+    for (int px = max_px; px >= 16; px >>= 1) {  // shrink the pixel tile until a channel chunk fits
+        plan_tile(a.Ho, a.Wo, a.KH, a.KW, a.stride, px, &p.TH, &p.TW);
+        p.tiles_y = cdiv(a.Ho, p.TH);
+        p.tiles_x = cdiv(a.Wo, p.TW);
+        p.PH = (p.TH - 1) * a.stride + a.KH;
+        p.PW = (p.TW - 1) * a.stride + a.KW;
+        if (p.flat) {
+            p.CC = 3;
+            p.S = 3;
+            p.LG = cdiv(a.KW * 3, kstep) * kstep;
+            const int G = a.KH;
+            p.lds_bytes = 4 * (((p.PH * p.PW * p.S + 8 + 3) & ~3) + G * p.LG * p.BN);
+            break;
+        }
         const int G = a.KH * a.KW;
-        int forced = env_int("FS_CONV_CC", 0);
+        const int forced = env_int("FS_CONV_CC", 0);
         int chosen = 0, chosen_bytes = 0;
         for (int cc = 32; cc >= 4; cc >>= 1) {
             if (a.Cin % cc) continue;
-            const int bytes = 4 * (((p.PH * p.PW * (cc + 1) + 8 + 3) & ~3) + G * cc * p.BN);
-            if (forced == cc || (!forced && bytes <= budget) || cc == 4) {
+            const int stage = 4 * (((p.PH * p.PW * (cc + 1) + 8 + 3) & ~3) + G * cc * p.BN);
+            const int bytes = 2 * stage + 8 * a.Cin;
+            // the pipelined kernel keeps <= 6 float4 of patch and of filter per thread in flight
+            const bool fits = p.PH * p.PW * (cc / 4) <= 6 * 256 && G * cc * (p.BN / 4) <= 6 * 256;
+            if (forced == cc || (!forced && fits && stage <= budget)) {
                 chosen = cc;
                 chosen_bytes = bytes;
                 break;
@@ -447,6 +599,7 @@ static void plan_variant(const ConvArgs& a, int variant, ConvPlan* out) {
         p.S = chosen + 1;
         p.LG = chosen;
         p.lds_bytes = chosen_bytes;
+        if (chosen) break;
     }
     if (p.lds_bytes < 4 * 5 * p.BN) p.lds_bytes = 4 * 5 * p.BN;  // stats scratch
     *out = p;
@@ -454,8 +607,8 @@ static void plan_variant(const ConvArgs& a, int variant, ConvPlan* out) {
 
 ConvPlan conv_plan(const ConvArgs& a) {
     ConvPlan p;
-    if (a.Cout <= 16) {
-        plan_variant(a, 2, &p);
+    if (a.Cout <= 16 || a.Cin == 3) {  // narrow outputs, and the flat Cin==3 path, have one variant each
+        plan_variant(a, a.Cout <= 16 ? 2 : 0, &p);
         return p;
     }
     // widest tile first; halve the workgroup tile while the launch cannot fill the chip
@@ -475,7 +628,7 @@ ConvPlan conv_plan(const ConvArgs& a) {
 int conv_launch(const ConvArgs& a, hipStream_t s) {
     const ConvPlan& p = a.p;
     if (p.CC <= 0 || (!p.flat && (a.Cin % 4 || a.Cin % p.CC))) return -1;
-    if (p.lds_bytes > 64 * 1024) return -2;
+    if (p.lds_bytes > 160 * 1024) return -2;
     dim3 grid((unsigned)(a.N * p.tiles_y * p.tiles_x), (unsigned)cdiv(a.Cout, p.BN));
     Profiler* prof = Profiler::current();
     if (prof) {
@@ -484,16 +637,35 @@ int conv_launch(const ConvArgs& a, hipStream_t s) {
         if (a.src_mode == SRC_DILATE2) fl *= 0.25;
         prof->begin(p.variant < 3 ? p.variant : p.variant + 1, fl, s);
     }
-    if (p.variant == 0)
-        hipLaunchKernelGGL((conv_igemm_kernel<32, 2, 2>), grid, dim3(256), (size_t)p.lds_bytes, s, a);
-    else if (p.variant == 1)
-        hipLaunchKernelGGL((conv_igemm_kernel<32, 2, 1>), grid, dim3(256), (size_t)p.lds_bytes, s, a);
-    else if (p.variant == 2)
-        hipLaunchKernelGGL((conv_igemm_kernel<16, 4, 1>), grid, dim3(256), (size_t)p.lds_bytes, s, a);
-    else if (p.variant == 3)
-        hipLaunchKernelGGL((conv_igemm_kernel<32, 1, 2>), grid, dim3(256), (size_t)p.lds_bytes, s, a);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<32, 1, 1>), grid, dim3(256), (size_t)p.lds_bytes, s, a);
+#define FS_LAUNCH(MT_, WM_, WN_, FL_)                                                                              \
+    do {                                                                                                           \
+        static bool attr_done = false;                                                                             \
+        if (!attr_done) { /* allow > 64 KiB of dynamic LDS (gfx950: 160 KiB per CU) */                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<MT_, WM_, WN_, FL_>),        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
+            attr_done = true;                                                                                      \
+        }                                                                                                          \
+        hipLaunchKernelGGL((conv_igemm_kernel<MT_, WM_, WN_, FL_>), grid, dim3(256), (size_t)p.lds_bytes, s, a);   \
+    } while (0)
+    if (p.flat) {
+        if (p.variant == 0)
+            FS_LAUNCH(32, 2, 2, true);
+        else if (p.variant == 2)
+            FS_LAUNCH(16, 4, 1, true);
+        else
+            return -4;
+    } else if (p.variant == 0) {
+        FS_LAUNCH(32, 2, 2, false);
+    } else if (p.variant == 1) {
+        FS_LAUNCH(32, 2, 1, false);
+    } else if (p.variant == 2) {
+        FS_LAUNCH(16, 4, 1, false);
+    } else if (p.variant == 3) {
+        FS_LAUNCH(32, 1, 2, false);
+    } else {
+        FS_LAUNCH(32, 1, 1, false);
+    }
+#undef FS_LAUNCH
     if (prof) prof->end(s);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
