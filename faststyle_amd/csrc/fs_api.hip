@@ -336,19 +336,19 @@ static int fill_wgrad(fs_wgrad_desc* d, fs::WgradArgs* a) {
 size_t fs_conv2d_wgrad_workspace_bytes(fs_wgrad_desc* d) {
     fs::WgradArgs a;
     if (fill_wgrad(d, &a)) return 0;
-    return (size_t)(a.per_sample ? a.N : 1) * a.p.n_wg * a.p.K * a.Cout * sizeof(float);
+    return (size_t)(a.per_sample ? a.N : 1) * a.p.n_slabs * a.p.K * a.Cout * sizeof(float);
 }
 
 int fs_conv2d_wgrad(fs_ctx* ctx, fs_wgrad_desc* d, void* ws, size_t ws_bytes) {
     if (!ctx || !ws) return fail(-1, "fs_conv2d_wgrad: null argument");
     fs::WgradArgs a;
     if (int rc = fill_wgrad(d, &a)) return rc;
-    const size_t need = (size_t)(a.per_sample ? a.N : 1) * a.p.n_wg * a.p.K * a.Cout * sizeof(float);
+    const size_t need = (size_t)(a.per_sample ? a.N : 1) * a.p.n_slabs * a.p.K * a.Cout * sizeof(float);
     if (ws_bytes < need) return fail(-3, "fs_conv2d_wgrad: workspace too small");
     a.slabs = (float*)ws;
     int rc = fs::wgrad_launch(a, ctx->stream);
     if (rc) return fail(rc, "fs_conv2d_wgrad: launch failed (%d)", rc);
-    return fs::reduce_slabs(a.slabs, a.per_sample ? a.N : 1, a.p.n_wg, (size_t)a.p.K * a.Cout, d->scale, d->dw, ctx->stream);
+    return fs::reduce_slabs(a.slabs, a.per_sample ? a.N : 1, a.p.n_slabs, (size_t)a.p.K * a.Cout, d->scale, d->dw, ctx->stream);
 }
 
 }  // extern "C"

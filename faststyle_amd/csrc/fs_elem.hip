@@ -203,41 +203,46 @@ __global__ __launch_bounds__(256) void in_bwd_final_kernel(const float* partial,
     __shared__ float sh[512];
     const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    float g1 = 0.f, g2 = 0.f;
-    for (int n = 0; n < N; ++n) {
-        float t1 = 0.f, t2 = 0.f;
-        if (c < C)
-            for (int k = tl; k < chunks; k += 16) {
-                const float* p = partial + (((size_t)n * chunks + k) * C + c) * 2;
-                t1 += p[0];
-                t2 += p[1];
-            }
-        __syncthreads();
-        sh[threadIdx.x] = t1;
-        sh[256 + threadIdx.x] = t2;
-        __syncthreads();
-        if (tl == 0 && c < C) {
-            float u1 = 0.f, u2 = 0.f;
-            for (int j = 0; j < 16; ++j) {
-                u1 += sh[j * 16 + cl];
-                u2 += sh[256 + j * 16 + cl];
-            }
-            S[(n * C + c) * 2] = u1;
-            S[(n * C + c) * 2 + 1] = u2;
-            g1 += u1;
-            g2 += u2;
+    const int n = blockIdx.y;  // one block per (16 channels, sample); dgamma/dbeta are summed by the apply kernel
+    (void)N;
+    (void)dgamma;
+    (void)dbeta;
+    float t1 = 0.f, t2 = 0.f;
+    if (c < C)
+        for (int k = tl; k < chunks; k += 16) {
+            const float* p = partial + (((size_t)n * chunks + k) * C + c) * 2;
+            t1 += p[0];
+            t2 += p[1];
         }
-    }
+    sh[threadIdx.x] = t1;
+    sh[256 + threadIdx.x] = t2;
+    __syncthreads();
     if (tl == 0 && c < C) {
-        dbeta[c] = g1;
-        dgamma[c] = g2;
+        float u1 = 0.f, u2 = 0.f;
+        for (int j = 0; j < 16; ++j) {
+            u1 += sh[j * 16 + cl];
+            u2 += sh[256 + j * 16 + cl];
+        }
+        S[(n * C + c) * 2] = u1;
+        S[(n * C + c) * 2 + 1] = u2;
     }
 }
 
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* gin, const float* z, const float* mean,
                                                            const float* rstd, const float* a, const float* b, int mode,
-                                                           const float* S, float* dz, int HW, int C, size_t total) {
+                                                           const float* S, float* dz, int HW, int C, size_t total, int N,
+                                                           float* dgamma, float* dbeta) {
     const float inv = 1.0f / (float)HW;
+    if (blockIdx.x == 0)  // dbeta[c] = sum_n S1, dgamma[c] = sum_n S2 (fixed order)
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float g1 = 0.f, g2 = 0.f;
+            for (int n = 0; n < N; ++n) {
+                g1 += S[(n * C + c) * 2];
+                g2 += S[(n * C + c) * 2 + 1];
+            }
+            dbeta[c] = g1;
+            dgamma[c] = g2;
+        }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const int n = (int)(i / ((size_t)HW * C));
@@ -261,10 +266,10 @@ int in_bwd(const float* gin, const float* z, const float* mean, const float* rst
     float* S = scratch + (size_t)N * chunks * C * 2;
     hipLaunchKernelGGL(in_bwd_partial_kernel, dim3(chunks, N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, partial, HW,
                        C, chunk_px);
-    hipLaunchKernelGGL(in_bwd_final_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partial, N, chunks, C, S, dgamma, dbeta);
+    hipLaunchKernelGGL(in_bwd_final_kernel, dim3(cdiv(C, 16), N), dim3(256), 0, s, partial, N, chunks, C, S, dgamma, dbeta);
     const size_t total = (size_t)N * HW * C;
     hipLaunchKernelGGL(in_bwd_apply_kernel, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0, s, gin, z,
-                       mean, rstd, a, b, mode, S, dz, HW, C, total);
+                       mean, rstd, a, b, mode, S, dz, HW, C, total, N, dgamma, dbeta);
     return 0;
 }
 size_t in_bwd_scratch_floats(int N, int HW, int C) { return (size_t)N * cdiv(HW, 64) * C * 2 + (size_t)N * C * 2; }

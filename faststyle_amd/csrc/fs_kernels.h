@@ -60,6 +60,8 @@ struct WgradPlan {
     int NB;       // cout blocks of 32 (ceil)
     int KWV;      // k-blocks per wave (1, 2 or 4); a wave owns KWV x (4/KWV) MFMA tiles
     int n_wg;     // workgroups per sample-group (each strides over the tile list)
+    int waves_k;  // waves tiling the k dimension (1, 2, 4); the other 4/waves_k split the pixel rows
+    int n_slabs;  // partial slabs per sample-group = n_wg * 4/waves_k
     int lds_bytes;
 };
 

@@ -223,7 +223,7 @@ void tnet_layout(int N, int H, int W, TnetLayout* L) {
         Unit& u = L->u[i];
         WgradArgs wa = unit_wgrad_args(u, N);
         u.wplan = wgrad_plan(wa);
-        const size_t sl = (size_t)u.wplan.n_wg * u.wplan.K * wa.Cout;
+        const size_t sl = (size_t)u.wplan.n_slabs * u.wplan.K * wa.Cout;
         if (sl > max_slab) max_slab = sl;
     }
     L->slabs = b.take(max_slab);
@@ -359,10 +359,10 @@ static int unit_wgrad(const TnetLayout& L, const Unit& u, const float* xin, cons
     FS_TRY(wgrad_launch(a, s));
     const size_t count = (size_t)a.p.K * a.Cout;
     if (u.kind == 1) {
-        FS_TRY(reduce_slabs(ws + L.slabs, 1, a.p.n_wg, count, 1.0f, ws + L.dweff, s));
+        FS_TRY(reduce_slabs(ws + L.slabs, 1, a.p.n_slabs, count, 1.0f, ws + L.dweff, s));
         return wt_upconv_wgrad_fold(ws + L.dweff, grads + u.w_off, u.Cin, u.Cout, s);
     }
-    return reduce_slabs(ws + L.slabs, 1, a.p.n_wg, count, 1.0f, grads + u.w_off, s);
+    return reduce_slabs(ws + L.slabs, 1, a.p.n_slabs, count, 1.0f, grads + u.w_off, s);
 }
 
 int tnet_backward(const TnetLayout& L, const float* params, const float* x, const float* dy, float* grads, float* ws,

@@ -104,7 +104,7 @@ void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, 
         L->sm[i] = b.take((size_t)N * C * C);
         WgradArgs ga = gram_args(N, L->Hl[l], L->Wl[l], C);
         const WgradPlan p = wgrad_plan(ga);
-        const size_t sl = (size_t)N * p.n_wg * C * C;
+        const size_t sl = (size_t)N * p.n_slabs * C * C;
         if (sl > max_slab) max_slab = sl;
     }
     L->slabs = b.take(max_slab);
@@ -166,7 +166,7 @@ static int gram_forward(const VggLayout& L, int l, const float* F, float* G, flo
     ga.slabs = ws + L.slabs;
     ga.p = wgrad_plan(ga);
     FS_TRY(wgrad_launch(ga, s));
-    return reduce_slabs(ws + L.slabs, L.N, ga.p.n_wg, (size_t)C * C, 1.0f / ((float)H * W * C), G, s);
+    return reduce_slabs(ws + L.slabs, L.N, ga.p.n_slabs, (size_t)C * C, 1.0f / ((float)H * W * C), G, s);
 }
 
 int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],

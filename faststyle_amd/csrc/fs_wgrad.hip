@@ -48,7 +48,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int lm = lane & 31, kq = lane >> 5;
     const int cogroups = cdiv(p.NB, NWV);
     const int kbg = blockIdx.y / cogroups, nbg = blockIdx.y % cogroups;
-    const int kb0 = (kbg * 4 + wave) * KWV;           // this wave's first k-block
+    // waves_k waves tile the k dimension; when K is short (Gram of 64 channels, 9x9x3 filters) the
+    // remaining 4/waves_k waves split the tile's pixel rows and write their own partial slabs
+    const int waves_k = p.waves_k, wsplit = 4 / waves_k;
+    const int wk = wave % waves_k, ws = wave / waves_k;
+    const int kb0 = (kbg * waves_k + wk) * KWV;       // this wave's first k-block
     const int nbw = min(NWV, p.NB - nbg * NWV);       // co-blocks of this workgroup
     const int DP = nbw * 32;                          // dY LDS pitch
     const int co_g0 = nbg * NWV * 32;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         __syncthreads();
         // ---- MFMA sweep over pixel pairs ----
         if (kb0 < p.KB) {
-            for (int py = 0; py < p.TH; ++py) {
+            for (int py = ws; py < p.TH; py += wsplit) {
                 const int rowA = py * a.stride * PW;
 #pragma unroll 2
                 for (int px0 = 0; px0 < p.TW; px0 += 2) {
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
     }
     // ---- write this workgroup's partial slab ----
-    float* slab = a.slabs + ((size_t)blockIdx.z * p.n_wg + blockIdx.x) * (size_t)p.K * a.Cout;
+    float* slab = a.slabs + (((size_t)blockIdx.z * p.n_wg + blockIdx.x) * wsplit + ws) * (size_t)p.K * a.Cout;
 #pragma unroll
     for (int q = 0; q < KWV; ++q) {
         if (kb0 + q >= p.KB) continue;
@@ -253,11 +257,15 @@ WgradPlan wgrad_plan(const WgradArgs& a) {
     p.PW = (tw - 1) * a.stride + a.KW;
     p.S = CS + 1;
     p.lds_bytes = 4 * (((p.PH * p.PW * p.S + 4 + 3) & ~3) + th * tw * DP);
+    const int kblocks_w = cdiv(p.KB, p.KWV);  // k-blocks in units of one wave's share
+    p.waves_k = kblocks_w >= 4 ? 4 : (kblocks_w >= 2 ? 2 : 1);
     const int total = (a.per_sample ? 1 : a.N) * p.tiles_y * p.tiles_x;
-    const int groups = cdiv(p.KB, 4 * p.KWV) * cdiv(p.NB, NWV) * (a.per_sample ? a.N : 1);
+    const int groups = cdiv(p.KB, p.waves_k * p.KWV) * cdiv(p.NB, NWV) * (a.per_sample ? a.N : 1);
     int want = env_int2("FS_WGRAD_WGS", 512) / groups;  // aim for ~2 workgroups per CU in flight
     if (want < 1) want = 1;
-    p.n_wg = total < want ? total : want;
+    // equal number of tiles per workgroup (no straggler round)
+    p.n_wg = total <= want ? total : cdiv(total, cdiv(total, want));
+    p.n_slabs = p.n_wg * (4 / p.waves_k);
     return p;
 }
 
@@ -277,7 +285,7 @@ int wgrad_launch(const WgradArgs& a, hipStream_t s) {
     if (a.Cin > 128 && a.Cin % 128) return -1;
     if (p.lds_bytes > 160 * 1024) return -2;
     const int NWV = 4 / p.KWV;
-    dim3 grid((unsigned)p.n_wg, (unsigned)(cdiv(p.KB, 4 * p.KWV) * cdiv(p.NB, NWV)), (unsigned)(a.per_sample ? a.N : 1));
+    dim3 grid((unsigned)p.n_wg, (unsigned)(cdiv(p.KB, p.waves_k * p.KWV) * cdiv(p.NB, NWV)), (unsigned)(a.per_sample ? a.N : 1));
     Profiler* prof = Profiler::current();
     if (prof) prof->begin(3, 2.0 * a.N * a.Ho * a.Wo * (double)p.K * a.Cout, s);
     if (p.KWV == 1)
