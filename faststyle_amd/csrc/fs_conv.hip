@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             int kh = 0, kw = 0, kkg = 0, qload = 0;
             float a0[2][WM], b0[2][WN], a1[2][WM], b1[2][WN];
             auto load = [&](float (&av)[2][WM], float (&bv)[2][WN]) {
-                const int aoff = (kh * PW + kw) * S + kkg * 2 * KSTEP;
+                const int aoff = (kh * PW + kw * a.dil_x) * S + kkg * 2 * KSTEP;
                 const float* pa = patch + aoff;
                 const float* pq = pb + qload * 2 * KSTEP * BN;
 #pragma unroll
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             if (q < ngroups) mma(a0, b0);
         } else {
         for (int g = 0; g < G; ++g) {
-            const int aoff = FLAT ? g * PW * S : ((g / a.KW) * PW + (g % a.KW)) * S;
+            const int aoff = FLAT ? g * PW * S : ((g / a.KW) * PW + (g % a.KW) * a.dil_x) * S;
             const float* pa = patch + aoff;
             const float* pb = wl + g * LG * BN + laneB;
             for (int kk = 0; kk < LG; kk += KSTEP) {
@@ -571,7 +571,7 @@ static void plan_variant(const ConvArgs& a, int variant, ConvPlan* out) {
         p.tiles_y = cdiv(a.Ho, p.TH);
         p.tiles_x = cdiv(a.Wo, p.TW);
         p.PH = (p.TH - 1) * a.stride + a.KH;
-        p.PW = (p.TW - 1) * a.stride + a.KW;
+        p.PW = (p.TW - 1) * a.stride + (a.KW - 1) * (a.dil_x > 0 ? a.dil_x : 1) + 1;
         if (p.flat) {
             p.CC = 3;
             p.S = 3;
@@ -625,7 +625,9 @@ ConvPlan conv_plan(const ConvArgs& a) {
     return p;
 }
 
-int conv_launch(const ConvArgs& a, hipStream_t s) {
+int conv_launch(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    if (a.dil_x < 1) a.dil_x = 1;
     const ConvPlan& p = a.p;
     if (p.CC <= 0 || (!p.flat && (a.Cin % 4 || a.Cin % p.CC))) return -1;
     if (p.lds_bytes > 160 * 1024) return -2;

@@ -25,24 +25,42 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // ---------------------------------------------------------------- instance-norm finalize
 // stats: [N][T][Cv][3] = {mean, M2, count} per conv tile, Cv = groups*C (groups=4 for the
 // pixel-shuffled resize-conv whose 4 phases hold the same real channel).
+// One wave per channel (4 channels per block): 64 lanes stride over the tile list with 4 loads in
+// flight, merge with Chan's update in fp64, lane 0 folds the 64 lane results in a fixed order.
 __global__ __launch_bounds__(256) void in_finalize_kernel(const float* stats, int T, int C, int groups, const float* gamma,
                                                           const float* beta, float eps, float* mean, float* rstd,
                                                           float* oa, float* ob) {
     __shared__ double sc[256], sm[256], sq[256];
-    const int n = blockIdx.x, cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
-    const int c = blockIdx.y * 16 + cl;
+    const int n = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.y * 4 + w;
     const int Cv = C * groups;
     double cnt = 0, mu = 0, m2 = 0;
     if (c < C) {
-        for (int i = tl; i < T * groups; i += 16) {
-            const int t = i / groups, q = i - t * groups;
-            const float* st = stats + (((size_t)n * T + t) * Cv + q * C + c) * 3;
-            const double cb = st[2], mb = st[0], qb = st[1];
-            if (cb > 0) {
-                const double nn = cnt + cb, d = mb - mu;
-                mu += d * cb / nn;
-                m2 += qb + d * d * cnt * cb / nn;
-                cnt = nn;
+        const int total = T * groups;
+        for (int i0 = lane; i0 < total; i0 += 256) {
+            float vm[4], vq[4], vc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 64;
+                vc[u] = 0.f;
+                vm[u] = vq[u] = 0.f;
+                if (i < total) {
+                    const int t = i / groups, q = i - t * groups;
+                    const float* st = stats + (((size_t)n * T + t) * Cv + q * C + c) * 3;
+                    vm[u] = st[0];
+                    vq[u] = st[1];
+                    vc[u] = st[2];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double cb = vc[u], mb = vm[u], qb = vq[u];
+                if (cb > 0) {
+                    const double nn = cnt + cb, d = mb - mu;
+                    mu += d * cb / nn;
+                    m2 += qb + d * d * cnt * cb / nn;
+                    cnt = nn;
+                }
             }
         }
     }
@@ -50,9 +68,9 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* stats, in
     sm[threadIdx.x] = mu;
     sq[threadIdx.x] = m2;
     __syncthreads();
-    if (tl == 0 && c < C) {
-        for (int j = 1; j < 16; ++j) {
-            const double cb = sc[j * 16 + cl], mb = sm[j * 16 + cl], qb = sq[j * 16 + cl];
+    if (lane == 0 && c < C) {
+        for (int j = 1; j < 64; ++j) {
+            const double cb = sc[w * 64 + j], mb = sm[w * 64 + j], qb = sq[w * 64 + j];
             if (cb > 0) {
                 const double nn = cnt + cb, d = mb - mu;
                 mu += d * cb / nn;
@@ -73,7 +91,7 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* stats, in
 
 int in_finalize(const float* stats, int N, int T, int C, int groups, const float* gamma, const float* beta, float eps,
                 float* mean, float* rstd, float* a, float* b, hipStream_t s) {
-    hipLaunchKernelGGL(in_finalize_kernel, dim3(N, cdiv(C, 16)), dim3(256), 0, s, stats, T, C, groups, gamma, beta, eps,
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(N, cdiv(C, 4)), dim3(256), 0, s, stats, T, C, groups, gamma, beta, eps,
                        mean, rstd, a, b);
     return 0;
 }

@@ -38,6 +38,7 @@ struct ConvArgs {
     int N, H, W, Cin;
     int Ho, Wo, Cout;
     int KH, KW, stride, pad_t, pad_l;
+    int dil_x;  // horizontal tap spacing (0/1: dense; 5 for the kw-folded 9x9x16->3 layer)
     int src_mode, refl;
     const float* in_a;  // optional on-load affine: v = x*in_a[n*in_nstride+c] + in_b[...]
     const float* in_b;
@@ -71,6 +72,7 @@ struct WgradArgs {
     float* slabs;     // partial sums [groups][n_wg][K][Cout]; groups = N when per_sample else 1
     int N, H, W, Cin, Ho, Wo, Cout;
     int KH, KW, stride, pad_t, pad_l;
+    int dil_x;
     int src_mode, refl;
     const float* in_a;
     const float* in_b;
@@ -113,6 +115,11 @@ int wt_flip_transpose(const float* w, float* out, int KH, int KW, int Ci, int Co
 int wt_upconv_fwd(const float* w, float* weff, int Ci, int Co, hipStream_t s);
 int wt_upconv_dgrad(const float* w, float* v, int Ci, int Co, hipStream_t s);
 int wt_upconv_wgrad_fold(const float* dweff, float* dw, int Ci, int Co, hipStream_t s);
+// ---- fs_fold.hip: kw-folded 9x9 -> 3-channel output layer ----
+int wt_fold5_fwd(const float* w, float* wf, int Ci, hipStream_t s);
+int wt_fold5_back(const float* dwf, float* dw, int Ci, hipStream_t s);
+int fold5_fwd(const float* Z, float* z, float* stats, int N, int Ho, int Wo, hipStream_t s);
+int unfold5(const float* dz, float* dys, int N, int Ho, int Wo, hipStream_t s);
 }  // namespace fs
 
 namespace fs {

@@ -14,8 +14,10 @@ const ParamInfo* param_table();  // 48 entries, checkpoint key order
 
 // One conv + instance-norm unit of the net.
 struct Unit {
-    int kind;  // 0: conv, 1: phase-collapsed resize-conv (2x2 taps, pixel-shuffle store)
+    int kind;  // 0: conv, 1: phase-collapsed resize-conv (2x2 taps, pixel-shuffle store),
+               // 2: kw-folded 9x9 -> 3-channel output layer (fs_fold.hip)
     int K, stride, Cin, Cout;
+    int KWx, dil_x;    // horizontal taps / tap spacing the conv kernel sees (K / 1 except kind 2: 2 / 5)
     int Cc;            // channels the conv kernel produces (4*Cout for kind 1)
     int Hsrc, Wsrc;    // tensor the conv kernel reads (the unpadded image for initconv_0)
     int Hin, Win;      // conv input extent (after reflect padding)
@@ -34,6 +36,7 @@ struct TnetLayout {
     Unit u[16];
     size_t h[5];      // residual block outputs
     size_t weff[2];   // collapsed resize-conv filters
+    size_t zfold, wfold, dwfold;  // kw-folded output layer: Z / unfolded dY [N,Ho,Wo+4,16], filters, filter grads
     size_t fwd_floats;
     size_t g[3], dz, wT, dweff, inbwd, slabs;  // backward scratch
     size_t total_floats;

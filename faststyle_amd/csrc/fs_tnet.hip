@@ -93,7 +93,9 @@ static ConvArgs unit_args(const Unit& u, int N) {
     a.Ho = u.Hc;
     a.Wo = u.Wc;
     a.Cout = u.Cc;
-    a.KH = a.KW = u.K;
+    a.KH = u.K;
+    a.KW = u.KWx;
+    a.dil_x = u.dil_x;
     a.stride = u.stride;
     a.pad_t = u.pad_t;
     a.pad_l = u.pad_l;
@@ -123,6 +125,8 @@ void tnet_layout(int N, int H, int W, TnetLayout* L) {
         u.b_off = find_param(nm);
         u.kind = 0;
         u.K = K;
+        u.KWx = K;
+        u.dil_x = 1;
         u.stride = stride;
         u.Cin = Cin;
         u.Cout = u.Cc = Cout;
@@ -176,6 +180,7 @@ void tnet_layout(int N, int H, int W, TnetLayout* L) {
         Unit& u = conv_unit(l, "W", "INscale", "INshift", 3, 1, Cin, Cout, 0, h, w);
         u.kind = 1;
         u.K = 2;
+        u.KWx = 2;
         u.Cc = 4 * Cout;
         u.Hc = h;
         u.Wc = w;
@@ -185,7 +190,14 @@ void tnet_layout(int N, int H, int W, TnetLayout* L) {
         h = u.Hout;
         w = u.Wout;
     }
-    conv_unit("upsample_2", "W", "INscale", "INshift", 9, 1, 16, 3, 0, h, w);
+    {  // output layer: 9x9, 16 -> 3, computed kw-folded (fs_fold.hip): 9x2 taps, spacing 5, 16 virtual channels
+        Unit& u = conv_unit("upsample_2", "W", "INscale", "INshift", 9, 1, 16, 3, 0, h, w);
+        u.kind = 2;
+        u.KWx = 2;
+        u.dil_x = 5;
+        u.Cc = 16;
+        u.Wc = u.Wout + 4;
+    }
     L->Hy = h;
     L->Wy = w;
 
@@ -194,10 +206,10 @@ void tnet_layout(int N, int H, int W, TnetLayout* L) {
         Unit& u = L->u[i];
         ConvArgs a = unit_args(u, N);
         u.plan = conv_plan(a);
-        u.tiles = u.plan.tiles_y * u.plan.tiles_x;
+        u.tiles = u.kind == 2 ? cdiv(u.Hout * u.Wout, 256) : u.plan.tiles_y * u.plan.tiles_x;
         const size_t act = (size_t)N * u.Hout * u.Wout * u.Cout;
         u.z = b.take(act);
-        u.stats = b.take((size_t)N * u.tiles * u.Cc * 3);
+        u.stats = b.take((size_t)N * u.tiles * (u.kind == 2 ? u.Cout : u.Cc) * 3);
         u.mean = b.take((size_t)N * u.Cout);
         u.rstd = b.take((size_t)N * u.Cout);
         u.a = b.take((size_t)N * u.Cout);
@@ -212,6 +224,9 @@ void tnet_layout(int N, int H, int W, TnetLayout* L) {
     }
     L->weff[0] = b.take(4 * 64 * 128);
     L->weff[1] = b.take(4 * 32 * 64);
+    L->zfold = b.take((size_t)N * L->u[15].Hc * L->u[15].Wc * 16);
+    L->wfold = b.take(18 * 16 * 16);
+    L->dwfold = b.take(18 * 16 * 16);
     L->fwd_floats = b.off;
     // ---- backward scratch ----
     for (int k = 0; k < 3; ++k) L->g[k] = b.take(max_act);
@@ -239,7 +254,9 @@ WgradArgs unit_wgrad_args(const Unit& u, int N) {
     a.Ho = u.Hc;
     a.Wo = u.Wc;
     a.Cout = u.Cc;
-    a.KH = a.KW = u.K;
+    a.KH = u.K;
+    a.KW = u.KWx;
+    a.dil_x = u.dil_x;
     a.stride = u.stride;
     a.pad_t = u.pad_t;
     a.pad_l = u.pad_l;
@@ -261,6 +278,7 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
     // collapsed resize-conv filters (weights may have changed since the last call: training)
     FS_TRY(wt_upconv_fwd(params + L.u[13].w_off, ws + L.weff[0], 64, 32, s));
     FS_TRY(wt_upconv_fwd(params + L.u[14].w_off, ws + L.weff[1], 32, 16, s));
+    FS_TRY(wt_fold5_fwd(params + L.u[15].w_off, ws + L.wfold, 16, s));
     const float* src = x;
     const float* src_a = nullptr;
     const float* src_b = nullptr;
@@ -273,10 +291,12 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
         a.in_b = src_b;
         a.in_nstride = src_a ? u.Cin : 0;
         a.in_relu = src_a ? 1 : 0;
-        a.w = u.kind == 1 ? ws + L.weff[i - 13] : params + u.w_off;
-        a.y = ws + u.z;
-        a.stats = ws + u.stats;
+        a.w = u.kind == 1 ? ws + L.weff[i - 13] : (u.kind == 2 ? ws + L.wfold : params + u.w_off);
+        a.y = u.kind == 2 ? ws + L.zfold : ws + u.z;
+        a.stats = u.kind == 2 ? nullptr : ws + u.stats;
         FS_TRY(conv_launch(a, s));
+        if (u.kind == 2)  // shifted 5-term sum of the virtual channels -> z + statistics partials
+            FS_TRY(fold5_fwd(ws + L.zfold, ws + u.z, ws + u.stats, N, u.Hout, u.Wout, s));
         FS_TRY(in_finalize(ws + u.stats, N, u.tiles, u.Cout, u.kind == 1 ? 4 : 1, params + u.g_off, params + u.b_off, 1e-3f,
                            ws + u.mean, ws + u.rstd, ws + u.a, ws + u.b, s));
         // what the next conv reads
@@ -335,7 +355,7 @@ static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, c
         a.Ho = u.Hin;
         a.Wo = u.Win;
         a.Cout = u.Cin;
-        a.KH = a.KW = u.K;
+        a.KH = a.KW = u.K;  // the input gradient uses the original square filter (also for the kw-folded unit)
         a.stride = 1;
         a.pad_t = u.K - 1 - u.pad_t;
         a.pad_l = u.K - 1 - u.pad_l;
@@ -355,9 +375,17 @@ static int unit_wgrad(const TnetLayout& L, const Unit& u, const float* xin, cons
     a.in_nstride = xa ? u.Cin : 0;
     a.in_relu = xa ? 1 : 0;
     a.dy = dz;
+    if (u.kind == 2) {  // unfold dY to [q][(v,co)] (fs_fold.hip); the Z buffer of the forward is free by now
+        FS_TRY(unfold5(dz, ws + L.zfold, L.N, u.Hout, u.Wout, s));
+        a.dy = ws + L.zfold;
+    }
     a.slabs = ws + L.slabs;
     FS_TRY(wgrad_launch(a, s));
     const size_t count = (size_t)a.p.K * a.Cout;
+    if (u.kind == 2) {
+        FS_TRY(reduce_slabs(ws + L.slabs, 1, a.p.n_slabs, count, 1.0f, ws + L.dwfold, s));
+        return wt_fold5_back(ws + L.dwfold, grads + u.w_off, u.Cin, s);
+    }
     if (u.kind == 1) {
         FS_TRY(reduce_slabs(ws + L.slabs, 1, a.p.n_slabs, count, 1.0f, ws + L.dweff, s));
         return wt_upconv_wgrad_fold(ws + L.dweff, grads + u.w_off, u.Cin, u.Cout, s);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         if (kb0 + q < p.KB && k < p.K) {
             const int tap = k / a.Cin, ci = k - tap * a.Cin;
             const int kh = tap / a.KW, kw = tap - kh * a.KW;
-            abase[q] = (kh * PW + kw) * S + (ci - cA);
+            abase[q] = (kh * PW + kw * a.dil_x) * S + (ci - cA);
             amul[q] = 1;
         }
     }
@@ -254,7 +254,7 @@ WgradPlan wgrad_plan(const WgradArgs& a) {
     p.tiles_y = cdiv(a.Ho, th);
     p.tiles_x = cdiv(a.Wo, tw);
     p.PH = (th - 1) * a.stride + a.KH;
-    p.PW = (tw - 1) * a.stride + a.KW;
+    p.PW = (tw - 1) * a.stride + (a.KW - 1) * (a.dil_x > 0 ? a.dil_x : 1) + 1;
     p.S = CS + 1;
     p.lds_bytes = 4 * (((p.PH * p.PW * p.S + 4 + 3) & ~3) + th * tw * DP);
     const int kblocks_w = cdiv(p.KB, p.KWV);  // k-blocks in units of one wave's share
@@ -280,7 +280,9 @@ static void launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL((conv_wgrad_kernel<KWV>), grid, dim3(256), (size_t)a.p.lds_bytes, s, a);
 }
 
-int wgrad_launch(const WgradArgs& a, hipStream_t s) {
+int wgrad_launch(const WgradArgs& a_in, hipStream_t s) {
+    WgradArgs a = a_in;
+    if (a.dil_x < 1) a.dil_x = 1;
     const WgradPlan& p = a.p;
     if (a.Cin > 128 && a.Cin % 128) return -1;
     if (p.lds_bytes > 160 * 1024) return -2;
