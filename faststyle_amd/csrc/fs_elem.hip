@@ -56,28 +56,32 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* stats, in
             for (int u = 0; u < 4; ++u) {
                 const double cb = vc[u], mb = vm[u], qb = vq[u];
                 if (cb > 0) {
-                    const double nn = cnt + cb, d = mb - mu;
-                    mu += d * cb / nn;
-                    m2 += qb + d * d * cnt * cb / nn;
+                    const double nn = cnt + cb, d = mb - mu, r = cb / nn;
+                    mu += d * r;
+                    m2 += qb + d * d * cnt * r;
                     cnt = nn;
                 }
             }
         }
     }
-    sc[threadIdx.x] = cnt;
-    sm[threadIdx.x] = mu;
-    sq[threadIdx.x] = m2;
-    __syncthreads();
-    if (lane == 0 && c < C) {
-        for (int j = 1; j < 64; ++j) {
-            const double cb = sc[w * 64 + j], mb = sm[w * 64 + j], qb = sq[w * 64 + j];
+    // fixed-shape tree over the 64 lanes of the channel (6 levels, one fp64 divide per merge)
+    for (int stride = 32; stride > 0; stride >>= 1) {
+        sc[threadIdx.x] = cnt;
+        sm[threadIdx.x] = mu;
+        sq[threadIdx.x] = m2;
+        __syncthreads();
+        if (lane < stride) {
+            const double cb = sc[threadIdx.x + stride], mb = sm[threadIdx.x + stride], qb = sq[threadIdx.x + stride];
             if (cb > 0) {
-                const double nn = cnt + cb, d = mb - mu;
-                mu += d * cb / nn;
-                m2 += qb + d * d * cnt * cb / nn;
+                const double nn = cnt + cb, d = mb - mu, r = cb / nn;
+                mu += d * r;
+                m2 += qb + d * d * cnt * r;
                 cnt = nn;
             }
         }
+        __syncthreads();
+    }
+    if (lane == 0 && c < C) {
         const float var = (float)(m2 / cnt);
         const float r = 1.0f / sqrtf(var + eps);
         const float fm = (float)mu;

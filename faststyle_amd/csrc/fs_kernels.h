@@ -59,7 +59,7 @@ struct WgradPlan {
     int K;        // KH*KW*Cin
     int KB;       // k-blocks of 32 (ceil)
     int NB;       // cout blocks of 32 (ceil)
-    int KWV;      // k-blocks per wave (1, 2 or 4); a wave owns KWV x (4/KWV) MFMA tiles
+    int KWV, NWV; // a wave owns KWV k-blocks x NWV co-blocks of 32x32 MFMA tiles
     int n_wg;     // workgroups per sample-group (each strides over the tile list)
     int waves_k;  // waves tiling the k dimension (1, 2, 4); the other 4/waves_k split the pixel rows
     int n_slabs;  // partial slabs per sample-group = n_wg * 4/waves_k

@@ -39,9 +39,8 @@ __device__ __forceinline__ bool wsrc_coord(int mode, int refl, int v, int n_src,
     }
 }
 
-template <int KWV>
+template <int KWV, int NWV>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
-    constexpr int NWV = 4 / KWV;
     HIP_DYNAMIC_SHARED(float, smem)
     const WgradPlan& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -94,8 +93,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const bool xvec = (a.Cin & 3) == 0;
     const int Cr = a.dy_unshuffle ? a.Cout >> 2 : a.Cout;
 
-    bool first = true;
-    for (int t = blockIdx.x; t < total; t += p.n_wg) {
+    // Tile loop.  Staging is BATCHED: 8 independent 16-byte global loads per thread are issued
+    // back to back, then transformed and written to LDS -- a plain "load, use" loop serialises on
+    // the ~1-2 us global latency per iteration (the vector paths below; the scalar paths only serve
+    // the 3-channel first layer and ragged channel counts).
+    constexpr int XB = 8;
+    const int c4n = CS >> 2;
+    const int ne_x = PH * PW * c4n;
+    const int j4n = DP >> 2;
+    const int ne_d = p.TH * p.TW * j4n;
+    const bool dvec = (Cr & 3) == 0 && co_g0 + DP <= a.Cout;
+
+    auto stage = [&](int t) {
         const int n = a.per_sample ? (int)blockIdx.z : t / tiles;
         const int tr = t % tiles;
         const int ty0 = (tr / p.tiles_x) * p.TH, tx0 = (tr % p.tiles_x) * p.TW;
@@ -103,43 +112,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         const float* xn = a.x + (size_t)n * a.H * a.W * a.Cin;
         const float* ia = has_ab ? a.in_a + (size_t)n * a.in_nstride : nullptr;
         const float* ib = has_ab ? a.in_b + (size_t)n * a.in_nstride : nullptr;
-        if (!first) __syncthreads();
-        first = false;
-        // ---- stage x patch ----
         if (xvec) {
-            const int c4n = CS >> 2;
-            for (int e = tid; e < PH * PW * c4n; e += 256) {
-                const int pix = e / c4n, c4 = e - pix * c4n;
-                const int py = pix / PW, px = pix - py * PW;
-                int sy, sx;
-                const bool ok = wsrc_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) &&
-                                wsrc_coord(a.src_mode, a.refl, vx0 + px, a.W, sx);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) {
-                    const int c = cA + c4 * 4;
-                    v = *reinterpret_cast<const float4*>(xn + ((size_t)sy * a.W + sx) * a.Cin + c);
-                    if (has_ab) {
-                        const float4 va = *reinterpret_cast<const float4*>(ia + c);
-                        const float4 vb = *reinterpret_cast<const float4*>(ib + c);
-                        v.x = fmaf(v.x, va.x, vb.x);
-                        v.y = fmaf(v.y, va.y, vb.y);
-                        v.z = fmaf(v.z, va.z, vb.z);
-                        v.w = fmaf(v.w, va.w, vb.w);
-                    }
-                    if (a.in_relu) {
-                        v.x = fmaxf(v.x, 0.f);
-                        v.y = fmaxf(v.y, 0.f);
-                        v.z = fmaxf(v.z, 0.f);
-                        v.w = fmaxf(v.w, 0.f);
+            for (int e0 = tid; e0 < ne_x; e0 += XB * 256) {
+                float4 xv[XB];
+                unsigned valid = 0;
+#pragma unroll
+                for (int i = 0; i < XB; ++i) {
+                    const int e = e0 + i * 256;
+                    xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < ne_x) {
+                        const int pix = e / c4n, c4 = e - pix * c4n;
+                        const int py = pix / PW, px = pix - py * PW;
+                        int sy, sx;
+                        if (wsrc_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) &&
+                            wsrc_coord(a.src_mode, a.refl, vx0 + px, a.W, sx)) {
+                            xv[i] = *reinterpret_cast<const float4*>(xn + ((size_t)sy * a.W + sx) * a.Cin + cA + c4 * 4);
+                            valid |= 1u << i;
+                        }
                     }
                 }
-                float* d = patch + pix * S + c4 * 4;
-                d[0] = v.x;
-                d[1] = v.y;
-                d[2] = v.z;
-                d[3] = v.w;
+#pragma unroll
+                for (int i = 0; i < XB; ++i) {
+                    const int e = e0 + i * 256;
+                    if (e >= ne_x) continue;
+                    const int pix = e / c4n, c4 = e - pix * c4n;
+                    float4 v = xv[i];
+                    if (valid & (1u << i)) {
+                        const int c = cA + c4 * 4;
+                        if (has_ab) {
+                            const float4 va = *reinterpret_cast<const float4*>(ia + c);
+                            const float4 vb = *reinterpret_cast<const float4*>(ib + c);
+                            v.x = fmaf(v.x, va.x, vb.x);
+                            v.y = fmaf(v.y, va.y, vb.y);
+                            v.z = fmaf(v.z, va.z, vb.z);
+                            v.w = fmaf(v.w, va.w, vb.w);
+                        }
+                        if (a.in_relu) {
+                            v.x = fmaxf(v.x, 0.f);
+                            v.y = fmaxf(v.y, 0.f);
+                            v.z = fmaxf(v.z, 0.f);
+                            v.w = fmaxf(v.w, 0.f);
+                        }
+                    }
+                    float* d = patch + pix * S + c4 * 4;
+                    d[0] = v.x;
+                    d[1] = v.y;
+                    d[2] = v.z;
+                    d[3] = v.w;
+                }
             }
-        } else {
+        } else {  // Cin == 3 (the first layer): scalar
             for (int e = tid; e < PH * PW * CS; e += 256) {
                 const int pix = e / CS, c = e - pix * CS;
                 const int py = pix / PW, px = pix - py * PW;
@@ -156,11 +178,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             }
         }
         if (tid < 4) patch[PH * PW * S + tid] = 0.f;
-        // ---- stage dY tile [TH*TW][DP] (zero outside the image / beyond Cout) ----
-        {
-            const int j4n = DP >> 2;
-            const bool vec = (Cr & 3) == 0;
-            for (int e = tid; e < p.TH * p.TW * j4n; e += 256) {
+        if (dvec) {
+            for (int e0 = tid; e0 < ne_d; e0 += XB * 256) {
+                float4 dv[XB];
+#pragma unroll
+                for (int i = 0; i < XB; ++i) {
+                    const int e = e0 + i * 256;
+                    dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < ne_d) {
+                        const int pix = e / j4n, j4 = e - pix * j4n;
+                        const int py = pix / p.TW, px = pix - py * p.TW;
+                        const int oy = ty0 + py, ox = tx0 + px;
+                        const int co = co_g0 + j4 * 4;
+                        if (oy < a.Ho && ox < a.Wo) {
+                            const float* src;
+                            if (a.dy_unshuffle) {
+                                const int q = co / Cr, cr = co - q * Cr;
+                                src = a.dy + (((size_t)n * 2 * a.Ho + 2 * oy + (q >> 1)) * (2 * a.Wo) + 2 * ox + (q & 1)) * Cr + cr;
+                            } else {
+                                src = a.dy + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+                            }
+                            dv[i] = *reinterpret_cast<const float4*>(src);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < XB; ++i) {
+                    const int e = e0 + i * 256;
+                    if (e < ne_d) *reinterpret_cast<float4*>(dyl + e * 4) = dv[i];
+                }
+            }
+        } else {  // ragged channel counts: scalar
+            for (int e = tid; e < ne_d; e += 256) {
                 const int pix = e / j4n, j4 = e - pix * j4n;
                 const int py = pix / p.TW, px = pix - py * p.TW;
                 const int oy = ty0 + py, ox = tx0 + px;
@@ -174,18 +223,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                     } else {
                         src = a.dy + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
                     }
-                    if (vec && co + 3 < a.Cout) {
-                        v = *reinterpret_cast<const float4*>(src);
-                    } else {
-                        v.x = src[0];
-                        if (co + 1 < a.Cout) v.y = src[1];
-                        if (co + 2 < a.Cout) v.z = src[2];
-                        if (co + 3 < a.Cout) v.w = src[3];
-                    }
+                    v.x = src[0];
+                    if (co + 1 < a.Cout) v.y = src[1];
+                    if (co + 2 < a.Cout) v.z = src[2];
+                    if (co + 3 < a.Cout) v.w = src[3];
                 }
-                *reinterpret_cast<float4*>(dyl + pix * DP + j4 * 4) = v;
+                *reinterpret_cast<float4*>(dyl + e * 4) = v;
             }
         }
+    };
+
+    bool first = true;
+    for (int t = blockIdx.x; t < total; t += p.n_wg) {
+        if (!first) __syncthreads();
+        first = false;
+        stage(t);
         __syncthreads();
         // ---- MFMA sweep over pixel pairs ----
         if (kb0 < p.KB) {
@@ -238,27 +290,46 @@ WgradPlan wgrad_plan(const WgradArgs& a) {
     p.K = a.KH * a.KW * a.Cin;
     p.KB = cdiv(p.K, 32);
     p.NB = cdiv(a.Cout, 32);
-    p.KWV = (p.NB >= 4 || a.Cin > 128) ? 1 : (p.NB >= 2 ? 2 : 4);
-    const int NWV = 4 / p.KWV;
-    // pixel tile: 128 pixels (256 when the staged tensors are narrow), even width
+    // a wave owns KWV k-blocks x NWV co-blocks of MFMA tiles: <1,4> wide outputs / Gram, <4,1> narrow
+    // outputs, <2,2> 64-channel outputs with short K, <5,2> the 3x3 64->64 filters (K = 576 = 18 k-blocks:
+    // one workgroup covers all of K, so the tile is staged once instead of once per k-group)
+    if (p.NB >= 4 || a.Cin > 128) {
+        p.KWV = 1;
+        p.NWV = 4;
+    } else if (p.NB >= 2) {
+        p.NWV = 2;
+        p.KWV = p.KB > 8 ? 5 : 2;
+    } else {
+        p.KWV = 4;
+        p.NWV = 1;
+    }
+    const int NWV = p.NWV;
+    // pixel tile: the largest of 256/128/64/32 pixels (even width) that keeps the staged patch + dY
+    // tile within ~80 KiB of LDS (two workgroups per CU) and a few batches of loads per thread
     const int CS = a.Cin <= 128 ? a.Cin : 128;
     const int DP = 32 * (p.NB < NWV ? p.NB : NWV);
-    const int max_px = (CS + DP <= 64) ? 256 : 128;
-    int tw = a.Wo >= 16 ? 16 : ((a.Wo + 1) & ~1);
-    tw = cdiv(cdiv(a.Wo, cdiv(a.Wo, tw)), 2) * 2;
-    int th = max_px / tw;
-    if (th > a.Ho) th = a.Ho;
-    th = cdiv(a.Ho, cdiv(a.Ho, th));
-    p.TH = th;
-    p.TW = tw;
-    p.tiles_y = cdiv(a.Ho, th);
-    p.tiles_x = cdiv(a.Wo, tw);
-    p.PH = (th - 1) * a.stride + a.KH;
-    p.PW = (tw - 1) * a.stride + (a.KW - 1) * (a.dil_x > 0 ? a.dil_x : 1) + 1;
-    p.S = CS + 1;
-    p.lds_bytes = 4 * (((p.PH * p.PW * p.S + 4 + 3) & ~3) + th * tw * DP);
+    const int dil = a.dil_x > 0 ? a.dil_x : 1;
+    for (int max_px = 256; max_px >= 32; max_px >>= 1) {
+        int tw = a.Wo >= 16 ? 16 : ((a.Wo + 1) & ~1);
+        tw = cdiv(cdiv(a.Wo, cdiv(a.Wo, tw)), 2) * 2;
+        int th = max_px / tw;
+        if (th < 1) th = 1;
+        if (th > a.Ho) th = a.Ho;
+        th = cdiv(a.Ho, cdiv(a.Ho, th));
+        p.TH = th;
+        p.TW = tw;
+        p.tiles_y = cdiv(a.Ho, th);
+        p.tiles_x = cdiv(a.Wo, tw);
+        p.PH = (th - 1) * a.stride + a.KH;
+        p.PW = (tw - 1) * a.stride + (a.KW - 1) * dil + 1;
+        p.S = CS + 1;
+        p.lds_bytes = 4 * (((p.PH * p.PW * p.S + 4 + 3) & ~3) + th * tw * DP);
+        const bool xfit = (a.Cin & 3) || p.PH * p.PW * (CS / 4) <= 16 * 256;
+        const bool dfit = th * tw * (DP / 4) <= 16 * 256;
+        if ((xfit && dfit && p.lds_bytes <= 80 * 1024) || max_px == 32) break;
+    }
     const int kblocks_w = cdiv(p.KB, p.KWV);  // k-blocks in units of one wave's share
-    p.waves_k = kblocks_w >= 4 ? 4 : (kblocks_w >= 2 ? 2 : 1);
+    p.waves_k = kblocks_w >= 3 ? 4 : (kblocks_w >= 2 ? 2 : 1);
     const int total = (a.per_sample ? 1 : a.N) * p.tiles_y * p.tiles_x;
     const int groups = cdiv(p.KB, p.waves_k * p.KWV) * cdiv(p.NB, NWV) * (a.per_sample ? a.N : 1);
     int want = env_int2("FS_WGRAD_WGS", 512) / groups;  // aim for ~2 workgroups per CU in flight
@@ -269,15 +340,15 @@ WgradPlan wgrad_plan(const WgradArgs& a) {
     return p;
 }
 
-template <int KWV>
+template <int KWV, int NWV>
 static void launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KWV>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KWV, NWV>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wgrad_kernel<KWV>), grid, dim3(256), (size_t)a.p.lds_bytes, s, a);
+    hipLaunchKernelGGL((conv_wgrad_kernel<KWV, NWV>), grid, dim3(256), (size_t)a.p.lds_bytes, s, a);
 }
 
 int wgrad_launch(const WgradArgs& a_in, hipStream_t s) {
@@ -286,16 +357,18 @@ int wgrad_launch(const WgradArgs& a_in, hipStream_t s) {
     const WgradPlan& p = a.p;
     if (a.Cin > 128 && a.Cin % 128) return -1;
     if (p.lds_bytes > 160 * 1024) return -2;
-    const int NWV = 4 / p.KWV;
+    const int NWV = p.NWV;
     dim3 grid((unsigned)p.n_wg, (unsigned)(cdiv(p.KB, p.waves_k * p.KWV) * cdiv(p.NB, NWV)), (unsigned)(a.per_sample ? a.N : 1));
     Profiler* prof = Profiler::current();
     if (prof) prof->begin(3, 2.0 * a.N * a.Ho * a.Wo * (double)p.K * a.Cout, s);
     if (p.KWV == 1)
-        launch_wgrad<1>(a, grid, s);
+        launch_wgrad<1, 4>(a, grid, s);
     else if (p.KWV == 2)
-        launch_wgrad<2>(a, grid, s);
+        launch_wgrad<2, 2>(a, grid, s);
+    else if (p.KWV == 5)
+        launch_wgrad<5, 2>(a, grid, s);
     else
-        launch_wgrad<4>(a, grid, s);
+        launch_wgrad<4, 1>(a, grid, s);
     if (prof) prof->end(s);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
