@@ -169,6 +169,14 @@ def main():
         di = max(range(6), key=lambda f: fam[f][2])       # dominant = most GPU time in the timed region
         dom = fam[di]
         achieved = dom[1] / (dom[2] * 1e-3) / 1e12 if dom[2] > 0 else 0.0
+        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the
+        # figure comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
+        if os.path.exists(tpath):
+            k = json.load(open(tpath)).get("kernels", {}).get(names[di])
+            if k:
+                traffic, traffic_src = k["traffic_bytes_per_launch"], "profiles/r01_hbm_traffic_pmc.json"
         mfma_flops = sum(f[1] for f in fam)
         mfma_ms = sum(f[2] for f in fam)
         out = {
@@ -184,7 +192,8 @@ def main():
                        "style_image": "starry_night_crop.jpg 640x938"},
             "roofline": {"bound": "mfma", "kernel": names[di] + " (fp32 MFMA implicit-GEMM conv)",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE, KiB counters)", "traffic_source": traffic_src,
                          "timed_with": "HIP events on the launch stream, " + ("eager pass of the same K steps right after "
                                        "the hipGraph-replayed timed region" if graphed else "inside the timed region"),
                          "launches_per_step": round(dom[0] / args.steps, 1),

@@ -120,6 +120,9 @@ def load():
     """Load the in-tree HIP library (built for gfx950).  Fails loudly when it is absent."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm ships its own libamdhip64; import it FIRST so this library binds to the same
+        # HIP runtime instance (two runtimes in one process cannot both own the device).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise FaststyleError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

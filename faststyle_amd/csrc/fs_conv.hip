@@ -439,6 +439,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int ap = a.add_pad;
     const int aW = a.Wo - 2 * ap;
     const float* asn = a.add_src ? a.add_src + (size_t)n * (a.Ho - 2 * ap) * aW * a.Cout : nullptr;
+    const float* msn = a.mask_src ? a.mask_src + (size_t)n * a.Ho * a.Wo * a.Cout : nullptr;
     int cof[WN], qa[WN], qb[WN];  // per n-tile: channel offset inside a pixel, pixel-shuffle phase
     float bs[WN];
     bool cok[WN];
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                     o = ((2 * oy + qa[nn]) * (2 * a.Wo) + 2 * ox + qb[nn]) * Cr + cof[nn];
                 else
                     o = poff + cof[nn];
+                if (msn) v = msn[o] > 0.f ? v : 0.f;
                 yn[o] = v;
             }
         }

@@ -50,6 +50,7 @@ struct ConvArgs {
     float* stats;          // optional per-tile {mean, M2, count} partials [N*tiles][Cout][3]
     const float* add_src;  // optional residual [N,Ho-2*add_pad,Wo-2*add_pad,Cout] added in the interior
     int add_pad;
+    const float* mask_src;  // optional [N,Ho,Wo,Cout]: after the add, v = mask_src > 0 ? v : 0 (ReLU gradient of the consumer)
     long long w_nstride;
     ConvPlan p;
 };

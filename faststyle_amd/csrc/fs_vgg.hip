@@ -207,12 +207,10 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
     }
 
     // ---- backward ----
-    const float* d_above = nullptr;
-    int di = 0;
-    for (int l = L.lmax; l >= 0; --l) {
+    // tap gradient of layer l (content term first, the style term accumulates through add_src)
+    auto compute_tap = [&](int l, const float** out) -> int {
         const int C = kCout[l], H = L.Hl[l], W = L.Wl[l];
         const size_t act_n = (size_t)N * H * W * C;  // the y half
-        // tap gradient of this layer (content first, then the style term accumulates through add_src)
         const float* tap = nullptr;
         for (int i = 0; i < cfg.n_content; ++i)
             if (cfg.content_layer[i] == l) {
@@ -243,12 +241,23 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
                 FS_TRY(conv_launch(a, s));
                 tap = dst;
             }
-        if (!d_above && !tap) continue;  // nothing flows into this layer (cannot happen for lmax)
-        const bool pooled = d_above && pool_after(l);
-        FS_TRY(vgg_bwd_route(ws + L.act[l], d_above, tap, pooled ? 1 : 0, ws + L.d_pre, N, H, W, C, s));
-        // input gradient of conv l
+        *out = tap;
+        return 0;
+    };
+    // d_pre[l] = (gradient reaching act[l]) * (act[l] > 0).  For the last layer it is the tap gradient alone;
+    // below, the dgrad conv of layer l either writes d_pre[l-1] directly (no pool in between: tap add and
+    // ReLU mask fused into its epilogue) or writes the pooled gradient that vgg_bwd_route scatters.
+    float* pre_cur = ws + L.d_pre;
+    float* pre_nxt = ws + L.d_in[0];
+    {
+        const float* tap = nullptr;
+        FS_TRY(compute_tap(L.lmax, &tap));
+        FS_TRY(vgg_bwd_route(ws + L.act[L.lmax], nullptr, tap, 0, pre_cur, N, L.Hl[L.lmax], L.Wl[L.lmax], kCout[L.lmax], s));
+    }
+    for (int l = L.lmax; l >= 0; --l) {
+        const int C = kCout[l], H = L.Hl[l], W = L.Wl[l];
         ConvArgs a{};
-        a.x = ws + L.d_pre;
+        a.x = pre_cur;
         a.w = prepared + prepared_offset(l);
         a.N = N;
         a.H = a.Ho = H;
@@ -258,11 +267,30 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         a.KH = a.KW = 3;
         a.stride = 1;
         a.pad_t = a.pad_l = 1;
-        a.y = l == 0 ? dy : ws + L.d_in[di];
-        a.p = conv_plan(a);
-        FS_TRY(conv_launch(a, s));
-        d_above = ws + L.d_in[di];
-        di ^= 1;
+        if (l == 0) {
+            a.y = dy;
+            a.p = conv_plan(a);
+            FS_TRY(conv_launch(a, s));
+            break;
+        }
+        const float* tap = nullptr;
+        FS_TRY(compute_tap(l - 1, &tap));
+        if (!pool_after(l - 1)) {
+            a.y = pre_nxt;
+            a.add_src = tap;
+            a.add_pad = 0;
+            a.mask_src = ws + L.act[l - 1];
+            a.p = conv_plan(a);
+            FS_TRY(conv_launch(a, s));
+        } else {
+            a.y = ws + L.d_in[1];
+            a.p = conv_plan(a);
+            FS_TRY(conv_launch(a, s));
+            FS_TRY(vgg_bwd_route(ws + L.act[l - 1], ws + L.d_in[1], tap, 1, pre_nxt, N, L.Hl[l - 1], L.Wl[l - 1], kCout[l - 1], s));
+        }
+        float* t = pre_cur;
+        pre_cur = pre_nxt;
+        pre_nxt = t;
     }
     // TV term on y itself (reference losses.py:70-97, train.py:183-184); beta defaults to 0
     if (cfg.beta != 0.0f)

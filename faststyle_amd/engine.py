@@ -61,8 +61,8 @@ def default_loss_cfg():
 
 class Engine(object):
     def __init__(self, mem=None, lib=None):
+        self.mem = mem if mem is not None else TorchMem()      # initialises the HIP runtime PyTorch ships
         self.lib = lib if lib is not None else L.load()
-        self.mem = mem if mem is not None else TorchMem()
         ctx = ctypes.c_void_p()
         L.check(self.lib, self.lib.fs_ctx_create(self.mem.device_index(), ctypes.c_void_p(self.mem.stream()),
                                                  ctypes.byref(ctx)), "fs_ctx_create")

@@ -1,0 +1,81 @@
+"""The drop-in command lines on the GPU: stylize_image.py reproduces the reference's shipped golden
+(README.md:5-18); train.py runs the reference's loop (checkpoint names, logging cadence, final model)
+and its final checkpoint loads back through stylize_image.py."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests.imgutil import load_rgb, psnr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cli_flags_match_reference():
+    """Flag names/defaults of the reference's argparse (stylize_image.py:24-42, train.py:27-104)."""
+    sys.path.insert(0, ROOT)
+    import stylize_image
+    import train
+    s = vars(stylize_image.setup_parser().parse_args(["--input_img_path", "x.jpg"]))
+    assert s == {"input_img_path": "x.jpg", "output_img_path": "./results/styled.jpg",
+                 "model_path": "./models/starry_final.ckpt", "content_target_resize": 1.0, "upsample_method": "resize"}
+    t = vars(train.setup_parser().parse_args([]))
+    assert t == {"train_dir": None, "model_name": None, "style_img_path": "./style_images/starry_night_crop.jpg",
+                 "learn_rate": 1e-3, "batch_size": 4, "n_epochs": 2, "preprocess_size": [256, 256], "run_name": None,
+                 "loss_content_layers": ["conv3_3"], "loss_style_layers": ["conv1_2", "conv2_2", "conv3_3", "conv4_3"],
+                 "content_weights": [1.0], "style_weights": [5.0, 5.0, 5.0, 5.0], "num_steps_ckpt": 1000,
+                 "num_pipe_buffer": 4000, "num_steps_break": -1, "beta": 0.0, "style_target_resize": 1.0,
+                 "upsample_method": "resize"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("style", ["starry", "candy"])
+def test_stylize_image_cli_reproduces_golden(tmp_path, style, capsys):
+    # run in-process (main(argv)): the GPU boxes refuse a second process on the device while pytest holds it
+    sys.path.insert(0, ROOT)
+    import stylize_image
+    out = str(tmp_path / "styled.jpg")
+    stylize_image.main(["--input_img_path", os.path.join(ROOT, "tests", "golden", "ref_assets", "chicago.jpg"),
+                        "--output_img_path", out, "--model_path", os.path.join(ROOT, "models", style + "_final.ckpt")])
+    lines = [l for l in capsys.readouterr().out.splitlines() if l and "amdgpu" not in l]
+    assert lines == ["Loading up model...", "Evaluating...", "Saving image.", "Done."]      # stylize_image.py:72-82
+    got = load_rgb(out)
+    gold = load_rgb(os.path.join(ROOT, "tests", "golden", "ref_assets", style + "_chicago.jpg"))
+    assert got.shape == gold.shape == (476, 712, 3)
+    assert psnr(got, gold) >= 63.0 and (got == gold).mean() >= 0.985
+
+
+@pytest.mark.gpu
+def test_train_cli_runs_reference_loop(tmp_path, monkeypatch, capsys):
+    from faststyle_amd import ckpt, vgg16
+    sys.path.insert(0, ROOT)
+    import stylize_image
+    import train
+    work = tmp_path
+    (work / "libs").mkdir()
+    np.savez(str(work / "libs" / "vgg16_weights.npz"), **vgg16.synthetic_weights(3))     # train.py:148 reads it from CWD
+    monkeypatch.chdir(work)
+    train.main(train.setup_parser().parse_args(
+        ["--train_dir", "synthetic", "--model_name", "t",
+         "--style_img_path", os.path.join(ROOT, "style_images", "starry_night_crop.jpg"),
+         "--style_target_resize", "0.25", "--preprocess_size", "128", "128", "--batch_size", "2",
+         "--num_steps_break", "11", "--num_steps_ckpt", "10"]))
+    out = [l for l in capsys.readouterr().out.splitlines() if l and "amdgpu" not in l]
+    assert out[0] == "Precomputing target style layers." and "Starting training..." in out and out[-1] == "Done training."
+    steps = [int(l.split()[0]) for l in out if l.split()[0].isdigit()]
+    assert steps == [0, 10]                                                    # printed every 10 steps (train.py:265-272)
+    assert os.path.exists(str(work / "training" / "t.ckpt-0.index")) and os.path.exists(str(work / "training" / "t.ckpt-10.index"))
+    final = ckpt.load_checkpoint(str(work / "models" / "t_final.ckpt"))        # train.py:286
+    assert len(final) == 48 and all(k.startswith("img_t_net/") for k in final)
+    full = ckpt.load_checkpoint(str(work / "training" / "t.ckpt-10"))
+    assert int(full["global_step"]) == 10 and "img_t_net/initconv_0/W/Adam" in full
+    logs = [json.loads(l) for l in open(str(work / "summaries" / "train" / "t0" / "scalars.jsonl"))]
+    assert [d["step"] for d in logs] == [0, 10] and logs[1]["loss"] < logs[0]["loss"]
+    # the final model is a valid stylize_image.py --model_path
+    outimg = str(work / "o.jpg")
+    stylize_image.main(["--input_img_path", os.path.join(ROOT, "tests", "golden", "ref_assets", "chicago.jpg"),
+                        "--output_img_path", outimg, "--model_path", str(work / "models" / "t_final.ckpt"),
+                        "--content_target_resize", "0.25"])
+    assert load_rgb(outimg).shape[2] == 3
