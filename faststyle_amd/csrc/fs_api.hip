@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 #include "fs_tnet.h"
@@ -14,6 +15,9 @@ struct fs_ctx {
     // cached layouts (recomputed when the shape changes)
     fs::TnetLayout tnet;
     bool tnet_valid;
+    hipStream_t side;      // second stream for the filter-gradient branch of fs_tnet_backward
+    hipEvent_t ev[34];
+    bool have_side;
 };
 
 static thread_local char g_err[512] = "";
@@ -37,10 +41,22 @@ int fs_ctx_create(int device, void* hip_stream, fs_ctx** out) {
     c->device = device;
     c->stream = (hipStream_t)hip_stream;
     c->tnet_valid = false;
+    c->have_side = false;
+    if (!getenv("FS_NO_SIDE_STREAM") && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess) {
+        c->have_side = true;
+        for (int i = 0; i < 34; ++i)
+            if (hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) != hipSuccess) c->have_side = false;
+    }
     *out = c;
     return 0;
 }
-void fs_ctx_destroy(fs_ctx* ctx) { delete ctx; }
+void fs_ctx_destroy(fs_ctx* ctx) {
+    if (ctx && ctx->have_side) {
+        for (int i = 0; i < 34; ++i) (void)hipEventDestroy(ctx->ev[i]);
+        (void)hipStreamDestroy(ctx->side);
+    }
+    delete ctx;
+}
 int fs_ctx_set_stream(fs_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(-1, "null ctx");
     ctx->stream = (hipStream_t)hip_stream;
@@ -118,7 +134,8 @@ int fs_tnet_backward(fs_ctx* ctx, const float* params, const float* x, const flo
     if (N < 1 || H < 41 || W < 41) return fail(-2, "fs_tnet_backward: need N>=1 and H,W>=41");
     const fs::TnetLayout* L = get_layout(ctx, N, H, W);
     if (ws_bytes < L->total_floats * sizeof(float)) return fail(-3, "fs_tnet_backward: workspace too small");
-    const int rc = fs::tnet_backward(*L, params, x, dy, grads, (float*)ws, ctx->stream);
+    fs::StreamAux aux{ctx->side, ctx->ev, 34};
+    const int rc = fs::tnet_backward(*L, params, x, dy, grads, (float*)ws, ctx->stream, ctx->have_side ? &aux : nullptr);
     return rc ? fail(rc, "fs_tnet_backward: launch failed (%d)", rc) : 0;
 }
 

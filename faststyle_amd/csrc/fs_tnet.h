@@ -38,14 +38,21 @@ struct TnetLayout {
     size_t weff[2];   // collapsed resize-conv filters
     size_t zfold, wfold, dwfold;  // kw-folded output layer: Z / unfolded dY [N,Ho,Wo+4,16], filters, filter grads
     size_t fwd_floats;
-    size_t g[3], dz, wT, dweff, inbwd, slabs;  // backward scratch
+    size_t g[3], dz[2], wT, dweff, inbwd, slabs;  // backward scratch (dz double-buffered: filter gradients run on a side stream)
     size_t total_floats;
 };
 
 void tnet_layout(int N, int H, int W, TnetLayout* L);
 WgradArgs unit_wgrad_args(const Unit& u, int N);
 int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s);
+// Optional second stream + events: the filter gradients of unit i only need dz_i, so they run concurrently
+// with the input-gradient chain of the units below (both are small launches at batch 4).
+struct StreamAux {
+    hipStream_t side;
+    hipEvent_t* ev;
+    int nev;
+};
 int tnet_backward(const TnetLayout& L, const float* params, const float* x, const float* dy, float* grads, float* ws,
-                  hipStream_t s);
+                  hipStream_t s, const StreamAux* aux);
 
 }  // namespace fs

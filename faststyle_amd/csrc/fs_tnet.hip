@@ -230,7 +230,8 @@ void tnet_layout(int N, int H, int W, TnetLayout* L) {
     L->fwd_floats = b.off;
     // ---- backward scratch ----
     for (int k = 0; k < 3; ++k) L->g[k] = b.take(max_act);
-    L->dz = b.take(max_act);
+    L->dz[0] = b.take(max_act);
+    L->dz[1] = b.take(max_act);
     L->wT = b.take(81 * 16 * 3 > 9 * 64 * 64 ? 81 * 16 * 3 : 9 * 64 * 64);
     L->dweff = b.take(4 * 64 * 128);
     L->inbwd = b.take(max_inbwd);
@@ -394,13 +395,17 @@ static int unit_wgrad(const TnetLayout& L, const Unit& u, const float* xin, cons
 }
 
 int tnet_backward(const TnetLayout& L, const float* params, const float* x, const float* dy, float* grads, float* ws,
-                  hipStream_t s) {
+                  hipStream_t s, const StreamAux* aux) {
     const int N = L.N;
+    const bool fork = aux && aux->side && aux->nev >= 34;
+    hipStream_t ws_stream = fork ? aux->side : s;  // stream of the filter-gradient branch
     const float* g = dy;         // gradient wrt the current unit's output activation (or h_k)
     const float* res_g = nullptr;  // d h_k, kept alive until the block's first conv adds it to its dgrad
-    float* dz = ws + L.dz;
     for (int i = 15; i >= 0; --i) {
         const Unit& u = L.u[i];
+        float* dz = ws + L.dz[i & 1];
+        // dz[i&1] was last read by the filter gradient of unit i+2 on the side stream
+        if (fork && i + 2 <= 15 && hipStreamWaitEvent(s, aux->ev[16 + i + 2], 0) != hipSuccess) return -20;
         const bool res2 = i >= 4 && i <= 12 && ((i - 3) & 1);       // second conv of a block (no activation)
         const bool res1 = i >= 3 && i <= 11 && ((i - 3) & 1) == 0;  // first conv of a block
         if (res2) res_g = g;
@@ -426,7 +431,11 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
             xa = ws + L.u[i - 1].a;
             xb = ws + L.u[i - 1].b;
         }
-        FS_TRY(unit_wgrad(L, u, xin, xa, xb, dz, grads, ws, s));
+        if (fork) {  // dz_i ready -> side stream computes dW_i while this stream continues with the input gradient
+            if (hipEventRecord(aux->ev[i], s) != hipSuccess || hipStreamWaitEvent(ws_stream, aux->ev[i], 0) != hipSuccess) return -20;
+        }
+        FS_TRY(unit_wgrad(L, u, xin, xa, xb, dz, grads, ws, ws_stream));
+        if (fork && hipEventRecord(aux->ev[16 + i], ws_stream) != hipSuccess) return -20;
         if (i == 0) break;
         float* dst = nullptr;
         for (int k = 0; k < 3; ++k) {
@@ -439,6 +448,9 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
         FS_TRY(unit_dgrad(L, u, params, dz, dst, res1 ? res_g : nullptr, ws, s));
         if (res1) res_g = nullptr;
         g = dst;
+    }
+    if (fork) {  // join: every filter gradient done before the caller's stream proceeds (events 16..31 are ordered on the side stream)
+        if (hipStreamWaitEvent(s, aux->ev[16 + 0], 0) != hipSuccess) return -20;
     }
     return 0;
 }
