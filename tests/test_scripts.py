@@ -79,3 +79,24 @@ def test_train_cli_runs_reference_loop(tmp_path, monkeypatch, capsys):
                         "--output_img_path", outimg, "--model_path", str(work / "models" / "t_final.ckpt"),
                         "--content_target_resize", "0.25"])
     assert load_rgb(outimg).shape[2] == 3
+
+
+@pytest.mark.gpu
+def test_autograd_glue_matches_direct_calls():
+    """loss.backward() through the torch.autograd wrappers == the direct C-ABI call sequence."""
+    import torch
+    from faststyle_amd import autograd as fa, engine, im_transf_net, vgg16
+    e = engine.Engine()
+    e.vgg_load(vgg16.synthetic_weights(3))
+    cfg = engine.default_loss_cfg()
+    rng = np.random.default_rng(0)
+    tg = e.style_targets(e.mem.from_numpy(rng.uniform(0, 255, (1, 64, 80, 3)).astype(np.float32)), cfg)
+    X = e.mem.from_numpy(rng.uniform(0, 255, (2, 64, 64, 3)).astype(np.float32))
+    flat = e.mem.from_numpy(e.flatten_params(im_transf_net.initial_variables(0), scope=""))
+    v = flat.clone().requires_grad_(True)
+    loss = fa.PerceptualLoss.apply(fa.TransformNet.apply(v, X, e), X, e, tg, cfg)
+    loss.backward()
+    y = e.tnet_forward(flat, X, save_for_bwd=True)
+    losses, dy = e.perceptual_loss(y, X, tg, cfg)
+    g = e.tnet_backward(flat, X, dy)
+    assert torch.equal(v.grad, g) and float(loss) == float(losses[0])
