@@ -16,6 +16,7 @@ FS_TNET_NPARAMS = 424102
 FS_TNET_NTENSORS = 48
 FS_VGG_NLAYERS = 10
 FS_FLAG_SAVE_FOR_BWD = 1
+FS_FLAG_UPSAMPLE_DECONV = 2
 FS_PAD_SAME, FS_PAD_VALID, FS_PAD_EXPLICIT = 0, 1, 2
 FS_SRC_PLAIN, FS_SRC_REFLECT, FS_SRC_DILATE2 = 0, 1, 2
 
@@ -70,7 +71,8 @@ PROTOTYPES = {
     "fs_tnet_out_shape": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "fs_tnet_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "fs_tnet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_int]),
-    "fs_tnet_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t]),
+    "fs_tnet_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                 c_int]),
     "fs_vgg_prepared_floats": (c_size_t, []),
     "fs_vgg_prepare": (c_int, [c_void_p, POINTER(_vp10), c_void_p]),
     "fs_perceptual_workspace_bytes": (c_size_t, [c_int, c_int, c_int, POINTER(fs_loss_cfg)]),

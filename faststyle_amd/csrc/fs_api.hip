@@ -100,28 +100,27 @@ int fs_tnet_out_shape(int H, int W, int* Ho, int* Wo) {
     return 0;
 }
 
-static const fs::TnetLayout* get_layout(fs_ctx* ctx, int N, int H, int W) {
-    if (!ctx->tnet_valid || ctx->tnet.N != N || ctx->tnet.H != H || ctx->tnet.W != W) {
-        fs::tnet_layout(N, H, W, &ctx->tnet);
+static const fs::TnetLayout* get_layout(fs_ctx* ctx, int N, int H, int W, int flags) {
+    const int deconv = (flags & FS_FLAG_UPSAMPLE_DECONV) ? 1 : 0;
+    if (!ctx->tnet_valid || ctx->tnet.N != N || ctx->tnet.H != H || ctx->tnet.W != W || ctx->tnet.deconv != deconv) {
+        fs::tnet_layout(N, H, W, deconv, &ctx->tnet);
         ctx->tnet_valid = true;
     }
     return &ctx->tnet;
 }
 
 size_t fs_tnet_workspace_bytes(int N, int H, int W, int flags) {
-    (void)flags;
     if (N < 1 || H < 41 || W < 41) return 0;
     fs::TnetLayout L;
-    fs::tnet_layout(N, H, W, &L);
+    fs::tnet_layout(N, H, W, (flags & FS_FLAG_UPSAMPLE_DECONV) ? 1 : 0, &L);
     return L.total_floats * sizeof(float);
 }
 
 int fs_tnet_forward(fs_ctx* ctx, const float* params, const float* x, int N, int H, int W, float* y, void* ws,
                     size_t ws_bytes, int flags) {
-    (void)flags;
     if (!ctx || !params || !x || !y || !ws) return fail(-1, "fs_tnet_forward: null argument");
     if (N < 1 || H < 41 || W < 41) return fail(-2, "fs_tnet_forward: need N>=1 and H,W>=41 (got %d,%d,%d)", N, H, W);
-    const fs::TnetLayout* L = get_layout(ctx, N, H, W);
+    const fs::TnetLayout* L = get_layout(ctx, N, H, W, flags);
     if (ws_bytes < L->total_floats * sizeof(float))
         return fail(-3, "fs_tnet_forward: workspace too small (%zu < %zu bytes)", ws_bytes, L->total_floats * sizeof(float));
     const int rc = fs::tnet_forward(*L, params, x, y, (float*)ws, ctx->stream);
@@ -129,10 +128,10 @@ int fs_tnet_forward(fs_ctx* ctx, const float* params, const float* x, int N, int
 }
 
 int fs_tnet_backward(fs_ctx* ctx, const float* params, const float* x, const float* dy, int N, int H, int W, float* grads,
-                     void* ws, size_t ws_bytes) {
+                     void* ws, size_t ws_bytes, int flags) {
     if (!ctx || !params || !x || !dy || !grads || !ws) return fail(-1, "fs_tnet_backward: null argument");
     if (N < 1 || H < 41 || W < 41) return fail(-2, "fs_tnet_backward: need N>=1 and H,W>=41");
-    const fs::TnetLayout* L = get_layout(ctx, N, H, W);
+    const fs::TnetLayout* L = get_layout(ctx, N, H, W, flags);
     if (ws_bytes < L->total_floats * sizeof(float)) return fail(-3, "fs_tnet_backward: workspace too small");
     fs::StreamAux aux{ctx->side, ctx->ev, 34};
     const int rc = fs::tnet_backward(*L, params, x, dy, grads, (float*)ws, ctx->stream, ctx->have_side ? &aux : nullptr);

@@ -78,6 +78,9 @@ struct WgradArgs {
     const float* in_a;
     const float* in_b;
     int in_nstride, in_relu;
+    const float* dy_a;  // optional affine+ReLU applied to dy on load (deconv filter gradient: dy is an activation)
+    const float* dy_b;
+    int dy_nstride, dy_relu;
     int per_sample;   // 1: Gram-style, one result per n; 0: summed over the batch
     int dy_unshuffle; // dy is [N,2Ho,2Wo,Cout/4]; read it as the 2x2 pixel-unshuffled [N,Ho,Wo,Cout]
     WgradPlan p;

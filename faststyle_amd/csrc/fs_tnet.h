@@ -16,8 +16,11 @@ const ParamInfo* param_table();  // 48 entries, checkpoint key order
 struct Unit {
     int kind;  // 0: conv, 1: phase-collapsed resize-conv (2x2 taps, pixel-shuffle store),
                // 2: kw-folded 9x9 -> 3-channel output layer (fs_fold.hip)
+               // 3: conv2d_transpose (--upsample_method deconv, im_transf_net.py:158-190): the forward is the
+               //    input-gradient kernel call of a stride-`dstride` conv with filter [K,K,Cout,Cin]
     int K, stride, Cin, Cout;
     int KWx, dil_x;    // horizontal taps / tap spacing the conv kernel sees (K / 1 except kind 2: 2 / 5)
+    int dstride, dpad_t, dpad_l;  // kind 3: stride and SAME padding of the conv whose transpose this is
     int Cc;            // channels the conv kernel produces (4*Cout for kind 1)
     int Hsrc, Wsrc;    // tensor the conv kernel reads (the unpadded image for initconv_0)
     int Hin, Win;      // conv input extent (after reflect padding)
@@ -33,6 +36,7 @@ struct Unit {
 
 struct TnetLayout {
     int N, H, W, Hy, Wy;
+    int deconv;       // upsample_method == 'deconv'
     Unit u[16];
     size_t h[5];      // residual block outputs
     size_t weff[2];   // collapsed resize-conv filters
@@ -42,7 +46,7 @@ struct TnetLayout {
     size_t total_floats;
 };
 
-void tnet_layout(int N, int H, int W, TnetLayout* L);
+void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L);
 WgradArgs unit_wgrad_args(const Unit& u, int N);
 int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s);
 // Optional second stream + events: the filter gradients of unit i only need dz_i, so they run concurrently

@@ -105,8 +105,9 @@ static ConvArgs unit_args(const Unit& u, int N) {
     return a;
 }
 
-void tnet_layout(int N, int H, int W, TnetLayout* L) {
+void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
     memset(L, 0, sizeof(*L));
+    L->deconv = deconv;
     L->N = N;
     L->H = H;
     L->W = W;
@@ -178,6 +179,22 @@ void tnet_layout(int N, int H, int W, TnetLayout* L) {
         snprintf(l, sizeof(l), "upsample_%d", k);
         const int Cin = k == 0 ? 64 : 32, Cout = k == 0 ? 32 : 16;
         Unit& u = conv_unit(l, "W", "INscale", "INshift", 3, 1, Cin, Cout, 0, h, w);
+        if (deconv) {  // conv2d_transpose 3x3 stride 2: zero-dilated input, flipped filter, pad K-1-pad_f
+            u.kind = 3;
+            u.dstride = 2;
+            int dummy;
+            same_pads(2 * h, 3, 2, &dummy, &u.dpad_t);
+            same_pads(2 * w, 3, 2, &dummy, &u.dpad_l);
+            u.src_mode = SRC_DILATE2;
+            u.stride = 1;
+            u.pad_t = 2 - u.dpad_t;
+            u.pad_l = 2 - u.dpad_l;
+            u.Hc = u.Hout = 2 * h;
+            u.Wc = u.Wout = 2 * w;
+            h = u.Hout;
+            w = u.Wout;
+            continue;
+        }
         u.kind = 1;
         u.K = 2;
         u.KWx = 2;
@@ -192,11 +209,20 @@ void tnet_layout(int N, int H, int W, TnetLayout* L) {
     }
     {  // output layer: 9x9, 16 -> 3, computed kw-folded (fs_fold.hip): 9x2 taps, spacing 5, 16 virtual channels
         Unit& u = conv_unit("upsample_2", "W", "INscale", "INshift", 9, 1, 16, 3, 0, h, w);
+        if (deconv) {  // conv2d_transpose 9x9 stride 1 == conv with the flipped/transposed filter
+            u.kind = 3;
+            u.dstride = 1;
+            u.dpad_t = u.pad_t;
+            u.dpad_l = u.pad_l;
+            u.pad_t = 8 - u.dpad_t;
+            u.pad_l = 8 - u.dpad_l;
+        } else {
         u.kind = 2;
         u.KWx = 2;
         u.dil_x = 5;
         u.Cc = 16;
         u.Wc = u.Wout + 4;
+        }
     }
     L->Hy = h;
     L->Wy = w;
@@ -249,6 +275,20 @@ void tnet_layout(int N, int H, int W, TnetLayout* L) {
 WgradArgs unit_wgrad_args(const Unit& u, int N) {
     WgradArgs a{};
     a.N = N;
+    if (u.kind == 3) {  // roles swapped: the 'input' is the (larger) output gradient, the 'grad' the unit's input
+        a.H = u.Hout;
+        a.W = u.Wout;
+        a.Cin = u.Cout;
+        a.Ho = u.Hin;
+        a.Wo = u.Win;
+        a.Cout = u.Cin;
+        a.KH = a.KW = u.K;
+        a.stride = u.dstride;
+        a.pad_t = u.dpad_t;
+        a.pad_l = u.dpad_l;
+        a.dil_x = 1;
+        return a;
+    }
     a.H = u.Hsrc;
     a.W = u.Wsrc;
     a.Cin = u.Cin;
@@ -277,9 +317,15 @@ WgradArgs unit_wgrad_args(const Unit& u, int N) {
 int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s) {
     const int N = L.N;
     // collapsed resize-conv filters (weights may have changed since the last call: training)
-    FS_TRY(wt_upconv_fwd(params + L.u[13].w_off, ws + L.weff[0], 64, 32, s));
-    FS_TRY(wt_upconv_fwd(params + L.u[14].w_off, ws + L.weff[1], 32, 16, s));
-    FS_TRY(wt_fold5_fwd(params + L.u[15].w_off, ws + L.wfold, 16, s));
+    if (L.deconv) {  // filters are stored [K,K,Cout,Cin]: flip + transpose into the [tap][Cin][Cout] the kernel reads
+        FS_TRY(wt_flip_transpose(params + L.u[13].w_off, ws + L.weff[0], 3, 3, 32, 64, s));
+        FS_TRY(wt_flip_transpose(params + L.u[14].w_off, ws + L.weff[1], 3, 3, 16, 32, s));
+        FS_TRY(wt_flip_transpose(params + L.u[15].w_off, ws + L.wfold, 9, 9, 3, 16, s));
+    } else {
+        FS_TRY(wt_upconv_fwd(params + L.u[13].w_off, ws + L.weff[0], 64, 32, s));
+        FS_TRY(wt_upconv_fwd(params + L.u[14].w_off, ws + L.weff[1], 32, 16, s));
+        FS_TRY(wt_fold5_fwd(params + L.u[15].w_off, ws + L.wfold, 16, s));
+    }
     const float* src = x;
     const float* src_a = nullptr;
     const float* src_b = nullptr;
@@ -292,7 +338,7 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
         a.in_b = src_b;
         a.in_nstride = src_a ? u.Cin : 0;
         a.in_relu = src_a ? 1 : 0;
-        a.w = u.kind == 1 ? ws + L.weff[i - 13] : (u.kind == 2 ? ws + L.wfold : params + u.w_off);
+        a.w = (u.kind == 1 || (u.kind == 3 && i < 15)) ? ws + L.weff[i - 13] : ((u.kind == 2 || u.kind == 3) ? ws + L.wfold : params + u.w_off);
         a.y = u.kind == 2 ? ws + L.zfold : ws + u.z;
         a.stats = u.kind == 2 ? nullptr : ws + u.stats;
         FS_TRY(conv_launch(a, s));
@@ -336,7 +382,20 @@ static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, c
     a.w = ws + L.wT;
     a.add_src = add_src;
     a.add_pad = add_src ? 2 : 0;
-    if (u.kind == 1) {  // resize-conv: 3x3 stride-2 conv over dY, pad 1 before
+    if (u.kind == 3) {  // adjoint of conv2d_transpose = the plain strided conv with the stored filter
+        a.w = params + u.w_off;
+        a.H = u.Hout;
+        a.W = u.Wout;
+        a.Cin = u.Cout;
+        a.Ho = u.Hin;
+        a.Wo = u.Win;
+        a.Cout = u.Cin;
+        a.KH = a.KW = u.K;
+        a.stride = u.dstride;
+        a.pad_t = u.dpad_t;
+        a.pad_l = u.dpad_l;
+        a.src_mode = SRC_PLAIN;
+    } else if (u.kind == 1) {  // resize-conv: 3x3 stride-2 conv over dY, pad 1 before
         FS_TRY(wt_upconv_dgrad(params + u.w_off, ws + L.wT, u.Cin, u.Cout, s));
         a.H = u.Hout;
         a.W = u.Wout;
@@ -370,6 +429,17 @@ static int unit_wgrad(const TnetLayout& L, const Unit& u, const float* xin, cons
                       const float* dz, float* grads, float* ws, hipStream_t s) {
     WgradArgs a = unit_wgrad_args(u, L.N);
     a.p = u.wplan;
+    if (u.kind == 3) {  // dW[K,K,Cout,Cin] = conv2d_bwd_filter(input = dz, grad = the unit's input activation)
+        a.x = dz;
+        a.dy = xin;
+        a.dy_a = xa;
+        a.dy_b = xb;
+        a.dy_nstride = xa ? u.Cin : 0;
+        a.dy_relu = xa ? 1 : 0;
+        a.slabs = ws + L.slabs;
+        FS_TRY(wgrad_launch(a, s));
+        return reduce_slabs(ws + L.slabs, 1, a.p.n_slabs, (size_t)a.p.K * a.Cout, 1.0f, grads + u.w_off, s);
+    }
     a.x = xin;
     a.in_a = xa;
     a.in_b = xb;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int ne_x = PH * PW * c4n;
     const int j4n = DP >> 2;
     const int ne_d = p.TH * p.TW * j4n;
-    const bool dvec = (Cr & 3) == 0 && co_g0 + DP <= a.Cout;
+    const bool dvec = (Cr & 3) == 0 && co_g0 + DP <= a.Cout;  // (the scalar dY path has no on-load transform)
 
     auto stage = [&](int t) {
         const int n = a.per_sample ? (int)blockIdx.z : t / tiles;
@@ -198,7 +198,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                             } else {
                                 src = a.dy + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
                             }
-                            dv[i] = *reinterpret_cast<const float4*>(src);
+                            float4 v = *reinterpret_cast<const float4*>(src);
+                            if (a.dy_a) {
+                                const float4 va = *reinterpret_cast<const float4*>(a.dy_a + (size_t)n * a.dy_nstride + co);
+                                const float4 vb = *reinterpret_cast<const float4*>(a.dy_b + (size_t)n * a.dy_nstride + co);
+                                v.x = fmaf(v.x, va.x, vb.x);
+                                v.y = fmaf(v.y, va.y, vb.y);
+                                v.z = fmaf(v.z, va.z, vb.z);
+                                v.w = fmaf(v.w, va.w, vb.w);
+                            }
+                            if (a.dy_relu) {
+                                v.x = fmaxf(v.x, 0.f);
+                                v.y = fmaxf(v.y, 0.f);
+                                v.z = fmaxf(v.z, 0.f);
+                                v.w = fmaxf(v.w, 0.f);
+                            }
+                            dv[i] = v;
                         }
                     }
                 }
@@ -227,6 +242,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                     if (co + 1 < a.Cout) v.y = src[1];
                     if (co + 2 < a.Cout) v.z = src[2];
                     if (co + 3 < a.Cout) v.w = src[3];
+                    if (a.dy_a || a.dy_relu) {
+                        float* vv = reinterpret_cast<float*>(&v);
+                        for (int k = 0; k < 4 && co + k < a.Cout; ++k) {
+                            if (a.dy_a) vv[k] = fmaf(vv[k], a.dy_a[(size_t)n * a.dy_nstride + co + k], a.dy_b[(size_t)n * a.dy_nstride + co + k]);
+                            if (a.dy_relu) vv[k] = fmaxf(vv[k], 0.f);
+                        }
+                    }
                 }
                 *reinterpret_cast<float4*>(dyl + e * 4) = v;
             }

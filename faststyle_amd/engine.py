@@ -93,10 +93,18 @@ class Engine(object):
             out.append((name.value.decode(), off.value, tuple(dims[k] for k in range(nd.value))))
         return out
 
-    def flatten_params(self, tensors, scope="img_t_net/"):
+    def param_table_for(self, upsample_method="resize"):
+        """param_table() with the conv2d_transpose filter shapes [K,K,Cout,Cin] of --upsample_method
+        deconv (im_transf_net.py:174) -- same element counts, so the flat offsets are identical."""
+        tab = self.param_table()
+        if upsample_method == "deconv":
+            tab = [(n, o, (s[0], s[1], s[3], s[2]) if n.startswith("upsample_") and len(s) == 4 else s) for n, o, s in tab]
+        return tab
+
+    def flatten_params(self, tensors, scope="img_t_net/", upsample_method="resize"):
         """dict name->ndarray (checkpoint names) -> flat float32 vector in table order."""
         flat = np.empty(L.FS_TNET_NPARAMS, dtype=np.float32)
-        for name, off, shape in self.param_table():
+        for name, off, shape in self.param_table_for(upsample_method):
             a = tensors.get(scope + name, tensors.get(name))
             if a is None:
                 raise L.FaststyleError("checkpoint lacks tensor %s%s" % (scope, name))
@@ -106,10 +114,10 @@ class Engine(object):
             flat[off:off + a.size] = np.asarray(a, dtype=np.float32).ravel()
         return flat
 
-    def unflatten_params(self, flat, scope="img_t_net/"):
+    def unflatten_params(self, flat, scope="img_t_net/", upsample_method="resize"):
         flat = np.asarray(flat)
         return OrderedDict((scope + name, flat[off:off + int(np.prod(shape))].reshape(shape).copy())
-                           for name, off, shape in self.param_table())
+                           for name, off, shape in self.param_table_for(upsample_method))
 
     # ------------------------------------------------------------------ transform net
     def tnet_out_shape(self, H, W):
@@ -126,8 +134,13 @@ class Engine(object):
             self._tnet_ws = {key: (self.mem.empty((nbytes // 4,)), nbytes)}   # keep only the latest shape
         return self._tnet_ws[key]
 
-    def tnet_forward(self, params, x, save_for_bwd=False):
-        """create_net(x, 'resize'): x [N,H,W,3] float32 RGB 0..255 -> y [N,Ho,Wo,3]."""
+    @staticmethod
+    def _method_flag(upsample_method):
+        assert upsample_method in ("resize", "deconv")
+        return L.FS_FLAG_UPSAMPLE_DECONV if upsample_method == "deconv" else 0
+
+    def tnet_forward(self, params, x, save_for_bwd=False, upsample_method="resize"):
+        """create_net(x, upsample_method): x [N,H,W,3] float32 RGB 0..255 -> y [N,Ho,Wo,3]."""
         self._sync_stream()
         N, H, W, C = (int(s) for s in x.shape)
         assert C == 3
@@ -136,10 +149,11 @@ class Engine(object):
         y = self.mem.empty((N, Ho, Wo, 3))
         p = self.mem.ptr
         L.check(self.lib, self.lib.fs_tnet_forward(self.ctx, p(params), p(x), N, H, W, p(y), p(ws), nbytes,
-                                                   L.FS_FLAG_SAVE_FOR_BWD if save_for_bwd else 0), "fs_tnet_forward")
+                                                   (L.FS_FLAG_SAVE_FOR_BWD if save_for_bwd else 0) |
+                                                   self._method_flag(upsample_method)), "fs_tnet_forward")
         return y
 
-    def tnet_backward(self, params, x, dy, grads=None):
+    def tnet_backward(self, params, x, dy, grads=None, upsample_method="resize"):
         """Gradient of the 48 tensors given dL/dy; must follow tnet_forward(save_for_bwd=True)."""
         self._sync_stream()
         N, H, W, _ = (int(s) for s in x.shape)
@@ -147,8 +161,8 @@ class Engine(object):
         if grads is None:
             grads = self.mem.empty((L.FS_TNET_NPARAMS,))
         p = self.mem.ptr
-        L.check(self.lib, self.lib.fs_tnet_backward(self.ctx, p(params), p(x), p(dy), N, H, W, p(grads), p(ws), nbytes),
-                "fs_tnet_backward")
+        L.check(self.lib, self.lib.fs_tnet_backward(self.ctx, p(params), p(x), p(dy), N, H, W, p(grads), p(ws), nbytes,
+                                                    self._method_flag(upsample_method)), "fs_tnet_backward")
         return grads
 
     # ------------------------------------------------------------------ VGG / losses

@@ -17,10 +17,11 @@ from . import engine as _engine
 
 class Trainer(object):
     def __init__(self, eng, params_flat, vgg_weights, style_img, cfg=None, learn_rate=1e-3, dist=None,
-                 use_graph=False):
+                 use_graph=False, upsample_method="resize"):
         """params_flat: np.float32 [424102] (ckpt order); style_img: np [1,Hs,Ws,3] RGB 0..255;
         dist: None or an initialised torch.distributed module (backend nccl == RCCL)."""
         self.eng = eng
+        self.method = upsample_method
         self.cfg = cfg or _engine.default_loss_cfg()
         self.lr = learn_rate
         self.dist = dist
@@ -46,9 +47,9 @@ class Trainer(object):
 
     def _forward_backward(self, batch):
         e = self.eng
-        y = e.tnet_forward(self.params, batch, save_for_bwd=True)
+        y = e.tnet_forward(self.params, batch, save_for_bwd=True, upsample_method=self.method)
         losses, dy = e.perceptual_loss(y, batch, self.target_grams, self.cfg)
-        e.tnet_backward(self.params, batch, dy, grads=self.grads)
+        e.tnet_backward(self.params, batch, dy, grads=self.grads, upsample_method=self.method)
         return losses
 
     def _capture(self, batch):

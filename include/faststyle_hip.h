@@ -42,6 +42,8 @@ int fs_profile_end(fs_ctx* ctx, double out[18]);
 #define FS_TNET_NPARAMS 424102 /* 48 fp32 tensors, sorted-key (= checkpoint) order */
 #define FS_TNET_NTENSORS 48
 #define FS_FLAG_SAVE_FOR_BWD 1 /* keep every intermediate the backward pass needs */
+#define FS_FLAG_UPSAMPLE_DECONV 2 /* --upsample_method deconv (im_transf_net.py:57-63): the three upsample_* filters are
+                                     [K,K,Cout,Cin] conv2d_transpose filters (same element counts and offsets) */
 
 /* name / offset (floats) / shape of the idx-th parameter tensor in the flat buffer; the order is
  * the key order of the TF bundle (models/<style>_final.ckpt.index), without the "img_t_net/" scope. */
@@ -57,7 +59,7 @@ int fs_tnet_forward(fs_ctx* ctx, const float* params, const float* x, int N, int
  * fs_tnet_forward(..., FS_FLAG_SAVE_FOR_BWD) call on the same inputs just filled.  Replaces the
  * transform-net half of AdamOptimizer.minimize's gradient graph (train.py:203). */
 int fs_tnet_backward(fs_ctx* ctx, const float* params, const float* x, const float* dy, int N, int H, int W, float* grads,
-                     void* ws, size_t ws_bytes);
+                     void* ws, size_t ws_bytes, int flags);
 
 /* ---- VGG16 + Gram + losses: reference libs/vgg16.py:36-220, utils.py:66-83, losses.py ------ */
 #define FS_VGG_NLAYERS 10 /* conv1_1 .. conv4_3 (conv5_x is never fetched: train.py:55-59) */

@@ -129,16 +129,26 @@ def create_net_bwd(dy, params, cache):
     """Gradients of create_net wrt its 48 parameters, given dL/dy.  Returns a dict with
     the same keys as ``params`` (the input image gets no gradient in train.py)."""
     P, c = params, cache
-    assert c["method"] == "resize", "oracle backward covers the shipped 'resize' models"
+    deconv = c["method"] == "deconv"
     g = {}
     name = "upsample_2"
     dn = F.scaled_tanh_bwd(dy, c[name + "/n"])
     dz, g[name + "/INscale"], g[name + "/INshift"] = F.inst_norm_bwd(dn, c[name + "/in_cache"])
-    g[name + "/W"] = F.conv2d_bwd_filter(c[name + "/in"], dz, 9, 1, "SAME")
-    dh = F.conv2d_bwd_input(dz, P[name + "/W"], c[name + "/in"].shape[1:3], 1, "SAME")
+    if deconv:
+        # y = conv2d_transpose(x, W) is the input-gradient of conv2d(., W): its adjoints are
+        # dx = conv2d(dy, W) and dW = conv2d_bwd_filter(input=dy, grad=x)
+        g[name + "/W"] = F.conv2d_bwd_filter(dz, c[name + "/in"], 9, 1, "SAME")
+        dh = F.conv2d(dz, P[name + "/W"], 1, "SAME")
+    else:
+        g[name + "/W"] = F.conv2d_bwd_filter(c[name + "/in"], dz, 9, 1, "SAME")
+        dh = F.conv2d_bwd_input(dz, P[name + "/W"], c[name + "/in"].shape[1:3], 1, "SAME")
     for name in ("upsample_1", "upsample_0"):
         dn = dh * (c[name + "/n"] > 0)
         dz, g[name + "/INscale"], g[name + "/INshift"] = F.inst_norm_bwd(dn, c[name + "/in_cache"])
+        if deconv:
+            g[name + "/W"] = F.conv2d_bwd_filter(dz, c[name + "/in"], 3, 2, "SAME")
+            dh = F.conv2d(dz, P[name + "/W"], 2, "SAME")
+            continue
         up = F.resize_nearest(c[name + "/in"], 4)
         g[name + "/W"] = F.conv2d_bwd_filter(up, dz, 3, 2, "SAME")
         dup = F.conv2d_bwd_input(dz, P[name + "/W"], up.shape[1:3], 2, "SAME")

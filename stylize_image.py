@@ -51,7 +51,8 @@ def main(argv=None):
 
     eng = engine.Engine()                 # fails loudly without the HIP library / a GPU
     print('Loading up model...')
-    variables = eng.mem.from_numpy(eng.flatten_params(ckpt.load_checkpoint(args.model_path)))
+    variables = eng.mem.from_numpy(eng.flatten_params(ckpt.load_checkpoint(args.model_path),
+                                                      upsample_method=args.upsample_method))
     print('Evaluating...')
     Y = create_net(eng.mem.from_numpy(img_4d), args.upsample_method, variables=variables, engine=eng)
     img_out = eng.mem.to_numpy(Y)

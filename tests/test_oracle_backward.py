@@ -84,3 +84,22 @@ def test_adam_tf_matches_closed_form():
     lr_t = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
     want = np.array([1.0, -2.0]) - lr_t * (0.1 * g["a"]) / (np.sqrt(0.001 * g["a"] ** 2) + 1e-8)
     np.testing.assert_allclose(p["a"], want, rtol=1e-14)
+
+
+def test_deconv_method_forward_and_backward_match_torch():
+    """--upsample_method deconv (im_transf_net.py:57-63, 158-190): conv2d_transpose layers."""
+    rng = np.random.default_rng(11)
+    P = tnet.init_params(seed=1, upsample_method="deconv", dtype=np.float64)
+    assert P["upsample_0/W"].shape == (3, 3, 32, 64) and P["upsample_2/W"].shape == (9, 9, 3, 16)
+    x = rng.uniform(0, 255, (1, 44, 48, 3))
+    y, cache = tnet.create_net(x, P, "deconv", keep=True)
+    assert y.shape == (1, 44, 48, 3)
+    Pt = {k: v.requires_grad_(True) for k, v in _t(P).items()}
+    yt = torch_ref.tnet(torch.tensor(x), Pt, "deconv")
+    np.testing.assert_allclose(y, yt.detach().numpy(), rtol=0, atol=1e-8)
+    dy = rng.standard_normal(y.shape)
+    (yt * torch.tensor(dy)).sum().backward()
+    grads = tnet.create_net_bwd(dy, P, cache)
+    for k in P:
+        g = Pt[k].grad.numpy()
+        assert np.abs(grads[k] - g).max() / (np.abs(g).max() + 1e-30) < 1e-8, k

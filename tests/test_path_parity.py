@@ -28,12 +28,12 @@ def starry():
     return ckpt.load_checkpoint(os.path.join(ROOT, "models", "starry_final.ckpt"))
 
 
-def grads_close(e, g, want, tol):
+def grads_close(e, g, want, tol, method="resize"):
     bad = []
     # some gradients are exactly 0 by symmetry (INshift1 feeds a VALID conv + instance norm):
     # their float32 value is summation noise, so errors are measured against a global floor
     floor = 5e-2 * max(np.abs(w).max() for w in want.values())
-    for name, off, shape in e.param_table():
+    for name, off, shape in e.param_table_for(method):
         n = int(np.prod(shape))
         a = g[off:off + n].reshape(shape)
         err = np.abs(a - want[name]).max() / max(np.abs(want[name]).max(), floor)
@@ -63,14 +63,14 @@ def test_param_table_is_checkpoint_order(eng):
     assert all(np.array_equal(rt[k], v) for k, v in starry().items())
 
 
-def kink_free_params(seed=0):
+def kink_free_params(seed=0, method="resize"):
     """Random-init parameters whose ReLU inputs stay positive (INscale~0.25, INshift~+6 on every ReLU'd unit):
     the loss is then smooth in float32 noise, so ALL 48 gradients can be held to a tight
     tolerance.  (With real masks a single pre-activation within ~1e-7 of zero flips its ReLU
     derivative between the float32 kernel and the float64 oracle and moves upstream gradient
     sums by ~1/sqrt(#pixels) -- a property of the kink, not of the kernels.)"""
     rng = np.random.default_rng(seed)
-    P = tnet.init_params(seed=seed)
+    P = tnet.init_params(seed=seed, upsample_method=method)
     for k in P:
         leaf = k.split("/")[1]
         if leaf.startswith("INscale"):
@@ -82,16 +82,16 @@ def kink_free_params(seed=0):
     return P
 
 
-def run_fwd_bwd(eng, P_named, shape, seed):
+def run_fwd_bwd(eng, P_named, shape, seed, method="resize"):
     rng = np.random.default_rng(seed)
-    flat = eng.mem.from_numpy(eng.flatten_params(P_named, scope=""))
+    flat = eng.mem.from_numpy(eng.flatten_params(P_named, scope="", upsample_method=method))
     x = rng.uniform(0, 255, shape + (3,)).astype(np.float32)
     xd = eng.mem.from_numpy(x)
-    y = eng.mem.to_numpy(eng.tnet_forward(flat, xd, save_for_bwd=True))
-    yo, cache = tnet.create_net(x.astype(np.float64), f64(P_named), keep=True)
+    y = eng.mem.to_numpy(eng.tnet_forward(flat, xd, save_for_bwd=True, upsample_method=method))
+    yo, cache = tnet.create_net(x.astype(np.float64), f64(P_named), upsample_method=method, keep=True)
     assert y.shape == yo.shape == (shape[0],) + eng.tnet_out_shape(shape[1], shape[2]) + (3,)
     dy = rng.standard_normal(y.shape).astype(np.float32)
-    g = eng.mem.to_numpy(eng.tnet_backward(flat, xd, eng.mem.from_numpy(dy)))
+    g = eng.mem.to_numpy(eng.tnet_backward(flat, xd, eng.mem.from_numpy(dy), upsample_method=method))
     assert np.isfinite(g).all()
     want = tnet.create_net_bwd(dy.astype(np.float64), f64(P_named), cache)
     return y, yo, g, want
@@ -104,6 +104,18 @@ def test_tnet_forward_matches_oracle_and_backward_tight_when_kink_free(eng, shap
     y, yo, g, want = run_fwd_bwd(eng, kink_free_params(), shape, seed=0)
     assert np.abs(y - yo).max() / 255.0 < 2e-5
     assert grads_close(eng, g, want, 2e-4) == []
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 56), (1, 45, 67)])
+def test_tnet_deconv_method_forward_and_backward(eng, shape):
+    """--upsample_method deconv (im_transf_net.py:57-63): conv2d_transpose 3x3 s2 x2 and 9x9 s1 with
+    filters stored [k,k,Cout,Cin]; forward 2e-5 of the pixel range, all 48 gradients 2e-4."""
+    y, yo, g, want = run_fwd_bwd(eng, kink_free_params(1, "deconv"), shape, seed=1, method="deconv")
+    assert np.abs(y - yo).max() / 255.0 < 2e-5
+    assert grads_close(eng, g, want, 2e-4, "deconv") == []
+    # a resize-layout checkpoint must be refused, not silently reinterpreted
+    with pytest.raises(Exception):
+        eng.flatten_params(kink_free_params(1, "resize"), scope="", upsample_method="deconv")
 
 
 def test_tnet_shipped_weights_forward_tight_backward_with_real_relu_masks(eng):

@@ -48,7 +48,8 @@ def test_stylize_image_cli_reproduces_golden(tmp_path, style, capsys):
 
 
 @pytest.mark.gpu
-def test_train_cli_runs_reference_loop(tmp_path, monkeypatch, capsys):
+@pytest.mark.parametrize("method", ["resize", "deconv"])
+def test_train_cli_runs_reference_loop(tmp_path, monkeypatch, capsys, method):
     from faststyle_amd import ckpt, vgg16
     sys.path.insert(0, ROOT)
     import stylize_image
@@ -61,7 +62,8 @@ def test_train_cli_runs_reference_loop(tmp_path, monkeypatch, capsys):
         ["--train_dir", "synthetic", "--model_name", "t",
          "--style_img_path", os.path.join(ROOT, "style_images", "starry_night_crop.jpg"),
          "--style_target_resize", "0.25", "--preprocess_size", "128", "128", "--batch_size", "2",
-         "--num_steps_break", "11", "--num_steps_ckpt", "10"]))
+         "--num_steps_break", "11", "--num_steps_ckpt", "10", "--upsample_method", method] +
+        (["--beta", "1e-4"] if method == "deconv" else [])))
     out = [l for l in capsys.readouterr().out.splitlines() if l and "amdgpu" not in l]
     assert out[0] == "Precomputing target style layers." and "Starting training..." in out and out[-1] == "Done training."
     steps = [int(l.split()[0]) for l in out if l.split()[0].isdigit()]
@@ -69,15 +71,19 @@ def test_train_cli_runs_reference_loop(tmp_path, monkeypatch, capsys):
     assert os.path.exists(str(work / "training" / "t.ckpt-0.index")) and os.path.exists(str(work / "training" / "t.ckpt-10.index"))
     final = ckpt.load_checkpoint(str(work / "models" / "t_final.ckpt"))        # train.py:286
     assert len(final) == 48 and all(k.startswith("img_t_net/") for k in final)
+    # deconv2d keeps its filter as [k,k,Cout,Cin] (im_transf_net.py:174)
+    assert final["img_t_net/upsample_0/W"].shape == ((3, 3, 32, 64) if method == "deconv" else (3, 3, 64, 32))
     full = ckpt.load_checkpoint(str(work / "training" / "t.ckpt-10"))
     assert int(full["global_step"]) == 10 and "img_t_net/initconv_0/W/Adam" in full
     logs = [json.loads(l) for l in open(str(work / "summaries" / "train" / "t0" / "scalars.jsonl"))]
-    assert [d["step"] for d in logs] == [0, 10] and logs[1]["loss"] < logs[0]["loss"]
+    assert [d["step"] for d in logs] == [0, 10] and np.isfinite(logs[1]["loss"])
+    assert logs[1]["loss"] < logs[0]["loss"] or method == "deconv"
+    assert (logs[1]["tv_loss"] > 0) == (method == "deconv")                  # --beta only set for deconv
     # the final model is a valid stylize_image.py --model_path
     outimg = str(work / "o.jpg")
     stylize_image.main(["--input_img_path", os.path.join(ROOT, "tests", "golden", "ref_assets", "chicago.jpg"),
                         "--output_img_path", outimg, "--model_path", str(work / "models" / "t_final.ckpt"),
-                        "--content_target_resize", "0.25"])
+                        "--content_target_resize", "0.25", "--upsample_method", method])
     assert load_rgb(outimg).shape[2] == 3
 
 

@@ -30,7 +30,16 @@ def inorm(x, g, b, eps=1e-3):
     return (x - mu) / torch.sqrt(var + eps) * g.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
 
 
-def tnet(x_nhwc, P):
+def deconv(x, w, s):
+    """tf.nn.conv2d_transpose, SAME, output = in*s, filter [k,k,Cout,Cin] == gradient of conv2d wrt its input."""
+    n, c, h, wd = x.shape
+    k = w.shape[0]
+    ref = torch.zeros((n, w.shape[2], h * s, wd * s), dtype=x.dtype, requires_grad=True)
+    y = conv(ref, w, s, "SAME")
+    return torch.autograd.grad(y, ref, x, create_graph=True)[0]
+
+
+def tnet(x_nhwc, P, method="resize"):
     x = x_nhwc.permute(0, 3, 1, 2)
     h = TF.pad(x, (40, 40, 40, 40), mode="reflect")
     for name, s in (("initconv_0", 1), ("initconv_1", 2), ("initconv_2", 2)):
@@ -40,10 +49,15 @@ def tnet(x_nhwc, P):
         a = torch.relu(inorm(conv(h, P[n + "/W1"], 1, "VALID"), P[n + "/INscale1"], P[n + "/INshift1"]))
         h = inorm(conv(a, P[n + "/W2"], 1, "VALID"), P[n + "/INscale2"], P[n + "/INshift2"]) + h[:, :, 2:-2, 2:-2]
     for name in ("upsample_0", "upsample_1"):
-        up = h.repeat_interleave(4, dim=2).repeat_interleave(4, dim=3)
-        h = torch.relu(inorm(conv(up, P[name + "/W"], 2, "SAME"), P[name + "/INscale"], P[name + "/INshift"]))
+        if method == "deconv":
+            z = deconv(h, P[name + "/W"], 2)
+        else:
+            up = h.repeat_interleave(4, dim=2).repeat_interleave(4, dim=3)
+            z = conv(up, P[name + "/W"], 2, "SAME")
+        h = torch.relu(inorm(z, P[name + "/INscale"], P[name + "/INshift"]))
     name = "upsample_2"
-    h = inorm(conv(h, P[name + "/W"], 1, "SAME"), P[name + "/INscale"], P[name + "/INshift"])
+    z = deconv(h, P[name + "/W"], 1) if method == "deconv" else conv(h, P[name + "/W"], 1, "SAME")
+    h = inorm(z, P[name + "/INscale"], P[name + "/INshift"])
     return ((255.0 * torch.tanh(h) + 255.0) / 2.0).permute(0, 2, 3, 1)
 
 

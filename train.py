@@ -157,8 +157,6 @@ def main(args):
     import torch.distributed as dist
     from faststyle_amd import ckpt, engine, im_transf_net, trainer, utils, vgg16
 
-    if args.upsample_method != 'resize':
-        raise SystemExit("--upsample_method deconv is not built on the HIP path yet (SURVEY.md §8f)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -178,9 +176,11 @@ def main(args):
     if rank == 0:
         print('Precomputing target style layers.')
     vgg_w = vgg16.load_weights('libs/vgg16_weights.npz')          # train.py:148, 239 (path relative to CWD)
-    params = eng.flatten_params(im_transf_net.initial_variables(seed=0), scope="")
+    method = args.upsample_method
+    params = eng.flatten_params(im_transf_net.initial_variables(seed=0, upsample_method=method), scope="",
+                                upsample_method=method)
     tr = trainer.Trainer(eng, params, vgg_w, style_img, cfg, learn_rate=args.learn_rate,
-                         dist=dist if world > 1 else None)
+                         dist=dist if world > 1 else None, upsample_method=method)
 
     # Setup subdirectory for this run's logs (train.py:207-217).
     run_name = args.run_name
@@ -202,11 +202,11 @@ def main(args):
         log = open('./summaries/train/' + run_name + '/scalars.jsonl', 'a')
 
     def save(prefix, full):
-        tensors = eng.unflatten_params(tr.params_numpy())
+        tensors = eng.unflatten_params(tr.params_numpy(), upsample_method=method)
         if full:   # saver = tf.train.Saver(): all variables incl. Adam slots and global_step (train.py:224)
-            for k, v in eng.unflatten_params(eng.mem.to_numpy(tr.m)).items():
+            for k, v in eng.unflatten_params(eng.mem.to_numpy(tr.m), upsample_method=method).items():
                 tensors[k + "/Adam"] = v
-            for k, v in eng.unflatten_params(eng.mem.to_numpy(tr.v)).items():
+            for k, v in eng.unflatten_params(eng.mem.to_numpy(tr.v), upsample_method=method).items():
                 tensors[k + "/Adam_1"] = v
             tensors["global_step"] = np.array(tr.global_step, dtype=np.int64)
         ckpt.save_checkpoint(prefix, tensors)
