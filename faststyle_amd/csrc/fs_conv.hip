@@ -347,14 +347,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 if (e < ne_w) *reinterpret_cast<float4*>(wl + e * 4) = wv[i];
             }
         };
-        issue(0);
+        // split-K: blockIdx.z owns the chunk range [cbeg, cend)
+        const int cbeg = p.ksplit > 1 ? (int)blockIdx.z * nchunks / p.ksplit : 0;
+        const int cend = p.ksplit > 1 ? ((int)blockIdx.z + 1) * nchunks / p.ksplit : nchunks;
+        issue(cbeg);
         __syncthreads();  // abl visible
-        commit(0, smem, smem + patch_floats);
+        commit(cbeg, smem, smem + patch_floats);
         __syncthreads();
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            float* cur = smem + (chunk & 1) * buf_floats;
-            float* nxt = smem + ((chunk + 1) & 1) * buf_floats;
-            const bool more = chunk + 1 < nchunks;
+        for (int chunk = cbeg; chunk < cend; ++chunk) {
+            float* cur = smem + ((chunk - cbeg) & 1) * buf_floats;
+            float* nxt = smem + ((chunk - cbeg + 1) & 1) * buf_floats;
+            const bool more = chunk + 1 < cend;
             if (more) issue(chunk + 1);
             sweep(cur, cur + patch_floats);
             if (more) commit(chunk + 1, nxt, nxt + patch_floats);
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     // store: per-image base pointers are 64-bit scalars, everything per element is 32-bit
     const int Cr = a.shuffle ? a.Cout >> 2 : a.Cout;
-    float* yn = a.y + (size_t)n * a.Ho * a.Wo * a.Cout;
+    float* yn = a.y + ((size_t)n + (p.ksplit > 1 ? (size_t)blockIdx.z * a.N : 0)) * a.Ho * a.Wo * a.Cout;
     const int ap = a.add_pad;
     const int aW = a.Wo - 2 * ap;
     const float* asn = a.add_src ? a.add_src + (size_t)n * (a.Ho - 2 * ap) * aW * a.Cout : nullptr;
@@ -604,6 +607,7 @@ static void plan_variant(const ConvArgs& a, int variant, ConvPlan* out) {
         if (chosen) break;
     }
     if (p.lds_bytes < 4 * 5 * p.BN) p.lds_bytes = 4 * 5 * p.BN;  // stats scratch
+    p.ksplit = 1;
     *out = p;
 }
 
@@ -616,6 +620,43 @@ ConvPlan conv_plan(const ConvArgs& a) {
     // widest tile first; halve the workgroup tile while the launch cannot fill the chip
     // (256 CUs x >= 2 workgroups), e.g. VGG conv4_x at batch 4 or the 64-channel residual convs
     const int min_wgs = env_int("FS_CONV_MIN_WGS", 512);
+    const int forced_variant = env_int("FS_CONV_VARIANT", -1);  // tuning aid (tools/micro_conv.py)
+    if (forced_variant >= 0 && forced_variant <= 4 && forced_variant != 2) {
+        plan_variant(a, forced_variant, &p);
+        return p;
+    }
+    // Deep-K layers on a small pixel grid (VGG conv4_x at batch 4: 4096 px x 512 co, K = 4608) cannot fill
+    // the chip with wide tiles; the narrow tiles that do fill it move twice the bytes per FLOP through LDS.
+    // With scratch available, keep the wide tile and split the input-channel chunks over blockIdx.z instead;
+    // a streaming epilogue kernel sums the partials and applies bias / ReLU / tap-add / mask.
+    const int max_split = env_int("FS_CONV_KSPLIT", 4);
+    if (a.split_ws && max_split > 1 && a.Cout > 32 && !a.stats && !a.shuffle && !a.add_pad && a.w_nstride == 0) {
+        const int force = env_int("FS_CONV_FORCE_KSPLIT", 0);  // test hook: split regardless of the grid size
+        if (force > 1) {
+            plan_variant(a, 0, &p);
+            const int nchunks = p.CC > 0 ? a.Cin / p.CC : 0;
+            const int ks = force < nchunks ? force : nchunks;
+            if (ks > 1 && (size_t)ks * a.N * a.Ho * a.Wo * a.Cout <= a.split_ws_floats) {
+                p.ksplit = ks;
+                return p;
+            }
+        }
+        const int try_order[2] = {0, 3};
+        for (int i = 0; i < 2; ++i) {
+            plan_variant(a, try_order[i], &p);
+            if (p.CC <= 0) continue;
+            const long wgs = (long)a.N * p.tiles_y * p.tiles_x * cdiv(a.Cout, p.BN);
+            const int nchunks = a.Cin / p.CC;
+            int ks = (int)((min_wgs + wgs - 1) / wgs);
+            if (i == 0 && wgs * env_int("FS_CONV_KSPLIT_FILL", 4) > min_wgs) break;  // the plain variants already come close: not worth the extra pass
+            if (ks > max_split) ks = max_split;
+            while (ks > 1 && (nchunks / ks) * p.CC * a.KH * a.KW < 1024) --ks;  // keep >= 1024 of K per split
+            if (ks > 1 && wgs * ks >= min_wgs && (size_t)ks * a.N * a.Ho * a.Wo * a.Cout <= a.split_ws_floats) {
+                p.ksplit = ks;
+                return p;
+            }
+        }
+    }
     const int order_wide[3] = {0, 3, 4}, order_narrow[2] = {1, 4};
     const int* order = a.Cout > 32 ? order_wide : order_narrow;
     const int n = a.Cout > 32 ? 3 : 2;
@@ -627,13 +668,67 @@ ConvPlan conv_plan(const ConvArgs& a) {
     return p;
 }
 
+// Sum of the split-K partials + the conv epilogue (bias, tap-gradient add, consumer ReLU mask, ReLU); float4 per thread.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ part, int ks, size_t n4, int C,
+                                                              const float* __restrict__ bias, const float* __restrict__ add_src,
+                                                              const float* __restrict__ mask_src, int relu,
+                                                              float* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    float4 v = p4[i];
+    for (int k = 1; k < ks; ++k) {
+        const float4 u = p4[i + (size_t)k * n4];
+        v.x += u.x;
+        v.y += u.y;
+        v.z += u.z;
+        v.w += u.w;
+    }
+    if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + (int)((i * 4) % (size_t)C));
+        v.x += b.x;
+        v.y += b.y;
+        v.z += b.z;
+        v.w += b.w;
+    }
+    if (add_src) {
+        const float4 u = reinterpret_cast<const float4*>(add_src)[i];
+        v.x += u.x;
+        v.y += u.y;
+        v.z += u.z;
+        v.w += u.w;
+    }
+    if (mask_src) {
+        const float4 m = reinterpret_cast<const float4*>(mask_src)[i];
+        v.x = m.x > 0.f ? v.x : 0.f;
+        v.y = m.y > 0.f ? v.y : 0.f;
+        v.z = m.z > 0.f ? v.z : 0.f;
+        v.w = m.w > 0.f ? v.w : 0.f;
+    }
+    if (relu) {
+        v.x = fmaxf(v.x, 0.f);
+        v.y = fmaxf(v.y, 0.f);
+        v.z = fmaxf(v.z, 0.f);
+        v.w = fmaxf(v.w, 0.f);
+    }
+    reinterpret_cast<float4*>(y)[i] = v;
+}
+
 int conv_launch(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     if (a.dil_x < 1) a.dil_x = 1;
     const ConvPlan& p = a.p;
     if (p.CC <= 0 || (!p.flat && (a.Cin % 4 || a.Cin % p.CC))) return -1;
     if (p.lds_bytes > 160 * 1024) return -2;
-    dim3 grid((unsigned)(a.N * p.tiles_y * p.tiles_x), (unsigned)cdiv(a.Cout, p.BN));
+    dim3 grid((unsigned)(a.N * p.tiles_y * p.tiles_x), (unsigned)cdiv(a.Cout, p.BN), (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
+    if (p.ksplit > 1) {  // raw partial sums to scratch; the epilogue runs in splitk_epilogue_kernel
+        if (!a.split_ws || a.stats || a.shuffle || a.add_pad || p.flat) return -6;
+        a.y = a.split_ws;
+        a.bias = nullptr;
+        a.out_relu = 0;
+        a.add_src = nullptr;
+        a.mask_src = nullptr;
+    }
     Profiler* prof = Profiler::current();
     if (prof) {
         // algorithmic FLOPs: 2*M*K*N with the true extents; a zero-dilated dgrad only does 1/4 useful work
@@ -670,6 +765,11 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
         FS_LAUNCH(32, 1, 1, false);
     }
 #undef FS_LAUNCH
+    if (p.ksplit > 1) {
+        const size_t n4 = (size_t)a.N * a.Ho * a.Wo * a.Cout / 4;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.split_ws, p.ksplit, n4,
+                           a.Cout, a_in.bias, a_in.add_src, a_in.mask_src, a_in.out_relu, a_in.y);
+    }
     if (prof) prof->end(s);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

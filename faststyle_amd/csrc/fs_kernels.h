@@ -29,6 +29,7 @@ struct ConvPlan {
     int TH, TW, tiles_y, tiles_x;
     int PH, PW;   // staged patch extent
     int lds_bytes;
+    int ksplit;   // > 1: blockIdx.z splits the input-channel chunks; raw partials go to ConvArgs::split_ws
 };
 
 struct ConvArgs {
@@ -52,6 +53,8 @@ struct ConvArgs {
     int add_pad;
     const float* mask_src;  // optional [N,Ho,Wo,Cout]: after the add, v = mask_src > 0 ? v : 0 (ReLU gradient of the consumer)
     long long w_nstride;
+    float* split_ws;         // optional scratch for split-K partials (split_ws_floats capacity); enables ksplit plans
+    size_t split_ws_floats;
     ConvPlan p;
 };
 

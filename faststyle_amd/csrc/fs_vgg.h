@@ -15,6 +15,7 @@ struct VggLayout {
     size_t xin, ab, act[FS_VGG_NLAYERS], pool[3];
     size_t gram[4], sm[4], slabs;
     size_t d_pre, d_in[2], d_tap, d_tap2, scratch;
+    size_t splitws, splitws_floats;  // split-K partial sums of the deep, small-grid convs (conv4_x at batch 4)
     size_t total_floats;
 };
 

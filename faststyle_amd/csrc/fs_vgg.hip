@@ -114,11 +114,33 @@ void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, 
     L->d_tap = b.take(max_act);
     L->d_tap2 = b.take(max_act);
     L->scratch = b.take(2048);
+    // split-K scratch: plan every VGG conv (forward at its batch, dgrad at N) with unlimited scratch and keep the max need
+    size_t need = 0;
+    for (int l = 0; l <= lmax; ++l)
+        for (int dir = 0; dir < 2; ++dir) {
+            if (dir == 1 && l == 0) continue;
+            ConvArgs a{};
+            a.N = dir == 0 ? (l <= cmax ? L->NB : N) : N;
+            a.H = a.Ho = L->Hl[l];
+            a.W = a.Wo = L->Wl[l];
+            a.Cin = dir == 0 ? kCin[l] : kCout[l];
+            a.Cout = dir == 0 ? kCout[l] : kCin[l];
+            a.KH = a.KW = 3;
+            a.stride = 1;
+            a.pad_t = a.pad_l = 1;
+            a.split_ws = reinterpret_cast<float*>(16);
+            a.split_ws_floats = ~(size_t)0;
+            const ConvPlan p = conv_plan(a);
+            const size_t f = p.ksplit > 1 ? (size_t)p.ksplit * a.N * a.Ho * a.Wo * a.Cout : 0;
+            if (f > need) need = f;
+        }
+    L->splitws_floats = need;
+    L->splitws = b.take(need ? need : 4);
     L->total_floats = b.off;
 }
 
 static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, const float* bias, const float* ab, float* y,
-                    hipStream_t s) {
+                    float* split_ws, size_t split_ws_floats, hipStream_t s) {
     ConvArgs a{};
     a.x = x;
     a.w = w;
@@ -133,6 +155,8 @@ static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, 
     a.pad_t = a.pad_l = 1;
     a.bias = bias;
     a.out_relu = 1;
+    a.split_ws = split_ws;
+    a.split_ws_floats = split_ws_floats;
     if (l == 0) {  // images - mean folded into the load (padding stays zero, as in TF)
         a.in_a = ab;
         a.in_b = ab + 4;
@@ -148,7 +172,7 @@ static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS],
     const float* src = ws + L.xin;
     for (int l = 0; l <= L.lmax; ++l) {
         const int nb = l <= L.cmax ? L.NB : L.N;
-        FS_TRY(vgg_conv(src, nb, L.Hl[l], L.Wl[l], l, w[l], b[l], ws + L.ab, ws + L.act[l], s));
+        FS_TRY(vgg_conv(src, nb, L.Hl[l], L.Wl[l], l, w[l], b[l], ws + L.ab, ws + L.act[l], ws + L.splitws, L.splitws_floats, s));
         src = ws + L.act[l];
         if (pool_after(l) && l < L.lmax) {
             FS_TRY(maxpool(ws + L.act[l], ws + L.pool[pool_index(l)], nb, L.Hl[l], L.Wl[l], kCout[l], s));
@@ -267,6 +291,8 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         a.KH = a.KW = 3;
         a.stride = 1;
         a.pad_t = a.pad_l = 1;
+        a.split_ws = ws + L.splitws;
+        a.split_ws_floats = L.splitws_floats;
         if (l == 0) {
             a.y = dy;
             a.p = conv_plan(a);

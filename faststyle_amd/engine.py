@@ -225,8 +225,8 @@ class Engine(object):
                                    "of 4 (create_net maps H -> 4*ceil(ceil((H+80)/2)/2)-80)" % (tuple(content.shape), tuple(y.shape)))
         c = self._cfg(cfg, target_grams)
         key = (N, H, W, tuple(cfg["content_layers"]), tuple(cfg["style_layers"]))
-        if key not in self._perc_ws:
-            nbytes = self.lib.fs_perceptual_workspace_bytes(N, H, W, ctypes.byref(c))
+        nbytes = self.lib.fs_perceptual_workspace_bytes(N, H, W, ctypes.byref(c))
+        if key not in self._perc_ws or self._perc_ws[key][1] != nbytes:
             self._perc_ws = {key: (self.mem.empty((nbytes // 4,)), nbytes)}
         ws, nbytes = self._perc_ws[key]
         losses = self.mem.empty((4,))

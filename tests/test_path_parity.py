@@ -163,7 +163,12 @@ def test_instnorm_backward_modes(eng, mode):
         assert np.abs(eng.mem.to_numpy(got) - wnt).max() / np.abs(wnt).max() < 5e-5
 
 
-def test_perceptual_loss_and_gradient_match_oracle(eng):
+@pytest.mark.parametrize("force_ksplit", [0, 3])
+def test_perceptual_loss_and_gradient_match_oracle(eng, monkeypatch, force_ksplit):
+    """force_ksplit=3 drives every eligible VGG conv (forward and dgrad) through the split-K kernel path +
+    splitk_epilogue_kernel (bias/ReLU, tap add + ReLU mask), which otherwise only triggers at 256x256."""
+    if force_ksplit:
+        monkeypatch.setenv("FS_CONV_FORCE_KSPLIT", str(force_ksplit))
     rng = np.random.default_rng(1)
     Wv = perceptual.synthetic_vgg_weights(seed=3)
     eng.vgg_load(Wv)

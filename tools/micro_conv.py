@@ -17,6 +17,8 @@ CASES = {
     "vgg3_2_n8": (8, 64, 64, 256, 256, 3, 1, "SAME"),
     "vgg3_2_n4": (4, 64, 64, 256, 256, 3, 1, "SAME"),
     "vgg4_2_n4": (4, 32, 32, 512, 512, 3, 1, "SAME"),
+    "vgg4_1_n4": (4, 32, 32, 256, 512, 3, 1, "SAME"),
+    "vgg4_d1_n4": (4, 32, 32, 512, 256, 3, 1, "SAME"),
     "res_n4": (4, 80, 80, 64, 64, 3, 1, "VALID"),
     "final9x9": (4, 256, 256, 16, 3, 9, 1, "SAME"),
     "res_720p": (1, 196, 336, 64, 64, 3, 1, "VALID"),
