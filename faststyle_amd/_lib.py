@@ -1,4 +1,4 @@
-"""ctypes binding of libfaststyle_hip.so (include/faststyle_hip.h).
+"""ctypes binding of libfaststyle_hip.so (include/faststyle_hip.h, include/faststyle_io.h).
 
 The library is built in-tree by ``__graft_entry__.build()`` / ``python -m faststyle_amd.build``
 (hipcc, gfx950).  There is NO fallback: if the shared object is missing or does not export the
@@ -6,7 +6,7 @@ full C ABI, importing the HIP path raises -- the product never routes through a 
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p)
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t, c_uint32, c_uint64, c_void_p)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libfaststyle_hip.so"
@@ -92,6 +92,14 @@ PROTOTYPES = {
                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fs_conv2d_wgrad_workspace_bytes": (c_size_t, [POINTER(fs_wgrad_desc)]),
     "fs_conv2d_wgrad": (c_int, [c_void_p, POINTER(fs_wgrad_desc), c_void_p, c_size_t]),
+    # include/faststyle_io.h
+    "fs_crc32c": (c_uint32, [c_void_p, c_size_t]),
+    "fs_crc32c_masked": (c_uint32, [c_void_p, c_size_t]),
+    "fs_tfrecord_scan": (c_longlong, [c_void_p, c_size_t, c_int, POINTER(c_uint64), POINTER(c_uint64), c_size_t]),
+    "fs_tfrecord_frame": (c_size_t, [c_void_p, c_size_t, c_void_p]),
+    "fs_example_bytes": (c_int, [c_void_p, c_size_t, c_char_p, POINTER(c_uint64), POINTER(c_uint64)]),
+    "fs_example_int64": (c_int, [c_void_p, c_size_t, c_char_p, POINTER(c_longlong)]),
+    "fs_resize_bicubic_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int]),
 }
 
 
@@ -125,11 +133,12 @@ def load():
         # PyTorch-ROCm ships its own libamdhip64; import it FIRST so this library binds to the same
         # HIP runtime instance (two runtimes in one process cannot both own the device).
         import torch  # noqa: F401
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("FASTSTYLE_HIP_LIB", LIB_PATH)      # tuning builds (tools/); default: the in-tree library
+        if not os.path.exists(path):
             raise FaststyleError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
-        _lib = bind(ctypes.CDLL(LIB_PATH))
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
+        _lib = bind(ctypes.CDLL(path))
     return _lib
 
 

@@ -1,5 +1,6 @@
 // extern "C" surface of libfaststyle_hip.so (include/faststyle_hip.h).
 #include "../../include/faststyle_hip.h"
+#include "../../include/faststyle_io.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -29,7 +30,24 @@ static int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+namespace fs {
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace fs
+
 extern "C" {
+
+int fs_resize_bicubic_u8(fs_ctx* ctx, const unsigned char* src, int H, int W, float* dst, int Ho, int Wo) {
+    if (!ctx || !src || !dst) return fail(-1, "fs_resize_bicubic_u8: null argument");
+    if (H < 1 || W < 1 || Ho < 1 || Wo < 1) return fail(-1, "fs_resize_bicubic_u8: bad shape %dx%d -> %dx%d", H, W, Ho, Wo);
+    const int rc = fs::resize_bicubic_u8(src, H, W, dst, Ho, Wo, ctx->stream);
+    return rc ? fail(rc, "fs_resize_bicubic_u8: launch failed (%d)", rc) : 0;
+}
 
 const char* fs_last_error(void) { return g_err; }
 const char* fs_version(void) { return "faststyle_hip 0.1 (gfx950, fp32 MFMA)"; }

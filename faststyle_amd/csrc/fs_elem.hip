@@ -147,28 +147,57 @@ int apply_tanh(const float* z, const float* a, const float* b, float* y, int N, 
 }
 
 // ---------------------------------------------------------------- slab reduction
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs, int n_wg, size_t count, float scale,
-                                                           float* out) {
+// out[g][i] = scale * sum_w slabs[g][w][i].  The partial-slab sets are small (<= a few MB) but deep (up to ~500
+// slabs), so the reduction is latency-bound: a workgroup covers EL consecutive elements x SG slab groups
+// (EL*SG = 256); every thread sums its strided share of the slabs with 8 loads in flight and the SG partials are
+// combined through LDS in a fixed order (deterministic; no atomics).
+template <int EL>
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int n_wg, size_t count, float scale,
+                                                           float* __restrict__ out) {
+    constexpr int SG = 256 / EL;
+    __shared__ float sh[256];
     const size_t g = blockIdx.y;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    const int el = threadIdx.x % EL, sg = threadIdx.x / EL;
+    const size_t i = (size_t)blockIdx.x * EL + el;
+    float acc = 0.f;
+    if (i < count) {
         const float* p = slabs + g * n_wg * count + i;
-        float acc = 0.f;
-        int w = 0;
-        for (; w + 8 <= n_wg; w += 8) {  // 8 independent loads in flight, summed in slab order
+        int w = sg;
+        for (; w + 7 * SG < n_wg; w += 8 * SG) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(w + u) * count];
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(w + u * SG) * count];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc += v[u];
         }
-        for (; w < n_wg; ++w) acc += p[(size_t)w * count];
-        out[g * count + i] = acc * scale;
+        for (; w < n_wg; w += SG) acc += p[(size_t)w * count];
+    }
+    if (SG == 1) {
+        if (i < count) out[g * count + i] = acc * scale;
+        return;
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (sg == 0 && i < count) {
+        float t = sh[el];
+#pragma unroll
+        for (int k = 1; k < SG; ++k) t += sh[k * EL + el];
+        out[g * count + i] = t * scale;
     }
 }
 
 int reduce_slabs(const float* slabs, int groups, int n_wg, size_t count, float scale, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)min((size_t)1024, (count + 255) / 256), groups), dim3(256), 0, s,
-                       slabs, n_wg, count, scale, out);
+    const int deep = n_wg / 8;  // slab groups only while each still owns >= 8 slabs
+    if (deep >= 16) {
+        hipLaunchKernelGGL(reduce_slabs_kernel<16>, dim3((unsigned)((count + 15) / 16), groups), dim3(256), 0, s, slabs, n_wg, count,
+                           scale, out);
+    } else if (deep >= 4) {
+        hipLaunchKernelGGL(reduce_slabs_kernel<64>, dim3((unsigned)((count + 63) / 64), groups), dim3(256), 0, s, slabs, n_wg, count,
+                           scale, out);
+    } else {
+        hipLaunchKernelGGL(reduce_slabs_kernel<256>, dim3((unsigned)((count + 255) / 256), groups), dim3(256), 0, s, slabs, n_wg,
+                           count, scale, out);
+    }
     return 0;
 }
 
@@ -560,6 +589,60 @@ __global__ __launch_bounds__(256) void wt_upconv_wgrad_fold_kernel(const float* 
                             acc += dweff[(((dy * 2 + dx) * Ci + ci) * 4 + (a * 2 + b)) * Co + co];
         dw[i] = acc;
     }
+}
+
+// one launch for a list of re-layout jobs; element formulas identical to the single-job kernels above
+// (WT_FOLD5FWD: wf[kh][b][ci][16] from w[9][9][Ci][3], see fs_fold.hip)
+__global__ __launch_bounds__(256) void wt_batch_kernel(WtBatch b) {
+    const WtJob& q = b.j[blockIdx.y];
+    const float* __restrict__ w = q.src;
+    const int Ci = q.Ci, Co = q.Co;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < q.total; i += gridDim.x * 256) {
+        float acc = 0.f;
+        if (q.kind == WT_FLIPT) {
+            const int ci = i % Ci;
+            int r = i / Ci;
+            const int co = r % Co;
+            r /= Co;
+            const int kw = r % q.KW, kh = r / q.KW;
+            acc = w[(((q.KH - 1 - kh) * q.KW + (q.KW - 1 - kw)) * Ci + ci) * Co + co];
+        } else if (q.kind == WT_UPFWD) {
+            const int j = i % (4 * Co);
+            const int r = i / (4 * Co);
+            const int ci = r % Ci, tap = r / Ci;
+            const int dy = tap >> 1, dx = tap & 1;
+            const int qq = j / Co, co = j % Co, a = qq >> 1, bb = qq & 1;
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw)
+                    if (up_in_R(a, dy, kh) && up_in_R(bb, dx, kw)) acc += w[((kh * 3 + kw) * Ci + ci) * Co + co];
+        } else if (q.kind == WT_UPDGRAD) {
+            const int ci = i % Ci;
+            const int r = i / Ci;
+            const int co = r % Co, tap = r / Co;
+            const int t = tap / 3, s2 = tap % 3;
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw)
+                    if (up_in_V(t, kh) && up_in_V(s2, kw)) acc += w[((kh * 3 + kw) * Ci + ci) * Co + co];
+        } else {  // WT_FOLD5FWD
+            const int j = i & 15;
+            int r = i >> 4;
+            const int ci = r % Ci;
+            r /= Ci;
+            const int bb = r & 1, kh = r >> 1;
+            const int v = j / 3, co = j - v * 3, kw = 5 * bb + v;
+            acc = (j < 15 && kw < 9) ? w[((kh * 9 + kw) * Ci + ci) * 3 + co] : 0.f;
+        }
+        q.dst[i] = acc;
+    }
+}
+
+int wt_batch(const WtBatch& b, hipStream_t s) {
+    if (b.n <= 0) return 0;
+    int mx = 0;
+    for (int k = 0; k < b.n; ++k)
+        if (b.j[k].total > mx) mx = b.j[k].total;
+    hipLaunchKernelGGL(wt_batch_kernel, dim3(cdiv(mx, 256), b.n), dim3(256), 0, s, b);
+    return 0;
 }
 
 int wt_upconv_fwd(const float* w, float* weff, int Ci, int Co, hipStream_t s) {

@@ -106,6 +106,10 @@ int apply_res(const float* z, const float* a, const float* b, const float* skip,
               int skip_relu, float* out, int N, int H, int W, int C, hipStream_t s);
 int apply_tanh(const float* z, const float* a, const float* b, float* y, int N, int HW, int C, hipStream_t s);
 int reduce_slabs(const float* slabs, int groups, int n_wg, size_t count, float scale, float* out, hipStream_t s);
+// thread-local message behind fs_last_error(); returns `code` (fs_api.hip)
+int set_error(int code, const char* fmt, ...);
+// tf.image.resize_images(method=2) of TF 1.0 on device u8 [H,W,3] -> f32 [Ho,Wo,3] (fs_io.hip)
+int resize_bicubic_u8(const unsigned char* src, int H, int W, float* dst, int Ho, int Wo, hipStream_t s);
 int in_bwd(const float* gin, const float* z, const float* mean, const float* rstd, const float* a, const float* b, int mode,
            float* dz, float* dgamma, float* dbeta, float* scratch, int N, int HW, int C, hipStream_t s);
 size_t in_bwd_scratch_floats(int N, int HW, int C);
@@ -118,6 +122,30 @@ int tv_loss(const float* x, int N, int H, int W, int C, float lscale, float gsca
             float* scratch, hipStream_t s);
 int axpby(const float* x, const float* y, float a, float b, float* out, size_t n, hipStream_t s);
 int adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s);
+// Several filter re-layouts in ONE launch (blockIdx.y = job): the ~18 per-step re-layouts of the transform net
+// are a few microseconds of work each, so as separate launches they cost more in launch gaps than in compute.
+enum WtKind { WT_FLIPT = 0, WT_UPFWD = 1, WT_UPDGRAD = 2, WT_FOLD5FWD = 3 };
+struct WtJob {
+    int kind, KH, KW, Ci, Co, total;
+    const float* src;
+    float* dst;
+};
+struct WtBatch {
+    int n;
+    WtJob j[20];
+    void add(int kind, const float* src, float* dst, int KH, int KW, int Ci, int Co) {
+        WtJob& q = j[n++];
+        q.kind = kind;
+        q.src = src;
+        q.dst = dst;
+        q.KH = KH;
+        q.KW = KW;
+        q.Ci = Ci;
+        q.Co = Co;
+        q.total = kind == WT_UPFWD ? 16 * Ci * Co : (kind == WT_FOLD5FWD ? 18 * Ci * 16 : KH * KW * Ci * Co);
+    }
+};
+int wt_batch(const WtBatch& b, hipStream_t s);
 int wt_flip_transpose(const float* w, float* out, int KH, int KW, int Ci, int Co, hipStream_t s);
 int wt_upconv_fwd(const float* w, float* weff, int Ci, int Co, hipStream_t s);
 int wt_upconv_dgrad(const float* w, float* v, int Ci, int Co, hipStream_t s);

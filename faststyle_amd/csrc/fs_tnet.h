@@ -42,6 +42,7 @@ struct TnetLayout {
     size_t weff[2];   // collapsed resize-conv filters
     size_t zfold, wfold, dwfold;  // kw-folded output layer: Z / unfolded dY [N,Ho,Wo+4,16], filters, filter grads
     size_t fwd_floats;
+    size_t wTu[16];   // per-unit input-gradient filters (flip+transpose / collapsed), all built by one wt_batch launch
     size_t g[3], dz[2], wT, dweff, inbwd, slabs;  // backward scratch (dz double-buffered: filter gradients run on a side stream)
     size_t total_floats;
 };

@@ -258,7 +258,9 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
     for (int k = 0; k < 3; ++k) L->g[k] = b.take(max_act);
     L->dz[0] = b.take(max_act);
     L->dz[1] = b.take(max_act);
-    L->wT = b.take(81 * 16 * 3 > 9 * 64 * 64 ? 81 * 16 * 3 : 9 * 64 * 64);
+    L->wT = b.take(4);
+    for (int i = 1; i < 16; ++i)
+        L->wTu[i] = L->u[i].kind == 3 ? 0 : b.take((size_t)(L->u[i].kind == 1 ? 9 : L->u[i].K * L->u[i].K) * L->u[i].Cin * L->u[i].Cout);
     L->dweff = b.take(4 * 64 * 128);
     L->inbwd = b.take(max_inbwd);
     for (int i = 0; i < 16; ++i) {
@@ -317,15 +319,17 @@ WgradArgs unit_wgrad_args(const Unit& u, int N) {
 int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s) {
     const int N = L.N;
     // collapsed resize-conv filters (weights may have changed since the last call: training)
+    WtBatch wb{};
     if (L.deconv) {  // filters are stored [K,K,Cout,Cin]: flip + transpose into the [tap][Cin][Cout] the kernel reads
-        FS_TRY(wt_flip_transpose(params + L.u[13].w_off, ws + L.weff[0], 3, 3, 32, 64, s));
-        FS_TRY(wt_flip_transpose(params + L.u[14].w_off, ws + L.weff[1], 3, 3, 16, 32, s));
-        FS_TRY(wt_flip_transpose(params + L.u[15].w_off, ws + L.wfold, 9, 9, 3, 16, s));
+        wb.add(WT_FLIPT, params + L.u[13].w_off, ws + L.weff[0], 3, 3, 32, 64);
+        wb.add(WT_FLIPT, params + L.u[14].w_off, ws + L.weff[1], 3, 3, 16, 32);
+        wb.add(WT_FLIPT, params + L.u[15].w_off, ws + L.wfold, 9, 9, 3, 16);
     } else {
-        FS_TRY(wt_upconv_fwd(params + L.u[13].w_off, ws + L.weff[0], 64, 32, s));
-        FS_TRY(wt_upconv_fwd(params + L.u[14].w_off, ws + L.weff[1], 32, 16, s));
-        FS_TRY(wt_fold5_fwd(params + L.u[15].w_off, ws + L.wfold, 16, s));
+        wb.add(WT_UPFWD, params + L.u[13].w_off, ws + L.weff[0], 3, 3, 64, 32);
+        wb.add(WT_UPFWD, params + L.u[14].w_off, ws + L.weff[1], 3, 3, 32, 16);
+        wb.add(WT_FOLD5FWD, params + L.u[15].w_off, ws + L.wfold, 9, 9, 16, 3);
     }
+    FS_TRY(wt_batch(wb, s));
     const float* src = x;
     const float* src_a = nullptr;
     const float* src_b = nullptr;
@@ -379,7 +383,7 @@ static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, c
     a.N = N;
     a.x = dz;
     a.y = dst;
-    a.w = ws + L.wT;
+    a.w = ws + L.wTu[&u - L.u];  // built at the start of tnet_backward
     a.add_src = add_src;
     a.add_pad = add_src ? 2 : 0;
     if (u.kind == 3) {  // adjoint of conv2d_transpose = the plain strided conv with the stored filter
@@ -396,7 +400,6 @@ static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, c
         a.pad_l = u.dpad_l;
         a.src_mode = SRC_PLAIN;
     } else if (u.kind == 1) {  // resize-conv: 3x3 stride-2 conv over dY, pad 1 before
-        FS_TRY(wt_upconv_dgrad(params + u.w_off, ws + L.wT, u.Cin, u.Cout, s));
         a.H = u.Hout;
         a.W = u.Wout;
         a.Cin = u.Cout;
@@ -408,7 +411,6 @@ static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, c
         a.pad_t = a.pad_l = 1;
         a.src_mode = SRC_PLAIN;
     } else {
-        FS_TRY(wt_flip_transpose(params + u.w_off, ws + L.wT, u.K, u.K, u.Cin, u.Cout, s));
         a.H = u.Hout;
         a.W = u.Wout;
         a.Cin = u.Cout;
@@ -469,6 +471,16 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
     const int N = L.N;
     const bool fork = aux && aux->side && aux->nev >= 34;
     hipStream_t ws_stream = fork ? aux->side : s;  // stream of the filter-gradient branch
+    {  // every input-gradient filter of the step in one launch (the parameters are fixed during a backward)
+        WtBatch wb{};
+        for (int i = 1; i < 16; ++i) {
+            const Unit& u = L.u[i];
+            if (u.kind == 3) continue;  // conv2d_transpose units use the stored filter as is
+            const int K = u.kind == 1 ? 3 : u.K;  // (a resize-conv unit carries its collapsed 2x2 tap count in K)
+            wb.add(u.kind == 1 ? WT_UPDGRAD : WT_FLIPT, params + u.w_off, ws + L.wTu[i], K, K, u.Cin, u.Cout);
+        }
+        FS_TRY(wt_batch(wb, s));
+    }
     const float* g = dy;         // gradient wrt the current unit's output activation (or h_k)
     const float* res_g = nullptr;  // d h_k, kept alive until the block's first conv adds it to its dgrad
     for (int i = 15; i >= 0; --i) {

@@ -52,6 +52,20 @@ class TorchMem(object):
         n = int(np.prod(shape))
         return t.view(-1)[offset:offset + n].view(*shape)
 
+    # ---- input pipeline (datapipe.py): u8 uploads and the HBM-resident shuffle queue
+    def upload_u8(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint8)).to(self.device, non_blocking=True)
+
+    def ptr_u8(self, t):
+        assert t.is_contiguous() and t.dtype == self.torch.uint8 and t.is_cuda
+        return t.data_ptr()
+
+    def gather_rows(self, store, idx):
+        return store.index_select(0, self.torch.as_tensor(np.asarray(idx, dtype=np.int64), device=self.device))
+
+    def copy_row(self, store, src, dst):
+        store[dst].copy_(store[src])
+
 
 def default_loss_cfg():
     """train.py:52-70 defaults: content conv3_3 x1.0; style conv1_2/2_2/3_3/4_3 x5.0."""
@@ -236,6 +250,18 @@ class Engine(object):
                                                       p(self.vgg_prepared), ctypes.byref(c), p(y), p(content), N, H, W,
                                                       p(losses), p(dy), p(ws), nbytes), "fs_perceptual_loss")
         return losses, dy
+
+    def resize_bicubic_u8(self, img_u8, out):
+        """tf.image.resize_images(img, out.shape[:2], method=2) of TF 1.0 (datapipe.py:24) on the device:
+        img_u8 host uint8 [H,W,3] -> ``out`` (device float32 [Ho,Wo,3], written in place)."""
+        self._sync_stream()
+        H, W, C = (int(s) for s in img_u8.shape)
+        Ho, Wo, Co = (int(s) for s in out.shape)
+        assert C == 3 and Co == 3
+        src = self.mem.upload_u8(img_u8)
+        L.check(self.lib, self.lib.fs_resize_bicubic_u8(self.ctx, self.mem.ptr_u8(src), H, W, self.mem.ptr(out), Ho, Wo),
+                "fs_resize_bicubic_u8")
+        return out
 
     def adam_tf_step(self, p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
         """tf.train.AdamOptimizer(lr) update (train.py:203), in place; t = 1-based step."""

@@ -279,6 +279,10 @@ static inline float atomicAdd(float* p, float v) {
     return o;
 }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+// individually rounded float ops (the emulator build uses -ffp-contract=off semantics for these)
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 using std::max;
 using std::min;
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };

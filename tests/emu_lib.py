@@ -18,7 +18,8 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 def build_emu():
     srcs = [os.path.join(fsbuild.CSRC, s) for s in fsbuild.SOURCES]
     deps = srcs + [os.path.join(fsbuild.CSRC, h) for h in os.listdir(fsbuild.CSRC) if h.endswith(".h")] + \
-        [os.path.join(EMU_DIR, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "faststyle_hip.h")]
+        [os.path.join(EMU_DIR, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "faststyle_hip.h"),
+         os.path.join(ROOT, "include", "faststyle_io.h")]
     if os.path.exists(EMU_SO) and os.path.getmtime(EMU_SO) >= max(os.path.getmtime(p) for p in deps):
         return EMU_SO
     objs = []
@@ -56,6 +57,19 @@ class NumpyMem(object):
 
     def stream(self):
         return 0
+
+    def upload_u8(self, a):
+        return np.ascontiguousarray(a, dtype=np.uint8).copy()
+
+    def ptr_u8(self, t):
+        assert t.flags.c_contiguous and t.dtype == np.uint8
+        return t.ctypes.data
+
+    def gather_rows(self, store, idx):
+        return store[np.asarray(idx, dtype=np.int64)].copy()
+
+    def copy_row(self, store, src, dst):
+        store[dst] = store[src]
 
     def device_index(self):
         return 0

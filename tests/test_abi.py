@@ -10,9 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "faststyle_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(fs_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(fs_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_and_prototype_table_agree():

@@ -6,14 +6,17 @@ libfaststyle_hip.so on MI355X, optionally data-parallel (one process per GPU, la
 per-GPU batch and gradients are SUM-all-reduced once per step over RCCL).
 
 Differences from the reference that are forced by the environment and stated, not hidden:
-  * ``--train_dir`` may be a directory of JPEG/PNG files (decoded with PIL, bicubic-resized to
-    ``--preprocess_size``, shuffled with a ``--num_pipe_buffer`` buffer) or the literal
-    ``synthetic`` (uniform [0,255) images, MS-COCO train2014 count 82,783 per epoch); the
-    TFRecord queue pipeline (reference datapipe.py) is a "next" row (SURVEY.md §8f);
+  * ``--train_dir`` is, as in the reference, a directory of ``train-*`` TFRecord shards written by
+    tfrecords_writer.py (read by faststyle_amd/datapipe.py: native record/Example reader, threaded
+    JPEG decode, TF1-bicubic resize kernel, HBM-resident shuffle queue of ``--num_pipe_buffer``
+    images).  Two conveniences on top: a directory of plain JPEG/PNG files (PIL decode + PIL
+    bicubic), and the literal ``synthetic`` (uniform [0,255) images, MS-COCO train2014 count
+    82,783 per epoch) for benchmarking without a dataset;
   * TensorBoard event files are replaced by ``summaries/train/<run_name>/scalars.jsonl`` with the
     same four scalars at the same steps (reference train.py:185-189, 260-272).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -155,11 +158,11 @@ def batcher(train_dir, batch_size, resize, n_epochs, buffer_size, seed, rank, wo
 def main(args):
     import torch
     import torch.distributed as dist
-    from faststyle_amd import ckpt, engine, im_transf_net, trainer, utils, vgg16
+    from faststyle_amd import ckpt, datapipe, engine, im_transf_net, trainer, utils, vgg16
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -211,16 +214,30 @@ def main(args):
             tensors["global_step"] = np.array(tr.global_step, dtype=np.int64)
         ckpt.save_checkpoint(prefix, tensors)
 
+    # Input pipeline (train.py:192-196): TFRecord shards train-* when present
+    shards = sorted(glob.glob(os.path.join(args.train_dir, 'train-*'))) if args.train_dir != 'synthetic' else []
+    if shards:
+        cap = None
+        if world > 1:   # ranks read disjoint shards of unequal size: agree on the common number of steps
+            n_local = datapipe.count_records(shards[rank::world]) * args.n_epochs // args.batch_size
+            t = torch.tensor([n_local], device="cuda:%d" % local_rank, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            cap = int(t.item())
+        batches = datapipe.batcher(shards, args.batch_size, args.preprocess_size, args.n_epochs,
+                                   args.num_pipe_buffer, engine=eng, seed=1234, rank=rank, world=world,
+                                   max_batches=cap)
+    else:
+        batches = (eng.mem.from_numpy(b) for b in batcher(args.train_dir, args.batch_size, args.preprocess_size,
+                                                          args.n_epochs, args.num_pipe_buffer, 1234, rank, world))
     if rank == 0:
         print('Starting training...')
     try:
-        for batch in batcher(args.train_dir, args.batch_size, args.preprocess_size, args.n_epochs,
-                             args.num_pipe_buffer, 1234, rank, world):
+        for batch in batches:
             current_step = tr.global_step
             if rank == 0 and current_step % args.num_steps_ckpt == 0:
                 # Save a checkpoint (train.py:256-259), incl. step 0
                 save('training/' + args.model_name + '.ckpt-%d' % current_step, full=True)
-            losses = tr.step(eng.mem.from_numpy(batch))
+            losses = tr.step(batch)
             if current_step % args.num_steps_ckpt == 0 or current_step % 10 == 0:
                 if world > 1:
                     dist.all_reduce(losses, op=dist.ReduceOp.SUM)     # losses are batch-summed (losses.py:32,63)
