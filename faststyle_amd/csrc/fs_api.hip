@@ -49,6 +49,16 @@ int fs_resize_bicubic_u8(fs_ctx* ctx, const unsigned char* src, int H, int W, fl
     return rc ? fail(rc, "fs_resize_bicubic_u8: launch failed (%d)", rc) : 0;
 }
 
+int fs_u8_to_f32(fs_ctx* ctx, const unsigned char* src, size_t n, float* dst) {
+    if (!ctx || !src || !dst) return fail(-1, "fs_u8_to_f32: null argument");
+    if (((uintptr_t)src & 3) || ((uintptr_t)dst & 15)) return fail(-1, "fs_u8_to_f32: src must be 4-byte, dst 16-byte aligned");
+    return fs::u8_to_f32(src, dst, n, ctx->stream) ? fail(-3, "fs_u8_to_f32: launch failed") : 0;
+}
+int fs_f32_to_u8(fs_ctx* ctx, const float* src, size_t npix, int swap_rb, unsigned char* dst) {
+    if (!ctx || !src || !dst) return fail(-1, "fs_f32_to_u8: null argument");
+    return fs::f32_to_u8(src, dst, npix, swap_rb, ctx->stream) ? fail(-3, "fs_f32_to_u8: launch failed") : 0;
+}
+
 const char* fs_last_error(void) { return g_err; }
 const char* fs_version(void) { return "faststyle_hip 0.1 (gfx950, fp32 MFMA)"; }
 

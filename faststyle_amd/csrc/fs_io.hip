@@ -227,6 +227,39 @@ __global__ __launch_bounds__(256) void resize_bicubic_u8_kernel(const unsigned c
     }
 }
 
+// ---------------------------------------------------------------- frame streaming: u8 <-> f32
+// stylize_webcam.py:88-95: the captured u8 frame is fed to the net as float (channel order untouched), the
+// output goes through numpy .astype(np.uint8) -- truncation toward zero -- and a B<->R swap (cv2.COLOR_BGR2RGB).
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const uchar4 v = *reinterpret_cast<const uchar4*>(src + i);
+        *reinterpret_cast<float4*>(dst + i) = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+    } else {
+        for (size_t k = i; k < n; ++k) dst[k] = (float)src[k];
+    }
+}
+__global__ __launch_bounds__(256) void f32_to_u8_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, size_t npix,
+                                                        int swap_rb) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const float r = src[p * 3], g = src[p * 3 + 1], b = src[p * 3 + 2];
+    // values are in [0,255] (127.5*tanh+127.5); the clamp only guards the u8 conversion against NaN/garbage
+    const unsigned char ur = (unsigned char)fminf(fmaxf(r, 0.f), 255.f), ug = (unsigned char)fminf(fmaxf(g, 0.f), 255.f),
+                        ub = (unsigned char)fminf(fmaxf(b, 0.f), 255.f);
+    dst[p * 3] = swap_rb ? ub : ur;
+    dst[p * 3 + 1] = ug;
+    dst[p * 3 + 2] = swap_rb ? ur : ub;
+}
+int u8_to_f32(const unsigned char* src, float* dst, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(u8_to_f32_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, src, dst, n);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int f32_to_u8(const float* src, unsigned char* dst, size_t npix, int swap_rb, hipStream_t s) {
+    hipLaunchKernelGGL(f32_to_u8_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, src, dst, npix, swap_rb);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 int resize_bicubic_u8(const unsigned char* src, int H, int W, float* dst, int Ho, int Wo, hipStream_t s) {
     // CalculateResizeScale(in, out, align_corners=false) = in / static_cast<float>(out)
     const float hs = (float)H / (float)Ho, ws = (float)W / (float)Wo;

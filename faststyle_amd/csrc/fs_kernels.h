@@ -110,6 +110,8 @@ int reduce_slabs(const float* slabs, int groups, int n_wg, size_t count, float s
 int set_error(int code, const char* fmt, ...);
 // tf.image.resize_images(method=2) of TF 1.0 on device u8 [H,W,3] -> f32 [Ho,Wo,3] (fs_io.hip)
 int resize_bicubic_u8(const unsigned char* src, int H, int W, float* dst, int Ho, int Wo, hipStream_t s);
+int u8_to_f32(const unsigned char* src, float* dst, size_t n, hipStream_t s);
+int f32_to_u8(const float* src, unsigned char* dst, size_t npix, int swap_rb, hipStream_t s);
 int in_bwd(const float* gin, const float* z, const float* mean, const float* rstd, const float* a, const float* b, int mode,
            float* dz, float* dgamma, float* dbeta, float* scratch, int N, int HW, int C, hipStream_t s);
 size_t in_bwd_scratch_floats(int N, int HW, int C);

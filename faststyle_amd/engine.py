@@ -263,6 +263,21 @@ class Engine(object):
                 "fs_resize_bicubic_u8")
         return out
 
+    def u8_to_f32(self, src_u8, dst):
+        """device u8 buffer -> device float32 (same element order)."""
+        self._sync_stream()
+        n = int(np.prod(dst.shape))
+        L.check(self.lib, self.lib.fs_u8_to_f32(self.ctx, self.mem.ptr_u8(src_u8), n, self.mem.ptr(dst)), "fs_u8_to_f32")
+        return dst
+
+    def f32_to_u8(self, src, dst_u8, swap_rb=False):
+        """device float32 [...,3] -> device u8 by truncation (numpy astype(uint8)), optional R<->B swap."""
+        self._sync_stream()
+        npix = int(np.prod(src.shape)) // 3
+        L.check(self.lib, self.lib.fs_f32_to_u8(self.ctx, self.mem.ptr(src), npix, 1 if swap_rb else 0,
+                                                self.mem.ptr_u8(dst_u8)), "fs_f32_to_u8")
+        return dst_u8
+
     def adam_tf_step(self, p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
         """tf.train.AdamOptimizer(lr) update (train.py:203), in place; t = 1-based step."""
         self._sync_stream()

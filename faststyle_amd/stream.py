@@ -1,0 +1,72 @@
+"""Frame-streaming stylizer: the loop body of the reference's stylize_webcam.py (:84-96) on the HIP
+engine -- u8 frame in, u8 frame out, everything in between on the GPU.
+
+Per frame: upload u8 (3 B/pixel over PCIe instead of 12) -> fs_u8_to_f32 -> fs_tnet_forward ->
+fs_f32_to_u8 (``astype(np.uint8)`` truncation + the BGR<->RGB swap of cv2.cvtColor) -> download u8.
+The device part is captured ONCE into a hipGraph (fixed frame size, fixed weights) and replayed per
+frame: a batch-1 frame is ~45 short launches, so replay removes the per-launch host latency from
+the frame time.  Reference quirk kept: the webcam frame is BGR but is fed to the RGB-trained net
+as is, and the *output* channels are swapped before display (stylize_webcam.py:88-95).
+"""
+import numpy as np
+
+from . import _lib as L
+
+
+class FrameStylizer(object):
+    def __init__(self, eng, variables, height, width, upsample_method="resize", batch=1, swap_rb=True, use_graph=True):
+        self.eng = eng
+        self.variables = variables
+        self.method = upsample_method
+        self.shape = (int(batch), int(height), int(width), 3)
+        self.swap_rb = swap_rb
+        mem = eng.mem
+        Ho, Wo = eng.tnet_out_shape(height, width)
+        self.out_shape = (int(batch), Ho, Wo, 3)
+        self._in_u8 = mem.upload_u8(np.zeros(self.shape, np.uint8))
+        self._in_f32 = mem.empty(self.shape)
+        self._out_u8 = mem.upload_u8(np.zeros(self.out_shape, np.uint8))
+        self._graph = None
+        self._use_graph = use_graph and hasattr(mem, "torch")
+        self._y = None
+
+    def _device_pass(self):
+        e = self.eng
+        e.u8_to_f32(self._in_u8, self._in_f32)
+        self._y = e.tnet_forward(self.variables, self._in_f32, upsample_method=self.method)
+        e.f32_to_u8(self._y, self._out_u8, swap_rb=self.swap_rb)
+
+    def _capture(self):
+        torch = self.eng.mem.torch
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up outside capture (one-time initialisation)
+            self._device_pass()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._device_pass()
+        self._graph = g
+
+    def __call__(self, frames_u8):
+        """frames_u8: host uint8 [H,W,3] (or [B,H,W,3]) -> host uint8 stylized frame(s) of the net's output size."""
+        a = np.asarray(frames_u8)
+        single = a.ndim == 3
+        if single:
+            a = a[np.newaxis]
+        if a.shape != self.shape or a.dtype != np.uint8:
+            raise L.FaststyleError("frame shape %s dtype %s, stylizer was built for uint8 %s" % (a.shape, a.dtype, self.shape))
+        mem = self.eng.mem
+        if hasattr(mem, "torch"):
+            self._in_u8.copy_(mem.torch.from_numpy(np.ascontiguousarray(a)), non_blocking=True)
+        else:
+            self._in_u8[...] = a
+        if self._use_graph:
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        else:
+            self._device_pass()
+        out = np.array(mem.to_numpy(self._out_u8), copy=True)     # (synchronises; the device buffer is reused next frame)
+        return out[0] if single else out

@@ -51,6 +51,12 @@ int fs_example_int64(const void* ex, size_t n, const char* key, long long* value
  * src: device u8 [H,W,3]; dst: device f32 [Ho,Wo,3].  Asynchronous on the ctx stream. */
 int fs_resize_bicubic_u8(fs_ctx* ctx, const unsigned char* src, int H, int W, float* dst, int Ho, int Wo);
 
+/* Frame streaming (stylize_webcam.py:88-95): u8 frame -> float net input (channel order untouched), and
+ * net output -> u8 by truncation (numpy .astype(np.uint8)) with an optional R<->B swap
+ * (cv2.cvtColor(..., COLOR_BGR2RGB)).  src of _u8_to_f32: 4-byte aligned; dst: 16-byte aligned. */
+int fs_u8_to_f32(fs_ctx* ctx, const unsigned char* src, size_t n, float* dst);
+int fs_f32_to_u8(fs_ctx* ctx, const float* src, size_t npix, int swap_rb, unsigned char* dst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,116 @@
+#!/usr/bin/env python
+"""Drop-in for the reference's stylize_webcam.py (same flags): filters an OpenCV webcam feed through
+a trained model and writes output.avi, with the network on the MI355X (faststyle_amd/stream.py).
+
+OpenCV (camera capture, window, XVID writer) is a host-side dependency of the reference that this
+image does not ship; without it the script can still filter a *directory of frames*:
+    python stylize_webcam.py --model_path models/starry_final.ckpt --frames_dir in/ --output_dir out/
+(frames are read RGB with PIL and converted to the BGR order a cv2 capture would deliver, so the
+reference's channel handling -- BGR fed as is, output swapped -- is reproduced bit for bit).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def setup_parser():
+    """Options for command-line input (reference stylize_webcam.py:17-39)."""
+    parser = argparse.ArgumentParser(description="""Use a trained fast style
+                                     transfer model to filter webcam feed.""")
+    parser.add_argument('--model_path',
+                        default='./models/starry_final.ckpt',
+                        help='Path to .ckpt for the trained model.')
+    parser.add_argument('--upsample_method',
+                        help="""The upsample method that was used to construct
+                        the model being loaded. Note that if the wrong one is
+                        chosen an error will be thrown.""",
+                        choices=['resize', 'deconv'],
+                        default='resize')
+    parser.add_argument('--resolution',
+                        help="""Dimensions for webcam. Note that, depending on
+                        the webcam, only certain resolutions will be possible.
+                        Leave this argument blank if want to use default
+                        resolution.""",
+                        nargs=2,
+                        type=int,
+                        default=None)
+    parser.add_argument('--frames_dir', default=None,
+                        help='(addition) read frames from this directory instead of a webcam.')
+    parser.add_argument('--output_dir', default='./frames_out',
+                        help='(addition) where --frames_dir results are written.')
+    return parser
+
+
+def _load(args):
+    from faststyle_amd import ckpt, engine
+    eng = engine.Engine()
+    variables = eng.mem.from_numpy(eng.flatten_params(ckpt.load_checkpoint(args.model_path),
+                                                      upsample_method=args.upsample_method))
+    return eng, variables
+
+
+def run_frames_dir(args):
+    from PIL import Image
+    from faststyle_amd import stream
+    names = sorted(f for f in os.listdir(args.frames_dir) if f.lower().endswith(('.jpg', '.jpeg', '.png')))
+    if not names:
+        raise SystemExit('no frames under %s' % args.frames_dir)
+    eng, variables = _load(args)
+    if not os.path.isdir(args.output_dir):
+        os.makedirs(args.output_dir)
+    st = None
+    for n in names:
+        im = Image.open(os.path.join(args.frames_dir, n)).convert('RGB')
+        if args.resolution is not None:
+            im = im.resize(tuple(args.resolution))
+        frame = np.asarray(im, np.uint8)[:, :, ::-1]              # what cap.read() returns: BGR
+        if st is None or st.shape[1:3] != frame.shape[:2]:
+            print('Resolution is: {0} by {1}'.format(frame.shape[1], frame.shape[0]))
+            st = stream.FrameStylizer(eng, variables, frame.shape[0], frame.shape[1], args.upsample_method)
+        img_out = st(np.ascontiguousarray(frame))                 # = cvtColor(astype(uint8)(Y), BGR2RGB)
+        # cv2.imshow / VideoWriter interpret that array as BGR; save exactly what they would show
+        Image.fromarray(img_out[:, :, ::-1]).save(os.path.join(args.output_dir, os.path.splitext(n)[0] + '.png'))
+
+
+def run_webcam(args):
+    try:
+        import cv2
+    except ImportError:
+        raise SystemExit('stylize_webcam.py needs OpenCV (cv2) for camera capture and display, as the reference does; '
+                         'it is not installed here.  Use --frames_dir to filter a directory of frames.')
+    from faststyle_amd import stream
+    cap = cv2.VideoCapture(0)
+    if args.resolution is not None:
+        x_length, y_length = args.resolution
+        cap.set(3, x_length)  # 3 and 4 are OpenCV property IDs.
+        cap.set(4, y_length)
+    x_new, y_new = int(cap.get(3)), int(cap.get(4))
+    print('Resolution is: {0} by {1}'.format(x_new, y_new))
+    print('Loading up model...')
+    eng, variables = _load(args)
+    st = stream.FrameStylizer(eng, variables, y_new, x_new, args.upsample_method)
+    fourcc = cv2.VideoWriter_fourcc(*'XVID')
+    out = cv2.VideoWriter('output.avi', fourcc, 15.0, (x_new, y_new))
+    print('Begin filtering...')
+    while True:
+        ret, frame = cap.read()
+        img_out = st(np.ascontiguousarray(frame))
+        out.write(img_out)
+        cv2.imshow('frame', img_out)
+        if cv2.waitKey(1) & 0xFF == ord('q'):
+            break
+    cap.release()
+    out.release()
+    cv2.destroyAllWindows()
+
+
+if __name__ == '__main__':
+    args = setup_parser().parse_args()
+    if args.frames_dir is not None:
+        run_frames_dir(args)
+    else:
+        run_webcam(args)

@@ -42,6 +42,7 @@ struct dim3 {
 };
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
+struct uchar4 { unsigned char x, y, z, w; };
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }

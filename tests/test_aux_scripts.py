@@ -1,0 +1,117 @@
+"""slow_style.py (pixel optimisation) and the frame-streaming stylizer (stylize_webcam.py loop body):
+SURVEY.md §8f rank 4.  Both are thin compositions of the hot-path entry points, so parity is checked
+against the same oracle functions: two optimisation steps of slow_style against
+perceptual_loss + adam_tf, and a streamed frame against create_net + astype(uint8) + channel swap."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from faststyle_amd import ckpt, engine, stream
+from oracle import perceptual, tnet
+from tests.backends import engine_params, get_engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(params=engine_params())
+def eng(request):
+    return get_engine(request.param)
+
+
+def f64(d):
+    return {k: np.asarray(v, np.float64) for k, v in d.items()}
+
+
+def test_slow_style_flags_match_reference():
+    import slow_style
+    d = vars(slow_style.setup_parser().parse_args([]))
+    assert d["learn_rate"] == 10.0 and d["num_steps_break"] == 500 and d["beta"] == 1e-4      # slow_style.py:24-56
+    assert d["loss_style_layers"] == ["conv1_2", "conv2_2", "conv3_3", "conv4_3"] and d["output_img_path"] == "./out.jpg"
+    assert sorted(d) == ["beta", "cont_img_path", "cont_target_resize", "content_weights", "learn_rate",
+                         "loss_content_layers", "loss_style_layers", "num_steps_break", "output_img_path",
+                         "style_img_path", "style_target_resize", "style_weights"]
+
+
+def test_slow_style_steps_match_oracle(eng):
+    """num_steps_break=1 -> two Adam updates (the reference reads the step before updating)."""
+    import slow_style
+    rng = np.random.default_rng(0)
+    Wv = perceptual.synthetic_vgg_weights(seed=3)
+    cfg = engine.default_loss_cfg()
+    cfg["beta"] = 1e-4
+    style = rng.uniform(0, 255, (1, 24, 28, 3)).astype(np.float32)
+    cont = rng.uniform(0, 255, (1, 16, 20, 3)).astype(np.float32)
+    lines = []
+    got = slow_style.optimise(eng, Wv, style, cont, cfg, 10.0, 1, seed=7, log=lines.append)
+    assert [l.split()[0] for l in lines if l[0].isdigit()] == ["0"]
+    # oracle: same init (RandomState(7).rand), same two steps
+    X = (np.random.RandomState(7).rand(*cont.shape) * 255.0).astype(np.float32).astype(np.float64)
+    tg = perceptual.target_grams(style.astype(np.float64), f64(Wv), cfg["style_layers"])
+    feats = perceptual.vgg16(cont.astype(np.float64), f64(Wv), upto="conv3_3")
+    Xd, m, v = {"x": X}, {"x": np.zeros_like(X)}, {"x": np.zeros_like(X)}
+    first = None
+    for t in (1, 2):
+        lo, dX = perceptual.perceptual_loss(X, [feats["conv3_3"]], tg, f64(Wv), beta=1e-4)
+        first = first if first is not None else lo["loss"]
+        perceptual.adam_tf(Xd, {"x": dX}, m, v, t, lr=10.0)                          # X updated in place
+    assert abs(float(lines[-1].split()[1]) - first) / first < 2e-5
+    # Adam normalises the step to ~lr per pixel: compare the images on the 0..255 scale
+    assert np.abs(got - X).max() < 2e-2 and np.abs(got - X).mean() < 1e-4
+
+
+def test_frame_stylizer_matches_reference_loop_body(eng):
+    """Y = create_net(frame as float); out = cvtColor(astype(uint8)(Y), BGR2RGB)  (stylize_webcam.py:88-95)."""
+    P = tnet.strip_scope(ckpt.load_checkpoint(os.path.join(ROOT, "models", "starry_final.ckpt")))
+    variables = eng.mem.from_numpy(eng.flatten_params(P, scope=""))
+    rng = np.random.default_rng(1)
+    frame = rng.integers(0, 256, (44, 52, 3), dtype=np.uint8)
+    st = stream.FrameStylizer(eng, variables, 44, 52)
+    out = st(frame)
+    y = tnet.create_net(frame[np.newaxis].astype(np.float64), f64(P))[0]
+    want = y.astype(np.uint8)[:, :, ::-1]
+    assert out.shape == want.shape and out.dtype == np.uint8
+    diff = np.abs(out.astype(int) - want.astype(int))
+    # truncation makes a pixel flip by 1 when y sits within float32 noise of an integer; nothing larger
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
+    out2 = st(frame)                                           # second frame goes through the captured graph (GPU)
+    assert np.array_equal(out, out2)
+    with pytest.raises(Exception):
+        st(frame[:40])                                         # wrong frame size
+
+
+@pytest.mark.gpu
+def test_slow_style_cli_and_frames_dir_cli(tmp_path, monkeypatch, capsys):
+    from PIL import Image
+    from faststyle_amd import vgg16
+    import slow_style
+    import stylize_webcam
+    work = tmp_path
+    (work / "libs").mkdir()
+    np.savez(str(work / "libs" / "vgg16_weights.npz"), **vgg16.synthetic_weights(3))
+    monkeypatch.chdir(work)
+    chicago = os.path.join(ROOT, "tests", "golden", "ref_assets", "chicago.jpg")
+    slow_style.main(slow_style.setup_parser().parse_args(
+        ["--style_img_path", os.path.join(ROOT, "style_images", "starry_night_crop.jpg"), "--cont_img_path", chicago,
+         "--style_target_resize", "0.2", "--cont_target_resize", "0.2", "--num_steps_break", "30",
+         "--output_img_path", str(work / "o.jpg")]))
+    out = [l for l in capsys.readouterr().out.splitlines() if l and l[0].isdigit()]
+    steps = [int(l.split()[0]) for l in out]
+    losses = [float(l.split()[1]) for l in out]
+    assert steps == [0, 10, 20, 30] and losses[-1] < 0.5 * losses[0]
+    assert np.asarray(Image.open(str(work / "o.jpg"))).shape[2] == 3
+    # frames-dir mode of the webcam script
+    fd = work / "frames"
+    fd.mkdir()
+    im = Image.open(chicago).resize((160, 120))
+    for k in range(3):
+        im.save(str(fd / ("f%02d.png" % k)))
+    args = stylize_webcam.setup_parser().parse_args(["--model_path", os.path.join(ROOT, "models", "starry_final.ckpt"),
+                                                    "--frames_dir", str(fd), "--output_dir", str(work / "fo")])
+    stylize_webcam.run_frames_dir(args)
+    outs = sorted(os.listdir(str(work / "fo")))
+    assert outs == ["f00.png", "f01.png", "f02.png"]
+    a = np.asarray(Image.open(str(work / "fo" / "f00.png")))
+    assert a.shape == (120, 160, 3) and a.std() > 10
