@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "fs_bf16.h"
 #include "fs_tnet.h"
 #include "fs_vgg.h"
 
@@ -16,6 +17,7 @@ struct fs_ctx {
     // cached layouts (recomputed when the shape changes)
     fs::TnetLayout tnet;
     bool tnet_valid;
+    fs::BTnetLayout* btnet;  // bf16 inference layout (allocated on first use)
     hipStream_t side;      // second stream for the filter-gradient branch of fs_tnet_backward
     hipEvent_t ev[34];
     bool have_side;
@@ -69,6 +71,7 @@ int fs_ctx_create(int device, void* hip_stream, fs_ctx** out) {
     c->device = device;
     c->stream = (hipStream_t)hip_stream;
     c->tnet_valid = false;
+    c->btnet = nullptr;
     c->have_side = false;
     if (!getenv("FS_NO_SIDE_STREAM") && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess) {
         c->have_side = true;
@@ -83,6 +86,7 @@ void fs_ctx_destroy(fs_ctx* ctx) {
         for (int i = 0; i < 34; ++i) (void)hipEventDestroy(ctx->ev[i]);
         (void)hipStreamDestroy(ctx->side);
     }
+    if (ctx) delete ctx->btnet;
     delete ctx;
 }
 int fs_ctx_set_stream(fs_ctx* ctx, void* hip_stream) {
@@ -139,6 +143,14 @@ static const fs::TnetLayout* get_layout(fs_ctx* ctx, int N, int H, int W, int fl
 
 size_t fs_tnet_workspace_bytes(int N, int H, int W, int flags) {
     if (N < 1 || H < 41 || W < 41) return 0;
+    if (flags & FS_FLAG_BF16) {
+        if (flags & (FS_FLAG_SAVE_FOR_BWD | FS_FLAG_UPSAMPLE_DECONV)) return 0;  // inference, resize-conv models only
+        fs::BTnetLayout* B = new fs::BTnetLayout();
+        fs::tnet_layout_bf16(N, H, W, B);
+        const size_t bytes = B->total_bytes;
+        delete B;
+        return bytes;
+    }
     fs::TnetLayout L;
     fs::tnet_layout(N, H, W, (flags & FS_FLAG_UPSAMPLE_DECONV) ? 1 : 0, &L);
     return L.total_floats * sizeof(float);
@@ -148,6 +160,17 @@ int fs_tnet_forward(fs_ctx* ctx, const float* params, const float* x, int N, int
                     size_t ws_bytes, int flags) {
     if (!ctx || !params || !x || !y || !ws) return fail(-1, "fs_tnet_forward: null argument");
     if (N < 1 || H < 41 || W < 41) return fail(-2, "fs_tnet_forward: need N>=1 and H,W>=41 (got %d,%d,%d)", N, H, W);
+    if (flags & FS_FLAG_BF16) {
+        if (flags & (FS_FLAG_SAVE_FOR_BWD | FS_FLAG_UPSAMPLE_DECONV))
+            return fail(-2, "fs_tnet_forward: FS_FLAG_BF16 is inference-only and covers the resize-conv models");
+        if (!ctx->btnet) ctx->btnet = new fs::BTnetLayout();
+        fs::BTnetLayout* B = ctx->btnet;
+        if (B->geo.N != N || B->geo.H != H || B->geo.W != W) fs::tnet_layout_bf16(N, H, W, B);
+        if (ws_bytes < B->total_bytes)
+            return fail(-3, "fs_tnet_forward: workspace too small (%zu < %zu bytes)", ws_bytes, B->total_bytes);
+        const int rc = fs::tnet_forward_bf16(*B, params, x, y, ws, ctx->stream);
+        return rc ? fail(rc, "fs_tnet_forward(bf16): launch failed (%d)", rc) : 0;
+    }
     const fs::TnetLayout* L = get_layout(ctx, N, H, W, flags);
     if (ws_bytes < L->total_floats * sizeof(float))
         return fail(-3, "fs_tnet_forward: workspace too small (%zu < %zu bytes)", ws_bytes, L->total_floats * sizeof(float));

@@ -1,0 +1,665 @@
+// bf16 mixed-precision INFERENCE path of the transform net (BASELINE config 5: 1080p, batch 8 per GPU).
+//
+// Activations are stored in HBM as bf16 (raw conv outputs z, residual sums h), weights are packed to bf16 once
+// per call, every contraction runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, and the instance-norm
+// statistics are taken from the fp32 accumulators before rounding.  At 16x the fp32 MFMA rate the convs stop
+// being matrix-core bound: the design goal of this kernel is bytes, not FLOPs -- 2-byte activations in HBM and
+// LDS, 16-byte LDS fragment reads, producer instance-norm + ReLU folded into the staging load as in the fp32 path.
+//
+// The image-facing ends stay fp32: the input image [N,H,W,3] is read as fp32 (reflect-40 fused, packed to
+// 4-channel bf16 pixels in LDS), and the kw-folded output layer writes its 16 virtual channels as fp32 so the
+// 5-term fold, the last instance norm and the tanh run exactly as in the fp32 path (fs_fold.hip, fs_elem.hip).
+//
+// Reference: im_transf_net.py:14-75 (create_net), same layer semantics as fs_conv.hip / fs_tnet.hip.
+#include "fs_bf16.h"
+
+#include <cstring>
+
+namespace fs {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(unsigned short, (__bf16)f);  // v_cvt_pk_bf16_f32: round to nearest even
+#else
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+#endif
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+__device__ __forceinline__ bool bsrc_coord(int mode, int refl, int v, int n_src, int& s) {
+    if (mode == SRC_REFLECT) {
+        if (v < 0 || v >= n_src + 2 * refl) return false;
+        s = v - refl;
+        if (s < 0) s = -s;
+        if (s >= n_src) s = 2 * (n_src - 1) - s;
+        return true;
+    }
+    s = v;
+    return v >= 0 && v < n_src;
+}
+
+// ---------------------------------------------------------------------------------------------- conv kernel
+// 4 waves; workgroup tile = (4*WM*32 pixels) x (WN*32 channels); per input-channel chunk CC (16 or 32) the patch
+// with halo is staged as [pixel][CC+8] bf16 and the filter chunk as [tap][co][CC+8] bf16 (the +8 pad makes the
+// 16-byte fragment reads of 16 consecutive lanes hit disjoint banks).  The next chunk's global loads are issued
+// before the MFMA sweep of the current one (register prefetch), two barriers per chunk, one LDS stage, so two
+// workgroups fit a CU.  C4 = the 3-channel image layer: pixels are 4-channel bf16 (8 bytes), K runs over
+// (12 taps of a kernel row) x 4, i.e. 3 MFMA k-steps per kernel row, the whole 9x9 filter in one chunk.
+template <int WM, int WN, bool C4>
+__global__ __launch_bounds__(256) void conv_bf16_kernel(ConvBArgs a) {
+    constexpr int BN = WN * 32;
+    HIP_DYNAMIC_SHARED(float, smem_f)
+    unsigned short* smem = reinterpret_cast<unsigned short*>(smem_f);
+    const ConvBPlan& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int n = blockIdx.x / tiles, tr = blockIdx.x % tiles;
+    const int ty0 = (tr / p.tiles_x) * p.TH, tx0 = (tr % p.tiles_x) * p.TW;
+    const int co0 = blockIdx.y * BN;
+    const int PW = p.PW, PH = p.PH, CC = p.CC, PP = p.PP;
+    const int lm = lane & 31, kq = lane >> 5;
+    const int tile_px = p.TH * p.TW;
+    const int G = C4 ? a.KH : a.KH * a.KW;
+    const int WP = C4 ? 56 : PP;                   // filter row pitch (elements)
+    const int patch_elems = (PH * PW * (C4 ? 4 : PP) + 7) & ~7;
+    unsigned short* patch = smem;
+    unsigned short* wl = smem + patch_elems;
+    float* abl = reinterpret_cast<float*>(smem + patch_elems + G * BN * WP);  // [2][Cin] on-load affine
+
+    int laneA[WM];
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+        int t = (wave * WM + m) * 32 + lm;
+        if (t >= tile_px) t = 0;
+        const int py = t / p.TW, px = t - py * p.TW;
+        laneA[m] = C4 ? (py * PW + px) * 4 + kq * 8 : (py * a.stride * PW + px * a.stride) * PP + kq * 8;
+    }
+    const int laneB = lm * WP + kq * 8;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int nn = 0; nn < WN; ++nn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+
+    const int vy0 = ty0 * a.stride - a.pad_t, vx0 = tx0 * a.stride - a.pad_l;
+
+    if constexpr (C4) {
+        // ---- image layer: stage the fp32 RGB patch as 4-channel bf16 pixels, the whole packed filter, one sweep
+        const float* xn = static_cast<const float*>(a.x) + (size_t)n * a.H * a.W * 3;
+        for (int e = tid; e < PH * PW; e += 256) {
+            const int py = e / PW, px = e - py * PW;
+            int sy, sx;
+            const bool ok = bsrc_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) && bsrc_coord(a.src_mode, a.refl, vx0 + px, a.W, sx);
+            uint2 v = make_uint2(0u, 0u);
+            if (ok) {
+                const float* s = xn + ((size_t)sy * a.W + sx) * 3;
+                v.x = pack2(s[0], s[1]);
+                v.y = pack2(s[2], 0.f);
+            }
+            *reinterpret_cast<uint2*>(patch + e * 4) = v;
+        }
+        const int cpad = a.p.cout_pad;
+        for (int e = tid; e < G * BN * 6; e += 256) {  // 48 elements = 6 x 16 bytes per (kh, co)
+            const int row = e / 6, g8 = e - row * 6;
+            const int kh = row / BN, col = row - kh * BN;
+            const uint4 v = *reinterpret_cast<const uint4*>(a.w + ((size_t)kh * cpad + co0 + col) * 48 + g8 * 8);
+            *reinterpret_cast<uint4*>(wl + row * WP + g8 * 8) = v;
+        }
+        __syncthreads();
+        for (int kh = 0; kh < G; ++kh)
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                bf16x8 af[WM], bfr[WN];
+#pragma unroll
+                for (int m = 0; m < WM; ++m) {
+                    const unsigned short* src = patch + laneA[m] + kh * PW * 4 + ks * 16;  // 8-byte aligned
+                    uint4 u;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 4);
+                    u.x = lo.x;
+                    u.y = lo.y;
+                    u.z = hi.x;
+                    u.w = hi.y;
+                    af[m] = __builtin_bit_cast(bf16x8, u);
+                }
+#pragma unroll
+                for (int nn = 0; nn < WN; ++nn)
+                    bfr[nn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wl + (kh * BN + nn * 32) * WP + laneB + ks * 16));
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < WN; ++nn)
+                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[nn], acc[m][nn], 0, 0, 0);
+            }
+        __syncthreads();
+    } else {
+        const unsigned short* xn = static_cast<const unsigned short*>(a.x) + (size_t)n * a.H * a.W * a.Cin;
+        const bool has_ab = a.in_a != nullptr;
+        if (has_ab)
+            for (int c = tid; c < a.Cin; c += 256) {
+                abl[c] = a.in_a[(size_t)n * a.in_nstride + c];
+                abl[a.Cin + c] = a.in_b[(size_t)n * a.in_nstride + c];
+            }
+        constexpr int PMAX = 8, WMAX = 12;  // 16-byte granules per thread and chunk (the plan guarantees the bounds)
+        const int g8n = CC >> 3;            // granules per pixel / per filter row
+        const int g8sh = g8n == 2 ? 1 : 2;
+        const int ne_p = PH * PW * g8n, ne_w = G * BN * g8n;
+        const int cpad = a.p.cout_pad;
+        int goff[PMAX];  // >= 0: element offset of the granule in the image; -1 zero padding; -2 none
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i) {
+            const int e = tid + i * 256;
+            goff[i] = -2;
+            if (e < ne_p) {
+                const int pix = e >> g8sh, g8 = e & (g8n - 1);
+                const int py = pix / PW, px = pix - py * PW;
+                int sy, sx;
+                const bool ok = bsrc_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) && bsrc_coord(a.src_mode, a.refl, vx0 + px, a.W, sx);
+                goff[i] = ok ? (sy * a.W + sx) * a.Cin + g8 * 8 : -1;
+            }
+        }
+        int woff[WMAX];
+#pragma unroll
+        for (int i = 0; i < WMAX; ++i) {
+            const int e = tid + i * 256;
+            woff[i] = -1;
+            if (e < ne_w) {
+                const int row = e >> g8sh, g8 = e & (g8n - 1);
+                const int g = row / BN, col = row - g * BN;
+                woff[i] = (g * cpad + co0 + col) * a.Cin + g8 * 8;
+            }
+        }
+        uint4 pv[PMAX], wv[WMAX];
+        auto issue = [&](int c0) {
+#pragma unroll
+            for (int i = 0; i < PMAX; ++i) {
+                pv[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (goff[i] >= 0) pv[i] = *reinterpret_cast<const uint4*>(xn + goff[i] + c0);
+            }
+#pragma unroll
+            for (int i = 0; i < WMAX; ++i) {
+                wv[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (woff[i] >= 0) wv[i] = *reinterpret_cast<const uint4*>(a.w + woff[i] + c0);
+            }
+        };
+        auto commit = [&](int c0) {
+#pragma unroll
+            for (int i = 0; i < PMAX; ++i) {
+                if (goff[i] == -2) continue;
+                const int e = tid + i * 256;
+                const int pix = e >> g8sh, g8 = e & (g8n - 1);
+                uint4 v = pv[i];
+                if (goff[i] >= 0 && has_ab) {
+                    const float* pa = abl + c0 + g8 * 8;
+                    const float* pb = pa + a.Cin;
+                    unsigned* w32 = reinterpret_cast<unsigned*>(&v);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float lo = fmaf(bf2f((unsigned short)(w32[k] & 0xFFFFu)), pa[2 * k], pb[2 * k]);
+                        float hi = fmaf(bf2f((unsigned short)(w32[k] >> 16)), pa[2 * k + 1], pb[2 * k + 1]);
+                        if (a.in_relu) {
+                            lo = fmaxf(lo, 0.f);
+                            hi = fmaxf(hi, 0.f);
+                        }
+                        w32[k] = pack2(lo, hi);
+                    }
+                }
+                *reinterpret_cast<uint4*>(patch + pix * PP + g8 * 8) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < WMAX; ++i) {
+                const int e = tid + i * 256;
+                if (e < ne_w) {
+                    const int row = e >> g8sh, g8 = e & (g8n - 1);
+                    *reinterpret_cast<uint4*>(wl + row * WP + g8 * 8) = wv[i];
+                }
+            }
+        };
+        const int nks = CC >> 4;
+        issue(0);
+        __syncthreads();  // abl visible
+        for (int c0 = 0; c0 < a.Cin; c0 += CC) {
+            commit(c0);
+            __syncthreads();
+            if (c0 + CC < a.Cin) issue(c0 + CC);
+            for (int kh = 0; kh < a.KH; ++kh)
+                for (int kw = 0; kw < a.KW; ++kw) {
+                    const int g = kh * a.KW + kw;
+                    const int toff = (kh * PW + kw * a.dil_x) * PP;
+                    for (int ks = 0; ks < nks; ++ks) {
+                        bf16x8 af[WM], bfr[WN];
+#pragma unroll
+                        for (int m = 0; m < WM; ++m)
+                            af[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(patch + laneA[m] + toff + ks * 16));
+#pragma unroll
+                        for (int nn = 0; nn < WN; ++nn)
+                            bfr[nn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wl + (g * BN + nn * 32) * WP + laneB + ks * 16));
+#pragma unroll
+                        for (int m = 0; m < WM; ++m)
+#pragma unroll
+                            for (int nn = 0; nn < WN; ++nn)
+                                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[nn], acc[m][nn], 0, 0, 0);
+                    }
+                }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (same structure as fs_conv.hip): per-tile instance-norm partials from the fp32 accumulators, store
+    const int th_valid = min(p.TH, a.Ho - ty0), tw_valid = min(p.TW, a.Wo - tx0);
+    const float inv_tw = 1.0f / (float)p.TW;
+    auto row_of = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * kq; };
+    if (a.stats) {
+        float* red = smem_f;              // [4][BN]
+        float* meanl = smem_f + 4 * BN;   // [BN]
+        float s1[WN];
+#pragma unroll
+        for (int nn = 0; nn < WN; ++nn) s1[nn] = 0.f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = (wave * WM + m) * 32 + row_of(r);
+                const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
+                const bool ok = t < tile_px && py < th_valid && px < tw_valid;
+#pragma unroll
+                for (int nn = 0; nn < WN; ++nn) s1[nn] += ok ? acc[m][nn][r] : 0.f;
+            }
+#pragma unroll
+        for (int nn = 0; nn < WN; ++nn) s1[nn] += __shfl_xor(s1[nn], 32);
+        if (lane < 32)
+#pragma unroll
+            for (int nn = 0; nn < WN; ++nn) red[wave * BN + nn * 32 + lane] = s1[nn];
+        __syncthreads();
+        const float cnt = (float)(th_valid * tw_valid);
+        if (tid < BN) meanl[tid] = (red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid]) / cnt;
+        __syncthreads();
+        float mu[WN], s2[WN];
+#pragma unroll
+        for (int nn = 0; nn < WN; ++nn) {
+            mu[nn] = meanl[nn * 32 + lm];
+            s2[nn] = 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = (wave * WM + m) * 32 + row_of(r);
+                const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
+                const bool ok = t < tile_px && py < th_valid && px < tw_valid;
+#pragma unroll
+                for (int nn = 0; nn < WN; ++nn) {
+                    const float d = acc[m][nn][r] - mu[nn];
+                    s2[nn] += ok ? d * d : 0.f;
+                }
+            }
+#pragma unroll
+        for (int nn = 0; nn < WN; ++nn) s2[nn] += __shfl_xor(s2[nn], 32);
+        if (lane < 32)
+#pragma unroll
+            for (int nn = 0; nn < WN; ++nn) red[wave * BN + nn * 32 + lane] = s2[nn];
+        __syncthreads();
+        if (tid < BN && co0 + tid < a.Cout) {
+            float* st = a.stats + ((size_t)blockIdx.x * a.Cout + co0 + tid) * 3;
+            st[0] = meanl[tid];
+            st[1] = red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid];
+            st[2] = cnt;
+        }
+    }
+
+    const int Cr = a.shuffle ? a.Cout >> 2 : a.Cout;
+    const size_t img = (size_t)n * a.Ho * a.Wo * a.Cout;
+    unsigned short* yb = static_cast<unsigned short*>(a.y) + img;
+    float* yf = static_cast<float*>(a.y) + img;
+    int cof[WN], qa[WN], qb[WN];
+    bool cok[WN];
+#pragma unroll
+    for (int nn = 0; nn < WN; ++nn) {
+        const int co = co0 + nn * 32 + lm;
+        cok[nn] = co < a.Cout;
+        const int q = a.shuffle ? co / Cr : 0;
+        cof[nn] = a.shuffle ? co - q * Cr : co;
+        qa[nn] = q >> 1;
+        qb[nn] = q & 1;
+    }
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = (wave * WM + m) * 32 + row_of(r);
+            const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
+            if (!(t < tile_px && py < th_valid && px < tw_valid)) continue;
+            const int oy = ty0 + py, ox = tx0 + px;
+#pragma unroll
+            for (int nn = 0; nn < WN; ++nn) {
+                if (!cok[nn]) continue;
+                const int o = a.shuffle ? ((2 * oy + qa[nn]) * (2 * a.Wo) + 2 * ox + qb[nn]) * Cr + cof[nn]
+                                        : (oy * a.Wo + ox) * a.Cout + cof[nn];
+                if (a.y_f32)
+                    yf[o] = acc[m][nn][r];
+                else
+                    yb[o] = f2bf(acc[m][nn][r]);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------- plan / launch
+static inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+ConvBPlan conv_bf16_plan(const ConvBArgs& a) {
+    ConvBPlan p{};
+    p.c4 = a.Cin == 3;
+    p.BN = a.Cout > 32 ? 64 : 32;
+    p.cout_pad = roundup(a.Cout, p.BN);
+    const int dil = a.dil_x > 0 ? a.dil_x : 1;
+    const int kw_span = p.c4 ? 12 : (a.KW - 1) * dil + 1;
+    const int G = p.c4 ? a.KH : a.KH * a.KW;
+    // widest pixel tile / deepest channel chunk whose staging fits the per-thread register budget; the narrower
+    // tile when the launch could not fill the chip
+    for (p.WM = 2; p.WM >= 1; --p.WM) {
+        const int max_px = 4 * p.WM * 32;
+        plan_tile(a.Ho, a.Wo, a.KH, p.c4 ? 12 : a.KW, a.stride, max_px, &p.TH, &p.TW);
+        p.tiles_y = cdiv(a.Ho, p.TH);
+        p.tiles_x = cdiv(a.Wo, p.TW);
+        p.PH = (p.TH - 1) * a.stride + a.KH;
+        p.PW = (p.TW - 1) * a.stride + kw_span;
+        const long wgs = (long)a.N * p.tiles_y * p.tiles_x * (p.cout_pad / p.BN);
+        bool fits = false;
+        for (p.CC = p.c4 ? 4 : (a.Cin % 32 == 0 ? 32 : 16); p.CC >= (p.c4 ? 4 : 16); p.CC >>= 1) {
+            p.PP = p.CC + 8;
+            const int patch_elems = (p.PH * p.PW * (p.c4 ? 4 : p.PP) + 7) & ~7;
+            p.lds_bytes = 2 * (patch_elems + G * p.BN * (p.c4 ? 56 : p.PP)) + 8 * a.Cin + 16;
+            if (p.lds_bytes < 4 * 5 * p.BN) p.lds_bytes = 4 * 5 * p.BN;
+            fits = p.lds_bytes <= 80 * 1024 &&
+                   (p.c4 || (p.PH * p.PW * (p.CC / 8) <= 8 * 256 && G * p.BN * (p.CC / 8) <= 12 * 256));
+            if (fits || p.c4) break;
+        }
+        if (p.CC < (p.c4 ? 4 : 16)) p.CC = p.c4 ? 4 : 16;
+        if (p.WM == 1 || (fits && wgs >= 512)) break;
+    }
+    return p;
+}
+
+int conv_bf16_launch(const ConvBArgs& a_in, hipStream_t s) {
+    ConvBArgs a = a_in;
+    if (a.dil_x < 1) a.dil_x = 1;
+    const ConvBPlan& p = a.p;
+    if (!p.c4 && (a.Cin % p.CC)) return -1;
+    if (p.c4 && (a.stride != 1 || a.KW > 12 || !a.x_f32)) return -1;
+    if (p.lds_bytes > 160 * 1024) return -2;
+    const int G = p.c4 ? a.KH : a.KH * a.KW;
+    if (!p.c4 && (p.PH * p.PW * (p.CC / 8) > 8 * 256 || G * p.BN * (p.CC / 8) > 12 * 256)) return -2;
+    dim3 grid((unsigned)(a.N * p.tiles_y * p.tiles_x), (unsigned)(p.cout_pad / p.BN));
+#define FS_BLAUNCH(WM_, WN_, C4_)                                                                                       \
+    do {                                                                                                                \
+        static bool attr_done = false;                                                                                  \
+        if (!attr_done) {                                                                                               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_kernel<WM_, WN_, C4_>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
+            attr_done = true;                                                                                           \
+        }                                                                                                               \
+        hipLaunchKernelGGL((conv_bf16_kernel<WM_, WN_, C4_>), grid, dim3(256), (size_t)p.lds_bytes, s, a);              \
+    } while (0)
+    if (p.c4) {
+        if (p.BN != 32) return -4;
+        if (p.WM == 2)
+            FS_BLAUNCH(2, 1, true);
+        else
+            FS_BLAUNCH(1, 1, true);
+    } else if (p.BN == 64) {
+        if (p.WM == 2)
+            FS_BLAUNCH(2, 2, false);
+        else
+            FS_BLAUNCH(1, 2, false);
+    } else {
+        if (p.WM == 2)
+            FS_BLAUNCH(2, 1, false);
+        else
+            FS_BLAUNCH(1, 1, false);
+    }
+#undef FS_BLAUNCH
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// ---------------------------------------------------------------------------------------------- weight packing
+// One launch converts every filter of the net to the packed bf16 layouts the kernel reads:
+//   PK_CONV  [G][cout_pad][Cin]        from HWIO fp32
+//   PK_UP    same, G = 4, from the phase-collapsed resize-conv filter (im_transf_net.py:122-155; see fs_elem.hip)
+//   PK_FOLD  [18][32][16]              kw-folded output layer (fs_fold.hip): tap = kh*2+b, column j = v*3+co
+//   PK_C4    [9][32][48]               image layer: k = kw*4 + ci, zero for kw >= 9, ci == 3, co >= Cout
+struct PackJob {
+    int kind, G, Cin, Cout, cout_pad, total;
+    const float* src;
+    unsigned short* dst;
+};
+struct PackBatch {
+    int n;
+    PackJob j[16];
+};
+__device__ __forceinline__ bool bup_in_R(int a, int d, int k) {
+    if (a == 0) return d == 0;
+    return d == 0 ? k < 2 : k == 2;
+}
+__global__ __launch_bounds__(256) void pack_bf16_kernel(PackBatch b) {
+    const PackJob& q = b.j[blockIdx.y];
+    const float* __restrict__ w = q.src;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < q.total; i += gridDim.x * 256) {
+        float v = 0.f;
+        if (q.kind == PK_CONV) {
+            const int ci = i % q.Cin;
+            const int r = i / q.Cin;
+            const int co = r % q.cout_pad, g = r / q.cout_pad;
+            if (co < q.Cout) v = w[((size_t)g * q.Cin + ci) * q.Cout + co];
+        } else if (q.kind == PK_UP) {  // q.Cout = 4 * Co virtual channels
+            const int Co = q.Cout >> 2;
+            const int ci = i % q.Cin;
+            const int r = i / q.Cin;
+            const int j = r % q.cout_pad, tap = r / q.cout_pad;
+            if (j < q.Cout) {
+                const int dy = tap >> 1, dx = tap & 1;
+                const int qq = j / Co, co = j - qq * Co, aa = qq >> 1, bb = qq & 1;
+                for (int kh = 0; kh < 3; ++kh)
+                    for (int kw = 0; kw < 3; ++kw)
+                        if (bup_in_R(aa, dy, kh) && bup_in_R(bb, dx, kw)) v += w[((kh * 3 + kw) * q.Cin + ci) * Co + co];
+            }
+        } else if (q.kind == PK_FOLD) {
+            const int ci = i % q.Cin;
+            const int r = i / q.Cin;
+            const int j = r % q.cout_pad, tap = r / q.cout_pad;
+            const int kh = tap >> 1, bb = tap & 1;
+            const int vv = j / 3, co = j - vv * 3, kw = 5 * bb + vv;
+            if (j < 15 && kw < 9) v = w[((kh * 9 + kw) * q.Cin + ci) * 3 + co];
+        } else {  // PK_C4
+            const int k = i % 48;
+            const int r = i / 48;
+            const int co = r % q.cout_pad, kh = r / q.cout_pad;
+            const int kw = k >> 2, ci = k & 3;
+            if (kw < 9 && ci < 3 && co < q.Cout) v = w[((kh * 9 + kw) * 3 + ci) * q.Cout + co];
+        }
+        q.dst[i] = f2bf(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- elementwise
+// h = a*z + b + T(skip[y+2, x+2]) on bf16 tensors (im_transf_net.py:268-274); 8 channels (16 bytes) per thread
+__global__ __launch_bounds__(256) void apply_res_bf16_kernel(const unsigned short* __restrict__ z, const float* __restrict__ a,
+                                                             const float* __restrict__ b, const unsigned short* __restrict__ skip,
+                                                             const float* __restrict__ sa, const float* __restrict__ sb,
+                                                             int skip_relu, unsigned short* __restrict__ out, int H, int W, int C,
+                                                             size_t total8) {
+    const int c8n = C >> 3;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
+        const int c8 = (int)(i % c8n);
+        size_t pix = i / c8n;
+        const int x = (int)(pix % W);
+        pix /= W;
+        const int y = (int)(pix % H);
+        const int n = (int)(pix / H);
+        const uint4 zv = *reinterpret_cast<const uint4*>(z + i * 8);
+        const uint4 sv = *reinterpret_cast<const uint4*>(skip + ((((size_t)n * (H + 4) + y + 2) * (W + 4) + x + 2) * C + c8 * 8));
+        const unsigned* z32 = reinterpret_cast<const unsigned*>(&zv);
+        const unsigned* s32 = reinterpret_cast<const unsigned*>(&sv);
+        uint4 ov;
+        unsigned* o32 = reinterpret_cast<unsigned*>(&ov);
+        const int k0 = n * C + c8 * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float r[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = k0 + 2 * k + h;
+                float sk = bf2f((unsigned short)(h ? s32[k] >> 16 : s32[k] & 0xFFFFu));
+                if (sa) sk = fmaf(sk, sa[c], sb[c]);
+                if (skip_relu) sk = fmaxf(sk, 0.f);
+                const float zz = bf2f((unsigned short)(h ? z32[k] >> 16 : z32[k] & 0xFFFFu));
+                r[h] = fmaf(zz, a[c], b[c]) + sk;
+            }
+            o32[k] = pack2(r[0], r[1]);
+        }
+        *reinterpret_cast<uint4*>(out + i * 8) = ov;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- the forward
+static size_t take(size_t& off, size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+}
+
+static ConvBArgs unit_bargs(const Unit& u, int N) {
+    ConvBArgs a{};
+    a.N = N;
+    a.H = u.Hsrc;
+    a.W = u.Wsrc;
+    a.Cin = u.Cin;
+    a.Ho = u.Hc;
+    a.Wo = u.Wc;
+    a.Cout = u.Cc;
+    a.KH = u.K;
+    a.KW = u.KWx;
+    a.dil_x = u.dil_x;
+    a.stride = u.stride;
+    a.pad_t = u.pad_t;
+    a.pad_l = u.pad_l;
+    a.src_mode = u.src_mode;
+    a.refl = u.refl;
+    a.shuffle = u.kind == 1;
+    a.x_f32 = u.Cin == 3;
+    a.y_f32 = u.kind == 2;
+    return a;
+}
+
+int tnet_layout_bf16(int N, int H, int W, BTnetLayout* L) {
+    memset(L, 0, sizeof(*L));
+    tnet_layout(N, H, W, 0, &L->geo);
+    size_t off = 0;
+    for (int i = 0; i < 16; ++i) {
+        const Unit& u = L->geo.u[i];
+        ConvBArgs a = unit_bargs(u, N);
+        L->plan[i] = conv_bf16_plan(a);
+        const ConvBPlan& p = L->plan[i];
+        L->tiles[i] = u.kind == 2 ? cdiv(u.Hout * u.Wout, 256) : p.tiles_y * p.tiles_x;
+        const size_t act = (size_t)N * u.Hout * u.Wout * u.Cout;
+        L->z[i] = take(off, act * (i == 15 ? 4 : 2));
+        L->stats[i] = take(off, (size_t)N * L->tiles[i] * (u.kind == 2 ? u.Cout : u.Cc) * 3 * 4);
+        L->mean[i] = take(off, (size_t)N * u.Cout * 4);
+        L->rstd[i] = take(off, (size_t)N * u.Cout * 4);
+        L->a[i] = take(off, (size_t)N * u.Cout * 4);
+        L->b[i] = take(off, (size_t)N * u.Cout * 4);
+        const int G = p.c4 ? u.K : u.K * u.KWx;
+        L->wpk_elems[i] = (size_t)G * p.cout_pad * (p.c4 ? 48 : u.Cin);
+        L->wpk[i] = take(off, L->wpk_elems[i] * 2);
+    }
+    for (int k = 0; k < 5; ++k) {
+        const Unit& u2 = L->geo.u[3 + 2 * k + 1];
+        L->h[k] = take(off, (size_t)N * u2.Hout * u2.Wout * 64 * 2);
+    }
+    L->zfold = take(off, (size_t)N * L->geo.u[15].Hc * L->geo.u[15].Wc * 16 * 4);
+    L->total_bytes = off;
+    return 0;
+}
+
+int tnet_forward_bf16(const BTnetLayout& L, const float* params, const float* x, float* y, void* ws_v, hipStream_t s) {
+    unsigned char* ws = static_cast<unsigned char*>(ws_v);
+    const int N = L.geo.N;
+    PackBatch pb{};
+    int mx = 0;
+    for (int i = 0; i < 16; ++i) {
+        const Unit& u = L.geo.u[i];
+        PackJob& q = pb.j[pb.n++];
+        q.kind = i == 0 ? PK_C4 : (u.kind == 1 ? PK_UP : (u.kind == 2 ? PK_FOLD : PK_CONV));
+        q.G = L.plan[i].c4 ? u.K : u.K * u.KWx;
+        q.Cin = u.Cin;
+        q.Cout = u.kind == 2 ? 16 : (i == 0 ? u.Cout : u.Cc);
+        q.cout_pad = L.plan[i].cout_pad;
+        q.total = (int)L.wpk_elems[i];
+        q.src = params + u.w_off;
+        q.dst = reinterpret_cast<unsigned short*>(ws + L.wpk[i]);
+        if (q.total > mx) mx = q.total;
+    }
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(cdiv(mx, 256), pb.n), dim3(256), 0, s, pb);
+
+    const void* src = x;
+    const float* src_a = nullptr;
+    const float* src_b = nullptr;
+    for (int i = 0; i < 16; ++i) {
+        const Unit& u = L.geo.u[i];
+        ConvBArgs a = unit_bargs(u, N);
+        a.p = L.plan[i];
+        a.x = src;
+        a.in_a = src_a;
+        a.in_b = src_b;
+        a.in_nstride = src_a ? u.Cin : 0;
+        a.in_relu = src_a ? 1 : 0;
+        a.w = reinterpret_cast<const unsigned short*>(ws + L.wpk[i]);
+        a.y = u.kind == 2 ? static_cast<void*>(ws + L.zfold) : static_cast<void*>(ws + L.z[i]);
+        a.stats = u.kind == 2 ? nullptr : reinterpret_cast<float*>(ws + L.stats[i]);
+        int rc = conv_bf16_launch(a, s);
+        if (rc) return rc;
+        float* stats = reinterpret_cast<float*>(ws + L.stats[i]);
+        if (u.kind == 2) {
+            rc = fold5_fwd(reinterpret_cast<const float*>(ws + L.zfold), reinterpret_cast<float*>(ws + L.z[i]), stats, N, u.Hout,
+                           u.Wout, s);
+            if (rc) return rc;
+        }
+        float* ua = reinterpret_cast<float*>(ws + L.a[i]);
+        float* ub = reinterpret_cast<float*>(ws + L.b[i]);
+        rc = in_finalize(stats, N, L.tiles[i], u.Cout, u.kind == 1 ? 4 : 1, params + u.g_off, params + u.b_off, 1e-3f,
+                         reinterpret_cast<float*>(ws + L.mean[i]), reinterpret_cast<float*>(ws + L.rstd[i]), ua, ub, s);
+        if (rc) return rc;
+        src = ws + L.z[i];
+        src_a = ua;
+        src_b = ub;
+        if (i >= 4 && i <= 12 && ((i - 3) & 1)) {  // second conv of a residual block -> materialise h_k (bf16)
+            const int k = (i - 4) / 2;
+            const unsigned short* skip;
+            const float *sa = nullptr, *sb = nullptr;
+            if (k == 0) {
+                skip = reinterpret_cast<const unsigned short*>(ws + L.z[2]);
+                sa = reinterpret_cast<const float*>(ws + L.a[2]);
+                sb = reinterpret_cast<const float*>(ws + L.b[2]);
+            } else {
+                skip = reinterpret_cast<const unsigned short*>(ws + L.h[k - 1]);
+            }
+            const size_t total8 = (size_t)N * u.Hout * u.Wout * 64 / 8;
+            hipLaunchKernelGGL(apply_res_bf16_kernel, dim3((unsigned)min((size_t)4096, (total8 + 255) / 256)), dim3(256), 0, s,
+                               reinterpret_cast<const unsigned short*>(ws + L.z[i]), ua, ub, skip, sa, sb, k == 0 ? 1 : 0,
+                               reinterpret_cast<unsigned short*>(ws + L.h[k]), u.Hout, u.Wout, 64, total8);
+            src = ws + L.h[k];
+            src_a = src_b = nullptr;
+        }
+    }
+    const Unit& u = L.geo.u[15];
+    return apply_tanh(reinterpret_cast<const float*>(ws + L.z[15]), reinterpret_cast<const float*>(ws + L.a[15]),
+                      reinterpret_cast<const float*>(ws + L.b[15]), y, N, u.Hout * u.Wout, 3, s);
+}
+
+}  // namespace fs

@@ -534,7 +534,7 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-static void plan_tile(int Ho, int Wo, int KH, int KW, int stride, int max_px, int* TH, int* TW) {
+void plan_tile(int Ho, int Wo, int KH, int KW, int stride, int max_px, int* TH, int* TW) {
     double best = -1;
     int bth = 1, btw = 1;
     for (int tw = 1; tw <= Wo && tw <= max_px; ++tw) {

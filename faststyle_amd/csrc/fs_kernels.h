@@ -106,6 +106,8 @@ int apply_res(const float* z, const float* a, const float* b, const float* skip,
               int skip_relu, float* out, int N, int H, int W, int C, hipStream_t s);
 int apply_tanh(const float* z, const float* a, const float* b, float* y, int N, int HW, int C, hipStream_t s);
 int reduce_slabs(const float* slabs, int groups, int n_wg, size_t count, float scale, float* out, hipStream_t s);
+// output-pixel tile (TH x TW <= max_px) with the best fill / halo trade-off for an Ho x Wo image (fs_conv.hip)
+void plan_tile(int Ho, int Wo, int KH, int KW, int stride, int max_px, int* TH, int* TW);
 // thread-local message behind fs_last_error(); returns `code` (fs_api.hip)
 int set_error(int code, const char* fmt, ...);
 // tf.image.resize_images(method=2) of TF 1.0 on device u8 [H,W,3] -> f32 [Ho,Wo,3] (fs_io.hip)

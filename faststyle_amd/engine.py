@@ -139,10 +139,10 @@ class Engine(object):
         L.check(self.lib, self.lib.fs_tnet_out_shape(H, W, ctypes.byref(ho), ctypes.byref(wo)), "fs_tnet_out_shape")
         return ho.value, wo.value
 
-    def _tnet_workspace(self, N, H, W):
-        key = (N, H, W)
+    def _tnet_workspace(self, N, H, W, bf16=False):
+        key = (N, H, W, bf16)
         if key not in self._tnet_ws:
-            nbytes = self.lib.fs_tnet_workspace_bytes(N, H, W, L.FS_FLAG_SAVE_FOR_BWD)
+            nbytes = self.lib.fs_tnet_workspace_bytes(N, H, W, L.FS_FLAG_BF16 if bf16 else L.FS_FLAG_SAVE_FOR_BWD)
             if nbytes == 0:
                 raise L.FaststyleError("bad transform-net shape %s" % (key,))
             self._tnet_ws = {key: (self.mem.empty((nbytes // 4,)), nbytes)}   # keep only the latest shape
@@ -153,17 +153,19 @@ class Engine(object):
         assert upsample_method in ("resize", "deconv")
         return L.FS_FLAG_UPSAMPLE_DECONV if upsample_method == "deconv" else 0
 
-    def tnet_forward(self, params, x, save_for_bwd=False, upsample_method="resize"):
-        """create_net(x, upsample_method): x [N,H,W,3] float32 RGB 0..255 -> y [N,Ho,Wo,3]."""
+    def tnet_forward(self, params, x, save_for_bwd=False, upsample_method="resize", bf16=False):
+        """create_net(x, upsample_method): x [N,H,W,3] float32 RGB 0..255 -> y [N,Ho,Wo,3].
+        bf16=True: the mixed-precision inference path (FS_FLAG_BF16; ~1e-2 of the pixel range off the fp32 path)."""
         self._sync_stream()
         N, H, W, C = (int(s) for s in x.shape)
         assert C == 3
         Ho, Wo = self.tnet_out_shape(H, W)
-        ws, nbytes = self._tnet_workspace(N, H, W)
+        ws, nbytes = self._tnet_workspace(N, H, W, bf16)
         y = self.mem.empty((N, Ho, Wo, 3))
         p = self.mem.ptr
         L.check(self.lib, self.lib.fs_tnet_forward(self.ctx, p(params), p(x), N, H, W, p(y), p(ws), nbytes,
                                                    (L.FS_FLAG_SAVE_FOR_BWD if save_for_bwd else 0) |
+                                                   (L.FS_FLAG_BF16 if bf16 else 0) |
                                                    self._method_flag(upsample_method)), "fs_tnet_forward")
         return y
 

@@ -178,3 +178,79 @@ def strip_scope(tensors, scope="img_t_net/"):
     """Checkpoint names -> oracle names (drops the variable_scope prefix used at
     stylize_image.py:63 / train.py:159)."""
     return OrderedDict((k[len(scope):], v) for k, v in tensors.items() if k.startswith(scope))
+
+
+# ---------------------------------------------------------------------- bf16 mixed-precision restatement
+def bf16_round(x):
+    """float -> nearest bfloat16 (ties to even), returned as float32/float64 of the same shape."""
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+def create_net_bf16(x, params):
+    """create_net ('resize') with the rounding points of the HIP mixed-precision inference path
+    (fs_bf16.hip, FS_FLAG_BF16): weights, the image, every conv input (after the producer's
+    instance-norm + ReLU) and every stored activation are bfloat16; accumulation, instance-norm
+    statistics (taken before the output is rounded), the last layer's output, its instance norm and
+    the tanh are full precision.  The resize-conv is evaluated in its phase-collapsed form because
+    the kernel rounds the COLLAPSED filter.  Test infrastructure for the config-5 path only: the
+    parity bar of the project (1e-3 of the pixel range) applies to the fp32 path, not to this one."""
+    P = {k: np.asarray(v, np.float64) for k, v in params.items()}
+    r = lambda t: bf16_round(t).astype(np.float64)
+
+    def norm_consts(z, name, g="INscale", b="INshift"):
+        mean = z.mean(axis=(1, 2), keepdims=True)
+        var = z.var(axis=(1, 2), keepdims=True)
+        a = P[name + "/" + g] / np.sqrt(var + 1e-3)
+        return a, P[name + "/" + b] - mean * a
+
+    h = r(F.reflect_pad(np.asarray(x, np.float64), 40))                      # image pixels -> bf16
+    strides = {"initconv_0": 1, "initconv_1": 2, "initconv_2": 2}
+    for name in ("initconv_0", "initconv_1", "initconv_2"):
+        z = F.conv2d(h, r(P[name + "/W"]), strides[name], "SAME")
+        a, b = norm_consts(z, name)
+        zs = r(z)                                                              # stored bf16
+        h = r(np.maximum(a * zs + b, 0.0))                                     # consumer's staging: relu(a z + b) -> bf16
+    skip_raw = (zs, a, b)                                                      # block 0 reads the raw initconv_2 output
+    hk = None
+    for i in range(5):
+        name = "resblock_%d" % i
+        z1 = F.conv2d(h, r(P[name + "/W1"]), 1, "VALID")
+        a1, b1 = norm_consts(z1, name, "INscale1", "INshift1")
+        a1in = r(np.maximum(a1 * r(z1) + b1, 0.0))
+        z2 = F.conv2d(a1in, r(P[name + "/W2"]), 1, "VALID")
+        a2, b2 = norm_consts(z2, name, "INscale2", "INshift2")
+        if i == 0:
+            sk = np.maximum(skip_raw[1] * skip_raw[0] + skip_raw[2], 0.0)
+        else:
+            sk = hk
+        hk = r(a2 * r(z2) + b2 + sk[:, 2:-2, 2:-2, :])                         # h_k stored bf16
+        h = hk
+    for name in ("upsample_0", "upsample_1"):
+        w = P[name + "/W"].astype(np.float32)
+        ci, co = w.shape[2], w.shape[3]
+        R = {(0, 0): (0, 1, 2), (0, 1): (), (1, 0): (0, 1), (1, 1): (2,)}      # (phase, tap) -> source rows/cols
+        weff = np.zeros((2, 2, ci, 4, co), np.float32)
+        for pa in range(2):
+            for dy in range(2):
+                for pb in range(2):
+                    for dx in range(2):
+                        acc = np.zeros((ci, co), np.float32)
+                        for kh in range(3):
+                            for kw in range(3):
+                                if kh in R[(pa, dy)] and kw in R[(pb, dx)]:
+                                    acc = acc + w[kh, kw]
+                        weff[dy, dx, :, pa * 2 + pb, :] = acc
+        weff = r(weff.reshape(2, 2, ci, 4 * co))
+        hp = np.pad(h, ((0, 0), (0, 1), (0, 1), (0, 0)))
+        zc = F.conv2d(hp, weff, 1, "VALID")                                    # [N,H,W,4*co]
+        N, Hh, Ww, _ = zc.shape
+        z = zc.reshape(N, Hh, Ww, 2, 2, co).transpose(0, 1, 3, 2, 4, 5).reshape(N, 2 * Hh, 2 * Ww, co)
+        a, b = norm_consts(z, name)
+        h = r(np.maximum(a * r(z) + b, 0.0))
+    name = "upsample_2"
+    z = F.conv2d(h, r(P[name + "/W"]), 1, "SAME")                              # fp32 output in the kernel
+    n, _ = F.inst_norm(z, P[name + "/INscale"], P[name + "/INshift"])
+    return F.scaled_tanh(n)

@@ -43,6 +43,10 @@ struct dim3 {
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct uchar4 { unsigned char x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
@@ -84,6 +88,7 @@ enum State { RUN = 0, WAIT_WAVE, WAIT_BLOCK, DONE };
 
 struct Wave {
     float a[2][64], b[2][64];
+    float a8[2][64][8], b8[2][64][8];   // bf16 fragments of the 32x32x16 MFMA, widened to float
     float sh[2][64];
     unsigned arrived = 0, gen = 0;
 };
@@ -234,6 +239,32 @@ inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
     return c;
 }
 
+// v_mfma_f32_32x32x16_bf16: lane l holds A[i = l&31][k = 8*(l>>5) .. +7] and B[k = 8*(l>>5) .. +7][j = l&31];
+// products of bf16 values are exact in fp32, the sum order inside the instruction is not architecturally
+// specified -- the emulator adds k-ascending (parity tests of the bf16 path carry a tolerance, not bit equality).
+typedef __bf16 bf16x8_emu __attribute__((ext_vector_type(8)));
+inline f32x16 mfma_32x32x16_bf16(bf16x8_emu a, bf16x8_emu b, f32x16 c) {
+    Block& bk = blk(); Fiber* f = bk.cur; Wave& w = bk.waves[f->wave];
+    int s = f->mfma_seq++ & 1, l = f->lane;
+    unsigned short ra[8], rb[8];
+    __builtin_memcpy(ra, &a, 16);
+    __builtin_memcpy(rb, &b, 16);
+    for (int k = 0; k < 8; ++k) {
+        unsigned ua = (unsigned)ra[k] << 16, ub = (unsigned)rb[k] << 16;
+        __builtin_memcpy(&w.a8[s][l][k], &ua, 4);
+        __builtin_memcpy(&w.b8[s][l][k], &ub, 4);
+    }
+    wave_sync();
+    int j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) acc += w.a8[s][i + 32 * (k >> 3)][k & 7] * w.b8[s][j + 32 * (k >> 3)][k & 7];
+        c[r] = acc;
+    }
+    return c;
+}
+
 inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     Block& bk = blk(); Fiber* f = bk.cur; Wave& w = bk.waves[f->wave];
     int s = f->mfma_seq++ & 1, l = f->lane;
@@ -268,6 +299,7 @@ inline float shfl_idx(float v, int src) {
 
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) fsemu::mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) fsemu::mfma_16x16x4((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) fsemu::mfma_32x32x16_bf16((a), (b), (c))
 
 static inline float __shfl_xor(float v, int mask, int width = 64) { (void)width; return fsemu::shfl_idx(v, fsemu::blk().cur->lane ^ mask); }
 static inline float __shfl_down(float v, int d, int width = 64) { (void)width; int l = fsemu::blk().cur->lane; return fsemu::shfl_idx(v, l + d > 63 ? l : l + d); }

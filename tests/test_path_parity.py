@@ -271,3 +271,32 @@ def test_hip_train_step_256_matches_oracle_and_batch_sum_property():
     lo, go, _ = perceptual.train_step(P, x, tgo, Wv)
     np.testing.assert_allclose(l2[:3], [lo["loss"], lo["content_loss"], lo["style_loss"]], rtol=1e-3)
     assert flat_close(g2, np.concatenate([go[n].ravel() for n, _, _ in e.param_table()]), l2=5e-3, cos_min=0.9999)
+
+
+# ------------------------------------------------------------------ bf16 mixed-precision inference (BASELINE config 5)
+def test_bf16_rounding_helper_known_answers():
+    x = np.array([1.0, 1.00390625, 1.005859375, 1.01171875, 255.0, 0.1, -3.1415927], np.float32)
+    # 1 + 2^-8 is a tie -> even (1.0); 1 + 1.5*2^-8 -> 1 + 2^-7; 1 + 3*2^-8 is a tie -> even (1 + 2^-6)
+    want = np.array([1.0, 1.0, 1.0078125, 1.015625, 255.0, 0.10009765625, -3.140625], np.float32)
+    assert np.array_equal(tnet.bf16_round(x), want)
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 56), (1, 45, 67)])
+def test_tnet_bf16_forward_against_bf16_restatement_and_fp32_oracle(eng, shape):
+    """FS_FLAG_BF16 against (a) the numpy restatement with the same rounding points -- differences are
+    accumulation-order noise flipping an occasional bf16 rounding -- and (b) the fp32/fp64 oracle, where
+    the error is the precision of bfloat16 itself (~1e-2 of the range; reported, not held to 1e-3)."""
+    rng = np.random.default_rng(4)
+    P = tnet.strip_scope(starry())
+    flat = eng.mem.from_numpy(eng.flatten_params(P, scope=""))
+    x = rng.integers(0, 256, shape + (3,)).astype(np.float32)
+    y = eng.mem.to_numpy(eng.tnet_forward(flat, eng.mem.from_numpy(x), bf16=True))
+    yb = tnet.create_net_bf16(x, P)
+    yo = tnet.create_net(x.astype(np.float64), f64(P))
+    assert y.shape == yo.shape and np.isfinite(y).all()
+    e_b = np.abs(y - yb)
+    e_o = np.abs(y - yo)
+    print("bf16 path: vs bf16 restatement max %.3f mean %.4f psnr %.1f dB | vs fp32 oracle max %.2f mean %.3f psnr %.1f dB"
+          % (e_b.max(), e_b.mean(), psnr(y, yb), e_o.max(), e_o.mean(), psnr(y, yo)))
+    assert psnr(y, yb) > 45 and e_b.mean() < 1.0
+    assert psnr(y, yo) > 40 and e_o.mean() / 255.0 < 1e-2

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""720p forward (BASELINE config[1]) loop for profiling."""
+"""Forward-only loop for profiling: fwd720.py [H W [N [bf16]]] (default 720 1280 1; BASELINE configs 2 and 5)."""
 import os
 import sys
 import time
@@ -16,14 +16,15 @@ W = ckpt.load_checkpoint(os.path.join(root, "models", "starry_final.ckpt"))
 flat = e.mem.from_numpy(e.flatten_params(W))
 H, Wd = (int(v) for v in (sys.argv[1:3] if len(sys.argv) > 2 else (720, 1280)))
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+BF16 = len(sys.argv) > 4 and sys.argv[4] == "bf16"
 x = torch.rand((N, H, Wd, 3), device="cuda") * 255
 for _ in range(3):
-    e.tnet_forward(flat, x)
+    e.tnet_forward(flat, x, bf16=BF16)
 torch.cuda.synchronize()
 t = time.perf_counter()
 it = 20
 for _ in range(it):
-    e.tnet_forward(flat, x)
+    e.tnet_forward(flat, x, bf16=BF16)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / it
-print("forward %dx%dx%d: %.3f ms  %.1f fps" % (N, H, Wd, dt * 1e3, N / dt))
+print("forward %s %dx%dx%d: %.3f ms  %.1f fps" % ("bf16" if BF16 else "fp32", N, H, Wd, dt * 1e3, N / dt))
