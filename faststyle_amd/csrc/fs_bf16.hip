@@ -13,6 +13,7 @@
 // Reference: im_transf_net.py:14-75 (create_net), same layer semantics as fs_conv.hip / fs_tnet.hip.
 #include "fs_bf16.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace fs {
@@ -50,8 +51,60 @@ __device__ __forceinline__ bool bsrc_coord(int mode, int refl, int v, int n_src,
 // before the MFMA sweep of the current one (register prefetch), two barriers per chunk, one LDS stage, so two
 // workgroups fit a CU.  C4 = the 3-channel image layer: pixels are 4-channel bf16 (8 bytes), K runs over
 // (12 taps of a kernel row) x 4, i.e. 3 MFMA k-steps per kernel row, the whole 9x9 filter in one chunk.
+// Tile store through LDS: the accumulator layout gives a lane ONE channel of 16 pixel rows, i.e. 2-byte scattered
+// global stores; staging the tile as [pixel][BN] lets every thread write 16 contiguous bytes (8 bf16 channels or 4
+// fp32) of one pixel -- whole 64/128-byte pixel rows per wavefront.  `stg` must not alias live LDS data.
+template <int WM, int WN>
+__device__ __forceinline__ void store_tile(const ConvBArgs& a, const f32x16 (&acc)[WM][WN], void* stg, int n, int ty0, int tx0,
+                                           int co0, int th_valid, int tw_valid) {
+    constexpr int BN = WN * 32;
+    const ConvBPlan& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 31, kq = lane >> 5;
+    unsigned short* sb = static_cast<unsigned short*>(stg);
+    float* sf = static_cast<float*>(stg);
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = (wave * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+#pragma unroll
+            for (int nn = 0; nn < WN; ++nn) {
+                if (a.y_f32)
+                    sf[t * BN + nn * 32 + lm] = acc[m][nn][r];
+                else
+                    sb[t * BN + nn * 32 + lm] = f2bf(acc[m][nn][r]);
+            }
+        }
+    __syncthreads();
+    const int gsz = a.y_f32 ? 4 : 8;  // channels per 16-byte granule
+    const int gpp = BN / gsz;         // granules per staged pixel
+    const int Cr = a.shuffle ? a.Cout >> 2 : a.Cout;
+    const size_t img = (size_t)n * a.Ho * a.Wo * a.Cout;
+    const int tile_px = p.TH * p.TW;
+    for (int e = tid; e < tile_px * gpp; e += 256) {
+        const int pix = e / gpp, g = e - pix * gpp;
+        const int py = pix / p.TW, px = pix - py * p.TW;
+        const int co = co0 + g * gsz;
+        if (py >= th_valid || px >= tw_valid || co >= a.Cout) continue;
+        const int oy = ty0 + py, ox = tx0 + px;
+        size_t o;
+        if (a.shuffle) {
+            const int q = co / Cr, cof = co - q * Cr;
+            o = ((size_t)(2 * oy + (q >> 1)) * (2 * a.Wo) + 2 * ox + (q & 1)) * Cr + cof;
+        } else {
+            o = ((size_t)oy * a.Wo + ox) * a.Cout + co;
+        }
+        if (a.y_f32)
+            *reinterpret_cast<uint4*>(static_cast<float*>(a.y) + img + o) = *reinterpret_cast<const uint4*>(sf + pix * BN + g * 4);
+        else
+            *reinterpret_cast<uint4*>(static_cast<unsigned short*>(a.y) + img + o) =
+                *reinterpret_cast<const uint4*>(sb + pix * BN + g * 8);
+    }
+}
+
+// (1) chunked kernel: layers whose input channels span several chunks (Cin = 32/64).  One tile per workgroup.
 template <int WM, int WN, bool C4>
-__global__ __launch_bounds__(256) void conv_bf16_kernel(ConvBArgs a) {
+__global__ __launch_bounds__(256) void conv_bf16_chunked_kernel(ConvBArgs a) {
     constexpr int BN = WN * 32;
     HIP_DYNAMIC_SHARED(float, smem_f)
     unsigned short* smem = reinterpret_cast<unsigned short*>(smem_f);
@@ -314,40 +367,277 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvBArgs a) {
         }
     }
 
-    const int Cr = a.shuffle ? a.Cout >> 2 : a.Cout;
-    const size_t img = (size_t)n * a.Ho * a.Wo * a.Cout;
-    unsigned short* yb = static_cast<unsigned short*>(a.y) + img;
-    float* yf = static_cast<float*>(a.y) + img;
-    int cof[WN], qa[WN], qb[WN];
-    bool cok[WN];
+    if (a.stats) __syncthreads();  // the statistics scratch aliases the staging area
+    store_tile<WM, WN>(a, acc, smem, n, ty0, tx0, co0, th_valid, tw_valid);
+}
+
+// (2) resident kernel: single-chunk layers (the image layer, the Cin = 16 layers incl. the kw-folded output layer).
+template <int WM, int WN, bool C4>
+__global__ __launch_bounds__(256, 2) void conv_bf16_resident_kernel(ConvBArgs a) {
+    constexpr int BN = WN * 32;
+    HIP_DYNAMIC_SHARED(float, smem_f)
+    unsigned short* smem = reinterpret_cast<unsigned short*>(smem_f);
+    const ConvBPlan& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int total_tiles = a.N * tiles;
+    const int co0 = blockIdx.y * BN;
+    const int PW = p.PW, PH = p.PH, CC = p.CC, PP = p.PP;
+    const int lm = lane & 31, kq = lane >> 5;
+    const int tile_px = p.TH * p.TW;
+    const int G = C4 ? a.KH : a.KH * a.KW;
+    const int WP = C4 ? 56 : PP;  // filter row pitch (elements)
+    const int patch_elems = (PH * PW * (C4 ? 4 : PP) + 7) & ~7;
+    unsigned short* patch = smem;
+    unsigned short* wl = smem + patch_elems;
+    float* abl = reinterpret_cast<float*>(smem + patch_elems + G * BN * WP);  // [2][Cin] on-load affine
+    float* sred = abl + 2 * a.Cin;                                             // [5][BN] statistics scratch
+    float* stage = sred + 5 * BN + 3;                                          // tile staging for the coalesced store
+    stage = reinterpret_cast<float*>(reinterpret_cast<size_t>(stage) & ~(size_t)15);  // 16-byte aligned
+    const int cpad = p.cout_pad;
+    // The whole filter stays resident in LDS and the workgroup walks a strided list of tiles (persistent
+    // workgroups): the filter is staged once per workgroup instead of once per tile, and the next tile's patch is
+    // in flight (registers) while the current one is multiplied.
+
+    int laneA[WM];
 #pragma unroll
-    for (int nn = 0; nn < WN; ++nn) {
-        const int co = co0 + nn * 32 + lm;
-        cok[nn] = co < a.Cout;
-        const int q = a.shuffle ? co / Cr : 0;
-        cof[nn] = a.shuffle ? co - q * Cr : co;
-        qa[nn] = q >> 1;
-        qb[nn] = q & 1;
+    for (int m = 0; m < WM; ++m) {
+        int t = (wave * WM + m) * 32 + lm;
+        if (t >= tile_px) t = 0;
+        const int py = t / p.TW, px = t - py * p.TW;
+        laneA[m] = C4 ? (py * PW + px) * 4 + kq * 8 : (py * a.stride * PW + px * a.stride) * PP + kq * 8;
     }
+    const int laneB = lm * WP + kq * 8;
+    const float inv_tw = 1.0f / (float)p.TW;
+    auto row_of = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * kq; };
+
+    // ---- staging machinery ----
+    constexpr int PMAX = C4 ? 3 : 8;             // patch granules per thread and tile (the plan guarantees the bound)
+    const int g8n = C4 ? 1 : CC >> 3;            // 16-byte granules per pixel / per filter row
+    const int g8sh = g8n == 1 ? 0 : (g8n == 2 ? 1 : 2);
+    const int ne_p = PH * PW * g8n;
+    const int ne_w = C4 ? G * BN * 6 : G * BN * g8n;
+    uint4 pv[PMAX];
+    unsigned vmask = 0;  // bit i: pv[i] holds real pixels (not padding)
+    auto issue_patch = [&](int tile, int c0) {
+        const int n = tile / tiles, tr = tile - n * tiles;
+        const int vy0 = (tr / p.tiles_x) * p.TH * a.stride - a.pad_t, vx0 = (tr % p.tiles_x) * p.TW * a.stride - a.pad_l;
+        vmask = 0;
 #pragma unroll
-    for (int m = 0; m < WM; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = (wave * WM + m) * 32 + row_of(r);
-            const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
-            if (!(t < tile_px && py < th_valid && px < tw_valid)) continue;
-            const int oy = ty0 + py, ox = tx0 + px;
-#pragma unroll
-            for (int nn = 0; nn < WN; ++nn) {
-                if (!cok[nn]) continue;
-                const int o = a.shuffle ? ((2 * oy + qa[nn]) * (2 * a.Wo) + 2 * ox + qb[nn]) * Cr + cof[nn]
-                                        : (oy * a.Wo + ox) * a.Cout + cof[nn];
-                if (a.y_f32)
-                    yf[o] = acc[m][nn][r];
-                else
-                    yb[o] = f2bf(acc[m][nn][r]);
+        for (int i = 0; i < PMAX; ++i) {
+            const int e = tid + i * 256;
+            pv[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (e < ne_p) {
+                const int pix = e >> g8sh, g8 = e & (g8n - 1);
+                const int py = pix / PW, px = pix - py * PW;
+                int sy, sx;
+                if (bsrc_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) && bsrc_coord(a.src_mode, a.refl, vx0 + px, a.W, sx)) {
+                    vmask |= 1u << i;
+                    if constexpr (C4) {
+                        const float* s = static_cast<const float*>(a.x) + (((size_t)n * a.H + sy) * a.W + sx) * 3;
+                        pv[i].x = __builtin_bit_cast(unsigned, s[0]);
+                        pv[i].y = __builtin_bit_cast(unsigned, s[1]);
+                        pv[i].z = __builtin_bit_cast(unsigned, s[2]);
+                    } else {
+                        pv[i] = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(a.x) +
+                                                                (((size_t)n * a.H + sy) * a.W + sx) * a.Cin + c0 + g8 * 8);
+                    }
+                }
             }
         }
+    };
+    const bool has_ab = !C4 && a.in_a != nullptr;
+    auto commit_patch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < PMAX; ++i) {
+            const int e = tid + i * 256;
+            if (e >= ne_p) continue;
+            if constexpr (C4) {
+                uint2 v = make_uint2(0u, 0u);
+                if (vmask & (1u << i)) {
+                    v.x = pack2(__builtin_bit_cast(float, pv[i].x), __builtin_bit_cast(float, pv[i].y));
+                    v.y = pack2(__builtin_bit_cast(float, pv[i].z), 0.f);
+                }
+                *reinterpret_cast<uint2*>(patch + e * 4) = v;
+            } else {
+                const int pix = e >> g8sh, g8 = e & (g8n - 1);
+                uint4 v = pv[i];
+                if ((vmask & (1u << i)) && has_ab) {
+                    const float* pa = abl + c0 + g8 * 8;
+                    const float* pb = pa + a.Cin;
+                    unsigned* w32 = reinterpret_cast<unsigned*>(&v);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float lo = fmaf(bf2f((unsigned short)(w32[k] & 0xFFFFu)), pa[2 * k], pb[2 * k]);
+                        float hi = fmaf(bf2f((unsigned short)(w32[k] >> 16)), pa[2 * k + 1], pb[2 * k + 1]);
+                        if (a.in_relu) {
+                            lo = fmaxf(lo, 0.f);
+                            hi = fmaxf(hi, 0.f);
+                        }
+                        w32[k] = pack2(lo, hi);
+                    }
+                }
+                *reinterpret_cast<uint4*>(patch + pix * PP + g8 * 8) = v;
+            }
+        }
+    };
+    f32x16 acc[WM][WN];
+    auto sweep = [&]() {
+        if constexpr (C4) {
+            for (int kh = 0; kh < G; ++kh)
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    bf16x8 af[WM], bfr[WN];
+#pragma unroll
+                    for (int m = 0; m < WM; ++m) {
+                        const unsigned short* src = patch + laneA[m] + kh * PW * 4 + ks * 16;  // 8-byte aligned
+                        const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 4);
+                        af[m] = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                    }
+#pragma unroll
+                    for (int nn = 0; nn < WN; ++nn)
+                        bfr[nn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wl + (kh * BN + nn * 32) * WP + laneB + ks * 16));
+#pragma unroll
+                    for (int m = 0; m < WM; ++m)
+#pragma unroll
+                        for (int nn = 0; nn < WN; ++nn)
+                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[nn], acc[m][nn], 0, 0, 0);
+                }
+        } else {
+            const int nks = CC >> 4;
+            for (int kh = 0; kh < a.KH; ++kh)
+                for (int kw = 0; kw < a.KW; ++kw) {
+                    const int g = kh * a.KW + kw;
+                    const int toff = (kh * PW + kw * a.dil_x) * PP;
+                    for (int ks = 0; ks < nks; ++ks) {
+                        bf16x8 af[WM], bfr[WN];
+#pragma unroll
+                        for (int m = 0; m < WM; ++m)
+                            af[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(patch + laneA[m] + toff + ks * 16));
+#pragma unroll
+                        for (int nn = 0; nn < WN; ++nn)
+                            bfr[nn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wl + (g * BN + nn * 32) * WP + laneB + ks * 16));
+#pragma unroll
+                        for (int m = 0; m < WM; ++m)
+#pragma unroll
+                            for (int nn = 0; nn < WN; ++nn)
+                                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[nn], acc[m][nn], 0, 0, 0);
+                    }
+                }
+        }
+    };
+
+    // per-image on-load affine table; persistent workgroups reload it when they cross an image boundary
+    int abl_n = -1;
+    auto load_abl = [&](int n) {
+        if (has_ab && n != abl_n) {
+            for (int c = tid; c < a.Cin; c += 256) {
+                abl[c] = a.in_a[(size_t)n * a.in_nstride + c];
+                abl[a.Cin + c] = a.in_b[(size_t)n * a.in_nstride + c];
+            }
+        }
+        abl_n = n;
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
+    for (int e = tid; e < ne_w; e += 256) {  // the whole filter, once
+        if constexpr (C4) {  // 48 elements = 6 granules per (kh, co)
+            const int row = e / 6, g8 = e - row * 6;
+            const int kh = row / BN, col = row - kh * BN;
+            *reinterpret_cast<uint4*>(wl + row * WP + g8 * 8) =
+                *reinterpret_cast<const uint4*>(a.w + ((size_t)kh * cpad + co0 + col) * 48 + g8 * 8);
+        } else {
+            const int row = e >> g8sh, g8 = e & (g8n - 1);
+            const int g = row / BN, col = row - g * BN;
+            *reinterpret_cast<uint4*>(wl + row * WP + g8 * 8) =
+                *reinterpret_cast<const uint4*>(a.w + ((size_t)g * cpad + co0 + col) * a.Cin + g8 * 8);
+        }
+    }
+    issue_patch(tile, 0);
+    for (; tile < total_tiles; tile += gridDim.x) {
+        const int n = tile / tiles, tr = tile - n * tiles;
+        const int ty0 = (tr / p.tiles_x) * p.TH, tx0 = (tr % p.tiles_x) * p.TW;
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int nn = 0; nn < WN; ++nn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+        if (has_ab && n != abl_n) {
+            __syncthreads();  // nobody may still be reading the previous image's table
+            load_abl(n);
+            __syncthreads();
+        }
+        commit_patch(0);
+        __syncthreads();
+        if (tile + (int)gridDim.x < total_tiles) issue_patch(tile + gridDim.x, 0);
+        sweep();
+        __syncthreads();
+
+        // ---- epilogue (as in fs_conv.hip): per-tile instance-norm partials from the fp32 accumulators, then the store
+        const int th_valid = min(p.TH, a.Ho - ty0), tw_valid = min(p.TW, a.Wo - tx0);
+        if (a.stats) {
+            float* red = sred;             // [4][BN]
+            float* meanl = sred + 4 * BN;  // [BN]
+            float s1[WN];
+#pragma unroll
+            for (int nn = 0; nn < WN; ++nn) s1[nn] = 0.f;
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int t = (wave * WM + m) * 32 + row_of(r);
+                    const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
+                    const bool ok = t < tile_px && py < th_valid && px < tw_valid;
+#pragma unroll
+                    for (int nn = 0; nn < WN; ++nn) s1[nn] += ok ? acc[m][nn][r] : 0.f;
+                }
+#pragma unroll
+            for (int nn = 0; nn < WN; ++nn) s1[nn] += __shfl_xor(s1[nn], 32);
+            if (lane < 32)
+#pragma unroll
+                for (int nn = 0; nn < WN; ++nn) red[wave * BN + nn * 32 + lane] = s1[nn];
+            __syncthreads();
+            const float cnt = (float)(th_valid * tw_valid);
+            if (tid < BN) meanl[tid] = (red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid]) / cnt;
+            __syncthreads();
+            float mu[WN], s2[WN];
+#pragma unroll
+            for (int nn = 0; nn < WN; ++nn) {
+                mu[nn] = meanl[nn * 32 + lm];
+                s2[nn] = 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int t = (wave * WM + m) * 32 + row_of(r);
+                    const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
+                    const bool ok = t < tile_px && py < th_valid && px < tw_valid;
+#pragma unroll
+                    for (int nn = 0; nn < WN; ++nn) {
+                        const float d = acc[m][nn][r] - mu[nn];
+                        s2[nn] += ok ? d * d : 0.f;
+                    }
+                }
+#pragma unroll
+            for (int nn = 0; nn < WN; ++nn) s2[nn] += __shfl_xor(s2[nn], 32);
+            __syncthreads();  // meanl/red of the first pass fully consumed
+            if (lane < 32)
+#pragma unroll
+                for (int nn = 0; nn < WN; ++nn) red[wave * BN + nn * 32 + lane] = s2[nn];
+            __syncthreads();
+            if (tid < BN && co0 + tid < a.Cout) {
+                float* st = a.stats + ((size_t)tile * a.Cout + co0 + tid) * 3;
+                st[0] = meanl[tid];
+                st[1] = red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid];
+                st[2] = cnt;
+            }
+        }
+
+        store_tile<WM, WN>(a, acc, stage, n, ty0, tx0, co0, th_valid, tw_valid);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- plan / launch
@@ -375,8 +665,13 @@ ConvBPlan conv_bf16_plan(const ConvBArgs& a) {
         for (p.CC = p.c4 ? 4 : (a.Cin % 32 == 0 ? 32 : 16); p.CC >= (p.c4 ? 4 : 16); p.CC >>= 1) {
             p.PP = p.CC + 8;
             const int patch_elems = (p.PH * p.PW * (p.c4 ? 4 : p.PP) + 7) & ~7;
-            p.lds_bytes = 2 * (patch_elems + G * p.BN * (p.c4 ? 56 : p.PP)) + 8 * a.Cin + 16;
-            if (p.lds_bytes < 4 * 5 * p.BN) p.lds_bytes = 4 * 5 * p.BN;
+            const bool resident = p.c4 || a.Cin == p.CC;
+            const int stage_bytes = max_px * p.BN * (a.y_f32 ? 4 : 2);
+            p.lds_bytes = 2 * (patch_elems + G * p.BN * (p.c4 ? 56 : p.PP)) + 8 * a.Cin + 4 * 5 * p.BN + 32;
+            if (resident)
+                p.lds_bytes += stage_bytes;  // dedicated: the resident filter must survive the epilogue
+            else if (p.lds_bytes < stage_bytes)
+                p.lds_bytes = stage_bytes;   // staged over the (dead) patch + filter area
             fits = p.lds_bytes <= 80 * 1024 &&
                    (p.c4 || (p.PH * p.PW * (p.CC / 8) <= 8 * 256 && G * p.BN * (p.CC / 8) <= 12 * 256));
             if (fits || p.c4) break;
@@ -392,20 +687,34 @@ int conv_bf16_launch(const ConvBArgs& a_in, hipStream_t s) {
     if (a.dil_x < 1) a.dil_x = 1;
     const ConvBPlan& p = a.p;
     if (!p.c4 && (a.Cin % p.CC)) return -1;
+    if (a.Cout % 8 || (a.shuffle && (a.Cout >> 2) % 8)) return -1;  // 16-byte output granules
     if (p.c4 && (a.stride != 1 || a.KW > 12 || !a.x_f32)) return -1;
     if (p.lds_bytes > 160 * 1024) return -2;
     const int G = p.c4 ? a.KH : a.KH * a.KW;
     if (!p.c4 && (p.PH * p.PW * (p.CC / 8) > 8 * 256 || G * p.BN * (p.CC / 8) > 12 * 256)) return -2;
-    dim3 grid((unsigned)(a.N * p.tiles_y * p.tiles_x), (unsigned)(p.cout_pad / p.BN));
-#define FS_BLAUNCH(WM_, WN_, C4_)                                                                                       \
-    do {                                                                                                                \
-        static bool attr_done = false;                                                                                  \
-        if (!attr_done) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_kernel<WM_, WN_, C4_>),                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                          \
-            attr_done = true;                                                                                           \
-        }                                                                                                               \
-        hipLaunchKernelGGL((conv_bf16_kernel<WM_, WN_, C4_>), grid, dim3(256), (size_t)p.lds_bytes, s, a);              \
+    // resident kernels walk a strided list of tiles: cap the grid at a few waves of workgroups per CU so that the
+    // resident filter is amortised over many tiles
+    const long total_tiles = (long)a.N * p.tiles_y * p.tiles_x;
+    const char* cap_env = getenv("FS_BF16_GRID");  // (tests shrink it to force the multi-tile walk on small images)
+    const int cap = cap_env ? atoi(cap_env) : 2048;
+    const bool resident = p.c4 || a.Cin == p.CC;
+    dim3 grid((unsigned)(resident && total_tiles > cap ? cap : total_tiles), (unsigned)(p.cout_pad / p.BN));
+#define FS_BLAUNCH_K(KERNEL_)                                                                                             \
+    do {                                                                                                                  \
+        static bool attr_done = false;                                                                                    \
+        if (!attr_done) {                                                                                                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL_), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024);                                                                        \
+            attr_done = true;                                                                                             \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(KERNEL_, grid, dim3(256), (size_t)p.lds_bytes, s, a);                                          \
+    } while (0)
+#define FS_BLAUNCH(WM_, WN_, C4_)                                        \
+    do {                                                                 \
+        if (resident)                                                    \
+            FS_BLAUNCH_K((conv_bf16_resident_kernel<WM_, WN_, C4_>));    \
+        else                                                             \
+            FS_BLAUNCH_K((conv_bf16_chunked_kernel<WM_, WN_, false>));   \
     } while (0)
     if (p.c4) {
         if (p.BN != 32) return -4;
@@ -425,6 +734,7 @@ int conv_bf16_launch(const ConvBArgs& a_in, hipStream_t s) {
             FS_BLAUNCH(1, 1, false);
     }
 #undef FS_BLAUNCH
+#undef FS_BLAUNCH_K
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

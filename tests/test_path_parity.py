@@ -281,11 +281,13 @@ def test_bf16_rounding_helper_known_answers():
     assert np.array_equal(tnet.bf16_round(x), want)
 
 
-@pytest.mark.parametrize("shape", [(2, 48, 56), (1, 45, 67)])
-def test_tnet_bf16_forward_against_bf16_restatement_and_fp32_oracle(eng, shape):
+@pytest.mark.parametrize("shape,grid_cap", [((2, 48, 56), None), ((1, 45, 67), None), ((2, 48, 56), 3)])
+def test_tnet_bf16_forward_against_bf16_restatement_and_fp32_oracle(eng, shape, grid_cap, monkeypatch):
     """FS_FLAG_BF16 against (a) the numpy restatement with the same rounding points -- differences are
     accumulation-order noise flipping an occasional bf16 rounding -- and (b) the fp32/fp64 oracle, where
     the error is the precision of bfloat16 itself (~1e-2 of the range; reported, not held to 1e-3)."""
+    if grid_cap:      # persistent workgroups: 3 workgroups walk all the tiles of the single-chunk layers (crossing images)
+        monkeypatch.setenv("FS_BF16_GRID", str(grid_cap))
     rng = np.random.default_rng(4)
     P = tnet.strip_scope(starry())
     flat = eng.mem.from_numpy(eng.flatten_params(P, scope=""))
