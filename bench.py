@@ -16,6 +16,8 @@ Prints ONE JSON line on rank 0 (contract: see the task statement); extra keys:
   cpu_baseline  the numpy oracle (a port of the reference path; TF1 itself cannot be installed)
                 timed on this box's host cores on a bounded sample, rank 0 / N=1 only
   stylize_720p_fps  config[1]: im_transf_net forward on a 720p frame, batch 1, fp32
+  stylize_1080p_b8_bf16_fps / _fp32_fps  config[4]: 1080p, batch 8 per GPU, the bf16 mixed-precision path
+                (bf16 MFMA, fp32 statistics; NOT the parity path) beside the fp32 path on the same input
 """
 import argparse
 import json
@@ -160,6 +162,26 @@ def main():
             dt = float(t.item())
         fps = world * iters / dt
 
+        # config[4]: bf16 mixed-precision 1080p inference, batch 8 per GPU, independent frames (no collective)
+        def timed_fwd(x, bf16, iters):
+            for _ in range(2):
+                eng.tnet_forward(flat, x, bf16=bf16)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                eng.tnet_forward(flat, x, bf16=bf16)
+            sync()
+            d = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([d], device="cuda", dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                d = float(tt.item())
+            return world * iters * x.shape[0] / d
+        hd = torch.rand((8, 1080, 1920, 3), device="cuda", generator=g) * 255.0
+        fps_1080_bf16 = timed_fwd(hd, True, 10)
+        fps_1080_f32 = timed_fwd(hd, False, 5)
+        del hd
+
     if rank == 0:
         n_img = args.steps * B * world
         value = n_img / elapsed
@@ -210,6 +232,8 @@ def main():
         }
         if fps is not None:
             out["stylize_720p_fps"] = round(fps, 2)
+            out["stylize_1080p_b8_bf16_fps"] = round(fps_1080_bf16, 1)     # FS_FLAG_BF16: ~52 dB PSNR vs the fp32 path
+            out["stylize_1080p_b8_fp32_fps"] = round(fps_1080_f32, 1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_images, S)
         print(json.dumps(out))

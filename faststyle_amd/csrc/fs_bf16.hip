@@ -7,8 +7,8 @@
 // LDS, 16-byte LDS fragment reads, producer instance-norm + ReLU folded into the staging load as in the fp32 path.
 //
 // The image-facing ends stay fp32: the input image [N,H,W,3] is read as fp32 (reflect-40 fused, packed to
-// 4-channel bf16 pixels in LDS), and the kw-folded output layer writes its 16 virtual channels as fp32 so the
-// 5-term fold, the last instance norm and the tanh run exactly as in the fp32 path (fs_fold.hip, fs_elem.hip).
+// 4-channel bf16 pixels in LDS); the kw-folded output layer writes its 16 virtual channels as bf16, and the 5-term
+// fold, the last instance norm and the tanh run in fp32 as in the fp32 path (fs_fold.hip, fs_elem.hip).
 //
 // Reference: im_transf_net.py:14-75 (create_net), same layer semantics as fs_conv.hip / fs_tnet.hip.
 #include "fs_bf16.h"
@@ -863,7 +863,7 @@ static ConvBArgs unit_bargs(const Unit& u, int N) {
     a.refl = u.refl;
     a.shuffle = u.kind == 1;
     a.x_f32 = u.Cin == 3;
-    a.y_f32 = u.kind == 2;
+    a.y_f32 = 0;  // (the 16 virtual channels of the kw-folded output layer are bf16 too: 51.8 dB either way)
     return a;
 }
 
@@ -879,7 +879,7 @@ int tnet_layout_bf16(int N, int H, int W, BTnetLayout* L) {
         L->tiles[i] = u.kind == 2 ? cdiv(u.Hout * u.Wout, 256) : p.tiles_y * p.tiles_x;
         const size_t act = (size_t)N * u.Hout * u.Wout * u.Cout;
         L->z[i] = take(off, act * (i == 15 ? 4 : 2));
-        L->stats[i] = take(off, (size_t)N * L->tiles[i] * (u.kind == 2 ? u.Cout : u.Cc) * 3 * 4);
+        L->stats[i] = take(off, (size_t)N * (L->tiles[i] + kFinalizeSplit) * (u.kind == 2 ? u.Cout : u.Cc) * 3 * 4);
         L->mean[i] = take(off, (size_t)N * u.Cout * 4);
         L->rstd[i] = take(off, (size_t)N * u.Cout * 4);
         L->a[i] = take(off, (size_t)N * u.Cout * 4);
@@ -892,7 +892,7 @@ int tnet_layout_bf16(int N, int H, int W, BTnetLayout* L) {
         const Unit& u2 = L->geo.u[3 + 2 * k + 1];
         L->h[k] = take(off, (size_t)N * u2.Hout * u2.Wout * 64 * 2);
     }
-    L->zfold = take(off, (size_t)N * L->geo.u[15].Hc * L->geo.u[15].Wc * 16 * 4);
+    L->zfold = take(off, (size_t)N * L->geo.u[15].Hc * L->geo.u[15].Wc * 16 * 2);
     L->total_bytes = off;
     return 0;
 }
@@ -936,14 +936,15 @@ int tnet_forward_bf16(const BTnetLayout& L, const float* params, const float* x,
         if (rc) return rc;
         float* stats = reinterpret_cast<float*>(ws + L.stats[i]);
         if (u.kind == 2) {
-            rc = fold5_fwd(reinterpret_cast<const float*>(ws + L.zfold), reinterpret_cast<float*>(ws + L.z[i]), stats, N, u.Hout,
-                           u.Wout, s);
+            rc = fold5_fwd_bf16(reinterpret_cast<const unsigned short*>(ws + L.zfold), reinterpret_cast<float*>(ws + L.z[i]), stats,
+                                N, u.Hout, u.Wout, s);
             if (rc) return rc;
         }
         float* ua = reinterpret_cast<float*>(ws + L.a[i]);
         float* ub = reinterpret_cast<float*>(ws + L.b[i]);
         rc = in_finalize(stats, N, L.tiles[i], u.Cout, u.kind == 1 ? 4 : 1, params + u.g_off, params + u.b_off, 1e-3f,
-                         reinterpret_cast<float*>(ws + L.mean[i]), reinterpret_cast<float*>(ws + L.rstd[i]), ua, ub, s);
+                         reinterpret_cast<float*>(ws + L.mean[i]), reinterpret_cast<float*>(ws + L.rstd[i]), ua, ub, s,
+                         stats + (size_t)N * L.tiles[i] * (u.kind == 2 ? u.Cout : u.Cc) * 3);
         if (rc) return rc;
         src = ws + L.z[i];
         src_a = ua;

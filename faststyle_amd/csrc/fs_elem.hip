@@ -5,6 +5,8 @@
 //   loss reductions, slab reduction, TF-style Adam, filter re-layouts.
 #include "fs_kernels.h"
 
+#include <cstdlib>
+
 namespace fs {
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -93,8 +95,60 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* stats, in
     }
 }
 
+// Large images have thousands of tiles per sample (1080p: ~9000) and the finalize kernel only has N*C waves to
+// walk them, each lane with a strided 12-byte read.  Pre-reduction: grid (S, N), a workgroup merges a contiguous
+// range of tiles for ALL Cv channels (thread = (tile lane, channel): the Cv*3 floats of a tile are contiguous, so
+// the reads coalesce), fixed merge order, output in the same {mean, M2, count} record format with T := S.
+__global__ __launch_bounds__(256) void in_prereduce_kernel(const float* __restrict__ stats, int T, int Cv, int S,
+                                                           float* __restrict__ out) {
+    __shared__ double sc[256], sm[256], sq[256];
+    const int n = blockIdx.y, sp = blockIdx.x;
+    const int TL = 256 / Cv;  // tile lanes (Cv <= 256)
+    const int cv = threadIdx.x % Cv, tl = threadIdx.x / Cv;
+    const int t0 = (int)((long long)sp * T / S), t1 = (int)((long long)(sp + 1) * T / S);
+    double cnt = 0, mu = 0, m2 = 0;
+    if (tl < TL)
+        for (int t = t0 + tl; t < t1; t += TL) {
+            const float* st = stats + (((size_t)n * T + t) * Cv + cv) * 3;
+            const double cb = st[2], mb = st[0], qb = st[1];
+            if (cb > 0) {
+                const double nn = cnt + cb, d = mb - mu, r = cb / nn;
+                mu += d * r;
+                m2 += qb + d * d * cnt * r;
+                cnt = nn;
+            }
+        }
+    sc[threadIdx.x] = cnt;
+    sm[threadIdx.x] = mu;
+    sq[threadIdx.x] = m2;
+    __syncthreads();
+    if (tl == 0) {
+        for (int k = 1; k < TL; ++k) {
+            const double cb = sc[k * Cv + cv], mb = sm[k * Cv + cv], qb = sq[k * Cv + cv];
+            if (cb > 0) {
+                const double nn = cnt + cb, d = mb - mu, r = cb / nn;
+                mu += d * r;
+                m2 += qb + d * d * cnt * r;
+                cnt = nn;
+            }
+        }
+        float* o = out + (((size_t)n * S + sp) * Cv + cv) * 3;
+        o[0] = (float)mu;
+        o[1] = (float)m2;
+        o[2] = (float)cnt;
+    }
+}
+
 int in_finalize(const float* stats, int N, int T, int C, int groups, const float* gamma, const float* beta, float eps,
-                float* mean, float* rstd, float* a, float* b, hipStream_t s) {
+                float* mean, float* rstd, float* a, float* b, hipStream_t s, float* scratch) {
+    const int Cv = C * groups;
+    const char* mt = getenv("FS_FINALIZE_MIN_T");  // (tests lower it so small images take the two-level path)
+    const int min_t = mt ? atoi(mt) : 4 * kFinalizeSplit;
+    if (scratch && T > min_t && Cv <= 256) {  // scratch: N * kFinalizeSplit * Cv * 3 floats
+        hipLaunchKernelGGL(in_prereduce_kernel, dim3(kFinalizeSplit, N), dim3(256), 0, s, stats, T, Cv, kFinalizeSplit, scratch);
+        stats = scratch;
+        T = kFinalizeSplit;
+    }
     hipLaunchKernelGGL(in_finalize_kernel, dim3(N, cdiv(C, 4)), dim3(256), 0, s, stats, T, C, groups, gamma, beta, eps,
                        mean, rstd, a, b);
     return 0;

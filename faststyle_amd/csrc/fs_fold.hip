@@ -42,7 +42,10 @@ __global__ __launch_bounds__(256) void wt_fold5_back_kernel(const float* dwf, fl
 
 // z[n,oy,ox,co] = sum_v Z[n,oy,ox+v,(v,co)]; per-block {mean, M2, count} partials per channel for
 // the instance norm (same format as the conv epilogue's: [N][T][3][3], T = ceil(Ho*Wo/256)).
-__global__ __launch_bounds__(256) void fold5_fwd_kernel(const float* Z, float* z, float* stats, int HW, int Wo) {
+__device__ __forceinline__ float fold_ld(float v) { return v; }
+__device__ __forceinline__ float fold_ld(unsigned short v) { return __builtin_bit_cast(float, (unsigned)v << 16); }  // bf16
+template <typename TZ>
+__global__ __launch_bounds__(256) void fold5_fwd_kernel(const TZ* Z, float* z, float* stats, int HW, int Wo) {
     __shared__ float sh[4];
     const int n = blockIdx.y, T = gridDim.x;
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -50,12 +53,12 @@ __global__ __launch_bounds__(256) void fold5_fwd_kernel(const float* Z, float* z
     float y[3] = {0.f, 0.f, 0.f};
     if (ok) {
         const int oy = p / Wo, ox = p - oy * Wo;
-        const float* src = Z + (((size_t)n * (HW / Wo) + oy) * (Wo + 4) + ox) * 16;
+        const TZ* src = Z + (((size_t)n * (HW / Wo) + oy) * (Wo + 4) + ox) * 16;
 #pragma unroll
         for (int v = 0; v < 5; ++v) {
-            y[0] += src[v * 16 + v * 3 + 0];
-            y[1] += src[v * 16 + v * 3 + 1];
-            y[2] += src[v * 16 + v * 3 + 2];
+            y[0] += fold_ld(src[v * 16 + v * 3 + 0]);
+            y[1] += fold_ld(src[v * 16 + v * 3 + 1]);
+            y[2] += fold_ld(src[v * 16 + v * 3 + 2]);
         }
         float* dst = z + ((size_t)n * HW + p) * 3;
         dst[0] = y[0];
@@ -122,7 +125,11 @@ int wt_fold5_back(const float* dwf, float* dw, int Ci, hipStream_t s) {
     return 0;
 }
 int fold5_fwd(const float* Z, float* z, float* stats, int N, int Ho, int Wo, hipStream_t s) {
-    hipLaunchKernelGGL(fold5_fwd_kernel, dim3(cdiv(Ho * Wo, 256), N), dim3(256), 0, s, Z, z, stats, Ho * Wo, Wo);
+    hipLaunchKernelGGL(fold5_fwd_kernel<float>, dim3(cdiv(Ho * Wo, 256), N), dim3(256), 0, s, Z, z, stats, Ho * Wo, Wo);
+    return 0;
+}
+int fold5_fwd_bf16(const unsigned short* Z, float* z, float* stats, int N, int Ho, int Wo, hipStream_t s) {
+    hipLaunchKernelGGL(fold5_fwd_kernel<unsigned short>, dim3(cdiv(Ho * Wo, 256), N), dim3(256), 0, s, Z, z, stats, Ho * Wo, Wo);
     return 0;
 }
 int unfold5(const float* dz, float* dys, int N, int Ho, int Wo, hipStream_t s) {

@@ -100,8 +100,9 @@ __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 namespace fs {
 // ---- fs_elem.hip ----
+constexpr int kFinalizeSplit = 64;  // tile ranges of the statistics pre-reduction (scratch: N*64*Cv*3 floats)
 int in_finalize(const float* stats, int N, int T, int C, int groups, const float* gamma, const float* beta, float eps,
-                float* mean, float* rstd, float* a, float* b, hipStream_t s);
+                float* mean, float* rstd, float* a, float* b, hipStream_t s, float* scratch = nullptr);
 int apply_res(const float* z, const float* a, const float* b, const float* skip, const float* sa, const float* sb,
               int skip_relu, float* out, int N, int H, int W, int C, hipStream_t s);
 int apply_tanh(const float* z, const float* a, const float* b, float* y, int N, int HW, int C, hipStream_t s);
@@ -155,6 +156,7 @@ int wt_upconv_fwd(const float* w, float* weff, int Ci, int Co, hipStream_t s);
 int wt_upconv_dgrad(const float* w, float* v, int Ci, int Co, hipStream_t s);
 int wt_upconv_wgrad_fold(const float* dweff, float* dw, int Ci, int Co, hipStream_t s);
 // ---- fs_fold.hip: kw-folded 9x9 -> 3-channel output layer ----
+int fold5_fwd_bf16(const unsigned short* Z, float* z, float* stats, int N, int Ho, int Wo, hipStream_t s);  // bf16 Z (fs_bf16.hip)
 int wt_fold5_fwd(const float* w, float* wf, int Ci, hipStream_t s);
 int wt_fold5_back(const float* dwf, float* dw, int Ci, hipStream_t s);
 int fold5_fwd(const float* Z, float* z, float* stats, int N, int Ho, int Wo, hipStream_t s);

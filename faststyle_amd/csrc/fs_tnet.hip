@@ -235,7 +235,8 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
         u.tiles = u.kind == 2 ? cdiv(u.Hout * u.Wout, 256) : u.plan.tiles_y * u.plan.tiles_x;
         const size_t act = (size_t)N * u.Hout * u.Wout * u.Cout;
         u.z = b.take(act);
-        u.stats = b.take((size_t)N * u.tiles * (u.kind == 2 ? u.Cout : u.Cc) * 3);
+        // per-tile records + room for the pre-reduced records of in_finalize
+        u.stats = b.take((size_t)N * (u.tiles + kFinalizeSplit) * (u.kind == 2 ? u.Cout : u.Cc) * 3);
         u.mean = b.take((size_t)N * u.Cout);
         u.rstd = b.take((size_t)N * u.Cout);
         u.a = b.take((size_t)N * u.Cout);
@@ -349,7 +350,8 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
         if (u.kind == 2)  // shifted 5-term sum of the virtual channels -> z + statistics partials
             FS_TRY(fold5_fwd(ws + L.zfold, ws + u.z, ws + u.stats, N, u.Hout, u.Wout, s));
         FS_TRY(in_finalize(ws + u.stats, N, u.tiles, u.Cout, u.kind == 1 ? 4 : 1, params + u.g_off, params + u.b_off, 1e-3f,
-                           ws + u.mean, ws + u.rstd, ws + u.a, ws + u.b, s));
+                           ws + u.mean, ws + u.rstd, ws + u.a, ws + u.b, s,
+                           ws + u.stats + (size_t)N * u.tiles * (u.kind == 2 ? u.Cout : u.Cc) * 3));
         // what the next conv reads
         src = ws + u.z;
         src_a = ws + u.a;

@@ -14,10 +14,12 @@ from . import _lib as L
 
 
 class FrameStylizer(object):
-    def __init__(self, eng, variables, height, width, upsample_method="resize", batch=1, swap_rb=True, use_graph=True):
+    def __init__(self, eng, variables, height, width, upsample_method="resize", batch=1, swap_rb=True, use_graph=True,
+                 bf16=False):
         self.eng = eng
         self.variables = variables
         self.method = upsample_method
+        self.bf16 = bf16                 # FS_FLAG_BF16 mixed-precision path (~2x the frame rate, ~52 dB vs fp32)
         self.shape = (int(batch), int(height), int(width), 3)
         self.swap_rb = swap_rb
         mem = eng.mem
@@ -33,7 +35,7 @@ class FrameStylizer(object):
     def _device_pass(self):
         e = self.eng
         e.u8_to_f32(self._in_u8, self._in_f32)
-        self._y = e.tnet_forward(self.variables, self._in_f32, upsample_method=self.method)
+        self._y = e.tnet_forward(self.variables, self._in_f32, upsample_method=self.method, bf16=self.bf16)
         e.f32_to_u8(self._y, self._out_u8, swap_rb=self.swap_rb)
 
     def _capture(self):

@@ -193,8 +193,8 @@ def create_net_bf16(x, params):
     """create_net ('resize') with the rounding points of the HIP mixed-precision inference path
     (fs_bf16.hip, FS_FLAG_BF16): weights, the image, every conv input (after the producer's
     instance-norm + ReLU) and every stored activation are bfloat16; accumulation, instance-norm
-    statistics (taken before the output is rounded), the last layer's output, its instance norm and
-    the tanh are full precision.  The resize-conv is evaluated in its phase-collapsed form because
+    statistics (taken before the output is rounded), the last instance norm and the tanh are full
+    precision.  The resize-conv is evaluated in its phase-collapsed form because
     the kernel rounds the COLLAPSED filter.  Test infrastructure for the config-5 path only: the
     parity bar of the project (1e-3 of the pixel range) applies to the fp32 path, not to this one."""
     P = {k: np.asarray(v, np.float64) for k, v in params.items()}
@@ -251,6 +251,14 @@ def create_net_bf16(x, params):
         a, b = norm_consts(z, name)
         h = r(np.maximum(a * r(z) + b, 0.0))
     name = "upsample_2"
-    z = F.conv2d(h, r(P[name + "/W"]), 1, "SAME")                              # fp32 output in the kernel
+    # the kernel evaluates the 9x9 layer kw-folded (kw = 5b + v): five partial sums, each stored as bf16
+    wq = r(P[name + "/W"])
+    z = 0.0
+    for v in range(5):
+        wpart = np.zeros_like(wq)
+        for kw in (v, 5 + v):
+            if kw < 9:
+                wpart[:, kw] = wq[:, kw]
+        z = z + r(F.conv2d(h, wpart, 1, "SAME"))
     n, _ = F.inst_norm(z, P[name + "/INscale"], P[name + "/INshift"])
     return F.scaled_tanh(n)

@@ -97,6 +97,19 @@ def run_fwd_bwd(eng, P_named, shape, seed, method="resize"):
     return y, yo, g, want
 
 
+def test_tnet_forward_with_two_level_statistics_merge(eng, monkeypatch):
+    """Large images pre-reduce the per-tile instance-norm records (in_prereduce_kernel); force that path at a
+    small size: T > 1 tiles -> 64 ranges -> finalize."""
+    monkeypatch.setenv("FS_FINALIZE_MIN_T", "1")
+    rng = np.random.default_rng(6)
+    P = tnet.strip_scope(starry())
+    flat = eng.mem.from_numpy(eng.flatten_params(P, scope=""))
+    x = rng.uniform(0, 255, (2, 60, 72, 3)).astype(np.float32)
+    y = eng.mem.to_numpy(eng.tnet_forward(flat, eng.mem.from_numpy(x)))
+    yo = tnet.create_net(x.astype(np.float64), f64(P))
+    assert np.abs(y - yo).max() / 255.0 < 2e-5
+
+
 @pytest.mark.parametrize("shape", [(2, 48, 56), (1, 41, 41), (1, 45, 67)])
 def test_tnet_forward_matches_oracle_and_backward_tight_when_kink_free(eng, shape):
     """Smallest legal size (41: REFLECT needs pad < dim), odd sizes (asymmetric SAME padding of
