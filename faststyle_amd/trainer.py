@@ -64,7 +64,9 @@ class Trainer(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: calls made by OTHER threads (e.g. the RCCL watchdog of a data-parallel run) must not
+        # invalidate this thread's capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._static_losses = self._forward_backward(self._static_in)
         self.graph = g
 
