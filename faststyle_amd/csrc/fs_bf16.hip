@@ -15,6 +15,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace fs {
 
@@ -31,6 +32,11 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 __device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+// x / d for 0 <= x < 2^22 through a float reciprocal (exact: (x + 0.5)/d stays >= 0.5/d away from an integer while
+// the float error is < x * 2^-23 / d); an integer division costs ~35 instructions, and the persistent tile loop
+// would otherwise spend more time on index arithmetic than on its few dozen MFMAs
+__device__ __forceinline__ int fdiv(int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); }
 
 __device__ __forceinline__ bool bsrc_coord(int mode, int refl, int v, int n_src, int& s) {
     if (mode == SRC_REFLECT) {
@@ -51,6 +57,81 @@ __device__ __forceinline__ bool bsrc_coord(int mode, int refl, int v, int n_src,
 // before the MFMA sweep of the current one (register prefetch), two barriers per chunk, one LDS stage, so two
 // workgroups fit a CU.  C4 = the 3-channel image layer: pixels are 4-channel bf16 (8 bytes), K runs over
 // (12 taps of a kernel row) x 4, i.e. 3 MFMA k-steps per kernel row, the whole 9x9 filter in one chunk.
+// Per-tile instance-norm partial {mean, M2, count} per channel, from the fp32 accumulators, in ONE pass: every wave
+// sums d = z - pivot and d^2 over its rows (pivot = the wave's first row of that channel: the shifted-data form
+// keeps sum(d^2) - sum(d)^2/n free of cancellation), the four wave results are merged with Chan's update by one
+// thread per channel.  One barrier; interior tiles skip the per-row validity test.  wst: [4][BN][4] floats of LDS.
+template <int WM, int WN>
+__device__ __forceinline__ void tile_stats(const ConvBArgs& a, const f32x16 (&acc)[WM][WN], float* wst, size_t tile, int co0,
+                                           int th_valid, int tw_valid) {
+    constexpr int BN = WN * 32;
+    const ConvBPlan& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 31, kq = lane >> 5;
+    const int tile_px = p.TH * p.TW;
+    const bool full = th_valid == p.TH && tw_valid == p.TW && tile_px == 4 * WM * 32;
+    const float inv_tw = 1.0f / (float)p.TW;
+    unsigned okmask[WM];  // bit r: accumulator row r of tile m is a real pixel
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+        okmask[m] = 0xFFFFu;
+        if (!full) {
+            okmask[m] = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = (wave * WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+                const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
+                if (t < tile_px && py < th_valid && px < tw_valid) okmask[m] |= 1u << r;
+            }
+        }
+    }
+#pragma unroll
+    for (int nn = 0; nn < WN; ++nn) {
+        const float piv = __shfl(acc[0][nn][0], lm);
+        float sd = 0.f, sq = 0.f, cn = 0.f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = acc[m][nn][r] - piv;
+                if (full || (okmask[m] >> r) & 1u) {
+                    sd += d;
+                    sq = fmaf(d, d, sq);
+                    cn += 1.f;
+                }
+            }
+        sd += __shfl_xor(sd, 32);
+        sq += __shfl_xor(sq, 32);
+        cn += __shfl_xor(cn, 32);
+        if (lane < 32) {
+            float* o = wst + ((wave * BN + nn * 32 + lane) << 2);
+            o[0] = sd;
+            o[1] = sq;
+            o[2] = cn;
+            o[3] = piv;
+        }
+    }
+    __syncthreads();
+    if (tid < BN && co0 + tid < a.Cout) {
+        float cnt = 0.f, mu = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float* o = wst + ((w * BN + tid) << 2);
+            const float cb = o[2];
+            if (cb > 0.f) {
+                const float mb = o[3] + o[0] / cb, qb = fmaxf(o[1] - o[0] * o[0] / cb, 0.f);
+                const float nn2 = cnt + cb, dlt = mb - mu, rr = cb / nn2;
+                mu += dlt * rr;
+                m2 += qb + dlt * dlt * cnt * rr;
+                cnt = nn2;
+            }
+        }
+        float* st = a.stats + (tile * a.Cout + co0 + tid) * 3;
+        st[0] = mu;
+        st[1] = m2;
+        st[2] = cnt;
+    }
+}
+
 // Tile store through LDS: the accumulator layout gives a lane ONE channel of 16 pixel rows, i.e. 2-byte scattered
 // global stores; staging the tile as [pixel][BN] lets every thread write 16 contiguous bytes (8 bf16 channels or 4
 // fp32) of one pixel -- whole 64/128-byte pixel rows per wavefront.  `stg` must not alias live LDS data.
@@ -77,19 +158,21 @@ __device__ __forceinline__ void store_tile(const ConvBArgs& a, const f32x16 (&ac
         }
     __syncthreads();
     const int gsz = a.y_f32 ? 4 : 8;  // channels per 16-byte granule
-    const int gpp = BN / gsz;         // granules per staged pixel
+    const int gpp = BN / gsz;         // granules per staged pixel (a power of two)
+    const int gsh = gpp == 4 ? 2 : (gpp == 8 ? 3 : 4);
+    const float inv_tw = 1.0f / (float)p.TW;
     const int Cr = a.shuffle ? a.Cout >> 2 : a.Cout;
     const size_t img = (size_t)n * a.Ho * a.Wo * a.Cout;
     const int tile_px = p.TH * p.TW;
     for (int e = tid; e < tile_px * gpp; e += 256) {
-        const int pix = e / gpp, g = e - pix * gpp;
-        const int py = pix / p.TW, px = pix - py * p.TW;
+        const int pix = e >> gsh, g = e & (gpp - 1);
+        const int py = fdiv(pix, inv_tw), px = pix - py * p.TW;
         const int co = co0 + g * gsz;
         if (py >= th_valid || px >= tw_valid || co >= a.Cout) continue;
         const int oy = ty0 + py, ox = tx0 + px;
         size_t o;
         if (a.shuffle) {
-            const int q = co / Cr, cof = co - q * Cr;
+            const int q = fdiv(co, 1.0f / (float)Cr), cof = co - q * Cr;
             o = ((size_t)(2 * oy + (q >> 1)) * (2 * a.Wo) + 2 * ox + (q & 1)) * Cr + cof;
         } else {
             o = ((size_t)oy * a.Wo + ox) * a.Cout + co;
@@ -309,63 +392,7 @@ __global__ __launch_bounds__(256) void conv_bf16_chunked_kernel(ConvBArgs a) {
     const int th_valid = min(p.TH, a.Ho - ty0), tw_valid = min(p.TW, a.Wo - tx0);
     const float inv_tw = 1.0f / (float)p.TW;
     auto row_of = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * kq; };
-    if (a.stats) {
-        float* red = smem_f;              // [4][BN]
-        float* meanl = smem_f + 4 * BN;   // [BN]
-        float s1[WN];
-#pragma unroll
-        for (int nn = 0; nn < WN; ++nn) s1[nn] = 0.f;
-#pragma unroll
-        for (int m = 0; m < WM; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int t = (wave * WM + m) * 32 + row_of(r);
-                const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
-                const bool ok = t < tile_px && py < th_valid && px < tw_valid;
-#pragma unroll
-                for (int nn = 0; nn < WN; ++nn) s1[nn] += ok ? acc[m][nn][r] : 0.f;
-            }
-#pragma unroll
-        for (int nn = 0; nn < WN; ++nn) s1[nn] += __shfl_xor(s1[nn], 32);
-        if (lane < 32)
-#pragma unroll
-            for (int nn = 0; nn < WN; ++nn) red[wave * BN + nn * 32 + lane] = s1[nn];
-        __syncthreads();
-        const float cnt = (float)(th_valid * tw_valid);
-        if (tid < BN) meanl[tid] = (red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid]) / cnt;
-        __syncthreads();
-        float mu[WN], s2[WN];
-#pragma unroll
-        for (int nn = 0; nn < WN; ++nn) {
-            mu[nn] = meanl[nn * 32 + lm];
-            s2[nn] = 0.f;
-        }
-#pragma unroll
-        for (int m = 0; m < WM; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int t = (wave * WM + m) * 32 + row_of(r);
-                const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
-                const bool ok = t < tile_px && py < th_valid && px < tw_valid;
-#pragma unroll
-                for (int nn = 0; nn < WN; ++nn) {
-                    const float d = acc[m][nn][r] - mu[nn];
-                    s2[nn] += ok ? d * d : 0.f;
-                }
-            }
-#pragma unroll
-        for (int nn = 0; nn < WN; ++nn) s2[nn] += __shfl_xor(s2[nn], 32);
-        if (lane < 32)
-#pragma unroll
-            for (int nn = 0; nn < WN; ++nn) red[wave * BN + nn * 32 + lane] = s2[nn];
-        __syncthreads();
-        if (tid < BN && co0 + tid < a.Cout) {
-            float* st = a.stats + ((size_t)blockIdx.x * a.Cout + co0 + tid) * 3;
-            st[0] = meanl[tid];
-            st[1] = red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid];
-            st[2] = cnt;
-        }
-    }
+    if (a.stats) tile_stats<WM, WN>(a, acc, smem_f, blockIdx.x, co0, th_valid, tw_valid);
 
     if (a.stats) __syncthreads();  // the statistics scratch aliases the staging area
     store_tile<WM, WN>(a, acc, smem, n, ty0, tx0, co0, th_valid, tw_valid);
@@ -391,8 +418,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_resident_kernel(ConvBArgs a)
     unsigned short* patch = smem;
     unsigned short* wl = smem + patch_elems;
     float* abl = reinterpret_cast<float*>(smem + patch_elems + G * BN * WP);  // [2][Cin] on-load affine
-    float* sred = abl + 2 * a.Cin;                                             // [5][BN] statistics scratch
-    float* stage = sred + 5 * BN + 3;                                          // tile staging for the coalesced store
+    float* sred = abl + 2 * a.Cin;                                             // [4][BN][4] statistics scratch
+    float* stage = sred + 16 * BN + 3;                                          // tile staging for the coalesced store
     stage = reinterpret_cast<float*>(reinterpret_cast<size_t>(stage) & ~(size_t)15);  // 16-byte aligned
     const int cpad = p.cout_pad;
     // The whole filter stays resident in LDS and the workgroup walks a strided list of tiles (persistent
@@ -412,24 +439,41 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_resident_kernel(ConvBArgs a)
     auto row_of = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * kq; };
 
     // ---- staging machinery ----
-    constexpr int PMAX = C4 ? 3 : 8;             // patch granules per thread and tile (the plan guarantees the bound)
+    constexpr int PMAX = C4 ? 3 : 5;             // patch granules per thread and tile (the plan guarantees the bound)
+    constexpr int DEPTH = 3;                     // tiles in flight: a tile's MFMA work is far shorter than the HBM latency
     const int g8n = C4 ? 1 : CC >> 3;            // 16-byte granules per pixel / per filter row
     const int g8sh = g8n == 1 ? 0 : (g8n == 2 ? 1 : 2);
     const int ne_p = PH * PW * g8n;
     const int ne_w = C4 ? G * BN * 6 : G * BN * g8n;
-    uint4 pv[PMAX];
-    unsigned vmask = 0;  // bit i: pv[i] holds real pixels (not padding)
-    auto issue_patch = [&](int tile, int c0) {
-        const int n = tile / tiles, tr = tile - n * tiles;
-        const int vy0 = (tr / p.tiles_x) * p.TH * a.stride - a.pad_t, vx0 = (tr % p.tiles_x) * p.TW * a.stride - a.pad_l;
+    uint4 pvr[DEPTH][PMAX];
+    unsigned vmaskr[DEPTH];  // bit i: pvr[.][i] holds real pixels (not padding)
+    const float inv_tiles = 1.0f / (float)tiles, inv_tx = 1.0f / (float)p.tiles_x;
+    int pyx[PMAX];  // tile-independent patch coordinates of this thread's granules: py << 16 | px (-1: none)
+#pragma unroll
+    for (int i = 0; i < PMAX; ++i) {
+        const int e = tid + i * 256;
+        pyx[i] = -1;
+        if (e < ne_p) {
+            const int pix = e >> g8sh;
+            const int py = pix / PW;
+            pyx[i] = (py << 16) | (pix - py * PW);
+        }
+    }
+    auto issue_patch = [&](auto SET, int tile) {
+        uint4(&pv)[PMAX] = pvr[decltype(SET)::value];
+        unsigned& vmask = vmaskr[decltype(SET)::value];
+        const int c0 = 0;
+        const int n = fdiv(tile, inv_tiles), tr = tile - n * tiles;
+        const int tyi = fdiv(tr, inv_tx), txi = tr - tyi * p.tiles_x;
+        const int vy0 = tyi * p.TH * a.stride - a.pad_t, vx0 = txi * p.TW * a.stride - a.pad_l;
         vmask = 0;
 #pragma unroll
         for (int i = 0; i < PMAX; ++i) {
             const int e = tid + i * 256;
             pv[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (e < ne_p) {
-                const int pix = e >> g8sh, g8 = e & (g8n - 1);
-                const int py = pix / PW, px = pix - py * PW;
+            if (pyx[i] >= 0) {
+                const int g8 = e & (g8n - 1);
+                const int py = pyx[i] >> 16, px = pyx[i] & 0xFFFF;
                 int sy, sx;
                 if (bsrc_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) && bsrc_coord(a.src_mode, a.refl, vx0 + px, a.W, sx)) {
                     vmask |= 1u << i;
@@ -447,7 +491,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_resident_kernel(ConvBArgs a)
         }
     };
     const bool has_ab = !C4 && a.in_a != nullptr;
-    auto commit_patch = [&](int c0) {
+    auto commit_patch = [&](auto SET) {
+        const uint4(&pv)[PMAX] = pvr[decltype(SET)::value];
+        const unsigned vmask = vmaskr[decltype(SET)::value];
+        const int c0 = 0;
 #pragma unroll
         for (int i = 0; i < PMAX; ++i) {
             const int e = tid + i * 256;
@@ -554,10 +601,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_resident_kernel(ConvBArgs a)
                 *reinterpret_cast<const uint4*>(a.w + ((size_t)g * cpad + co0 + col) * a.Cin + g8 * 8);
         }
     }
-    issue_patch(tile, 0);
-    for (; tile < total_tiles; tile += gridDim.x) {
-        const int n = tile / tiles, tr = tile - n * tiles;
-        const int ty0 = (tr / p.tiles_x) * p.TH, tx0 = (tr % p.tiles_x) * p.TW;
+    const int gstep = (int)gridDim.x;
+    issue_patch(std::integral_constant<int, 0>{}, tile);
+    if (tile + gstep < total_tiles) issue_patch(std::integral_constant<int, 1>{}, tile + gstep);
+    if (tile + 2 * gstep < total_tiles) issue_patch(std::integral_constant<int, 2>{}, tile + 2 * gstep);
+    auto body = [&](auto SET) -> bool {  // one tile; its patch sits in register set SET
+        const int n = fdiv(tile, inv_tiles), tr = tile - n * tiles;
+        const int tyi = fdiv(tr, inv_tx);
+        const int ty0 = tyi * p.TH, tx0 = (tr - tyi * p.tiles_x) * p.TW;
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -569,74 +620,22 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_resident_kernel(ConvBArgs a)
             load_abl(n);
             __syncthreads();
         }
-        commit_patch(0);
+        commit_patch(SET);
         __syncthreads();
-        if (tile + (int)gridDim.x < total_tiles) issue_patch(tile + gridDim.x, 0);
+        if (tile + DEPTH * gstep < total_tiles) issue_patch(SET, tile + DEPTH * gstep);
         sweep();
         __syncthreads();
-
-        // ---- epilogue (as in fs_conv.hip): per-tile instance-norm partials from the fp32 accumulators, then the store
+        // ---- epilogue: per-tile instance-norm partials from the fp32 accumulators, then the coalesced store
         const int th_valid = min(p.TH, a.Ho - ty0), tw_valid = min(p.TW, a.Wo - tx0);
-        if (a.stats) {
-            float* red = sred;             // [4][BN]
-            float* meanl = sred + 4 * BN;  // [BN]
-            float s1[WN];
-#pragma unroll
-            for (int nn = 0; nn < WN; ++nn) s1[nn] = 0.f;
-#pragma unroll
-            for (int m = 0; m < WM; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int t = (wave * WM + m) * 32 + row_of(r);
-                    const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
-                    const bool ok = t < tile_px && py < th_valid && px < tw_valid;
-#pragma unroll
-                    for (int nn = 0; nn < WN; ++nn) s1[nn] += ok ? acc[m][nn][r] : 0.f;
-                }
-#pragma unroll
-            for (int nn = 0; nn < WN; ++nn) s1[nn] += __shfl_xor(s1[nn], 32);
-            if (lane < 32)
-#pragma unroll
-                for (int nn = 0; nn < WN; ++nn) red[wave * BN + nn * 32 + lane] = s1[nn];
-            __syncthreads();
-            const float cnt = (float)(th_valid * tw_valid);
-            if (tid < BN) meanl[tid] = (red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid]) / cnt;
-            __syncthreads();
-            float mu[WN], s2[WN];
-#pragma unroll
-            for (int nn = 0; nn < WN; ++nn) {
-                mu[nn] = meanl[nn * 32 + lm];
-                s2[nn] = 0.f;
-            }
-#pragma unroll
-            for (int m = 0; m < WM; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int t = (wave * WM + m) * 32 + row_of(r);
-                    const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
-                    const bool ok = t < tile_px && py < th_valid && px < tw_valid;
-#pragma unroll
-                    for (int nn = 0; nn < WN; ++nn) {
-                        const float d = acc[m][nn][r] - mu[nn];
-                        s2[nn] += ok ? d * d : 0.f;
-                    }
-                }
-#pragma unroll
-            for (int nn = 0; nn < WN; ++nn) s2[nn] += __shfl_xor(s2[nn], 32);
-            __syncthreads();  // meanl/red of the first pass fully consumed
-            if (lane < 32)
-#pragma unroll
-                for (int nn = 0; nn < WN; ++nn) red[wave * BN + nn * 32 + lane] = s2[nn];
-            __syncthreads();
-            if (tid < BN && co0 + tid < a.Cout) {
-                float* st = a.stats + ((size_t)tile * a.Cout + co0 + tid) * 3;
-                st[0] = meanl[tid];
-                st[1] = red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid];
-                st[2] = cnt;
-            }
-        }
-
+        if (a.stats) tile_stats<WM, WN>(a, acc, sred, tile, co0, th_valid, tw_valid);
         store_tile<WM, WN>(a, acc, stage, n, ty0, tx0, co0, th_valid, tw_valid);
+        tile += gstep;
+        return tile < total_tiles;
+    };
+    for (;;) {
+        if (!body(std::integral_constant<int, 0>{})) break;
+        if (!body(std::integral_constant<int, 1>{})) break;
+        if (!body(std::integral_constant<int, 2>{})) break;
     }
 }
 
@@ -667,13 +666,15 @@ ConvBPlan conv_bf16_plan(const ConvBArgs& a) {
             const int patch_elems = (p.PH * p.PW * (p.c4 ? 4 : p.PP) + 7) & ~7;
             const bool resident = p.c4 || a.Cin == p.CC;
             const int stage_bytes = max_px * p.BN * (a.y_f32 ? 4 : 2);
-            p.lds_bytes = 2 * (patch_elems + G * p.BN * (p.c4 ? 56 : p.PP)) + 8 * a.Cin + 4 * 5 * p.BN + 32;
+            p.lds_bytes = 2 * (patch_elems + G * p.BN * (p.c4 ? 56 : p.PP)) + 8 * a.Cin + 4 * 16 * p.BN + 32;
             if (resident)
                 p.lds_bytes += stage_bytes;  // dedicated: the resident filter must survive the epilogue
             else if (p.lds_bytes < stage_bytes)
                 p.lds_bytes = stage_bytes;   // staged over the (dead) patch + filter area
+            // staging registers: chunked kernel 8 patch + 12 filter granules per thread, resident kernel 5 patch
             fits = p.lds_bytes <= 80 * 1024 &&
-                   (p.c4 || (p.PH * p.PW * (p.CC / 8) <= 8 * 256 && G * p.BN * (p.CC / 8) <= 12 * 256));
+                   (p.c4 || (resident ? p.PH * p.PW * (p.CC / 8) <= 5 * 256
+                                      : (p.PH * p.PW * (p.CC / 8) <= 8 * 256 && G * p.BN * (p.CC / 8) <= 12 * 256)));
             if (fits || p.c4) break;
         }
         if (p.CC < (p.c4 ? 4 : 16)) p.CC = p.c4 ? 4 : 16;
@@ -691,7 +692,9 @@ int conv_bf16_launch(const ConvBArgs& a_in, hipStream_t s) {
     if (p.c4 && (a.stride != 1 || a.KW > 12 || !a.x_f32)) return -1;
     if (p.lds_bytes > 160 * 1024) return -2;
     const int G = p.c4 ? a.KH : a.KH * a.KW;
-    if (!p.c4 && (p.PH * p.PW * (p.CC / 8) > 8 * 256 || G * p.BN * (p.CC / 8) > 12 * 256)) return -2;
+    const bool resident_k = p.c4 || a.Cin == p.CC;
+    if (!p.c4 && resident_k && p.PH * p.PW * (p.CC / 8) > 5 * 256) return -2;
+    if (!resident_k && (p.PH * p.PW * (p.CC / 8) > 8 * 256 || G * p.BN * (p.CC / 8) > 12 * 256)) return -2;
     // resident kernels walk a strided list of tiles: cap the grid at a few waves of workgroups per CU so that the
     // resident filter is amortised over many tiles
     const long total_tiles = (long)a.N * p.tiles_y * p.tiles_x;
