@@ -143,7 +143,7 @@ int in_finalize(const float* stats, int N, int T, int C, int groups, const float
                 float* mean, float* rstd, float* a, float* b, hipStream_t s, float* scratch) {
     const int Cv = C * groups;
     const char* mt = getenv("FS_FINALIZE_MIN_T");  // (tests lower it so small images take the two-level path)
-    const int min_t = mt ? atoi(mt) : 4 * kFinalizeSplit;
+    const int min_t = mt ? atoi(mt) : 16 * kFinalizeSplit;  // 1024 tiles: 720p and up; training sizes stay single-level
     if (scratch && T > min_t && Cv <= 256) {  // scratch: N * kFinalizeSplit * Cv * 3 floats
         hipLaunchKernelGGL(in_prereduce_kernel, dim3(kFinalizeSplit, N), dim3(256), 0, s, stats, T, Cv, kFinalizeSplit, scratch);
         stats = scratch;

@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Fold two rocprofv3 PMC passes (one with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE; CSV output,
+--kernel-trace only) into per-kernel HBM traffic per launch.
+
+Units / corrections (MI355X_MICROARCH.md, HBM section): the counters are in KiB; on gfx950 FETCH_SIZE
+reports half of the bytes of wide coalesced reads -> doubled.  The doubling is calibrated in the same run
+on maxpool_kernel, whose algorithmic bytes are known (reads its whole input once, writes a quarter).
+
+usage: pmc_traffic.py <dir_fetch> <dir_write> <out.json> [provenance text]"""
+import csv
+import glob
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"(conv_igemm_kernel<[^>]*>|conv_wgrad_kernel<[^>]*>|conv_bf16_\w+<[^>]*>|[a-z_0-9]+_kernel)", name)
+    s = m.group(1) if m else name[:60]
+    return s.replace(", false", "").replace(", true", ",flat").replace(" ", "")
+
+
+def collect(d, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    dfetch, dwrite, out = sys.argv[1:4]
+    prov = sys.argv[4] if len(sys.argv) > 4 else ""
+    fe, wr = collect(dfetch, "FETCH_SIZE"), collect(dwrite, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fe) & set(wr), key=lambda k: -(2 * sum(fe[k]) + sum(wr[k]))):
+        f = sum(fe[k]) / len(fe[k])
+        w = sum(wr[k]) / len(wr[k])
+        kernels[k] = {"launches_sampled": len(fe[k]), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
+                      "traffic_bytes_per_launch": int((2 * f + w) * 1024)}
+    json.dump({"_provenance": prov, "kernels": kernels}, open(out, "w"), indent=1)
+    for k, v in list(kernels.items())[:12]:
+        print("%-40s %4d launches  %10.1f MB/launch" % (k, v["launches_sampled"], v["traffic_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
