@@ -262,3 +262,25 @@ def test_train_cli_reads_tfrecord_shards(tmp_path, monkeypatch, capsys):
     assert out[-1] == "Done training."
     logs = [json.loads(l) for l in open(str(work / "summaries" / "train" / "r0" / "scalars.jsonl"))]
     assert [d["step"] for d in logs] == [0, 10] and all(np.isfinite(d["loss"]) for d in logs)   # 26 images / 2 = 13 steps
+
+
+def test_tensorboard_event_file_layout(tmp_path):
+    """Event files are TFRecord files of tensorflow.Event protos (event.proto / summary.proto field numbers)."""
+    from faststyle_amd import tbevents
+    w = tbevents.EventWriter(str(tmp_path / "run"))
+    w.add_scalars(0, [("summaries/loss", 3.5), ("summaries/style_loss", 1.25)])
+    w.add_scalars(10, [("summaries/loss", 2.0)])
+    w.close()
+    assert os.path.basename(w.path).startswith("events.out.tfevents.")
+    recs = odp.read_tfrecord(w.path)
+    assert len(recs) == 3
+    # known answer by the wire format: step=10 -> 10 0a ; summary(5){value(1){tag(1) "summaries/loss", simple_value(2)=2.0f}}
+    tail = b"\x10\x0a" + b"\x2a\x17" + b"\x0a\x15" + b"\x0a\x0esummaries/loss" + b"\x15" + struct.pack("<f", 2.0)
+    assert recs[2][9:] == tail and recs[2][0] == 0x09
+    first = dict((f, v) for f, _, v in odp._fields(recs[0]))
+    assert first[3] == b"brain.Event:2" and abs(struct.unpack("<d", first[1])[0] - __import__("time").time()) < 600
+    ev = dict((f, v) for f, _, v in odp._fields(recs[1]))
+    assert 2 not in ev or ev[2] == 0                      # step 0 (varint 0 is written explicitly)
+    vals = [dict((f, v) for f, _, v in odp._fields(x)) for f0, _, x in odp._fields(ev[5]) if f0 == 1]
+    assert [v[1] for v in vals] == [b"summaries/loss", b"summaries/style_loss"]
+    assert [struct.unpack("<f", v[2])[0] for v in vals] == [3.5, 1.25]

@@ -75,6 +75,7 @@ def test_train_cli_runs_reference_loop(tmp_path, monkeypatch, capsys, method):
     assert final["img_t_net/upsample_0/W"].shape == ((3, 3, 32, 64) if method == "deconv" else (3, 3, 64, 32))
     full = ckpt.load_checkpoint(str(work / "training" / "t.ckpt-10"))
     assert int(full["global_step"]) == 10 and "img_t_net/initconv_0/W/Adam" in full
+    assert any(f.startswith("events.out.tfevents.") for f in os.listdir(str(work / "summaries" / "train" / "t0")))
     logs = [json.loads(l) for l in open(str(work / "summaries" / "train" / "t0" / "scalars.jsonl"))]
     assert [d["step"] for d in logs] == [0, 10] and np.isfinite(logs[1]["loss"])
     assert logs[1]["loss"] < logs[0]["loss"] or method == "deconv"

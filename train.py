@@ -12,8 +12,9 @@ Differences from the reference that are forced by the environment and stated, no
     images).  Two conveniences on top: a directory of plain JPEG/PNG files (PIL decode + PIL
     bicubic), and the literal ``synthetic`` (uniform [0,255) images, MS-COCO train2014 count
     82,783 per epoch) for benchmarking without a dataset;
-  * TensorBoard event files are replaced by ``summaries/train/<run_name>/scalars.jsonl`` with the
-    same four scalars at the same steps (reference train.py:185-189, 260-272).
+  * next to the TensorBoard event file (``summaries/train/<run_name>/events.out.tfevents.*`` with the
+    reference's four scalars ``summaries/{loss,style_loss,content_loss,tv_loss}`` at the same steps,
+    train.py:185-189, 260-272; no graph definition in it) the same values go to ``scalars.jsonl``.
 """
 import argparse
 import glob
@@ -158,7 +159,7 @@ def batcher(train_dir, batch_size, resize, n_epochs, buffer_size, seed, rank, wo
 def main(args):
     import torch
     import torch.distributed as dist
-    from faststyle_amd import ckpt, datapipe, engine, im_transf_net, trainer, utils, vgg16
+    from faststyle_amd import ckpt, datapipe, engine, im_transf_net, tbevents, trainer, utils, vgg16
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -203,6 +204,7 @@ def main(args):
             if not os.path.exists(d):
                 os.makedirs(d)
         log = open('./summaries/train/' + run_name + '/scalars.jsonl', 'a')
+        train_writer = tbevents.EventWriter('./summaries/train/' + run_name)      # train.py:216-217
 
     def save(prefix, full):
         tensors = eng.unflatten_params(tr.params_numpy(), upsample_method=method)
@@ -246,6 +248,8 @@ def main(args):
                     log.write(json.dumps({"step": current_step, "loss": lv[0], "content_loss": lv[1],
                                           "style_loss": lv[2], "tv_loss": lv[3]}) + "\n")
                     log.flush()
+                    train_writer.add_scalars(current_step, [("summaries/loss", lv[0]), ("summaries/style_loss", lv[2]),
+                                                            ("summaries/content_loss", lv[1]), ("summaries/tv_loss", lv[3])])
                     print(current_step, lv[0])
             if current_step == args.num_steps_break:
                 print('Done training.')
@@ -257,6 +261,7 @@ def main(args):
         # Save the model (the image transformation network) for later usage (train.py:283-286)
         if rank == 0:
             save('models/' + args.model_name + '_final.ckpt', full=False)
+            train_writer.close()
         if world > 1:
             dist.destroy_process_group()
 
