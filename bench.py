@@ -15,6 +15,7 @@ Prints ONE JSON line on rank 0 (contract: see the task statement); extra keys:
                 FLOP / HIP-event time, measured live on the launch stream during the timed steps
   cpu_baseline  the numpy oracle (a port of the reference path; TF1 itself cannot be installed)
                 timed on this box's host cores on a bounded sample, rank 0 / N=1 only
+  train_b32_one_gpu_images_per_sec  the same train step at batch 32 on ONE GPU (N=1 runs only; eager launches)
   stylize_720p_fps  config[1]: im_transf_net forward on a 720p frame, batch 1, fp32
   stylize_1080p_b8_bf16_fps / _fp32_fps  config[4]: 1080p, batch 8 per GPU, the bf16 mixed-precision path
                 (bf16 MFMA, fp32 statistics; NOT the parity path) beside the fp32 path on the same input
@@ -140,6 +141,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the metric's "b32" on ONE GPU (N=1 only; at N=8 the timed region above already is global batch 32)
+    b32 = None
+    if world == 1 and not args.no_stylize and B != 32:
+        big = [torch.rand((32, S, S, 3), device="cuda", generator=g) * 255.0 for _ in range(2)]
+        tr.use_graph = False
+        for i in range(2):
+            tr.step(big[i % 2])
+        sync()
+        tb = time.perf_counter()
+        for i in range(6):
+            tr.step(big[i % 2])
+        sync()
+        b32 = 6 * 32 / (time.perf_counter() - tb)
+        tr.use_graph = not args.no_graph
+        del big
+
     # config[1]: 720p stylize, batch 1 per GPU, independent frames (no collective)
     fps = None
     if not args.no_stylize:
@@ -230,6 +247,8 @@ def main():
             "step_frac_of_f32_mfma_peak": round(GFLOP_PER_IMG_AS_WRITTEN * value / 1e3 / world / PEAK_F32_MFMA_TFLOPS, 4),
             "final_loss": loss_val, "hip_graph": graphed,
         }
+        if b32 is not None:
+            out["train_b32_one_gpu_images_per_sec"] = round(b32, 1)      # same step at batch 32 on this one GPU
         if fps is not None:
             out["stylize_720p_fps"] = round(fps, 2)
             out["stylize_1080p_b8_bf16_fps"] = round(fps_1080_bf16, 1)     # FS_FLAG_BF16: ~52 dB PSNR vs the fp32 path
