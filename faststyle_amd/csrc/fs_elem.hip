@@ -27,23 +27,27 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // ---------------------------------------------------------------- instance-norm finalize
 // stats: [N][T][Cv][3] = {mean, M2, count} per conv tile, Cv = groups*C (groups=4 for the
 // pixel-shuffled resize-conv whose 4 phases hold the same real channel).
-// One wave per channel (4 channels per block): 64 lanes stride over the tile list with 4 loads in
-// flight, merge with Chan's update in fp64, lane 0 folds the 64 lane results in a fixed order.
+// LPC lanes per channel (256/LPC channels per block): the lanes stride over the tile list with 4 loads in
+// flight, merge with Chan's update in fp64, then a fixed-shape tree folds the LPC lane results.  LPC = 64 (one wave
+// per channel) when there are many (sample, channel) pairs; LPC = 256 (a whole workgroup per channel) when there
+// are few, so that a batch-1 frame still spreads its tile list over enough lanes.
+template <int LPC>
 __global__ __launch_bounds__(256) void in_finalize_kernel(const float* stats, int T, int C, int groups, const float* gamma,
                                                           const float* beta, float eps, float* mean, float* rstd,
                                                           float* oa, float* ob) {
     __shared__ double sc[256], sm[256], sq[256];
-    const int n = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = blockIdx.y * 4 + w;
+    constexpr int CPB = 256 / LPC;
+    const int n = blockIdx.x, lane = threadIdx.x % LPC, w = threadIdx.x / LPC;
+    const int c = blockIdx.y * CPB + w;
     const int Cv = C * groups;
     double cnt = 0, mu = 0, m2 = 0;
     if (c < C) {
         const int total = T * groups;
-        for (int i0 = lane; i0 < total; i0 += 256) {
+        for (int i0 = lane; i0 < total; i0 += 4 * LPC) {
             float vm[4], vq[4], vc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 64;
+                const int i = i0 + u * LPC;
                 vc[u] = 0.f;
                 vm[u] = vq[u] = 0.f;
                 if (i < total) {
@@ -66,8 +70,8 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* stats, in
             }
         }
     }
-    // fixed-shape tree over the 64 lanes of the channel (6 levels, one fp64 divide per merge)
-    for (int stride = 32; stride > 0; stride >>= 1) {
+    // fixed-shape tree over the LPC lanes of the channel (one fp64 divide per merge)
+    for (int stride = LPC / 2; stride > 0; stride >>= 1) {
         sc[threadIdx.x] = cnt;
         sm[threadIdx.x] = mu;
         sq[threadIdx.x] = m2;
@@ -144,13 +148,17 @@ int in_finalize(const float* stats, int N, int T, int C, int groups, const float
     const int Cv = C * groups;
     const char* mt = getenv("FS_FINALIZE_MIN_T");  // (tests lower it so small images take the two-level path)
     const int min_t = mt ? atoi(mt) : 16 * kFinalizeSplit;  // 1024 tiles: 720p and up; training sizes stay single-level
-    if (scratch && T > min_t && Cv <= 256) {  // scratch: N * kFinalizeSplit * Cv * 3 floats
+    if (scratch && T * groups > min_t && T > kFinalizeSplit && Cv <= 256) {  // scratch: N * kFinalizeSplit * Cv * 3 floats
         hipLaunchKernelGGL(in_prereduce_kernel, dim3(kFinalizeSplit, N), dim3(256), 0, s, stats, T, Cv, kFinalizeSplit, scratch);
         stats = scratch;
         T = kFinalizeSplit;
     }
-    hipLaunchKernelGGL(in_finalize_kernel, dim3(N, cdiv(C, 4)), dim3(256), 0, s, stats, T, C, groups, gamma, beta, eps,
-                       mean, rstd, a, b);
+    if (N * C <= 512 && T * groups >= 256)
+        hipLaunchKernelGGL(in_finalize_kernel<256>, dim3(N, C), dim3(256), 0, s, stats, T, C, groups, gamma, beta, eps, mean,
+                           rstd, a, b);
+    else
+        hipLaunchKernelGGL(in_finalize_kernel<64>, dim3(N, cdiv(C, 4)), dim3(256), 0, s, stats, T, C, groups, gamma, beta,
+                           eps, mean, rstd, a, b);
     return 0;
 }
 

@@ -36,13 +36,16 @@ def main():
         if os.environ.get("ZERO"):            # DVFS probe: all-zero operands draw less power -> higher clock
             x.zero_()
             w.zero_()
-        y = e.conv2d(x, w, s, pad)
+        kw = {"want_stats": True} if os.environ.get("STATS") else {}
+        y = e.conv2d(x, w, s, pad, **kw)
         torch.cuda.synchronize()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0.record()
         for _ in range(iters):
-            y = e.conv2d(x, w, s, pad)
+            y = e.conv2d(x, w, s, pad, **kw)
         t1.record()
+        if kw:
+            y = y[0]
         torch.cuda.synchronize()
         ms = t0.elapsed_time(t1) / iters
         fl = 2.0 * y.numel() * K * K * Ci
