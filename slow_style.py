@@ -9,7 +9,6 @@ image's shape, loss = content + style + beta*tv with beta defaulting to 1e-4, Ad
 loop ``while current_step < num_steps_break`` that reads the step BEFORE the update -- i.e.
 num_steps_break + 1 updates, a loss line at every step divisible by 10.
 """
-import argparse
 import os
 import sys
 
@@ -19,56 +18,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def setup_parser():
-    """Used to interface with the command-line (reference slow_style.py:17-67)."""
-    parser = argparse.ArgumentParser(
-                description='Train a style transfer net.')
-    parser.add_argument('--style_img_path',
-                        help='Path to style template image.')
-    parser.add_argument('--cont_img_path',
-                        help='Path to content template image.')
-    parser.add_argument('--learn_rate',
-                        help='Learning rate for optimizer.',
-                        default=1e1, type=float)
-    parser.add_argument('--loss_content_layers',
-                        help='Names of layers to define content loss.',
-                        nargs='*',
-                        default=['conv3_3'])
-    parser.add_argument('--loss_style_layers',
-                        help='Names of layers to define style loss.',
-                        nargs='*',
-                        default=['conv1_2', 'conv2_2', 'conv3_3', 'conv4_3'])
-    parser.add_argument('--content_weights',
-                        help="""Weights that multiply the content loss
-                        terms.""",
-                        nargs='*',
-                        default=[1.0],
-                        type=float)
-    parser.add_argument('--style_weights',
-                        help="""Weights that multiply the style loss terms.""",
-                        nargs='*',
-                        default=[5.0, 5.0, 5.0, 5.0],
-                        type=float)
-    parser.add_argument('--num_steps_break',
-                        help='Max number of steps to iterate optimizer.',
-                        default=500,
-                        type=int)
-    parser.add_argument('--beta',
-                        help="""TV regularization weight.""",
-                        default=1.e-4,
-                        type=float)
-    parser.add_argument('--style_target_resize',
-                        help="""Scale factor to apply to the style target image.
-                        Can change the features that get pronounced.""",
-                        default=1.0, type=float)
-    parser.add_argument('--cont_target_resize',
-                        help="""Resizes content input by this size. Output
-                        image will have the same size.""",
-                        default=1.0,
-                        type=float)
-    parser.add_argument('--output_img_path',
-                        help='Desired output path. Defaults to out.jpg',
-                        default='./out.jpg')
-    return parser
+    """The reference flag surface (slow_style.py:17-67), defined in faststyle_amd/cli.py."""
+    from faststyle_amd import cli
+    return cli.slow_style_parser()
 
 
 def optimise(eng, vgg_weights, style_img, cont_img, cfg, learn_rate, num_steps_break, seed=None, log=print):

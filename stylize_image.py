@@ -3,7 +3,6 @@
 loads a TF bundle-V2 checkpoint of the image-transform net and filters one image -- on the
 MI355X through libfaststyle_hip.so instead of a TF1 session (reference stylize_image.py:19-82).
 """
-import argparse
 import os
 import sys
 
@@ -13,30 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def setup_parser():
-    """Options for command-line input (reference stylize_image.py:19-43)."""
-    parser = argparse.ArgumentParser(description="""Use a trained fast style
-                                     transfer model to filter an input
-                                     image, and save to an output image.""")
-    parser.add_argument('--input_img_path',
-                        help='Input content image that will be stylized.')
-    parser.add_argument('--output_img_path',
-                        help='Desired output image path.',
-                        default='./results/styled.jpg')
-    parser.add_argument('--model_path',
-                        default='./models/starry_final.ckpt',
-                        help='Path to .ckpt for the trained model.')
-    parser.add_argument('--content_target_resize',
-                        help="""Resize input content image. Useful if having
-                        OOM issues.""",
-                        default=1.0,
-                        type=float)
-    parser.add_argument('--upsample_method',
-                        help="""The upsample method that was used to construct
-                        the model being loaded. Note that if the wrong one is
-                        chosen an error will occur.""",
-                        choices=['resize', 'deconv'],
-                        default='resize')
-    return parser
+    """The reference flag surface (stylize_image.py:19-43), defined in faststyle_amd/cli.py."""
+    from faststyle_amd import cli
+    return cli.stylize_image_parser()
 
 
 def main(argv=None):

@@ -8,7 +8,6 @@ image does not ship; without it the script can still filter a *directory of fram
 (frames are read RGB with PIL and converted to the BGR order a cv2 capture would deliver, so the
 reference's channel handling -- BGR fed as is, output swapped -- is reproduced bit for bit).
 """
-import argparse
 import os
 import sys
 
@@ -18,31 +17,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def setup_parser():
-    """Options for command-line input (reference stylize_webcam.py:17-39)."""
-    parser = argparse.ArgumentParser(description="""Use a trained fast style
-                                     transfer model to filter webcam feed.""")
-    parser.add_argument('--model_path',
-                        default='./models/starry_final.ckpt',
-                        help='Path to .ckpt for the trained model.')
-    parser.add_argument('--upsample_method',
-                        help="""The upsample method that was used to construct
-                        the model being loaded. Note that if the wrong one is
-                        chosen an error will be thrown.""",
-                        choices=['resize', 'deconv'],
-                        default='resize')
-    parser.add_argument('--resolution',
-                        help="""Dimensions for webcam. Note that, depending on
-                        the webcam, only certain resolutions will be possible.
-                        Leave this argument blank if want to use default
-                        resolution.""",
-                        nargs=2,
-                        type=int,
-                        default=None)
-    parser.add_argument('--frames_dir', default=None,
-                        help='(addition) read frames from this directory instead of a webcam.')
-    parser.add_argument('--output_dir', default='./frames_out',
-                        help='(addition) where --frames_dir results are written.')
-    return parser
+    """The reference flag surface (stylize_webcam.py:17-39) plus --frames_dir/--output_dir, in faststyle_amd/cli.py."""
+    from faststyle_amd import cli
+    return cli.stylize_webcam_parser()
 
 
 def _load(args):

@@ -16,7 +16,6 @@ Differences from the reference that are forced by the environment and stated, no
     reference's four scalars ``summaries/{loss,style_loss,content_loss,tv_loss}`` at the same steps,
     train.py:185-189, 260-272; no graph definition in it) the same values go to ``scalars.jsonl``.
 """
-import argparse
 import glob
 import json
 import os
@@ -28,88 +27,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def setup_parser():
-    """Used to interface with the command-line (reference train.py:23-105)."""
-    parser = argparse.ArgumentParser(
-                description='Train a style transfer net.')
-    parser.add_argument('--train_dir',
-                        help='Directory of TFRecords training data.')
-    parser.add_argument('--model_name',
-                        help='Name of model being trained.')
-    parser.add_argument('--style_img_path',
-                        default='./style_images/starry_night_crop.jpg',
-                        help='Path to style target image.')
-    parser.add_argument('--learn_rate',
-                        help='Learning rate for Adam optimizer.',
-                        default=1e-3, type=float)
-    parser.add_argument('--batch_size',
-                        help='Batch size for training.',
-                        default=4, type=int)
-    parser.add_argument('--n_epochs',
-                        help='Number of training epochs.',
-                        default=2, type=int)
-    parser.add_argument('--preprocess_size',
-                        help="""Dimensions to resize training images to before passing
-                        them into the image transformation network.""",
-                        default=[256, 256], nargs=2, type=int)
-    parser.add_argument('--run_name',
-                        help="""Name of log directory within the Tensoboard
-                        directory (./summaries). If not set, will use
-                        --model_name to create a unique directory.""",
-                        default=None)
-    parser.add_argument('--loss_content_layers',
-                        help='Names of layers to define content loss.',
-                        nargs='*',
-                        default=['conv3_3'])
-    parser.add_argument('--loss_style_layers',
-                        help='Names of layers to define style loss.',
-                        nargs='*',
-                        default=['conv1_2', 'conv2_2', 'conv3_3', 'conv4_3'])
-    parser.add_argument('--content_weights',
-                        help="""Weights that multiply the content loss
-                        terms.""",
-                        nargs='*',
-                        default=[1.0],
-                        type=float)
-    parser.add_argument('--style_weights',
-                        help="""Weights that multiply the style loss terms.""",
-                        nargs='*',
-                        default=[5.0, 5.0, 5.0, 5.0],
-                        type=float)
-    parser.add_argument('--num_steps_ckpt',
-                        help="""Save a checkpoint everytime this number of
-                        steps passes in training.""",
-                        default=1000,
-                        type=int)
-    parser.add_argument('--num_pipe_buffer',
-                        help="""Number of images loaded into RAM in pipeline.
-                        The larger, the better the shuffling, but the more RAM
-                        filled, and a slower startup.""",
-                        default=4000,
-                        type=int)
-    parser.add_argument('--num_steps_break',
-                        help="""Max on number of steps. Training ends when
-                        either num_epochs or this is reached (whichever comes
-                        first).""",
-                        default=-1,
-                        type=int)
-    parser.add_argument('--beta',
-                        help="""TV regularization weight. If using deconv for
-                        --upsample_method, try 1.e-4 for starters. Otherwise,
-                        this is not needed.""",
-                        default=0.0,
-                        type=float)
-    parser.add_argument('--style_target_resize',
-                        help="""Scale factor to apply to the style target image.
-                        Can change the dominant stylistic features.""",
-                        default=1.0, type=float)
-    parser.add_argument('--upsample_method',
-                        help="""Either deconvolution as in the original paper,
-                        or the resize convolution method. The latter seems
-                        superior and does not require TV regularization through
-                        beta.""",
-                        choices=['deconv', 'resize'],
-                        default='resize')
-    return parser
+    """The reference flag surface (train.py:23-105), defined in faststyle_amd/cli.py."""
+    from faststyle_amd import cli
+    return cli.train_parser()
 
 
 COCO_TRAIN2014 = 82783
