@@ -82,6 +82,11 @@ PROTOTYPES = {
     "fs_style_targets_workspace_bytes": (c_size_t, [c_int, c_int]),
     "fs_style_targets": (c_int, [c_void_p, POINTER(_vp10), POINTER(_vp10), POINTER(fs_loss_cfg), c_void_p, c_int, c_int,
                                  POINTER(_vp4), c_void_p, c_size_t]),
+    "fs_vgg_features_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "fs_vgg_features": (c_int, [c_void_p, POINTER(_vp10), POINTER(_vp10), c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int),
+                                POINTER(c_void_p), c_void_p, c_size_t]),
+    "fs_loss_sqdiff": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_void_p, c_void_p]),
+    "fs_loss_tv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fs_adam_tf_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,
                                 c_float, c_longlong]),
     "fs_conv2d_fwd": (c_int, [c_void_p, POINTER(fs_conv_desc)]),

@@ -264,6 +264,44 @@ int fs_style_targets(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const fl
     return rc ? fail(rc, "fs_style_targets: launch failed (%d)", rc) : 0;
 }
 
+static void features_layout(int N, int H, int W, int max_layer, fs::VggLayout* L) {
+    fs_loss_cfg cfg{};
+    cfg.n_style = 1;
+    cfg.style_layer[0] = max_layer;
+    fs::vgg_layout(N, H, W, cfg, false, L);
+}
+size_t fs_vgg_features_workspace_bytes(int N, int H, int W, int max_layer) {
+    if (N < 1 || H < 1 || W < 1 || max_layer < 0 || max_layer >= FS_VGG_NLAYERS) return 0;
+    fs::VggLayout L;
+    features_layout(N, H, W, max_layer, &L);
+    return L.total_floats * sizeof(float);
+}
+int fs_vgg_features(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS], const float* x,
+                    int N, int H, int W, int n_layers, const int* layers, float* const* out, void* ws, size_t ws_bytes) {
+    if (!ctx || !w || !b || !x || !layers || !out || !ws) return fail(-1, "fs_vgg_features: null argument");
+    if (N < 1 || n_layers < 1 || n_layers > FS_VGG_NLAYERS) return fail(-2, "fs_vgg_features: bad N / layer count");
+    int lmax = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        if (layers[i] < 0 || layers[i] >= FS_VGG_NLAYERS) return fail(-2, "fs_vgg_features: layer %d out of range", layers[i]);
+        if (!out[i]) return fail(-1, "fs_vgg_features: null output %d", i);
+        if (layers[i] > lmax) lmax = layers[i];
+    }
+    fs::VggLayout L;
+    features_layout(N, H, W, lmax, &L);
+    if (ws_bytes < L.total_floats * sizeof(float)) return fail(-3, "fs_vgg_features: workspace too small");
+    const int rc = fs::vgg_features(L, w, b, x, n_layers, layers, out, (float*)ws, ctx->stream);
+    return rc ? fail(rc, "fs_vgg_features: launch failed (%d)", rc) : 0;
+}
+
+int fs_loss_sqdiff(fs_ctx* ctx, const float* x, const float* t, size_t t_period, size_t n, float scale, float* out, void* scratch) {
+    if (!ctx || !x || !t || !out || !scratch || !t_period) return fail(-1, "fs_loss_sqdiff: null argument");
+    return fs::sqdiff_loss(x, t, t_period, n, scale, 0.f, nullptr, out, 0, (float*)scratch, ctx->stream);
+}
+int fs_loss_tv(fs_ctx* ctx, const float* x, int N, int H, int W, int C, float* out, void* scratch) {
+    if (!ctx || !x || !out || !scratch) return fail(-1, "fs_loss_tv: null argument");
+    return fs::tv_loss(x, N, H, W, C, 1.0f, 0.f, nullptr, out, (float*)scratch, ctx->stream);
+}
+
 int fs_adam_tf_step(fs_ctx* ctx, float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
                     float beta2, float eps, long long t) {
     if (!ctx || !p || !g || !m || !v) return fail(-1, "fs_adam_tf_step: null argument");

@@ -27,6 +27,9 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
                     float* dy, float* ws, hipStream_t s);
 int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
                   const fs_loss_cfg& cfg, const float* img, float* const grams[4], float* ws, hipStream_t s);
+// libs/vgg16.py:36-220 for N images (RGB 0..255): post-ReLU activations of the requested layers copied to out[i]
+int vgg_features(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS], const float* x,
+                 int n_layers, const int* layers, float* const* out, float* ws, hipStream_t s);
 int vgg_consts(float* ab, hipStream_t s);
 int loss_total(float* losses, hipStream_t s);
 

@@ -193,6 +193,19 @@ static int gram_forward(const VggLayout& L, int l, const float* F, float* G, flo
     return reduce_slabs(ws + L.slabs, L.N, ga.p.n_slabs, (size_t)C * C, 1.0f / ((float)H * W * C), G, s);
 }
 
+int vgg_features(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS], const float* x,
+                 int n_layers, const int* layers, float* const* out, float* ws, hipStream_t s) {
+    if (hipMemcpyAsync(ws + L.xin, x, (size_t)L.N * L.H * L.W * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return -10;
+    FS_TRY(vgg_forward(L, w, b, ws, s));
+    for (int i = 0; i < n_layers; ++i) {
+        const int l = layers[i];
+        const size_t bytes = (size_t)L.N * L.Hl[l] * L.Wl[l] * kCout[l] * sizeof(float);
+        if (hipMemcpyAsync(out[i], ws + L.act[l], bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return -10;
+    }
+    return 0;
+}
+
 int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
                   const fs_loss_cfg& cfg, const float* img, float* const grams[4], float* ws, hipStream_t s) {
     if (hipMemcpyAsync(ws + L.xin, img, (size_t)L.H * L.W * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)

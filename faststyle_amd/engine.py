@@ -253,6 +253,49 @@ class Engine(object):
                                                       p(losses), p(dy), p(ws), nbytes), "fs_perceptual_loss")
         return losses, dy
 
+    # ------------------------------------------------------------------ builder-level pieces (vgg16 / utils / losses)
+    def vgg_features(self, x, layer_names):
+        """libs/vgg16.py:36-220: post-ReLU activations `convX_Y` of x [N,H,W,3] (RGB 0..255); needs vgg_load()."""
+        self._sync_stream()
+        N, H, W, _ = (int(s) for s in x.shape)
+        ids = [L.VGG_LAYER_NAMES.index(n) for n in layer_names]
+        outs, h, w, shapes = [], H, W, {}
+        for l in range(max(ids) + 1):
+            shapes[l] = (N, h, w, L.VGG_COUT[l])
+            if l in (1, 3, 6, 9):                        # max_pool 2x2 s2 SAME after conv1_2 / 2_2 / 3_3 / 4_3
+                h, w = (h + 1) // 2, (w + 1) // 2
+        outs = [self.mem.empty(shapes[l]) for l in ids]
+        nbytes = self.lib.fs_vgg_features_workspace_bytes(N, H, W, max(ids))
+        ws = self.mem.empty((nbytes // 4,))
+        lay = (ctypes.c_int * len(ids))(*ids)
+        op = (ctypes.c_void_p * len(ids))(*[self.mem.ptr(t) for t in outs])
+        L.check(self.lib, self.lib.fs_vgg_features(self.ctx, ctypes.byref(self._wp), ctypes.byref(self._bp), self.mem.ptr(x), N, H, W,
+                                                   len(ids), lay, op, self.mem.ptr(ws), nbytes), "fs_vgg_features")
+        return outs
+
+    def gram(self, feat):
+        """utils.get_grams for one layer (utils.py:76-82): feat [N,h,w,c] -> [N,c,c] = F^T F / (h*w*c)."""
+        N, h, w, c = (int(s) for s in feat.shape)
+        return self.conv2d_wgrad(feat, feat, 1, 1, "VALID", per_sample=True, scale=1.0 / (h * w * c))
+
+    def loss_sqdiff(self, x, t, scale):
+        """scale * sum((x - t)^2) with t broadcast over the leading (batch) axis when smaller; device scalar [1]."""
+        self._sync_stream()
+        n, period = int(np.prod(x.shape)), int(np.prod(t.shape))
+        assert n % period == 0
+        out, scratch = self.mem.empty((1,)), self.mem.empty((1024,))
+        p = self.mem.ptr
+        L.check(self.lib, self.lib.fs_loss_sqdiff(self.ctx, p(x), p(t), period, n, float(scale), p(out), p(scratch)), "fs_loss_sqdiff")
+        return out
+
+    def loss_tv(self, x):
+        self._sync_stream()
+        N, H, W, C = (int(s) for s in x.shape)
+        out, scratch = self.mem.empty((1,)), self.mem.empty((1024,))
+        p = self.mem.ptr
+        L.check(self.lib, self.lib.fs_loss_tv(self.ctx, p(x), N, H, W, C, p(out), p(scratch)), "fs_loss_tv")
+        return out
+
     def resize_bicubic_u8(self, img_u8, out):
         """tf.image.resize_images(img, out.shape[:2], method=2) of TF 1.0 (datapipe.py:24) on the device:
         img_u8 host uint8 [H,W,3] -> ``out`` (device float32 [Ho,Wo,3], written in place)."""

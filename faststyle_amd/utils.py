@@ -38,3 +38,13 @@ def imwrite(path, img):
         Image.fromarray(u8).save(path, format="JPEG", quality=95, subsampling="4:2:0")
     else:
         Image.fromarray(u8).save(path)
+
+
+def get_layers(layer_names, vgg):
+    """utils.get_layers (utils.py:55-63): the named VGG tensors (here: of an explicit vgg16 builder)."""
+    return vgg.layers([n.split("/")[-1].split(":")[0] for n in layer_names])
+
+
+def get_grams(layer_names, vgg):
+    """utils.get_grams (utils.py:66-83): per-sample Gram matrices [b,c,c] = F^T F / (h*w*c) of the named layers."""
+    return [vgg.engine.gram(f) for f in get_layers(layer_names, vgg)]

@@ -32,3 +32,34 @@ def synthetic_weights(seed=3):
         w[n + "_W"] = (rng.standard_normal((3, 3, ci, co)) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)
         w[n + "_b"] = (rng.standard_normal((co,)) * 0.05).astype(np.float32)
     return w
+
+
+class vgg16(object):
+    """Builder with the reference's shape (libs/vgg16.py:26-33): ``vgg16(imgs, weights, engine=...)`` then the
+    layers as attributes ``conv1_1 ... conv4_3`` (post-ReLU device tensors, computed on first access through
+    fs_vgg_features; conv5_x / fc layers are never used by the reference's scripts and are not built)."""
+
+    def __init__(self, imgs, weights=None, sess=None, engine=None):
+        if engine is None:
+            raise L.FaststyleError("vgg16 needs the Engine that owns the device")
+        self.imgs = imgs
+        self.engine = engine
+        self._feats = {}
+        if weights is not None:
+            self.load_weights(weights)
+
+    def load_weights(self, weight_file, sess=None):
+        self.engine.vgg_load(load_weights(weight_file) if isinstance(weight_file, str) else weight_file)
+        self._feats = {}
+
+    def layers(self, names):
+        need = [n for n in names if n not in self._feats]
+        if need:
+            for n, t in zip(need, self.engine.vgg_features(self.imgs, need)):
+                self._feats[n] = t
+        return [self._feats[n] for n in names]
+
+    def __getattr__(self, name):
+        if name in L.VGG_LAYER_NAMES:
+            return self.layers([name])[0]
+        raise AttributeError(name)

@@ -101,6 +101,21 @@ int fs_style_targets(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const fl
                      size_t ws_bytes);
 
 /* ---- optimiser: tf.train.AdamOptimizer (train.py:203), TF1 epsilon placement ---------------- */
+/* ---- builder-level pieces (the reference's Python helpers, for scripts that compose their own loss) ----
+ * fs_vgg_features: libs/vgg16.py:36-220 -- the post-ReLU tensors `vgg/convX_Y:0` of N images (RGB 0..255, the
+ *   ImageNet mean is subtracted inside); layers[i] in 0..9 = conv1_1..conv4_3; out[i] device [N,H_l,W_l,C_l].
+ *   utils.get_grams (utils.py:66-83) on such a tensor is fs_conv2d_wgrad with per_sample, KH=KW=1, x==dy,
+ *   scale 1/(h*w*c).
+ * fs_loss_sqdiff: out[0] = scale * sum_i (x[i] - t[i % t_period])^2 -- losses.content_loss (losses.py:32-37, scale
+ *   w/(h*w*c)) and losses.style_loss (losses.py:61-64, scale w/(c*c), t = the [1,c,c] target broadcast over the batch).
+ * fs_loss_tv: losses.tv_loss (losses.py:70-97).  scratch: 4096 bytes of device memory; out: device scalar. */
+size_t fs_vgg_features_workspace_bytes(int N, int H, int W, int max_layer);
+int fs_vgg_features(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS], const float* x,
+                    int N, int H, int W, int n_layers, const int* layers, float* const* out, void* ws, size_t ws_bytes);
+int fs_loss_sqdiff(fs_ctx* ctx, const float* x, const float* t, size_t t_period, size_t n, float scale, float* out,
+                   void* scratch);
+int fs_loss_tv(fs_ctx* ctx, const float* x, int N, int H, int W, int C, float* out, void* scratch);
+
 int fs_adam_tf_step(fs_ctx* ctx, float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
                     float beta2, float eps, long long t /* 1-based step */);
 

@@ -115,3 +115,37 @@ def test_slow_style_cli_and_frames_dir_cli(tmp_path, monkeypatch, capsys):
     assert outs == ["f00.png", "f01.png", "f02.png"]
     a = np.asarray(Image.open(str(work / "fo" / "f00.png")))
     assert a.shape == (120, 160, 3) and a.std() > 10
+
+
+def test_builder_level_api_matches_oracle(eng):
+    """vgg16 / get_layers / get_grams / content_loss / style_loss / tv_loss against the oracle."""
+    from faststyle_amd import losses, utils, vgg16
+    from oracle import nnops
+    rng = np.random.default_rng(5)
+    Wv = perceptual.synthetic_vgg_weights(seed=3)
+    x = rng.uniform(0, 255, (2, 21, 26, 3)).astype(np.float32)               # odd sizes: SAME pooling
+    tgt_img = rng.uniform(0, 255, (1, 21, 26, 3)).astype(np.float32)
+    net = vgg16.vgg16(eng.mem.from_numpy(x), Wv, engine=eng)
+    names = ["conv1_2", "conv2_2", "conv3_3", "conv4_3"]
+    feats_o = perceptual.vgg16(x.astype(np.float64), f64(Wv), upto="conv4_3")
+    for n, f in zip(names + ["conv2_1"], utils.get_layers(["vgg/%s:0" % n for n in names] + ["conv2_1"], net)):
+        got = eng.mem.to_numpy(f)
+        assert got.shape == feats_o[n].shape
+        assert np.abs(got - feats_o[n]).max() / np.abs(feats_o[n]).max() < 2e-5
+    assert eng.mem.to_numpy(net.conv3_3).shape == feats_o["conv3_3"].shape
+    grams = utils.get_grams(names, net)
+    grams_o = [perceptual.gram(feats_o[n]) for n in names]
+    for g, go in zip(grams, grams_o):
+        assert np.abs(eng.mem.to_numpy(g) - go).max() / np.abs(go).max() < 2e-5
+    tg_o = perceptual.target_grams(tgt_img.astype(np.float64), f64(Wv), names)
+    tgt = [eng.mem.from_numpy(t.astype(np.float32)) for t in tg_o]
+    sl = float(eng.mem.to_numpy(losses.style_loss(grams, tgt, [5.0] * 4, engine=eng))[0])
+    sl_o = sum(5.0 * np.sum((go - t) ** 2) / (go.shape[-1] ** 2) for go, t in zip(grams_o, tg_o))
+    assert abs(sl - sl_o) / sl_o < 1e-4
+    phi_t = rng.standard_normal(feats_o["conv3_3"].shape).astype(np.float32)
+    cl = float(eng.mem.to_numpy(losses.content_loss([net.conv3_3], [eng.mem.from_numpy(phi_t)], [1.0], engine=eng))[0])
+    cl_o = np.sum((feats_o["conv3_3"] - phi_t) ** 2) / np.prod(phi_t.shape[1:])
+    assert abs(cl - cl_o) / cl_o < 1e-4
+    tv = float(eng.mem.to_numpy(losses.tv_loss(eng.mem.from_numpy(x), engine=eng))[0])
+    tv_o, _ = perceptual.tv_loss(x.astype(np.float64))
+    assert abs(tv - tv_o) / tv_o < 1e-5
