@@ -142,3 +142,48 @@ def test_gram_is_symmetric_psd_and_matches_oracle(eng, hw, c):
     assert np.abs(g - g.transpose(0, 2, 1)).max() <= 1e-6 * np.abs(g).max()
     ev = np.linalg.eigvalsh(g[0].astype(np.float64))
     assert ev.min() > -1e-5 * ev.max()
+
+
+# ------------------------------------------------------------------ full-size properties (no CPU oracle at these sizes)
+FULL = [("vgg3_2_b8", (8, 64, 64, 256), 256, 3, 1), ("vgg1_2_b8", (8, 256, 256, 64), 64, 3, 1),
+        ("vgg4_2_b4", (4, 32, 32, 512), 512, 3, 1), ("initconv_1_b4", (4, 336, 336, 16), 32, 3, 2),
+        ("res_720p", (1, 196, 336, 64), 64, 3, 1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", FULL, ids=[c[0] for c in FULL])
+def test_full_size_adjoint_linearity_and_shift(case):
+    """At BASELINE's sizes the float64 oracle is too slow, so the three conv kernels are tied together by
+    size-independent identities: <conv(x,w), dy> = <w, wgrad(x,dy)> = <x, dgrad(dy,w)> (adjoints), linearity
+    in x, and translation equivariance of the interior (tiling / halo / split-K logic at scale)."""
+    import torch
+    from tests.backends import get_engine
+    eng = get_engine("hip")
+    _, xs, co, k, stride = case
+    N, H, W, ci = xs
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(xs, device="cuda", generator=g)
+    x2 = torch.randn(xs, device="cuda", generator=g)
+    w = torch.randn((k, k, ci, co), device="cuda", generator=g) * 0.05
+    y = eng.conv2d(x, w, stride, "SAME")
+    dy = torch.randn(y.shape, device="cuda", generator=g)
+    Ho, Wo = y.shape[1], y.shape[2]
+    pt = max((Ho - 1) * stride + k - H, 0) // 2
+    pl = max((Wo - 1) * stride + k - W, 0) // 2
+    s1 = float((y.double() * dy.double()).sum())
+    dw = eng.conv2d_wgrad(x, dy, k, stride, "SAME")
+    s2 = float((w.double() * dw.double()).sum())
+    wT = w.flip(0, 1).permute(0, 1, 3, 2).contiguous()
+    dx = eng.conv2d(dy, wT, 1, (k - 1 - pt, k - 1 - pl, H, W), src_mode=2 if stride == 2 else 0)
+    s3 = float((x.double() * dx.double()).sum())
+    scale = float(y.double().norm() * dy.double().norm())
+    assert abs(s1 - s2) / scale < 1e-5 and abs(s1 - s3) / scale < 1e-5, (s1, s2, s3)
+    # linearity
+    y12 = eng.conv2d(x + 2.0 * x2, w, stride, "SAME")
+    y2 = eng.conv2d(x2, w, stride, "SAME")
+    assert float((y12 - (y + 2.0 * y2)).abs().max()) / float(y12.abs().max()) < 1e-5
+    # translation: shifting the input by `stride` pixels shifts the output by one, away from the borders
+    xs_ = torch.roll(x, shifts=(stride, stride), dims=(1, 2))
+    ys = eng.conv2d(xs_, w, stride, "SAME")
+    a, b = ys[:, 3:-3, 3:-3], y[:, 2:-4, 2:-4]
+    assert float((a - b).abs().max()) / float(y.abs().max()) < 1e-5
