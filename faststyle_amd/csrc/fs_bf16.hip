@@ -652,7 +652,12 @@ ConvBPlan conv_bf16_plan(const ConvBArgs& a) {
     const int G = p.c4 ? a.KH : a.KH * a.KW;
     // widest pixel tile / deepest channel chunk whose staging fits the per-thread register budget; the narrower
     // tile when the launch could not fill the chip
-    for (p.WM = 2; p.WM >= 1; --p.WM) {
+    const char* wm_env = getenv("FS_BF16_WM");  // tuning aid: cap the pixel tile (1: 128 pixels)
+    // the resident kernel with 64 output channels and the 256-pixel tile does not fit the register file (it spills
+    // ~1 KB per lane and measures 1.5x slower than the 128-pixel tile): start it at WM = 1
+    const bool single_chunk = p.c4 || a.Cin <= 32;
+    const int wm0 = wm_env ? atoi(wm_env) : (single_chunk && p.BN == 64 ? 1 : 2);
+    for (p.WM = wm0; p.WM >= 1; --p.WM) {
         const int max_px = 4 * p.WM * 32;
         plan_tile(a.Ho, a.Wo, a.KH, p.c4 ? 12 : a.KW, a.stride, max_px, &p.TH, &p.TW);
         p.tiles_y = cdiv(a.Ho, p.TH);
