@@ -14,6 +14,7 @@ struct ConvBPlan {
     int CC, PP;    // channels per staged chunk; LDS pixel pitch in elements (CC + 8)
     int TH, TW, tiles_y, tiles_x, PH, PW;
     int lds_bytes;
+    int wst_off;   // byte offset of the per-tile statistics scratch [4][BN][4] in LDS
 };
 
 struct ConvBArgs {

@@ -62,8 +62,8 @@ __device__ __forceinline__ bool bsrc_coord(int mode, int refl, int v, int n_src,
 // keeps sum(d^2) - sum(d)^2/n free of cancellation), the four wave results are merged with Chan's update by one
 // thread per channel.  One barrier; interior tiles skip the per-row validity test.  wst: [4][BN][4] floats of LDS.
 template <int WM, int WN>
-__device__ __forceinline__ void tile_stats(const ConvBArgs& a, const f32x16 (&acc)[WM][WN], float* wst, size_t tile, int co0,
-                                           int th_valid, int tw_valid) {
+__device__ __forceinline__ void tile_stats_write(const ConvBArgs& a, const f32x16 (&acc)[WM][WN], float* wst, int th_valid,
+                                                 int tw_valid) {
     constexpr int BN = WN * 32;
     const ConvBPlan& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 31, kq = lane >> 5;
@@ -110,7 +110,12 @@ __device__ __forceinline__ void tile_stats(const ConvBArgs& a, const f32x16 (&ac
             o[3] = piv;
         }
     }
-    __syncthreads();
+}
+// second half, after a workgroup barrier: one thread per channel merges the four wave results
+template <int WN>
+__device__ __forceinline__ void tile_stats_finish(const ConvBArgs& a, const float* wst, size_t tile, int co0) {
+    constexpr int BN = WN * 32;
+    const int tid = threadIdx.x;
     if (tid < BN && co0 + tid < a.Cout) {
         float cnt = 0.f, mu = 0.f, m2 = 0.f;
 #pragma unroll
@@ -136,10 +141,8 @@ __device__ __forceinline__ void tile_stats(const ConvBArgs& a, const f32x16 (&ac
 // global stores; staging the tile as [pixel][BN] lets every thread write 16 contiguous bytes (8 bf16 channels or 4
 // fp32) of one pixel -- whole 64/128-byte pixel rows per wavefront.  `stg` must not alias live LDS data.
 template <int WM, int WN>
-__device__ __forceinline__ void store_tile(const ConvBArgs& a, const f32x16 (&acc)[WM][WN], void* stg, int n, int ty0, int tx0,
-                                           int co0, int th_valid, int tw_valid) {
+__device__ __forceinline__ void store_tile_write(const ConvBArgs& a, const f32x16 (&acc)[WM][WN], void* stg) {
     constexpr int BN = WN * 32;
-    const ConvBPlan& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 31, kq = lane >> 5;
     unsigned short* sb = static_cast<unsigned short*>(stg);
     float* sf = static_cast<float*>(stg);
@@ -156,7 +159,16 @@ __device__ __forceinline__ void store_tile(const ConvBArgs& a, const f32x16 (&ac
                     sb[t * BN + nn * 32 + lm] = f2bf(acc[m][nn][r]);
             }
         }
-    __syncthreads();
+}
+// second half, after a workgroup barrier: 16-byte cooperative stores
+template <int WN>
+__device__ __forceinline__ void store_tile_finish(const ConvBArgs& a, const void* stg, int n, int ty0, int tx0, int co0,
+                                                  int th_valid, int tw_valid) {
+    constexpr int BN = WN * 32;
+    const ConvBPlan& p = a.p;
+    const int tid = threadIdx.x;
+    const unsigned short* sb = static_cast<const unsigned short*>(stg);
+    const float* sf = static_cast<const float*>(stg);
     const int gsz = a.y_f32 ? 4 : 8;  // channels per 16-byte granule
     const int gpp = BN / gsz;         // granules per staged pixel (a power of two)
     const int gsh = gpp == 4 ? 2 : (gpp == 8 ? 3 : 4);
@@ -392,11 +404,15 @@ __global__ __launch_bounds__(256) void conv_bf16_chunked_kernel(ConvBArgs a) {
     const int th_valid = min(p.TH, a.Ho - ty0), tw_valid = min(p.TW, a.Wo - tx0);
     const float inv_tw = 1.0f / (float)p.TW;
     auto row_of = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * kq; };
-    if (a.stats) tile_stats<WM, WN>(a, acc, smem_f, blockIdx.x, co0, th_valid, tw_valid);
-
-    if (a.stats) __syncthreads();  // the statistics scratch aliases the staging area
-    store_tile<WM, WN>(a, acc, smem, n, ty0, tx0, co0, th_valid, tw_valid);
+    // statistics partials and the staged tile go to LDS together: one barrier for both
+    float* wst = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(smem_f) + p.wst_off);
+    if (a.stats) tile_stats_write<WM, WN>(a, acc, wst, th_valid, tw_valid);
+    store_tile_write<WM, WN>(a, acc, smem);
+    __syncthreads();
+    if (a.stats) tile_stats_finish<WN>(a, wst, blockIdx.x, co0);
+    store_tile_finish<WN>(a, smem, n, ty0, tx0, co0, th_valid, tw_valid);
 }
+
 
 // (2) resident kernel: single-chunk layers (the image layer, the Cin = 16 layers incl. the kw-folded output layer).
 template <int WM, int WN, bool C4>
@@ -627,8 +643,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_resident_kernel(ConvBArgs a)
         __syncthreads();
         // ---- epilogue: per-tile instance-norm partials from the fp32 accumulators, then the coalesced store
         const int th_valid = min(p.TH, a.Ho - ty0), tw_valid = min(p.TW, a.Wo - tx0);
-        if (a.stats) tile_stats<WM, WN>(a, acc, sred, tile, co0, th_valid, tw_valid);
-        store_tile<WM, WN>(a, acc, stage, n, ty0, tx0, co0, th_valid, tw_valid);
+        if (a.stats) tile_stats_write<WM, WN>(a, acc, sred, th_valid, tw_valid);
+        store_tile_write<WM, WN>(a, acc, stage);
+        __syncthreads();  // one barrier for the statistics partials and the staged tile
+        if (a.stats) tile_stats_finish<WN>(a, sred, tile, co0);
+        store_tile_finish<WN>(a, stage, n, ty0, tx0, co0, th_valid, tw_valid);
         tile += gstep;
         return tile < total_tiles;
     };
@@ -671,11 +690,14 @@ ConvBPlan conv_bf16_plan(const ConvBArgs& a) {
             const int patch_elems = (p.PH * p.PW * (p.c4 ? 4 : p.PP) + 7) & ~7;
             const bool resident = p.c4 || a.Cin == p.CC;
             const int stage_bytes = max_px * p.BN * (a.y_f32 ? 4 : 2);
-            p.lds_bytes = 2 * (patch_elems + G * p.BN * (p.c4 ? 56 : p.PP)) + 8 * a.Cin + 4 * 16 * p.BN + 32;
-            if (resident)
-                p.lds_bytes += stage_bytes;  // dedicated: the resident filter must survive the epilogue
-            else if (p.lds_bytes < stage_bytes)
-                p.lds_bytes = stage_bytes;   // staged over the (dead) patch + filter area
+            const int main_bytes = 2 * (patch_elems + G * p.BN * (p.c4 ? 56 : p.PP)) + 8 * a.Cin;
+            if (resident) {  // dedicated staging: the resident filter must survive the epilogue
+                p.wst_off = main_bytes;
+                p.lds_bytes = main_bytes + 4 * 16 * p.BN + 32 + stage_bytes;
+            } else {         // tile staged over the (dead) patch + filter area, statistics partials behind it
+                p.wst_off = (main_bytes > stage_bytes ? main_bytes : stage_bytes);
+                p.lds_bytes = p.wst_off + 4 * 16 * p.BN + 32;
+            }
             // staging registers: chunked kernel 8 patch + 12 filter granules per thread, resident kernel 5 patch
             fits = p.lds_bytes <= 80 * 1024 &&
                    (p.c4 || (resident ? p.PH * p.PW * (p.CC / 8) <= 5 * 256
