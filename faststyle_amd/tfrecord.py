@@ -40,13 +40,16 @@ class RecordFile(object):
         self._addr = self._np.ctypes.data
         lib = _lib()
         n = lib.fs_tfrecord_scan(self._addr, size, 0, None, None, 0)
-        if n < 0:
-            raise L.FaststyleError("%s: %s" % (path, lib.fs_last_error().decode()))
-        off = (ctypes.c_uint64 * n)()
-        ln = (ctypes.c_uint64 * n)()
-        rc = lib.fs_tfrecord_scan(self._addr, size, 1 if verify_crc else 0, off, ln, n)
+        off = ln = None
+        rc = n
+        if n >= 0:
+            off = (ctypes.c_uint64 * n)()
+            ln = (ctypes.c_uint64 * n)()
+            rc = lib.fs_tfrecord_scan(self._addr, size, 1 if verify_crc else 0, off, ln, n)
         if rc < 0:
-            raise L.FaststyleError("%s: %s" % (path, lib.fs_last_error().decode()))
+            msg = lib.fs_last_error().decode()
+            self.close()                       # do not leak the mapping / descriptor of a corrupt shard
+            raise L.FaststyleError("%s: %s" % (path, msg))
         self.n, self.off, self.len = int(n), off, ln
 
     def __len__(self):
