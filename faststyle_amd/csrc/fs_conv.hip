@@ -78,10 +78,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const ConvPlan& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = p.tiles_y * p.tiles_x;
-    const int n = blockIdx.x / tiles;
-    const int tr = blockIdx.x % tiles;
+    // XCD-aware workgroup -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in
+    // linear dispatch order; give every XCD a CONTIGUOUS range of (tile, channel-block) work, channel blocks of a
+    // tile adjacent: the 2..8 workgroups that read the same input patch then run on the same XCD at about the
+    // same time and share it through that L2, and neighbouring tiles (shared halos) stay on one XCD too.
+    int tile_id = blockIdx.x, cob = blockIdx.y;
+    if (p.xcd_swizzle) {
+        const unsigned total = gridDim.x * gridDim.y;
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned xcd = lin & 7u, slot = lin >> 3;
+        const unsigned q = total >> 3, r = total & 7u;
+        const unsigned j = xcd * q + (xcd < r ? xcd : r) + slot;
+        tile_id = (int)(j / gridDim.y);
+        cob = (int)(j - (unsigned)tile_id * gridDim.y);
+    }
+    const int n = tile_id / tiles;
+    const int tr = tile_id % tiles;
     const int ty0 = (tr / p.tiles_x) * p.TH, tx0 = (tr % p.tiles_x) * p.TW;
-    const int co0 = blockIdx.y * BN;
+    const int co0 = cob * BN;
     const int S = p.S, PW = p.PW, PH = p.PH, LG = p.LG, CC = p.CC;
     const int patch_floats = (PH * PW * S + 8 + 3) & ~3;
     float* patch = smem;
@@ -429,7 +443,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             for (int nn = 0; nn < WN; ++nn) red[wave * BN + nn * MT + lane] = s2[nn];
         __syncthreads();
         if (tid < BN && co0 + tid < a.Cout) {
-            float* st = a.stats + ((size_t)blockIdx.x * a.Cout + co0 + tid) * 3;
+            float* st = a.stats + ((size_t)tile_id * a.Cout + co0 + tid) * 3;
             st[0] = meanl[tid];
             st[1] = red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid];
             st[2] = cnt;
@@ -608,6 +622,7 @@ static void plan_variant(const ConvArgs& a, int variant, ConvPlan* out) {
     }
     if (p.lds_bytes < 4 * 5 * p.BN) p.lds_bytes = 4 * 5 * p.BN;  // stats scratch
     p.ksplit = 1;
+    p.xcd_swizzle = env_int("FS_CONV_XCD", 1);
     *out = p;
 }
 

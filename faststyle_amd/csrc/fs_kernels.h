@@ -30,6 +30,7 @@ struct ConvPlan {
     int PH, PW;   // staged patch extent
     int lds_bytes;
     int ksplit;   // > 1: blockIdx.z splits the input-channel chunks; raw partials go to ConvArgs::split_ws
+    int xcd_swizzle;  // workgroup -> (tile, channel block) map that keeps sharers of an input patch on one XCD
 };
 
 struct ConvArgs {
