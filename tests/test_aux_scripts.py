@@ -120,7 +120,6 @@ def test_slow_style_cli_and_frames_dir_cli(tmp_path, monkeypatch, capsys):
 def test_builder_level_api_matches_oracle(eng):
     """vgg16 / get_layers / get_grams / content_loss / style_loss / tv_loss against the oracle."""
     from faststyle_amd import losses, utils, vgg16
-    from oracle import nnops
     rng = np.random.default_rng(5)
     Wv = perceptual.synthetic_vgg_weights(seed=3)
     x = rng.uniform(0, 255, (2, 21, 26, 3)).astype(np.float32)               # odd sizes: SAME pooling

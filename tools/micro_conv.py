@@ -4,7 +4,6 @@ usage: micro_conv.py [name ...]   (names from CASES; default all)"""
 import os
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -4,7 +4,6 @@ Times tnet_forward(b4 256^2) and a VGG+Gram pass on a 512x512 image alone and co
 import os
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
