@@ -832,39 +832,40 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(PackBatch b) {
 __global__ __launch_bounds__(256) void apply_res_bf16_kernel(const unsigned short* __restrict__ z, const float* __restrict__ a,
                                                              const float* __restrict__ b, const unsigned short* __restrict__ skip,
                                                              const float* __restrict__ sa, const float* __restrict__ sb,
-                                                             int skip_relu, unsigned short* __restrict__ out, int H, int W, int C,
-                                                             size_t total8) {
-    const int c8n = C >> 3;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
-        const int c8 = (int)(i % c8n);
-        size_t pix = i / c8n;
-        const int x = (int)(pix % W);
-        pix /= W;
-        const int y = (int)(pix % H);
-        const int n = (int)(pix / H);
-        const uint4 zv = *reinterpret_cast<const uint4*>(z + i * 8);
-        const uint4 sv = *reinterpret_cast<const uint4*>(skip + ((((size_t)n * (H + 4) + y + 2) * (W + 4) + x + 2) * C + c8 * 8));
-        const unsigned* z32 = reinterpret_cast<const unsigned*>(&zv);
-        const unsigned* s32 = reinterpret_cast<const unsigned*>(&sv);
-        uint4 ov;
-        unsigned* o32 = reinterpret_cast<unsigned*>(&ov);
-        const int k0 = n * C + c8 * 8;
+                                                             int skip_relu, unsigned short* __restrict__ out, int H, int W) {
+    // grid (row segments, H, N), C = 64: a thread owns 8 channels (16 bytes) of one pixel; no divisions on the path
+    constexpr int C = 64, c8n = 8;
+    const int n = blockIdx.z, y = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;  // (x, c8) within the row
+    if (j >= W * c8n) return;
+    const int x = j >> 3, c8 = j & 7;
+    const size_t i = ((size_t)n * H + y) * W * c8n + j;
+    const uint4 zv = *reinterpret_cast<const uint4*>(z + i * 8);
+    const uint4 sv = *reinterpret_cast<const uint4*>(skip + ((((size_t)n * (H + 4) + y + 2) * (W + 4) + x + 2) * C + c8 * 8));
+    const unsigned* z32 = reinterpret_cast<const unsigned*>(&zv);
+    const unsigned* s32 = reinterpret_cast<const unsigned*>(&sv);
+    const int k0 = n * C + c8 * 8;
+    const float4 a0 = *reinterpret_cast<const float4*>(a + k0), a1 = *reinterpret_cast<const float4*>(a + k0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(b + k0), b1 = *reinterpret_cast<const float4*>(b + k0 + 4);
+    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    uint4 ov;
+    unsigned* o32 = reinterpret_cast<unsigned*>(&ov);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float r[2];
+    for (int k = 0; k < 4; ++k) {
+        float r[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int c = k0 + 2 * k + h;
-                float sk = bf2f((unsigned short)(h ? s32[k] >> 16 : s32[k] & 0xFFFFu));
-                if (sa) sk = fmaf(sk, sa[c], sb[c]);
-                if (skip_relu) sk = fmaxf(sk, 0.f);
-                const float zz = bf2f((unsigned short)(h ? z32[k] >> 16 : z32[k] & 0xFFFFu));
-                r[h] = fmaf(zz, a[c], b[c]) + sk;
-            }
-            o32[k] = pack2(r[0], r[1]);
+        for (int h = 0; h < 2; ++h) {
+            const int c = k0 + 2 * k + h;
+            float sk = bf2f((unsigned short)(h ? s32[k] >> 16 : s32[k] & 0xFFFFu));
+            if (sa) sk = fmaf(sk, sa[c], sb[c]);
+            if (skip_relu) sk = fmaxf(sk, 0.f);
+            const float zz = bf2f((unsigned short)(h ? z32[k] >> 16 : z32[k] & 0xFFFFu));
+            r[h] = fmaf(zz, av[2 * k + h], bv[2 * k + h]) + sk;
         }
-        *reinterpret_cast<uint4*>(out + i * 8) = ov;
+        o32[k] = pack2(r[0], r[1]);
     }
+    *reinterpret_cast<uint4*>(out + i * 8) = ov;
 }
 
 // ---------------------------------------------------------------------------------------------- the forward
@@ -990,10 +991,9 @@ int tnet_forward_bf16(const BTnetLayout& L, const float* params, const float* x,
             } else {
                 skip = reinterpret_cast<const unsigned short*>(ws + L.h[k - 1]);
             }
-            const size_t total8 = (size_t)N * u.Hout * u.Wout * 64 / 8;
-            hipLaunchKernelGGL(apply_res_bf16_kernel, dim3((unsigned)min((size_t)4096, (total8 + 255) / 256)), dim3(256), 0, s,
+            hipLaunchKernelGGL(apply_res_bf16_kernel, dim3(cdiv(u.Wout * 8, 256), u.Hout, N), dim3(256), 0, s,
                                reinterpret_cast<const unsigned short*>(ws + L.z[i]), ua, ub, skip, sa, sb, k == 0 ? 1 : 0,
-                               reinterpret_cast<unsigned short*>(ws + L.h[k]), u.Hout, u.Wout, 64, total8);
+                               reinterpret_cast<unsigned short*>(ws + L.h[k]), u.Hout, u.Wout);
             src = ws + L.h[k];
             src_a = src_b = nullptr;
         }
