@@ -341,29 +341,52 @@ __global__ __launch_bounds__(256) void in_bwd_final_kernel(const float* partial,
     }
 }
 
+// dz = a * (g - S1/HW - xhat * S2/HW).  Grid (blocks over one sample, N): the sample comes from blockIdx.y and the
+// index inside it is 32-bit, so the per-element cost is one 32-bit remainder instead of two 64-bit divisions; when
+// C % 4 == 0 a thread handles 4 channels of one pixel with float4 loads.
+template <bool VEC>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* gin, const float* z, const float* mean,
                                                            const float* rstd, const float* a, const float* b, int mode,
-                                                           const float* S, float* dz, int HW, int C, size_t total, int N,
-                                                           float* dgamma, float* dbeta) {
+                                                           const float* S, float* dz, int HW, int C, int N, float* dgamma,
+                                                           float* dbeta) {
     const float inv = 1.0f / (float)HW;
-    if (blockIdx.x == 0)  // dbeta[c] = sum_n S1, dgamma[c] = sum_n S2 (fixed order)
+    const int n = blockIdx.y;
+    if (blockIdx.x == 0 && n == 0)  // dbeta[c] = sum_n S1, dgamma[c] = sum_n S2 (fixed order)
         for (int c = threadIdx.x; c < C; c += 256) {
             float g1 = 0.f, g2 = 0.f;
-            for (int n = 0; n < N; ++n) {
-                g1 += S[(n * C + c) * 2];
-                g2 += S[(n * C + c) * 2 + 1];
+            for (int m = 0; m < N; ++m) {
+                g1 += S[(m * C + c) * 2];
+                g2 += S[(m * C + c) * 2 + 1];
             }
             dbeta[c] = g1;
             dgamma[c] = g2;
         }
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const int n = (int)(i / ((size_t)HW * C));
+    const size_t base = (size_t)n * HW * C;
+    const int per = HW * C;
+    if (VEC) {
+        const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+        if (j >= per) return;
+        const int c = j % C;
         const int k = n * C + c;
-        const float zz = z[i];
-        const float g = in_bwd_g(gin[i], zz, a[k], b[k], mode);
-        const float xh = (zz - mean[k]) * rstd[k];
-        dz[i] = a[k] * (g - S[2 * k] * inv - xh * S[2 * k + 1] * inv);
+        const float4 zz = *reinterpret_cast<const float4*>(z + base + j);
+        const float4 gg = *reinterpret_cast<const float4*>(gin + base + j);
+        const float zv[4] = {zz.x, zz.y, zz.z, zz.w}, gv[4] = {gg.x, gg.y, gg.z, gg.w};
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float g = in_bwd_g(gv[q], zv[q], a[k + q], b[k + q], mode);
+            const float xh = (zv[q] - mean[k + q]) * rstd[k + q];
+            o[q] = a[k + q] * (g - S[2 * (k + q)] * inv - xh * S[2 * (k + q) + 1] * inv);
+        }
+        *reinterpret_cast<float4*>(dz + base + j) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        for (int j = blockIdx.x * 256 + threadIdx.x; j < per; j += gridDim.x * 256) {
+            const int k = n * C + j % C;
+            const float zz = z[base + j];
+            const float g = in_bwd_g(gin[base + j], zz, a[k], b[k], mode);
+            const float xh = (zz - mean[k]) * rstd[k];
+            dz[base + j] = a[k] * (g - S[2 * k] * inv - xh * S[2 * k + 1] * inv);
+        }
     }
 }
 
@@ -380,86 +403,113 @@ int in_bwd(const float* gin, const float* z, const float* mean, const float* rst
     hipLaunchKernelGGL(in_bwd_partial_kernel, dim3(chunks, N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, partial, HW,
                        C, chunk_px);
     hipLaunchKernelGGL(in_bwd_final_kernel, dim3(cdiv(C, 16), N), dim3(256), 0, s, partial, N, chunks, C, S, dgamma, dbeta);
-    const size_t total = (size_t)N * HW * C;
-    hipLaunchKernelGGL(in_bwd_apply_kernel, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0, s, gin, z,
-                       mean, rstd, a, b, mode, S, dz, HW, C, total, N, dgamma, dbeta);
+    const int per = HW * C;
+    if (C % 4 == 0)
+        hipLaunchKernelGGL(in_bwd_apply_kernel<true>, dim3(cdiv(per / 4, 256), N), dim3(256), 0, s, gin, z, mean, rstd, a, b,
+                           mode, S, dz, HW, C, N, dgamma, dbeta);
+    else
+        hipLaunchKernelGGL(in_bwd_apply_kernel<false>, dim3(min(2048, cdiv(per, 256)), N), dim3(256), 0, s, gin, z, mean, rstd,
+                           a, b, mode, S, dz, HW, C, N, dgamma, dbeta);
     return 0;
 }
 size_t in_bwd_scratch_floats(int N, int HW, int C) { return (size_t)N * cdiv(HW, 64) * C * 2 + (size_t)N * C * 2; }
 
 // ---------------------------------------------------------------- VGG: max-pool + gradient routing
 // tf.nn.max_pool 2x2/2 SAME (reference libs/vgg16.py:63-67): out = ceil(in/2), padded cells never win.
-__global__ __launch_bounds__(256) void maxpool_kernel(const float* x, float* y, int H, int W, int C, int Ho, int Wo,
-                                                      size_t total) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        size_t pix = i / C;
-        const int ox = (int)(pix % Wo);
-        pix /= Wo;
-        const int oy = (int)(pix % Ho);
-        const int n = (int)(pix / Ho);
-        const float* base = x + ((size_t)n * H * W) * C + c;
-        const int y0 = 2 * oy, x0 = 2 * ox;
-        float m = base[((size_t)y0 * W + x0) * C];
-        if (x0 + 1 < W) m = fmaxf(m, base[((size_t)y0 * W + x0 + 1) * C]);
-        if (y0 + 1 < H) {
-            m = fmaxf(m, base[((size_t)(y0 + 1) * W + x0) * C]);
-            if (x0 + 1 < W) m = fmaxf(m, base[((size_t)(y0 + 1) * W + x0 + 1) * C]);
-        }
-        y[i] = m;
+// grid (blocks over one output row, Ho, N); a thread owns 4 channels of one output pixel (C % 4 == 0 in VGG16)
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
+                                                      int Ho, int Wo) {
+    const int c4n = C >> 2;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Wo * c4n) return;
+    const int ox = j / c4n, c = (j - ox * c4n) * 4;
+    const int oy = blockIdx.y, n = blockIdx.z;
+    const int y0 = 2 * oy, x0 = 2 * ox;
+    const float* base = x + (((size_t)n * H + y0) * W + x0) * C + c;
+    float4 m = *reinterpret_cast<const float4*>(base);
+    auto mx = [&](const float* p) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        m.x = fmaxf(m.x, v.x);
+        m.y = fmaxf(m.y, v.y);
+        m.z = fmaxf(m.z, v.z);
+        m.w = fmaxf(m.w, v.w);
+    };
+    if (x0 + 1 < W) mx(base + C);
+    if (y0 + 1 < H) {
+        mx(base + (size_t)W * C);
+        if (x0 + 1 < W) mx(base + (size_t)W * C + C);
     }
+    *reinterpret_cast<float4*>(y + (((size_t)n * Ho + oy) * Wo + ox) * C + c) = m;
 }
 
 int maxpool(const float* x, float* y, int N, int H, int W, int C, hipStream_t s) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    const size_t total = (size_t)N * Ho * Wo * C;
-    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0, s, x, y, H, W,
-                       C, Ho, Wo, total);
+    if (C % 4) return -1;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(cdiv(Wo * (C / 4), 256), Ho, N), dim3(256), 0, s, x, y, H, W, C, Ho, Wo);
     return 0;
 }
 
 // d_pre[n,y,x,c] = (route(d_above) + d_tap) * (out > 0)
 //   pooled=0: d_above has the shape of `out`;   pooled=1: d_above is the gradient of max_pool(out)
 //   and goes to the FIRST maximum of each window (TF MaxPoolGrad).  d_above / d_tap may be null.
-__global__ __launch_bounds__(256) void vgg_bwd_route_kernel(const float* out, const float* d_above, const float* d_tap,
-                                                            int pooled, float* d_pre, int H, int W, int C, size_t total) {
-    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const float v = out[i];
-        float g = d_tap ? d_tap[i] : 0.f;
-        if (d_above) {
-            if (!pooled) {
-                g += d_above[i];
-            } else {
-                const int c = (int)(i % C);
-                size_t pix = i / C;
-                const int x = (int)(pix % W);
-                pix /= W;
-                const int y = (int)(pix % H);
-                const int n = (int)(pix / H);
-                const int y0 = y & ~1, x0 = x & ~1;
-                const float* base = out + ((size_t)n * H * W) * C + c;
-                const int me = (y - y0) * 2 + (x - x0);
-                bool win = true;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int yy = y0 + (e >> 1), xx = x0 + (e & 1);
-                    if (e == me || yy >= H || xx >= W) continue;
-                    const float o = base[((size_t)yy * W + xx) * C];
-                    if (e < me ? o >= v : o > v) win = false;
-                }
-                if (win) g += d_above[(((size_t)n * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c];
-            }
-        }
-        d_pre[i] = v > 0.f ? g : 0.f;
+// grid (blocks over one row, H, N); a thread owns 4 channels of one pixel.
+__global__ __launch_bounds__(256) void vgg_bwd_route_kernel(const float* __restrict__ out, const float* __restrict__ d_above,
+                                                            const float* __restrict__ d_tap, int pooled, float* __restrict__ d_pre,
+                                                            int H, int W, int C) {
+    const int c4n = C >> 2;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= W * c4n) return;
+    const int x = j / c4n, c = (j - x * c4n) * 4;
+    const int y = blockIdx.y, n = blockIdx.z;
+    const size_t i = (((size_t)n * H + y) * W + x) * C + c;
+    const float4 v4 = *reinterpret_cast<const float4*>(out + i);
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (d_tap) {
+        const float4 t = *reinterpret_cast<const float4*>(d_tap + i);
+        g[0] = t.x;
+        g[1] = t.y;
+        g[2] = t.z;
+        g[3] = t.w;
     }
+    if (d_above) {
+        if (!pooled) {
+            const float4 t = *reinterpret_cast<const float4*>(d_above + i);
+            g[0] += t.x;
+            g[1] += t.y;
+            g[2] += t.z;
+            g[3] += t.w;
+        } else {
+            const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+            const int y0 = y & ~1, x0 = x & ~1;
+            const int me = (y - y0) * 2 + (x - x0);
+            bool win[4] = {true, true, true, true};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int yy = y0 + (e >> 1), xx = x0 + (e & 1);
+                if (e == me || yy >= H || xx >= W) continue;
+                const float4 o4 = *reinterpret_cast<const float4*>(out + (((size_t)n * H + yy) * W + xx) * C + c);
+                const float o[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (e < me ? o[q] >= v[q] : o[q] > v[q]) win[q] = false;
+            }
+            const float4 da = *reinterpret_cast<const float4*>(d_above + (((size_t)n * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c);
+            const float dav[4] = {da.x, da.y, da.z, da.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (win[q]) g[q] += dav[q];
+        }
+    }
+    *reinterpret_cast<float4*>(d_pre + i) =
+        make_float4(v[0] > 0.f ? g[0] : 0.f, v[1] > 0.f ? g[1] : 0.f, v[2] > 0.f ? g[2] : 0.f, v[3] > 0.f ? g[3] : 0.f);
 }
 
 int vgg_bwd_route(const float* out, const float* d_above, const float* d_tap, int pooled, float* d_pre, int N, int H, int W,
                   int C, hipStream_t s) {
-    const size_t total = (size_t)N * H * W * C;
-    hipLaunchKernelGGL(vgg_bwd_route_kernel, dim3((unsigned)min((size_t)8192, (total + 255) / 256)), dim3(256), 0, s, out,
-                       d_above, d_tap, pooled, d_pre, H, W, C, total);
+    if (C % 4) return -1;
+    hipLaunchKernelGGL(vgg_bwd_route_kernel, dim3(cdiv(W * (C / 4), 256), H, N), dim3(256), 0, s, out, d_above, d_tap, pooled,
+                       d_pre, H, W, C);
     return 0;
 }
 
