@@ -165,28 +165,41 @@ int in_finalize(const float* stats, int N, int T, int C, int groups, const float
 // ---------------------------------------------------------------- residual add / tanh
 // out[n,y,x,c] = z*a+b + T(skip[n,y+2,x+2,c]),  T = optional affine+ReLU (block 0 reads the raw
 // initconv_2 output).  reference im_transf_net.py:268-274
-__global__ __launch_bounds__(256) void apply_res_kernel(const float* z, const float* a, const float* b, const float* skip,
-                                                        const float* sa, const float* sb, int skip_relu, float* out,
-                                                        int H, int W, int C, size_t total) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        size_t pix = i / C;
-        const int x = (int)(pix % W);
-        pix /= W;
-        const int y = (int)(pix % H);
-        const int n = (int)(pix / H);
-        float sk = skip[(((size_t)n * (H + 4) + y + 2) * (W + 4) + x + 2) * C + c];
-        if (sa) sk = fmaf(sk, sa[n * C + c], sb[n * C + c]);
-        if (skip_relu) sk = fmaxf(sk, 0.f);
-        out[i] = fmaf(z[i], a[n * C + c], b[n * C + c]) + sk;
+// grid (blocks over one row, H, N); a thread owns 4 channels of one pixel (C = 64)
+__global__ __launch_bounds__(256) void apply_res_kernel(const float* __restrict__ z, const float* __restrict__ a,
+                                                        const float* __restrict__ b, const float* __restrict__ skip,
+                                                        const float* __restrict__ sa, const float* __restrict__ sb, int skip_relu,
+                                                        float* __restrict__ out, int H, int W, int C) {
+    const int c4n = C >> 2;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= W * c4n) return;
+    const int x = j / c4n, c = (j - x * c4n) * 4;
+    const int y = blockIdx.y, n = blockIdx.z;
+    const size_t i = (((size_t)n * H + y) * W + x) * C + c;
+    const float4 zz = *reinterpret_cast<const float4*>(z + i);
+    const float4 s4 = *reinterpret_cast<const float4*>(skip + (((size_t)n * (H + 4) + y + 2) * (W + 4) + x + 2) * C + c);
+    const float4 av = *reinterpret_cast<const float4*>(a + n * C + c), bv = *reinterpret_cast<const float4*>(b + n * C + c);
+    float sk[4] = {s4.x, s4.y, s4.z, s4.w};
+    if (sa) {
+        const float4 sav = *reinterpret_cast<const float4*>(sa + n * C + c), sbv = *reinterpret_cast<const float4*>(sb + n * C + c);
+        sk[0] = fmaf(sk[0], sav.x, sbv.x);
+        sk[1] = fmaf(sk[1], sav.y, sbv.y);
+        sk[2] = fmaf(sk[2], sav.z, sbv.z);
+        sk[3] = fmaf(sk[3], sav.w, sbv.w);
     }
+    if (skip_relu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sk[q] = fmaxf(sk[q], 0.f);
+    }
+    *reinterpret_cast<float4*>(out + i) = make_float4(fmaf(zz.x, av.x, bv.x) + sk[0], fmaf(zz.y, av.y, bv.y) + sk[1],
+                                                      fmaf(zz.z, av.z, bv.z) + sk[2], fmaf(zz.w, av.w, bv.w) + sk[3]);
 }
 
 int apply_res(const float* z, const float* a, const float* b, const float* skip, const float* sa, const float* sb,
               int skip_relu, float* out, int N, int H, int W, int C, hipStream_t s) {
-    const size_t total = (size_t)N * H * W * C;
-    hipLaunchKernelGGL(apply_res_kernel, dim3((unsigned)min((size_t)2048, (total + 255) / 256)), dim3(256), 0, s, z, a, b,
-                       skip, sa, sb, skip_relu, out, H, W, C, total);
+    if (C % 4) return -1;
+    hipLaunchKernelGGL(apply_res_kernel, dim3(cdiv(W * (C / 4), 256), H, N), dim3(256), 0, s, z, a, b, skip, sa, sb, skip_relu,
+                       out, H, W, C);
     return 0;
 }
 
@@ -516,17 +529,19 @@ int vgg_bwd_route(const float* out, const float* d_above, const float* d_tap, in
 // ---------------------------------------------------------------- losses
 // partial[b] = sum (x - t)^2 over the block's elements; grad = gscale*(x - t) (optional).
 // t index = i % t_period (style targets broadcast over the batch; reference losses.py:61-64).
-__global__ __launch_bounds__(256) void sqdiff_kernel(const float* x, const float* t, size_t t_period, size_t total,
-                                                     float gscale, float* grad, float* partial) {
+// grid (blocks per period, periods): the target index is the offset inside the period -- no 64-bit modulo per element
+__global__ __launch_bounds__(256) void sqdiff_kernel(const float* __restrict__ x, const float* __restrict__ t, size_t t_period,
+                                                     float gscale, float* __restrict__ grad, float* __restrict__ partial) {
     __shared__ float sh[4];
     float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const float d = x[i] - t[i % t_period];
+    const size_t base = (size_t)blockIdx.y * t_period;
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < t_period; j += (size_t)gridDim.x * 256) {
+        const float d = x[base + j] - t[j];
         acc = fmaf(d, d, acc);
-        if (grad) grad[i] = gscale * d;
+        if (grad) grad[base + j] = gscale * d;
     }
     const float tot = block_sum(acc, sh);
-    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
 }
 
 // out[0] (+)= scale * sum(partial[0..n))  -- single block, fixed order
@@ -542,9 +557,12 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* partial,
 // loss_out (+)= lscale*sum((x-t)^2);  grad = gscale*(x-t).  scratch: >= 1024 floats.
 int sqdiff_loss(const float* x, const float* t, size_t t_period, size_t total, float lscale, float gscale, float* grad,
                 float* loss_out, int accumulate, float* scratch, hipStream_t s) {
-    const int blocks = (int)min((size_t)1024, (total + 255) / 256);
-    hipLaunchKernelGGL(sqdiff_kernel, dim3(blocks), dim3(256), 0, s, x, t, t_period, total, gscale, grad, scratch);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, scratch, blocks, lscale, loss_out, accumulate);
+    const int periods = (int)(total / t_period);  // (total is a whole number of periods: the batch)
+    if (periods < 1 || periods > 1024 || (size_t)periods * t_period != total) return -1;  // scratch holds 1024 partials
+    int bx = (int)min((size_t)(1024 / periods > 0 ? 1024 / periods : 1), (t_period + 255) / 256);
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(bx, periods), dim3(256), 0, s, x, t, t_period, gscale, grad, scratch);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, scratch, bx * periods, lscale, loss_out, accumulate);
     return 0;
 }
 
