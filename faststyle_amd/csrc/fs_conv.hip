@@ -92,11 +92,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         tile_id = (int)(j / gridDim.y);
         cob = (int)(j - (unsigned)tile_id * gridDim.y);
     }
-    const int n = tile_id / tiles;
-    const int tr = tile_id % tiles;
-    const int ty0 = (tr / p.tiles_x) * p.TH, tx0 = (tr % p.tiles_x) * p.TW;
+    // x / d through a float reciprocal: exact for these magnitudes (x < 2^22), ~5 instructions instead of ~35
+    auto fdiv = [](int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); };
+    const int n = fdiv(tile_id, 1.0f / (float)tiles);
+    const int tr = tile_id - n * tiles;
+    const int tyi = fdiv(tr, 1.0f / (float)p.tiles_x);
+    const int ty0 = tyi * p.TH, tx0 = (tr - tyi * p.tiles_x) * p.TW;
     const int co0 = cob * BN;
     const int S = p.S, PW = p.PW, PH = p.PH, LG = p.LG, CC = p.CC;
+    const float inv_pw = 1.0f / (float)PW;
     const int patch_floats = (PH * PW * S + 8 + 3) & ~3;
     float* patch = smem;
     float* wl = smem + patch_floats;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int m = 0; m < WM; ++m) {
         int t = (wave * WM + m) * MT + lm;
         if (t >= tile_px) t = 0;
-        const int py = t / p.TW, px = t - py * p.TW;
+        const int py = fdiv(t, 1.0f / (float)p.TW), px = t - py * p.TW;
         laneA[m] = (py * a.stride * PW + px * a.stride) * S + kq;
     }
     const int laneB = kq * BN + lm;
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         float* patch = smem;
         float* wl = smem + patch_floats;
         for (int pix = tid; pix < PH * PW; pix += 256) {
-            const int py = pix / PW, px = pix - py * PW;
+            const int py = fdiv(pix, inv_pw), px = pix - py * PW;
             int sy, sx;
             const bool ok = src_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) &&
                             src_coord(a.src_mode, a.refl, vx0 + px, a.W, sx);
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             goff[i] = -2;
             if (e < ne_p) {
                 const int pix = e >> c4sh, c4 = e & (c4n - 1);
-                const int py = pix / PW, px = pix - py * PW;
+                const int py = fdiv(pix, inv_pw), px = pix - py * PW;
                 int sy, sx;
                 const bool ok = src_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) &&
                                 src_coord(a.src_mode, a.refl, vx0 + px, a.W, sx);
