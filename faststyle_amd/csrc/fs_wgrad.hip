@@ -104,10 +104,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int ne_d = p.TH * p.TW * j4n;
     const bool dvec = (Cr & 3) == 0 && co_g0 + DP <= a.Cout;  // (the scalar dY path has no on-load transform)
 
+    // x / d through a float reciprocal (exact for x < 2^22): the staging loops decompose ~30 element indices per
+    // thread and tile, and an integer division costs ~35 instructions
+    auto fdiv = [](int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); };
+    const float inv_c4n = 1.0f / (float)(c4n > 0 ? c4n : 1), inv_pw = 1.0f / (float)PW, inv_j4n = 1.0f / (float)j4n;
+    const float inv_tw = 1.0f / (float)p.TW, inv_cs = 1.0f / (float)CS, inv_cr = 1.0f / (float)Cr;
+    const float inv_tiles = 1.0f / (float)tiles, inv_tx = 1.0f / (float)p.tiles_x;
+
     auto stage = [&](int t) {
-        const int n = a.per_sample ? (int)blockIdx.z : t / tiles;
-        const int tr = t % tiles;
-        const int ty0 = (tr / p.tiles_x) * p.TH, tx0 = (tr % p.tiles_x) * p.TW;
+        const int n = a.per_sample ? (int)blockIdx.z : fdiv(t, inv_tiles);
+        const int tr = t - fdiv(t, inv_tiles) * tiles;
+        const int tyi = fdiv(tr, inv_tx);
+        const int ty0 = tyi * p.TH, tx0 = (tr - tyi * p.tiles_x) * p.TW;
         const int vy0 = ty0 * a.stride - a.pad_t, vx0 = tx0 * a.stride - a.pad_l;
         const float* xn = a.x + (size_t)n * a.H * a.W * a.Cin;
         const float* ia = has_ab ? a.in_a + (size_t)n * a.in_nstride : nullptr;
@@ -121,8 +129,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                     const int e = e0 + i * 256;
                     xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (e < ne_x) {
-                        const int pix = e / c4n, c4 = e - pix * c4n;
-                        const int py = pix / PW, px = pix - py * PW;
+                        const int pix = fdiv(e, inv_c4n), c4 = e - pix * c4n;
+                        const int py = fdiv(pix, inv_pw), px = pix - py * PW;
                         int sy, sx;
                         if (wsrc_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) &&
                             wsrc_coord(a.src_mode, a.refl, vx0 + px, a.W, sx)) {
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 for (int i = 0; i < XB; ++i) {
                     const int e = e0 + i * 256;
                     if (e >= ne_x) continue;
-                    const int pix = e / c4n, c4 = e - pix * c4n;
+                    const int pix = fdiv(e, inv_c4n), c4 = e - pix * c4n;
                     float4 v = xv[i];
                     if (valid & (1u << i)) {
                         const int c = cA + c4 * 4;
@@ -163,8 +171,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             }
         } else {  // Cin == 3 (the first layer): scalar
             for (int e = tid; e < PH * PW * CS; e += 256) {
-                const int pix = e / CS, c = e - pix * CS;
-                const int py = pix / PW, px = pix - py * PW;
+                const int pix = fdiv(e, inv_cs), c = e - pix * CS;
+                const int py = fdiv(pix, inv_pw), px = pix - py * PW;
                 int sy, sx;
                 const bool ok = wsrc_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) &&
                                 wsrc_coord(a.src_mode, a.refl, vx0 + px, a.W, sx);
@@ -186,14 +194,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                     const int e = e0 + i * 256;
                     dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (e < ne_d) {
-                        const int pix = e / j4n, j4 = e - pix * j4n;
-                        const int py = pix / p.TW, px = pix - py * p.TW;
+                        const int pix = fdiv(e, inv_j4n), j4 = e - pix * j4n;
+                        const int py = fdiv(pix, inv_tw), px = pix - py * p.TW;
                         const int oy = ty0 + py, ox = tx0 + px;
                         const int co = co_g0 + j4 * 4;
                         if (oy < a.Ho && ox < a.Wo) {
                             const float* src;
                             if (a.dy_unshuffle) {
-                                const int q = co / Cr, cr = co - q * Cr;
+                                const int q = fdiv(co, inv_cr), cr = co - q * Cr;
                                 src = a.dy + (((size_t)n * 2 * a.Ho + 2 * oy + (q >> 1)) * (2 * a.Wo) + 2 * ox + (q & 1)) * Cr + cr;
                             } else {
                                 src = a.dy + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
@@ -225,15 +233,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             }
         } else {  // ragged channel counts: scalar
             for (int e = tid; e < ne_d; e += 256) {
-                const int pix = e / j4n, j4 = e - pix * j4n;
-                const int py = pix / p.TW, px = pix - py * p.TW;
+                const int pix = fdiv(e, inv_j4n), j4 = e - pix * j4n;
+                const int py = fdiv(pix, inv_tw), px = pix - py * p.TW;
                 const int oy = ty0 + py, ox = tx0 + px;
                 const int co = co_g0 + j4 * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (oy < a.Ho && ox < a.Wo && co < a.Cout) {
                     const float* src;
                     if (a.dy_unshuffle) {
-                        const int q = co / Cr, cr = co - q * Cr;
+                        const int q = fdiv(co, inv_cr), cr = co - q * Cr;
                         src = a.dy + (((size_t)n * 2 * a.Ho + 2 * oy + (q >> 1)) * (2 * a.Wo) + 2 * ox + (q & 1)) * Cr + cr;
                     } else {
                         src = a.dy + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
