@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     // so a wave never waits on ds_read latency inside a chunk (B advances linearly through the
     // staged filter; A's tap offset is tracked with scalar counters).
     auto sweep = [&](const float* patch, const float* wl) {
-        if constexpr (!FLAT && MT == 32) {  // LG is 4, 8, 16 or 32: a whole number of 2-k-step groups
+        // LG is a whole number of 2-k-step groups for MT = 32 (4, 8, 16, 32) and, for MT = 16, unless CC = 4
+        if (!FLAT && (MT == 32 || (LG & 7) == 0)) {
             const int gpt = LG / (2 * KSTEP);
             const int ngroups = G * gpt;
             const float* pb = wl + laneB;
