@@ -79,7 +79,8 @@ class Trainer(object):
                 try:
                     self._capture(batch)
                 except Exception as ex:                     # fall back loudly, once
-                    print("faststyle: hipGraph capture failed (%s); running eagerly" % ex)
+                    import sys
+                    print("faststyle: hipGraph capture failed (%s); running eagerly" % ex, file=sys.stderr)
                     self.use_graph = False
                     self.graph = None
         if self.use_graph and self.graph is not None:
