@@ -457,7 +457,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     // store: per-image base pointers are 64-bit scalars, everything per element is 32-bit
     const int Cr = a.shuffle ? a.Cout >> 2 : a.Cout;
-    float* yn = a.y + ((size_t)n + (p.ksplit > 1 ? (size_t)blockIdx.z * a.N : 0)) * a.Ho * a.Wo * a.Cout;
+    const int SH = a.shuf_H > 0 ? a.shuf_H : 2 * a.Ho, SW = a.shuf_W > 0 ? a.shuf_W : 2 * a.Wo;  // shuffled extent
+    float* yn = a.shuffle ? a.y + (size_t)n * SH * SW * Cr
+                          : a.y + ((size_t)n + (p.ksplit > 1 ? (size_t)blockIdx.z * a.N : 0)) * a.Ho * a.Wo * a.Cout;
     const int ap = a.add_pad;
     const int aW = a.Wo - 2 * ap;
     const float* asn = a.add_src ? a.add_src + (size_t)n * (a.Ho - 2 * ap) * aW * a.Cout : nullptr;
@@ -493,9 +495,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 if (a.out_relu) v = fmaxf(v, 0.f);
                 if (inner) v += asn[aoff + cof[nn]];
                 int o;
-                if (a.shuffle)
-                    o = ((2 * oy + qa[nn]) * (2 * a.Wo) + 2 * ox + qb[nn]) * Cr + cof[nn];
-                else
+                if (a.shuffle) {
+                    if (2 * oy + qa[nn] >= SH || 2 * ox + qb[nn] >= SW) continue;  // odd extents: the last row/column is clipped
+                    o = ((2 * oy + qa[nn]) * SW + 2 * ox + qb[nn]) * Cr + cof[nn];
+                } else
                     o = poff + cof[nn];
                 if (msn) v = msn[o] > 0.f ? v : 0.f;
                 yn[o] = v;

@@ -753,6 +753,22 @@ __global__ __launch_bounds__(256) void wt_batch_kernel(WtBatch b) {
             for (int kh = 0; kh < 3; ++kh)
                 for (int kw = 0; kw < 3; ++kw)
                     if (up_in_V(t, kh) && up_in_V(s2, kw)) acc += w[((kh * 3 + kw) * Ci + ci) * Co + co];
+        } else if (q.kind == WT_S2DGRAD) {
+            // input gradient of a 3x3 stride-2 SAME conv, phase-decomposed: a 2x2-tap conv over dz whose 4*Ci output
+            // channels are the 4 parities (a,b) of the gradient pixel (2j+a, 2i+b), pixel-shuffle stored.
+            //   dx[2j+a] = sum_k dz[j + (a+p-k)/2] w[k]   for a+p-k even   (p = top/left SAME pad of the forward, 0 or 1)
+            // out[tap=(dy,dx)][co][(a*2+b)*Ci + ci];  job fields KH/KW carry pad_t/pad_l
+            const int j = i % (4 * Ci);
+            const int r = i / (4 * Ci);
+            const int co = r % Co, tap = r / Co;
+            const int dy = tap >> 1, dx = tap & 1;
+            const int qq = j / Ci, ci = j - qq * Ci, pa = qq >> 1, pb = qq & 1;
+            auto ksel = [](int p, int d, int par) {  // which filter row feeds tap d for parity par (-1: none)
+                if (p == 0) return d == 0 ? (par == 0 ? 2 : -1) : (par == 0 ? 0 : 1);
+                return d == 0 ? (par == 0 ? 1 : 2) : (par == 0 ? -1 : 0);
+            };
+            const int kh = ksel(q.KH, dy, pa), kw = ksel(q.KW, dx, pb);
+            acc = (kh >= 0 && kw >= 0) ? w[((kh * 3 + kw) * Ci + ci) * Co + co] : 0.f;
         } else {  // WT_FOLD5FWD
             const int j = i & 15;
             int r = i >> 4;

@@ -48,7 +48,8 @@ struct ConvArgs {
     int in_relu;
     const float* bias;  // optional [Cout]
     int out_relu;
-    int shuffle;           // 2x2 pixel-shuffle store (phase-collapsed resize-conv)
+    int shuffle;           // 2x2 pixel-shuffle store (phase-collapsed resize-conv, phase-decomposed stride-2 dgrad)
+    int shuf_H, shuf_W;    // extent of the shuffled output when it is not exactly 2Ho x 2Wo (odd sizes are clipped); 0: exact
     float* stats;          // optional per-tile {mean, M2, count} partials [N*tiles][Cout][3]
     const float* add_src;  // optional residual [N,Ho-2*add_pad,Wo-2*add_pad,Cout] added in the interior
     int add_pad;
@@ -130,7 +131,7 @@ int axpby(const float* x, const float* y, float a, float b, float* out, size_t n
 int adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s);
 // Several filter re-layouts in ONE launch (blockIdx.y = job): the ~18 per-step re-layouts of the transform net
 // are a few microseconds of work each, so as separate launches they cost more in launch gaps than in compute.
-enum WtKind { WT_FLIPT = 0, WT_UPFWD = 1, WT_UPDGRAD = 2, WT_FOLD5FWD = 3 };
+enum WtKind { WT_FLIPT = 0, WT_UPFWD = 1, WT_UPDGRAD = 2, WT_FOLD5FWD = 3, WT_S2DGRAD = 4 };
 struct WtJob {
     int kind, KH, KW, Ci, Co, total;
     const float* src;
@@ -148,7 +149,7 @@ struct WtBatch {
         q.KW = KW;
         q.Ci = Ci;
         q.Co = Co;
-        q.total = kind == WT_UPFWD ? 16 * Ci * Co : (kind == WT_FOLD5FWD ? 18 * Ci * 16 : KH * KW * Ci * Co);
+        q.total = (kind == WT_UPFWD || kind == WT_S2DGRAD) ? 16 * Ci * Co : (kind == WT_FOLD5FWD ? 18 * Ci * 16 : KH * KW * Ci * Co);
     }
 };
 int wt_batch(const WtBatch& b, hipStream_t s);

@@ -261,7 +261,9 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
     L->dz[1] = b.take(max_act);
     L->wT = b.take(4);
     for (int i = 1; i < 16; ++i)
-        L->wTu[i] = L->u[i].kind == 3 ? 0 : b.take((size_t)(L->u[i].kind == 1 ? 9 : L->u[i].K * L->u[i].K) * L->u[i].Cin * L->u[i].Cout);
+        L->wTu[i] = L->u[i].kind == 3 ? 0
+                                      : b.take((size_t)(L->u[i].kind == 1 ? 9 : (L->u[i].stride == 2 ? 16 : L->u[i].K * L->u[i].K)) *
+                                               L->u[i].Cin * L->u[i].Cout);
     L->dweff = b.take(4 * 64 * 128);
     L->inbwd = b.take(max_inbwd);
     for (int i = 0; i < 16; ++i) {
@@ -412,6 +414,24 @@ static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, c
         a.stride = 2;
         a.pad_t = a.pad_l = 1;
         a.src_mode = SRC_PLAIN;
+    } else if (u.stride == 2) {
+        // 3x3 stride-2 conv: the four parities of the gradient pixel are four 1-, 2-, 2-, 4-tap convs over dz; run them
+        // as ONE 2x2-tap conv with 4*Cin channels and a pixel-shuffle store (9 of the 16 tap/parity slots are
+        // non-zero) instead of a 3x3 conv over the zero-dilated dz (where 3/4 of the multiplied inputs are zeros)
+        a.H = u.Hout;
+        a.W = u.Wout;
+        a.Cin = u.Cout;
+        a.Ho = u.Hout;
+        a.Wo = u.Wout;
+        a.Cout = 4 * u.Cin;
+        a.KH = a.KW = 2;
+        a.stride = 1;
+        a.pad_t = u.pad_t == 0 ? 1 : 0;
+        a.pad_l = u.pad_l == 0 ? 1 : 0;
+        a.src_mode = SRC_PLAIN;
+        a.shuffle = 1;
+        a.shuf_H = u.Hin;
+        a.shuf_W = u.Win;
     } else {
         a.H = u.Hout;
         a.W = u.Wout;
@@ -479,7 +499,10 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
             const Unit& u = L.u[i];
             if (u.kind == 3) continue;  // conv2d_transpose units use the stored filter as is
             const int K = u.kind == 1 ? 3 : u.K;  // (a resize-conv unit carries its collapsed 2x2 tap count in K)
-            wb.add(u.kind == 1 ? WT_UPDGRAD : WT_FLIPT, params + u.w_off, ws + L.wTu[i], K, K, u.Cin, u.Cout);
+            if (u.kind == 0 && u.stride == 2)  // phase-decomposed stride-2 input gradient (KH/KW fields = forward pads)
+                wb.add(WT_S2DGRAD, params + u.w_off, ws + L.wTu[i], u.pad_t, u.pad_l, u.Cin, u.Cout);
+            else
+                wb.add(u.kind == 1 ? WT_UPDGRAD : WT_FLIPT, params + u.w_off, ws + L.wTu[i], K, K, u.Cin, u.Cout);
         }
         FS_TRY(wt_batch(wb, s));
     }
