@@ -761,6 +761,7 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
         // algorithmic FLOPs: 2*M*K*N with the true extents; a zero-dilated dgrad only does 1/4 useful work
         double fl = 2.0 * a.N * a.Ho * a.Wo * (double)a.KH * a.KW * a.Cin * a.Cout;
         if (a.src_mode == SRC_DILATE2) fl *= 0.25;
+        if (a.shuffle) fl *= 9.0 / 16.0;  // phase-collapsed resize-conv / stride-2 dgrad: 9 of the 16 tap-parity slots are non-zero
         prof->begin(p.variant < 3 ? p.variant : p.variant + 1, fl, s);
     }
 #define FS_LAUNCH(MT_, WM_, WN_, FL_)                                                                              \
