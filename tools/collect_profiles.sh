@@ -7,8 +7,10 @@ R=$PWD
 O=$R/gpurun_out/prof
 rm -rf $O && mkdir -p $O
 cd /tmp
-# 1. per-kernel time of the default bench command (hipGraph-replayed timed region + the eager instrumented pass)
-rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python $R/bench.py --no-cpu-baseline > $O/bench_under_rocprofv3.json 2> $O/bench_stderr.txt
+# 1. per-kernel time of the bench command restricted to the training step (--no-stylize: otherwise the 720p/1080p
+#    inference extras launch the same conv kernels at other shapes and the per-kernel averages are no longer those of
+#    the step; hipGraph-replayed timed region + the eager instrumented pass, both counted)
+rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python $R/bench.py --no-cpu-baseline --no-stylize > $O/bench_under_rocprofv3.json 2> $O/bench_stderr.txt
 # 2. HBM traffic counters, one pass each, eager launches so every launch is a separate dispatch record
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stylize --no-graph > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stylize --no-graph > /dev/null 2>&1
