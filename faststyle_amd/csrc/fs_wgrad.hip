@@ -15,6 +15,7 @@
 #include "fs_kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace fs {
 
@@ -270,26 +271,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         stage(t);
         __syncthreads();
         // ---- MFMA sweep over pixel pairs ----
+        // (the common case -- every co-block of the workgroup present -- is compiled WITHOUT the per-MFMA `j < nbw`
+        // guard: with the guard each matrix instruction sits behind its own branch and s_waitcnt)
         if (kb0 < p.KB) {
-            for (int py = ws; py < p.TH; py += wsplit) {
-                const int rowA = py * a.stride * PW;
+            auto sweep = [&](auto FULL) {
+                constexpr bool full = decltype(FULL)::value;
+                for (int py = ws; py < p.TH; py += wsplit) {
+                    const int rowA = py * a.stride * PW;
 #pragma unroll 2
-                for (int px0 = 0; px0 < p.TW; px0 += 2) {
-                    const int px = px0 + kq;
-                    const int poff = (rowA + px * a.stride) * S;
-                    float av[KWV], bv[NWV];
+                    for (int px0 = 0; px0 < p.TW; px0 += 2) {
+                        const int px = px0 + kq;
+                        const int poff = (rowA + px * a.stride) * S;
+                        float av[KWV], bv[NWV];
 #pragma unroll
-                    for (int q = 0; q < KWV; ++q) av[q] = patch[abase[q] + amul[q] * poff];
-                    const float* pb = dyl + (py * p.TW + px) * DP + lm;
+                        for (int q = 0; q < KWV; ++q) av[q] = patch[abase[q] + amul[q] * poff];
+                        const float* pb = dyl + (py * p.TW + px) * DP + lm;
 #pragma unroll
-                    for (int j = 0; j < NWV; ++j) bv[j] = j < nbw ? pb[j * 32] : 0.f;
+                        for (int j = 0; j < NWV; ++j) bv[j] = (full || j < nbw) ? pb[j * 32] : 0.f;
 #pragma unroll
-                    for (int q = 0; q < KWV; ++q)
+                        for (int q = 0; q < KWV; ++q)
 #pragma unroll
-                        for (int j = 0; j < NWV; ++j)
-                            if (j < nbw) acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[j], acc[q][j], 0, 0, 0);
+                            for (int j = 0; j < NWV; ++j)
+                                if (full || j < nbw)
+                                    acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[j], acc[q][j], 0, 0, 0);
+                    }
                 }
-            }
+            };
+            if (nbw == NWV)
+                sweep(std::true_type{});
+            else
+                sweep(std::false_type{});
         }
     }
     // ---- write this workgroup's partial slab ----
@@ -339,7 +350,11 @@ WgradPlan wgrad_plan(const WgradArgs& a) {
     const int CS = a.Cin <= 128 ? a.Cin : 128;
     const int DP = 32 * (p.NB < NWV ? p.NB : NWV);
     const int dil = a.dil_x > 0 ? a.dil_x : 1;
-    for (int max_px = 256; max_px >= 32; max_px >>= 1) {
+    const int kblocks_w0 = cdiv(p.KB, p.KWV);
+    const int waves_k0 = kblocks_w0 >= 3 ? 4 : (kblocks_w0 >= 2 ? 2 : 1);
+    const int groups0 = cdiv(p.KB, waves_k0 * p.KWV) * cdiv(p.NB, NWV) * (a.per_sample ? a.N : 1);
+    const int start_px = env_int2("FS_WGRAD_MAXPX", 256);
+    for (int max_px = start_px; max_px >= 32; max_px >>= 1) {
         int tw = a.Wo >= 16 ? 16 : ((a.Wo + 1) & ~1);
         tw = cdiv(cdiv(a.Wo, cdiv(a.Wo, tw)), 2) * 2;
         int th = max_px / tw;
@@ -356,7 +371,24 @@ WgradPlan wgrad_plan(const WgradArgs& a) {
         p.lds_bytes = 4 * (((p.PH * p.PW * p.S + 4 + 3) & ~3) + th * tw * DP);
         const bool xfit = (a.Cin & 3) || p.PH * p.PW * (CS / 4) <= 16 * 256;
         const bool dfit = th * tw * (DP / 4) <= 16 * 256;
-        if ((xfit && dfit && p.lds_bytes <= 80 * 1024) || max_px == 32) break;
+        if (!((xfit && dfit && p.lds_bytes <= 80 * 1024) || max_px == 32)) continue;
+        // CU balance: every workgroup gets the same number of tiles, but with n_wg between 256 and 512 some CUs run two
+        // workgroups and the others one (e.g. 441 -> 86 % of the chip).  If halving the tile lands the workgroup count
+        // just under a multiple of 256, take the smaller tile.
+        if (max_px > 64 && env_int2("FS_WGRAD_BALANCE", 1)) {
+            auto eff = [&](long total_tiles) {
+                int want = env_int2("FS_WGRAD_WGS", 512) / groups0;
+                if (want < 1) want = 1;
+                const long t = total_tiles <= want ? 1 : cdiv((int)total_tiles, want);  // tiles per workgroup
+                const long nwg = total_tiles <= want ? total_tiles : cdiv((int)total_tiles, (int)t);
+                const long per_cu = cdiv((int)(nwg * groups0), 256);                     // workgroups on the busiest CU
+                return (double)total_tiles / (double)(per_cu * t * 256 / groups0 > 0 ? per_cu * t * 256.0 / groups0 : 1.0);
+            };
+            const long tot_here = (long)(a.per_sample ? 1 : a.N) * p.tiles_y * p.tiles_x;
+            // the half-size tile has ~2x the tiles
+            if (eff(tot_here) < 0.9 && eff(2 * tot_here) > eff(tot_here) + 0.08) continue;
+        }
+        break;
     }
     const int kblocks_w = cdiv(p.KB, p.KWV);  // k-blocks in units of one wave's share
     p.waves_k = kblocks_w >= 3 ? 4 : (kblocks_w >= 2 ? 2 : 1);

@@ -15,6 +15,8 @@ CASES = {
     "gram3_3": (4, 64, 64, 256, 256, 1, 1, "SAME", True),
     "gram4_3": (4, 32, 32, 512, 512, 1, 1, "SAME", True),
     "s2_16_32": (4, 336, 336, 16, 32, 3, 2, "SAME", False),
+    "first9x9": (4, 336, 336, 3, 16, 9, 1, "SAME", False),
+    "fold_like": (4, 256, 256, 16, 16, 9, 1, "SAME", False),
 }
 
 
