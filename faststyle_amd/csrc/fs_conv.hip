@@ -187,22 +187,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             }
             if (q < ngroups) mma(a0, b0);
         } else {
-        for (int g = 0; g < G; ++g) {
-            const int aoff = FLAT ? g * PW * S : ((g / a.KW) * PW + (g % a.KW) * a.dil_x) * S;
-            const float* pa = patch + aoff;
-            const float* pb = wl + g * LG * BN + laneB;
-            for (int kk = 0; kk < LG; kk += KSTEP) {
-                float av[WM], bv[WN];
+            // General path (the flat Cin == 3 layout; CC = 4 with the 16-row MFMA): one k-step per stage, software-
+            // pipelined through two register sets like the fast path -- without it the compiler emits
+            // "ds_read, s_waitcnt, mfma" per step and the LDS latency is paid once per matrix instruction.
+            const int spg = LG / KSTEP;  // k-steps per tap group (LG is a multiple of KSTEP)
+            const int nsteps = G * spg;
+            int g = 0, kk = 0;
+            float a0[WM], b0[WN], a1[WM], b1[WN];
+            auto load = [&](float (&av)[WM], float (&bv)[WN]) {
+                const int aoff = FLAT ? g * PW * S : ((g / a.KW) * PW + (g % a.KW) * a.dil_x) * S;
+                const float* pa = patch + aoff + kk;
+                const float* pb = wl + (g * LG + kk) * BN + laneB;
 #pragma unroll
-                for (int m = 0; m < WM; ++m) av[m] = pa[laneA[m] + kk];
+                for (int m = 0; m < WM; ++m) av[m] = pa[laneA[m]];
 #pragma unroll
-                for (int nn = 0; nn < WN; ++nn) bv[nn] = pb[kk * BN + nn * MT];
+                for (int nn = 0; nn < WN; ++nn) bv[nn] = pb[nn * MT];
+                kk += KSTEP;
+                if (kk >= LG) {
+                    kk = 0;
+                    ++g;
+                }
+            };
+            auto mma = [&](const float (&av)[WM], const float (&bv)[WN]) {
 #pragma unroll
                 for (int m = 0; m < WM; ++m)
 #pragma unroll
                     for (int nn = 0; nn < WN; ++nn) acc[m][nn] = F::mma(av[m], bv[nn], acc[m][nn]);
+            };
+            if (nsteps > 0) load(a0, b0);
+            int q = 0;
+            for (; q + 2 <= nsteps; q += 2) {
+                load(a1, b1);
+                mma(a0, b0);
+                if (q + 2 < nsteps) load(a0, b0);
+                mma(a1, b1);
             }
-        }
+            if (q < nsteps) mma(a0, b0);
         }
     };
 
