@@ -167,10 +167,29 @@ def main():
         for _ in range(3):
             eng.tnet_forward(flat, frame)
         sync()
+        # one hipGraph per frame, as the streaming driver does (faststyle_amd/stream.py): a batch-1 frame is ~45 short
+        # launches and the host's launch rate should not be part of the number
+        run_frame = lambda: eng.tnet_forward(flat, frame)
+        if not args.no_graph:
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    eng.tnet_forward(flat, frame)
+                torch.cuda.current_stream().wait_stream(side)
+                sync()
+                fg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(fg, capture_error_mode="thread_local"):
+                    eng.tnet_forward(flat, frame)
+                run_frame = fg.replay
+            except Exception as ex:
+                print("bench: frame graph capture failed (%s); eager launches" % ex, file=sys.stderr)
+        run_frame()
+        sync()
         t1 = time.perf_counter()
         iters = 20
         for _ in range(iters):
-            eng.tnet_forward(flat, frame)
+            run_frame()
         sync()
         dt = time.perf_counter() - t1
         if world > 1:
