@@ -57,6 +57,49 @@ __device__ __forceinline__ bool bsrc_coord(int mode, int refl, int v, int n_src,
 // before the MFMA sweep of the current one (register prefetch), two barriers per chunk, one LDS stage, so two
 // workgroups fit a CU.  C4 = the 3-channel image layer: pixels are 4-channel bf16 (8 bytes), K runs over
 // (12 taps of a kernel row) x 4, i.e. 3 MFMA k-steps per kernel row, the whole 9x9 filter in one chunk.
+// MFMA sweep over (tap, 16-channel k-step) of one staged chunk, software-pipelined through two register sets: the
+// 16-byte LDS fragment reads of step i+1 are issued before the MFMAs of step i.  (Left to the compiler the loop
+// becomes "ds_read, s_waitcnt, mfma" per step -- and a bf16 MFMA is only 32 cycles, a fraction of the LDS latency.)
+template <int WM, int WN>
+__device__ __forceinline__ void sweep_bf16(f32x16 (&acc)[WM][WN], const unsigned short* patch, const unsigned short* wl,
+                                           const int (&laneA)[WM], int laneB, int KH, int KW, int dil_x, int PW, int PP, int WP,
+                                           int BN, int nks) {
+    const int nsteps = KH * KW * nks;
+    int kh = 0, kw = 0, ks = 0, g = 0;
+    auto load = [&](bf16x8 (&af)[WM], bf16x8 (&bfr)[WN]) {
+        const int toff = (kh * PW + kw * dil_x) * PP + ks * 16;
+        const int woff = g * BN * WP + ks * 16 + laneB;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) af[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(patch + laneA[m] + toff));
+#pragma unroll
+        for (int nn = 0; nn < WN; ++nn) bfr[nn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wl + woff + nn * 32 * WP));
+        if (++ks == nks) {
+            ks = 0;
+            ++g;
+            if (++kw == KW) {
+                kw = 0;
+                ++kh;
+            }
+        }
+    };
+    auto mma = [&](const bf16x8 (&af)[WM], const bf16x8 (&bfr)[WN]) {
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int nn = 0; nn < WN; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[nn], acc[m][nn], 0, 0, 0);
+    };
+    bf16x8 a0[WM], b0[WN], a1[WM], b1[WN];
+    if (nsteps > 0) load(a0, b0);
+    int q = 0;
+    for (; q + 2 <= nsteps; q += 2) {
+        load(a1, b1);
+        mma(a0, b0);
+        if (q + 2 < nsteps) load(a0, b0);
+        mma(a1, b1);
+    }
+    if (q < nsteps) mma(a0, b0);
+}
+
 // Per-tile instance-norm partial {mean, M2, count} per channel, from the fp32 accumulators, in ONE pass: every wave
 // sums d = z - pivot and d^2 over its rows (pivot = the wave's first row of that channel: the shifted-data form
 // keeps sum(d^2) - sum(d)^2/n free of cancellation), the four wave results are merged with Chan's update by one
@@ -377,25 +420,7 @@ __global__ __launch_bounds__(256) void conv_bf16_chunked_kernel(ConvBArgs a) {
             commit(c0);
             __syncthreads();
             if (c0 + CC < a.Cin) issue(c0 + CC);
-            for (int kh = 0; kh < a.KH; ++kh)
-                for (int kw = 0; kw < a.KW; ++kw) {
-                    const int g = kh * a.KW + kw;
-                    const int toff = (kh * PW + kw * a.dil_x) * PP;
-                    for (int ks = 0; ks < nks; ++ks) {
-                        bf16x8 af[WM], bfr[WN];
-#pragma unroll
-                        for (int m = 0; m < WM; ++m)
-                            af[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(patch + laneA[m] + toff + ks * 16));
-#pragma unroll
-                        for (int nn = 0; nn < WN; ++nn)
-                            bfr[nn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wl + (g * BN + nn * 32) * WP + laneB + ks * 16));
-#pragma unroll
-                        for (int m = 0; m < WM; ++m)
-#pragma unroll
-                            for (int nn = 0; nn < WN; ++nn)
-                                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[nn], acc[m][nn], 0, 0, 0);
-                    }
-                }
+            sweep_bf16<WM, WN>(acc, patch, wl, laneA, laneB, a.KH, a.KW, a.dil_x, PW, PP, WP, BN, nks);
             __syncthreads();
         }
     }
@@ -567,26 +592,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_resident_kernel(ConvBArgs a)
                             acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[nn], acc[m][nn], 0, 0, 0);
                 }
         } else {
-            const int nks = CC >> 4;
-            for (int kh = 0; kh < a.KH; ++kh)
-                for (int kw = 0; kw < a.KW; ++kw) {
-                    const int g = kh * a.KW + kw;
-                    const int toff = (kh * PW + kw * a.dil_x) * PP;
-                    for (int ks = 0; ks < nks; ++ks) {
-                        bf16x8 af[WM], bfr[WN];
-#pragma unroll
-                        for (int m = 0; m < WM; ++m)
-                            af[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(patch + laneA[m] + toff + ks * 16));
-#pragma unroll
-                        for (int nn = 0; nn < WN; ++nn)
-                            bfr[nn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wl + (g * BN + nn * 32) * WP + laneB + ks * 16));
-#pragma unroll
-                        for (int m = 0; m < WM; ++m)
-#pragma unroll
-                            for (int nn = 0; nn < WN; ++nn)
-                                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[nn], acc[m][nn], 0, 0, 0);
-                    }
-                }
+            sweep_bf16<WM, WN>(acc, patch, wl, laneA, laneB, a.KH, a.KW, a.dil_x, PW, PP, WP, BN, CC >> 4);
         }
     };
 
