@@ -48,6 +48,8 @@ def train_parser():
         ('--num_steps_ckpt', dict(default=1000, type=int, help='checkpoint period in steps')),
         ('--num_pipe_buffer', dict(default=4000, type=int, help='images held by the shuffle queue (min_after_dequeue)')),
         ('--num_steps_break', dict(default=-1, type=int, help='stop after this step (-1: run all epochs)')),
+        ('--resume_from', dict(default=None, help='bundle prefix of a training/<model_name>.ckpt-<step> to continue from '
+                                             '(weights, Adam slots, global_step); not in the reference')),
         ('--beta', dict(default=0.0, type=float, help='total-variation weight (about 1e-4 helps deconv models)')),
         ('--style_target_resize', dict(default=1.0, type=float, help='scale factor applied to the style image')),
         ('--upsample_method', dict(UPSAMPLE)),

@@ -97,3 +97,46 @@ class Trainer(object):
 
     def params_numpy(self):
         return self.eng.mem.to_numpy(self.params).copy()
+
+    def state_tensors(self, full=True):
+        """Checkpoint contents by TF variable name.  full=False: the 48 img_t_net tensors (what
+        stylize_image.py restores); full=True: what tf.train.Saver() of train.py:224 writes --
+        plus every variable's Adam slots ``<name>/Adam`` (m), ``<name>/Adam_1`` (v) and the int64
+        ``global_step``."""
+        e = self.eng
+        tensors = e.unflatten_params(self.params_numpy(), upsample_method=self.method)
+        if full:
+            for k, val in e.unflatten_params(e.mem.to_numpy(self.m), upsample_method=self.method).items():
+                tensors[k + "/Adam"] = val
+            for k, val in e.unflatten_params(e.mem.to_numpy(self.v), upsample_method=self.method).items():
+                tensors[k + "/Adam_1"] = val
+            tensors["global_step"] = np.array(self.global_step, dtype=np.int64)
+        return tensors
+
+    def load_state(self, tensors):
+        """Inverse of state_tensors: continue a run from a ``training/<name>.ckpt-<step>`` bundle
+        (the reference writes these but has no way to read them back, train.py:256-259).  A bundle
+        without Adam slots (a ``*_final.ckpt``) restores the weights only and keeps m = v = 0, step 0."""
+        e = self.eng
+        mem = e.mem
+        names = [k for k in tensors if not k.endswith("/Adam") and not k.endswith("/Adam_1") and k != "global_step"]
+        weights = dict((k, tensors[k]) for k in names)
+        scope = "img_t_net/" if any(k.startswith("img_t_net/") for k in names) else ""
+        flat = e.flatten_params(weights, scope=scope, upsample_method=self.method)
+        self.params = mem.from_numpy(flat)
+        has_slots = all((k + "/Adam") in tensors and (k + "/Adam_1") in tensors for k in names)
+        if has_slots:
+            self.m = mem.from_numpy(e.flatten_params(dict((k, tensors[k + "/Adam"]) for k in names), scope=scope,
+                                                     upsample_method=self.method))
+            self.v = mem.from_numpy(e.flatten_params(dict((k, tensors[k + "/Adam_1"]) for k in names), scope=scope,
+                                                     upsample_method=self.method))
+            self.global_step = int(np.asarray(tensors.get("global_step", 0)).reshape(-1)[0])
+        else:
+            self.m = mem.zeros(self.params.shape)
+            self.v = mem.zeros(self.params.shape)
+            self.global_step = 0
+        self.graph = None                      # a captured graph holds the old buffers
+        if self._world() > 1:
+            for t in (self.params, self.m, self.v):
+                self.dist.broadcast(t, src=0)
+        return self.global_step

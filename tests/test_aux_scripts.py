@@ -148,3 +148,28 @@ def test_builder_level_api_matches_oracle(eng):
     tv = float(eng.mem.to_numpy(losses.tv_loss(eng.mem.from_numpy(x), engine=eng))[0])
     tv_o, _ = perceptual.tv_loss(x.astype(np.float64))
     assert abs(tv - tv_o) / tv_o < 1e-5
+
+
+def test_trainer_state_roundtrip_through_bundle(eng, tmp_path):
+    """Trainer.state_tensors / load_state: the full bundle (train.py:224 saver: weights, Adam slots,
+    global_step) restores every buffer bit for bit; a weights-only bundle restores weights and
+    resets the optimiser."""
+    from faststyle_amd import im_transf_net, trainer, vgg16
+    rng = np.random.default_rng(4)
+    style = rng.uniform(0, 255, (1, 24, 28, 3)).astype(np.float32)
+    p0 = eng.flatten_params(im_transf_net.initial_variables(seed=0), scope="")
+    a = trainer.Trainer(eng, p0, vgg16.synthetic_weights(3), style)
+    a.m = eng.mem.from_numpy(rng.standard_normal(p0.shape).astype(np.float32))
+    a.v = eng.mem.from_numpy(rng.uniform(0, 1, p0.shape).astype(np.float32))
+    a.global_step = 7
+    full = a.state_tensors(full=True)
+    assert len(full) == 48 * 3 + 1 and full["global_step"].dtype == np.int64
+    assert full["img_t_net/upsample_2/W/Adam_1"].shape == (9, 9, 16, 3)
+    ckpt.save_checkpoint(str(tmp_path / "t.ckpt-7"), full)
+    ckpt.save_checkpoint(str(tmp_path / "t_final.ckpt"), a.state_tensors(full=False))
+    b = trainer.Trainer(eng, np.zeros_like(p0), vgg16.synthetic_weights(3), style)
+    assert b.load_state(ckpt.load_checkpoint(str(tmp_path / "t.ckpt-7"))) == 7
+    for name in ("params", "m", "v"):
+        assert np.array_equal(eng.mem.to_numpy(getattr(a, name)), eng.mem.to_numpy(getattr(b, name))), name
+    assert b.load_state(ckpt.load_checkpoint(str(tmp_path / "t_final.ckpt"))) == 0
+    assert np.array_equal(eng.mem.to_numpy(b.params), p0) and not eng.mem.to_numpy(b.m).any()

@@ -26,7 +26,7 @@ def test_cli_flags_match_reference():
                  "learn_rate": 1e-3, "batch_size": 4, "n_epochs": 2, "preprocess_size": [256, 256], "run_name": None,
                  "loss_content_layers": ["conv3_3"], "loss_style_layers": ["conv1_2", "conv2_2", "conv3_3", "conv4_3"],
                  "content_weights": [1.0], "style_weights": [5.0, 5.0, 5.0, 5.0], "num_steps_ckpt": 1000,
-                 "num_pipe_buffer": 4000, "num_steps_break": -1, "beta": 0.0, "style_target_resize": 1.0,
+                 "num_pipe_buffer": 4000, "num_steps_break": -1, "resume_from": None, "beta": 0.0, "style_target_resize": 1.0,
                  "upsample_method": "resize"}
 
 
@@ -80,6 +80,17 @@ def test_train_cli_runs_reference_loop(tmp_path, monkeypatch, capsys, method):
     assert [d["step"] for d in logs] == [0, 10] and np.isfinite(logs[1]["loss"])
     assert logs[1]["loss"] < logs[0]["loss"] or method == "deconv"
     assert (logs[1]["tv_loss"] > 0) == (method == "deconv")                  # --beta only set for deconv
+    # continue from the step-10 bundle (weights + Adam slots + global_step): the step counter carries on
+    train.main(train.setup_parser().parse_args(
+        ["--train_dir", "synthetic", "--model_name", "t", "--run_name", "t0",
+         "--style_img_path", os.path.join(ROOT, "style_images", "starry_night_crop.jpg"),
+         "--style_target_resize", "0.25", "--preprocess_size", "128", "128", "--batch_size", "2",
+         "--num_steps_break", "20", "--num_steps_ckpt", "10", "--upsample_method", method,
+         "--resume_from", str(work / "training" / "t.ckpt-10")]))
+    out2 = [l for l in capsys.readouterr().out.splitlines() if l and "amdgpu" not in l]
+    assert any(l.startswith("Resumed from") and l.endswith("at step 10.") for l in out2)
+    assert [int(l.split()[0]) for l in out2 if l.split()[0].isdigit()] == [10, 20]
+    assert int(ckpt.load_checkpoint(str(work / "training" / "t.ckpt-20"))["global_step"]) == 20
     # the final model is a valid stylize_image.py --model_path
     outimg = str(work / "o.jpg")
     stylize_image.main(["--input_img_path", os.path.join(ROOT, "tests", "golden", "ref_assets", "chicago.jpg"),
@@ -107,3 +118,25 @@ def test_autograd_glue_matches_direct_calls():
     losses, dy = e.perceptual_loss(y, X, tg, cfg)
     g = e.tnet_backward(flat, X, dy)
     assert torch.equal(v.grad, g) and float(loss) == float(losses[0])
+
+
+@pytest.mark.gpu
+def test_resume_is_bit_identical_to_uninterrupted_run(tmp_path):
+    """state_tensors -> bundle on disk -> load_state continues exactly where the run stopped."""
+    import torch
+    from faststyle_amd import ckpt, engine, im_transf_net, trainer, vgg16
+    e = engine.Engine()
+    rng = np.random.default_rng(0)
+    style = rng.uniform(0, 255, (1, 64, 80, 3)).astype(np.float32)
+    p0 = e.flatten_params(im_transf_net.initial_variables(0), scope="")
+    batches = [e.mem.from_numpy(rng.uniform(0, 255, (2, 64, 64, 3)).astype(np.float32)) for _ in range(3)]
+    a = trainer.Trainer(e, p0, vgg16.synthetic_weights(3), style)
+    a.step(batches[0])
+    a.step(batches[1])
+    ckpt.save_checkpoint(str(tmp_path / "run.ckpt-2"), a.state_tensors(full=True))
+    a.step(batches[2])
+    b = trainer.Trainer(e, p0, vgg16.synthetic_weights(3), style)
+    assert b.load_state(ckpt.load_checkpoint(str(tmp_path / "run.ckpt-2"))) == 2
+    b.step(batches[2])
+    assert b.global_step == 3
+    assert torch.equal(a.params, b.params) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v)

@@ -127,14 +127,13 @@ def main(args):
         train_writer = tbevents.EventWriter('./summaries/train/' + run_name)      # train.py:216-217
 
     def save(prefix, full):
-        tensors = eng.unflatten_params(tr.params_numpy(), upsample_method=method)
-        if full:   # saver = tf.train.Saver(): all variables incl. Adam slots and global_step (train.py:224)
-            for k, v in eng.unflatten_params(eng.mem.to_numpy(tr.m), upsample_method=method).items():
-                tensors[k + "/Adam"] = v
-            for k, v in eng.unflatten_params(eng.mem.to_numpy(tr.v), upsample_method=method).items():
-                tensors[k + "/Adam_1"] = v
-            tensors["global_step"] = np.array(tr.global_step, dtype=np.int64)
-        ckpt.save_checkpoint(prefix, tensors)
+        # full: saver = tf.train.Saver() -- all variables incl. Adam slots and global_step (train.py:224)
+        ckpt.save_checkpoint(prefix, tr.state_tensors(full=full))
+
+    if args.resume_from:
+        step0 = tr.load_state(ckpt.load_checkpoint(args.resume_from))
+        if rank == 0:
+            print('Resumed from %s at step %d.' % (args.resume_from, step0))
 
     # Input pipeline (train.py:192-196): TFRecord shards train-* when present
     shards = sorted(glob.glob(os.path.join(args.train_dir, 'train-*'))) if args.train_dir != 'synthetic' else []
