@@ -22,6 +22,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace fs {
 
@@ -68,6 +69,12 @@ struct Frag<16> {
     __device__ static __forceinline__ int row(int r, int lane) { return 4 * (lane >> 4) + r; }
 };
 
+#ifdef FS_CONV_TRACE
+// debug build only (tools/conv_trace.py): per-workgroup phase cycle counts of the last launch
+__device__ long long g_conv_trace[4096 * 8];
+#define FS_TRACE_NOW() ((long long)__builtin_readcyclecounter())
+#endif
+
 template <int MT, int WM, int WN, bool FLAT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     typedef Frag<MT> F;
@@ -77,6 +84,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     HIP_DYNAMIC_SHARED(float, smem)
     const ConvPlan& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef FS_CONV_TRACE
+    const long long tr_t0 = FS_TRACE_NOW();
+    long long tr_pro = tr_t0, tr_sweep = 0, tr_commit = 0, tr_bar = 0;
+#endif
+    if (p.skew > 0) {
+        // Two workgroups share a CU (one wave of each per SIMD).  Launched together and doing identical work they
+        // run in lockstep: both stage, both multiply, both store at the same time, and the MFMA pipe idles whenever
+        // they are not both in a sweep.  Delaying the workgroup in the odd wave slot by about half a chunk period
+        // puts its staging / epilogue phases under the other one's sweeps.  Only the first round needs it: later
+        // workgroups inherit the stagger from the slot they replace.
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lin < 512u) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_ID; bits 3:0 = wave slot on the SIMD
+            if (hw & 1u)
+                for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     const int tiles = p.tiles_y * p.tiles_x;
     // XCD-aware workgroup -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in
     // linear dispatch order; give every XCD a CONTIGUOUS range of (tile, channel-block) work, channel blocks of a
@@ -393,37 +417,70 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         __syncthreads();  // abl visible
         commit(cbeg, smem, smem + patch_floats);
         __syncthreads();
+#ifdef FS_CONV_TRACE
+        tr_pro = FS_TRACE_NOW();
+#endif
         for (int chunk = cbeg; chunk < cend; ++chunk) {
             float* cur = smem + ((chunk - cbeg) & 1) * buf_floats;
             float* nxt = smem + ((chunk - cbeg + 1) & 1) * buf_floats;
             const bool more = chunk + 1 < cend;
+#ifdef FS_CONV_TRACE
+            const long long q0 = FS_TRACE_NOW();
+#endif
             if (more) issue(chunk + 1);
             sweep(cur, cur + patch_floats);
+#ifdef FS_CONV_TRACE
+            const long long q1 = FS_TRACE_NOW();
+#endif
             if (more) commit(chunk + 1, nxt, nxt + patch_floats);
+#ifdef FS_CONV_TRACE
+            const long long q2 = FS_TRACE_NOW();
+#endif
             __syncthreads();
+#ifdef FS_CONV_TRACE
+            const long long q3 = FS_TRACE_NOW();
+            tr_sweep += q1 - q0;
+            tr_commit += q2 - q1;
+            tr_bar += q3 - q2;
+#endif
         }
     }
+#ifdef FS_CONV_TRACE
+    const long long tr_main = FS_TRACE_NOW();
+#endif
 
     // ---- epilogue ----
     const int th_valid = min(p.TH, a.Ho - ty0), tw_valid = min(p.TW, a.Wo - tx0);
-    // validity + coordinates of the rows this lane holds
-    // (row index within the workgroup tile: t = (wave*WM+m)*MT + F::row(r,lane));
-    // t / TW through a float reciprocal: exact for these small integers, 3 VALU instead of ~25
+    // The accumulator registers of a lane come in groups of four consecutive tile rows (Frag::row).  Walk them with
+    // ONE division per group (float reciprocal: exact for these small integers) and increments inside the group:
+    // fn(m, r, ok, py, px) with (py, px) the pixel of the workgroup tile that acc[m][.][r] belongs to.
     const float inv_tw = 1.0f / (float)p.TW;
+    auto for_rows = [&](auto&& fn) {
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int rg = 0; rg < NACC; rg += 4) {
+                const int t = (wave * WM + m) * MT + F::row(rg, lane);
+                int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    fn(m, rg + j, t + j < tile_px && py < th_valid && px < tw_valid, py, px);
+                    ++px;
+                    if (px == p.TW) {
+                        px = 0;
+                        ++py;
+                    }
+                }
+            }
+    };
     if (a.stats) {
         float s1[WN];
 #pragma unroll
         for (int nn = 0; nn < WN; ++nn) s1[nn] = 0.f;
+        for_rows([&](int m, int r, bool ok, int, int) {
 #pragma unroll
-        for (int m = 0; m < WM; ++m)
-#pragma unroll
-            for (int r = 0; r < NACC; ++r) {
-                const int t = (wave * WM + m) * MT + F::row(r, lane);
-                const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
-                const bool ok = t < tile_px && py < th_valid && px < tw_valid;
-#pragma unroll
-                for (int nn = 0; nn < WN; ++nn) s1[nn] += ok ? acc[m][nn][r] : 0.f;
-            }
+            for (int nn = 0; nn < WN; ++nn) s1[nn] += ok ? acc[m][nn][r] : 0.f;
+        });
 #pragma unroll
         for (int nn = 0; nn < WN; ++nn) {
             s1[nn] += __shfl_xor(s1[nn], 32);
@@ -445,19 +502,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             mu[nn] = meanl[nn * MT + lm];
             s2[nn] = 0.f;
         }
+        for_rows([&](int m, int r, bool ok, int, int) {
 #pragma unroll
-        for (int m = 0; m < WM; ++m)
-#pragma unroll
-            for (int r = 0; r < NACC; ++r) {
-                const int t = (wave * WM + m) * MT + F::row(r, lane);
-                const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
-                const bool ok = t < tile_px && py < th_valid && px < tw_valid;
-#pragma unroll
-                for (int nn = 0; nn < WN; ++nn) {
-                    const float d = acc[m][nn][r] - mu[nn];
-                    s2[nn] += ok ? d * d : 0.f;
-                }
+            for (int nn = 0; nn < WN; ++nn) {
+                const float d = acc[m][nn][r] - mu[nn];
+                s2[nn] += ok ? d * d : 0.f;
             }
+        });
 #pragma unroll
         for (int nn = 0; nn < WN; ++nn) {
             s2[nn] += __shfl_xor(s2[nn], 32);
@@ -497,13 +548,77 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         qb[nn] = q & 1;
         bs[nn] = (a.bias && cok[nn]) ? a.bias[co] : 0.f;
     }
+    const bool relu_out = a.out_relu != 0;
+    if (!a.shuffle && !asn) {
+        // the common stores (every VGG conv, most transform-net convs): bias, ReLU floor, optional consumer mask.
+        // Offsets advance by additions: row offset + column offset, no multiply per element.
+        const int row_stride = a.Wo * a.Cout;
+        auto run = [&](auto MASKED, auto FULL) {
+            constexpr bool kFull = decltype(FULL)::value;  // every lane has a valid pixel and channel: no per-element predicate
+            constexpr int RB = NACC < 8 ? NACC : 8;  // rows per batch (bounds the registers of the mask batch)
 #pragma unroll
-    for (int m = 0; m < WM; ++m)
+            for (int m = 0; m < WM; ++m)
 #pragma unroll
-        for (int r = 0; r < NACC; ++r) {
-            const int t = (wave * WM + m) * MT + F::row(r, lane);
-            const int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
-            if (!(t < tile_px && py < th_valid && px < tw_valid)) continue;
+                for (int r0 = 0; r0 < NACC; r0 += RB) {
+                    int off[RB];  // element offset of the pixel of row r0+i (channel 0); -1: outside the tile / image
+#pragma unroll
+                    for (int rg = 0; rg < RB; rg += 4) {
+                        const int t = (wave * WM + m) * MT + F::row(r0 + rg, lane);
+                        int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
+                        int roff = (ty0 + py) * row_stride, coff = (tx0 + px) * a.Cout;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            off[rg + j] = (kFull || (t + j < tile_px && py < th_valid && px < tw_valid)) ? roff + coff : -1;
+                            ++px;
+                            coff += a.Cout;
+                            if (px == p.TW) {
+                                px = 0;
+                                ++py;
+                                coff = tx0 * a.Cout;
+                                roff += row_stride;
+                            }
+                        }
+                    }
+                    // consumer-ReLU mask: ALL loads of the batch first (unconditional, clamped to element 0 where the
+                    // lane has nothing to store), so that their latencies overlap instead of chaining
+                    // load -> wait -> store per element
+                    float mk[RB][WN];
+                    if (decltype(MASKED)::value) {
+#pragma unroll
+                        for (int i = 0; i < RB; ++i)
+#pragma unroll
+                            for (int nn = 0; nn < WN; ++nn)
+                                mk[i][nn] = msn[(kFull || (off[i] >= 0 && cok[nn])) ? off[i] + cof[nn] : 0];
+                    }
+#pragma unroll
+                    for (int i = 0; i < RB; ++i) {
+                        if (!kFull && off[i] < 0) continue;
+#pragma unroll
+                        for (int nn = 0; nn < WN; ++nn) {
+                            if (!kFull && !cok[nn]) continue;
+                            float v = acc[m][nn][r0 + i] + bs[nn];
+                            v = relu_out ? fmaxf(v, 0.f) : v;
+                            if (decltype(MASKED)::value) v = mk[i][nn] > 0.f ? v : 0.f;
+                            yn[off[i] + cof[nn]] = v;
+                        }
+                    }
+                }
+        };
+        const bool full = th_valid == p.TH && tw_valid == p.TW && tile_px == 4 * WM * MT && co0 + BN <= a.Cout;
+        if (msn) {
+            if (full)
+                run(std::true_type{}, std::true_type{});
+            else
+                run(std::true_type{}, std::false_type{});
+        } else {
+            if (full)
+                run(std::false_type{}, std::true_type{});
+            else
+                run(std::false_type{}, std::false_type{});
+        }
+    } else {
+        for_rows([&](int m, int r, bool ok, int py, int px) {
+            if (!ok) return;
             const int oy = ty0 + py, ox = tx0 + px;
             const bool inner = asn && oy >= ap && oy < a.Ho - ap && ox >= ap && ox < a.Wo - ap;
             const int aoff = ((oy - ap) * aW + (ox - ap)) * a.Cout;
@@ -512,7 +627,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             for (int nn = 0; nn < WN; ++nn) {
                 if (!cok[nn]) continue;
                 float v = acc[m][nn][r] + bs[nn];
-                if (a.out_relu) v = fmaxf(v, 0.f);
+                v = relu_out ? fmaxf(v, 0.f) : v;
                 if (inner) v += asn[aoff + cof[nn]];
                 int o;
                 if (a.shuffle) {
@@ -523,10 +638,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 if (msn) v = msn[o] > 0.f ? v : 0.f;
                 yn[o] = v;
             }
+        });
+    }
+#ifdef FS_CONV_TRACE
+    {
+        const long long tr_end = FS_TRACE_NOW();
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (tid == 0 && lin < 4096) {
+            long long* t = g_conv_trace + lin * 8;
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            t[0] = tr_t0;
+            t[1] = tr_pro - tr_t0;
+            t[2] = tr_sweep;
+            t[3] = tr_commit;
+            t[4] = tr_bar;
+            t[5] = tr_end - tr_main;
+            t[6] = tr_end;
+            t[7] = hw;
         }
+    }
+#endif
 }
 
 // -------------------------------------------------------------------------------------- host
+#ifdef FS_CONV_TRACE
+extern "C" int fs_debug_conv_trace_reset() {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_conv_trace)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(long long) * 8 * 4096);
+}
+extern "C" int fs_debug_conv_trace(long long* out, int n_wg) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_trace), sizeof(long long) * 8 * (size_t)n_wg, 0, hipMemcpyDeviceToHost);
+}
+#endif
 Profiler*& Profiler::current() {
     static thread_local Profiler* p = nullptr;
     return p;
@@ -651,6 +795,7 @@ static void plan_variant(const ConvArgs& a, int variant, ConvPlan* out) {
     if (p.lds_bytes < 4 * 5 * p.BN) p.lds_bytes = 4 * 5 * p.BN;  // stats scratch
     p.ksplit = 1;
     p.xcd_swizzle = env_int("FS_CONV_XCD", 1);
+    p.skew = env_int("FS_CONV_SKEW", 0);
     *out = p;
 }
 

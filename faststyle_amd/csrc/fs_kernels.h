@@ -31,6 +31,7 @@ struct ConvPlan {
     int lds_bytes;
     int ksplit;   // > 1: blockIdx.z splits the input-channel chunks; raw partials go to ConvArgs::split_ws
     int xcd_swizzle;  // workgroup -> (tile, channel block) map that keeps sharers of an input patch on one XCD
+    int skew;  // > 0: first-round workgroups in odd wave slots start late by skew x 2048 cycles (see conv_igemm_kernel)
 };
 
 struct ConvArgs {

@@ -300,6 +300,8 @@ inline float shfl_idx(float v, int src) {
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) fsemu::mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) fsemu::mfma_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) fsemu::mfma_32x32x16_bf16((a), (b), (c))
+#define __builtin_amdgcn_s_getreg(imm) 0u   /* hardware id register: slot 0 everywhere */
+#define __builtin_amdgcn_s_sleep(imm) ((void)0)
 
 static inline float __shfl_xor(float v, int mask, int width = 64) { (void)width; return fsemu::shfl_idx(v, fsemu::blk().cur->lane ^ mask); }
 static inline float __shfl_down(float v, int d, int width = 64) { (void)width; int l = fsemu::blk().cur->lane; return fsemu::shfl_idx(v, l + d > 63 ? l : l + d); }

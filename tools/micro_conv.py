@@ -14,6 +14,8 @@ CASES = {
     "vgg1_2_n8": (8, 256, 256, 64, 64, 3, 1, "SAME"),
     "vgg2_2_n8": (8, 128, 128, 128, 128, 3, 1, "SAME"),
     "vgg3_2_n8": (8, 64, 64, 256, 256, 3, 1, "SAME"),
+    "vgg1_2_n4": (4, 256, 256, 64, 64, 3, 1, "SAME"),
+    "vgg2_2_n4": (4, 128, 128, 128, 128, 3, 1, "SAME"),
     "vgg3_2_n4": (4, 64, 64, 256, 256, 3, 1, "SAME"),
     "vgg4_2_n4": (4, 32, 32, 512, 512, 3, 1, "SAME"),
     "vgg4_1_n4": (4, 32, 32, 256, 512, 3, 1, "SAME"),
