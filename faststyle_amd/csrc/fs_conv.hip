@@ -113,14 +113,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const unsigned xcd = lin & 7u, slot = lin >> 3;
         const unsigned q = total >> 3, r = total & 7u;
         const unsigned j = xcd * q + (xcd < r ? xcd : r) + slot;
-        tile_id = (int)(j / gridDim.y);
+        tile_id = __builtin_amdgcn_readfirstlane((int)(j / gridDim.y));
         cob = (int)(j - (unsigned)tile_id * gridDim.y);
     }
     // x / d through a float reciprocal: exact for these magnitudes (x < 2^22), ~5 instructions instead of ~35
     auto fdiv = [](int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); };
-    const int n = fdiv(tile_id, 1.0f / (float)tiles);
+    // (the divisions run on the vector ALU; readfirstlane tells the compiler the results are wave-uniform, so that
+    // everything derived from them -- base pointers, buffer resources, loop bounds -- lives in scalar registers)
+    const int n = __builtin_amdgcn_readfirstlane(fdiv(tile_id, 1.0f / (float)tiles));
     const int tr = tile_id - n * tiles;
-    const int tyi = fdiv(tr, 1.0f / (float)p.tiles_x);
+    const int tyi = __builtin_amdgcn_readfirstlane(fdiv(tr, 1.0f / (float)p.tiles_x));
     const int ty0 = tyi * p.TH, tx0 = (tr - tyi * p.tiles_x) * p.TW;
     const int co0 = cob * BN;
     const int S = p.S, PW = p.PW, PH = p.PH, LG = p.LG, CC = p.CC;
@@ -151,8 +153,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
     const int G = FLAT ? a.KH : a.KH * a.KW;
     const int nchunks = FLAT ? 1 : a.Cin / CC;
-    const float* wbase = a.w + (size_t)n * a.w_nstride;
-    const float* xn = a.x + (size_t)n * a.H * a.W * a.Cin;
+    auto uniform_ptr = [](const float* ptr) {  // a wave-uniform pointer, pinned to scalar registers
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    };
+    const float* wbase = uniform_ptr(a.w + (size_t)n * a.w_nstride);
+    const float* xn = uniform_ptr(a.x + (size_t)n * a.H * a.W * a.Cin);
     const int vy0 = ty0 * a.stride - a.pad_t, vx0 = tx0 * a.stride - a.pad_l;
     const bool has_ab = a.in_a != nullptr;
     const float* ia = has_ab ? a.in_a + (size_t)n * a.in_nstride : nullptr;
@@ -311,47 +318,63 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 abl[c] = ia[c];
                 abl[a.Cin + c] = ib[c];
             }
-        int goff[PMAX];  // >=0: source offset (floats) of this thread's i-th patch element; -1: zero pad; -2: none
+        // Staging is branch-free.  Global reads go through buffer resources: an element outside the image (zero
+        // padding) or outside this thread's share gets the offset kOOB, which the hardware range check turns into a
+        // load of zeros -- no predicate, no select.  LDS writes of elements the thread does not own go to the
+        // patch's slack floats (as zeros).  The MFMA pipe idles while a workgroup stages, so every instruction
+        // removed here is time gained (tools/conv_trace.py).
+        constexpr unsigned kOOB = 0x80000000u;
+        unsigned gvo[PMAX];  // byte offset of this thread's i-th patch element in the image, or kOOB
+        int pdst[PMAX];      // its LDS position (floats, relative to the stage)
 #pragma unroll
         for (int i = 0; i < PMAX; ++i) {
             const int e = tid + i * 256;
-            goff[i] = -2;
+            gvo[i] = kOOB;
+            pdst[i] = PH * PW * S;  // slack
             if (e < ne_p) {
                 const int pix = e >> c4sh, c4 = e & (c4n - 1);
                 const int py = fdiv(pix, inv_pw), px = pix - py * PW;
                 int sy, sx;
                 const bool ok = src_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) &&
                                 src_coord(a.src_mode, a.refl, vx0 + px, a.W, sx);
-                goff[i] = ok ? (sy * a.W + sx) * a.Cin + c4 * 4 : -1;
+                if (ok) gvo[i] = (unsigned)((sy * a.W + sx) * a.Cin + c4 * 4) * 4u;
+                pdst[i] = pix * S + c4 * 4;
             }
         }
         float4 pv[PMAX], wv[WMAX];
         const bool vec = (a.Cout & 3) == 0;
         const bool wfast = vec && co0 + BN <= a.Cout;  // whole filter rows in range: precomputed offsets
-        int woff[WMAX];
+        unsigned wvo[WMAX];  // byte offset of the i-th filter element (chunk 0), or kOOB
+        int wdst[WMAX];      // LDS position (floats, relative to the stage's filter area)
 #pragma unroll
         for (int i = 0; i < WMAX; ++i) {
             const int e = tid + i * 256;
-            woff[i] = -1;
+            wvo[i] = kOOB;
+            wdst[i] = -4;  // the last four slack floats of the patch area (16-byte aligned)
             if (e < ne_w) {
                 const int k = e / J4N, j4 = e - k * J4N;
-                woff[i] = ((k >> lgsh) * a.Cin + (k & (CC - 1))) * a.Cout + co0 + j4 * 4;
+                wvo[i] = (unsigned)(((k >> lgsh) * a.Cin + (k & (CC - 1))) * a.Cout + co0 + j4 * 4) * 4u;
+                wdst[i] = e * 4;
             }
         }
+        const unsigned x_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * a.Cin) * 4u);
+        const unsigned w_bytes = __builtin_amdgcn_readfirstlane((unsigned)(G * a.Cin * a.Cout) * 4u);
         auto issue = [&](int chunk) {
             const int ci0 = chunk * CC;
+            // (descriptors are rebuilt from the scalar base pointers at every call: kept across the loop the compiler
+            // parks them in vector registers and wraps every load in a readfirstlane loop)
+            const __amdgpu_buffer_rsrc_t xr =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(xn)), 0, x_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t wr =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(wbase)), 0, w_bytes, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < PMAX; ++i) {
-                pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (goff[i] >= 0) pv[i] = *reinterpret_cast<const float4*>(xn + goff[i] + ci0);
-            }
+            for (int i = 0; i < PMAX; ++i)
+                pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, gvo[i], ci0 * 4, 0));
             if (wfast) {
-                const float* wc = wbase + (size_t)ci0 * a.Cout;
+                const int wso = ci0 * a.Cout * 4;
 #pragma unroll
-                for (int i = 0; i < WMAX; ++i) {
-                    wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (woff[i] >= 0) wv[i] = *reinterpret_cast<const float4*>(wc + woff[i]);
-                }
+                for (int i = 0; i < WMAX; ++i)
+                    wv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, wvo[i], wso, 0));
                 return;
             }
 #pragma unroll
@@ -374,45 +397,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 }
             }
         };
-        auto commit = [&](int chunk, float* patch, float* wl) {
+        // ReLU as ONE instruction (v_med3_f32); fmaxf would add a canonicalising max per value
+        auto relu1 = [](float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); };
+        auto commit_as = [&](auto AB, auto RELU, int chunk, float* patch, float* wl) {
             const int ci0 = chunk * CC;
 #pragma unroll
             for (int i = 0; i < PMAX; ++i) {
-                if (goff[i] == -2) continue;
-                const int e = tid + i * 256;
-                const int pix = e >> c4sh, c4 = e & (c4n - 1);
                 float4 v = pv[i];
-                if (goff[i] >= 0) {
-                    if (has_ab) {
-                        const float* pa_ = abl + ci0 + c4 * 4;
-                        const float* pb_ = pa_ + a.Cin;
-                        v.x = fmaf(v.x, pa_[0], pb_[0]);
-                        v.y = fmaf(v.y, pa_[1], pb_[1]);
-                        v.z = fmaf(v.z, pa_[2], pb_[2]);
-                        v.w = fmaf(v.w, pa_[3], pb_[3]);
-                    }
-                    if (a.in_relu) {
-                        v.x = fmaxf(v.x, 0.f);
-                        v.y = fmaxf(v.y, 0.f);
-                        v.z = fmaxf(v.z, 0.f);
-                        v.w = fmaxf(v.w, 0.f);
-                    }
+                if (decltype(AB)::value) {  // producer instance norm folded into the load; padding stays zero
+                    const int c4 = (tid + i * 256) & (c4n - 1);
+                    const float* pa_ = abl + ci0 + c4 * 4;
+                    const float* pb_ = pa_ + a.Cin;
+                    // padding arrives as 0 and must stay 0: clear the shift with a bit mask (fma(0, a, 0) = 0);
+                    // a select here makes the compiler branch around the table reads, once per component
+                    const unsigned okm = gvo[i] != kOOB ? 0xFFFFFFFFu : 0u;
+                    const float4 sc = *reinterpret_cast<const float4*>(pa_);
+                    const uint4 sh = *reinterpret_cast<const uint4*>(pb_);
+                    v.x = fmaf(v.x, sc.x, __uint_as_float(sh.x & okm));
+                    v.y = fmaf(v.y, sc.y, __uint_as_float(sh.y & okm));
+                    v.z = fmaf(v.z, sc.z, __uint_as_float(sh.z & okm));
+                    v.w = fmaf(v.w, sc.w, __uint_as_float(sh.w & okm));
                 }
-                float* d = patch + pix * S + c4 * 4;
+                if (decltype(RELU)::value) {
+                    v.x = relu1(v.x);
+                    v.y = relu1(v.y);
+                    v.z = relu1(v.z);
+                    v.w = relu1(v.w);
+                }
+                float* d = patch + pdst[i];
                 d[0] = v.x;
                 d[1] = v.y;
                 d[2] = v.z;
                 d[3] = v.w;
             }
 #pragma unroll
-            for (int i = 0; i < WMAX; ++i) {
-                const int e = tid + i * 256;
-                if (e < ne_w) *reinterpret_cast<float4*>(wl + e * 4) = wv[i];
-            }
+            for (int i = 0; i < WMAX; ++i) *reinterpret_cast<float4*>(wl + wdst[i]) = wv[i];
+        };
+        const int cmode = (has_ab ? 2 : 0) + (a.in_relu ? 1 : 0);  // wave-uniform: one straight-line variant each
+        auto commit = [&](int chunk, float* patch, float* wl) {
+            if (cmode == 0)
+                commit_as(std::false_type{}, std::false_type{}, chunk, patch, wl);
+            else if (cmode == 1)
+                commit_as(std::false_type{}, std::true_type{}, chunk, patch, wl);
+            else if (cmode == 2)
+                commit_as(std::true_type{}, std::false_type{}, chunk, patch, wl);
+            else
+                commit_as(std::true_type{}, std::true_type{}, chunk, patch, wl);
         };
         // split-K: blockIdx.z owns the chunk range [cbeg, cend)
-        const int cbeg = p.ksplit > 1 ? (int)blockIdx.z * nchunks / p.ksplit : 0;
-        const int cend = p.ksplit > 1 ? ((int)blockIdx.z + 1) * nchunks / p.ksplit : nchunks;
+        const int cbeg = __builtin_amdgcn_readfirstlane(p.ksplit > 1 ? (int)blockIdx.z * nchunks / p.ksplit : 0);
+        const int cend = __builtin_amdgcn_readfirstlane(p.ksplit > 1 ? ((int)blockIdx.z + 1) * nchunks / p.ksplit : nchunks);
         issue(cbeg);
         __syncthreads();  // abl visible
         commit(cbeg, smem, smem + patch_floats);

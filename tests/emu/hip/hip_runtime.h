@@ -301,7 +301,31 @@ inline float shfl_idx(float v, int src) {
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) fsemu::mfma_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) fsemu::mfma_32x32x16_bf16((a), (b), (c))
 #define __builtin_amdgcn_s_getreg(imm) 0u   /* hardware id register: slot 0 everywhere */
+
+/* buffer resources: a (base, size) pair; loads beyond the size return zeros, as the hardware range check does */
+namespace fsemu {
+struct buffer_rsrc { const unsigned char* base; unsigned nbytes; };
+static inline uint4 raw_buffer_load_b128(buffer_rsrc r, unsigned voff, unsigned soff) {
+    uint4 v{0u, 0u, 0u, 0u};
+    const unsigned long long end = (unsigned long long)voff + soff + 16ull;
+    if (voff < 0x80000000u && end <= r.nbytes) memcpy(&v, r.base + voff + soff, 16);
+    else if (voff < 0x80000000u) { fprintf(stderr, "emu: buffer load out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
+    return v;
+}
+static inline float fmed3f(float a, float b, float c) {
+    const float lo = a < b ? a : b, hi = a < b ? b : a;
+    return c < lo ? lo : (c > hi ? hi : c);
+}
+}  // namespace fsemu
+#define __amdgpu_buffer_rsrc_t fsemu::buffer_rsrc
+#define __builtin_amdgcn_make_buffer_rsrc(ptr, stride, nbytes, flags) \
+    fsemu::buffer_rsrc{reinterpret_cast<const unsigned char*>(ptr), (unsigned)(nbytes)}
+#define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) fsemu::raw_buffer_load_b128((r), (unsigned)(voff), (unsigned)(soff))
+#define __builtin_amdgcn_fmed3f(a, b, c) fsemu::fmed3f((a), (b), (c))
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 #define __builtin_amdgcn_s_sleep(imm) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)   /* only ever applied to wave-uniform values */
 
 static inline float __shfl_xor(float v, int mask, int width = 64) { (void)width; return fsemu::shfl_idx(v, fsemu::blk().cur->lane ^ mask); }
 static inline float __shfl_down(float v, int d, int width = 64) { (void)width; int l = fsemu::blk().cur->lane; return fsemu::shfl_idx(v, l + d > 63 ? l : l + d); }
