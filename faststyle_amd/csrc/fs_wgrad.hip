@@ -40,9 +40,27 @@ __device__ __forceinline__ bool wsrc_coord(int mode, int refl, int v, int n_src,
     }
 }
 
+#ifdef FS_CONV_TRACE
+// debug build only (tools/conv_trace.py): per-workgroup phase cycle counts of the last launch
+__device__ long long g_wgrad_trace[4096 * 8];
+#define FS_WTRACE_NOW() ((long long)__builtin_readcyclecounter())
+extern "C" int fs_debug_wgrad_trace(long long* out, int n_wg) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgrad_trace), sizeof(long long) * 8 * (size_t)n_wg, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int fs_debug_wgrad_trace_reset() {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wgrad_trace)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(long long) * 8 * 4096);
+}
+#endif
+
 template <int KWV, int NWV>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     HIP_DYNAMIC_SHARED(float, smem)
+#ifdef FS_CONV_TRACE
+    const long long tr_t0 = FS_WTRACE_NOW();
+    long long tr_stage = 0, tr_sweep = 0, tr_bar = 0;
+#endif
     const WgradPlan& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lm = lane & 31, kq = lane >> 5;
@@ -266,10 +284,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
     bool first = true;
     for (int t = blockIdx.x; t < total; t += p.n_wg) {
+#ifdef FS_CONV_TRACE
+        const long long q0 = FS_WTRACE_NOW();
+#endif
         if (!first) __syncthreads();
         first = false;
+#ifdef FS_CONV_TRACE
+        const long long q1 = FS_WTRACE_NOW();
+#endif
         stage(t);
+#ifdef FS_CONV_TRACE
+        const long long q2 = FS_WTRACE_NOW();
+#endif
         __syncthreads();
+#ifdef FS_CONV_TRACE
+        const long long q3 = FS_WTRACE_NOW();
+        tr_bar += (q1 - q0) + (q3 - q2);
+        tr_stage += q2 - q1;
+#endif
         // ---- MFMA sweep over pixel pairs ----
         // (the common case -- every co-block of the workgroup present -- is compiled WITHOUT the per-MFMA `j < nbw`
         // guard: with the guard each matrix instruction sits behind its own branch and s_waitcnt)
@@ -302,7 +334,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             else
                 sweep(std::false_type{});
         }
+#ifdef FS_CONV_TRACE
+        tr_sweep += FS_WTRACE_NOW() - q3;
+#endif
     }
+#ifdef FS_CONV_TRACE
+    const long long tr_main = FS_WTRACE_NOW();
+#endif
     // ---- write this workgroup's partial slab ----
     float* slab = a.slabs + (((size_t)blockIdx.z * p.n_wg + blockIdx.x) * wsplit + ws) * (size_t)p.K * a.Cout;
 #pragma unroll
@@ -319,6 +357,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             }
         }
     }
+#ifdef FS_CONV_TRACE
+    {
+        const long long tr_end = FS_WTRACE_NOW();
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (tid == 0 && lin < 4096) {
+            long long* t = g_wgrad_trace + lin * 8;
+            t[0] = tr_t0;
+            t[1] = 0;
+            t[2] = tr_sweep;
+            t[3] = tr_stage;
+            t[4] = tr_bar;
+            t[5] = tr_end - tr_main;
+            t[6] = tr_end;
+            t[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        }
+    }
+#endif
 }
 
 static int env_int2(const char* name, int dflt) {
