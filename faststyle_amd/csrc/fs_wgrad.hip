@@ -130,15 +130,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const float inv_tw = 1.0f / (float)p.TW, inv_cs = 1.0f / (float)CS, inv_cr = 1.0f / (float)Cr;
     const float inv_tiles = 1.0f / (float)tiles, inv_tx = 1.0f / (float)p.tiles_x;
 
+    auto uniform_ptr = [](const float* ptr) {  // a wave-uniform pointer, pinned to scalar registers
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    };
     auto stage = [&](int t) {
-        const int n = a.per_sample ? (int)blockIdx.z : fdiv(t, inv_tiles);
-        const int tr = t - fdiv(t, inv_tiles) * tiles;
-        const int tyi = fdiv(tr, inv_tx);
+        // (tile coordinates are wave-uniform but come out of the vector ALU: readfirstlane moves them, and the base
+        // pointers derived from them, to scalar registers)
+        const int tq = __builtin_amdgcn_readfirstlane(fdiv(t, inv_tiles));
+        const int n = a.per_sample ? (int)blockIdx.z : tq;
+        const int tr = t - tq * tiles;
+        const int tyi = __builtin_amdgcn_readfirstlane(fdiv(tr, inv_tx));
         const int ty0 = tyi * p.TH, tx0 = (tr - tyi * p.tiles_x) * p.TW;
         const int vy0 = ty0 * a.stride - a.pad_t, vx0 = tx0 * a.stride - a.pad_l;
-        const float* xn = a.x + (size_t)n * a.H * a.W * a.Cin;
-        const float* ia = has_ab ? a.in_a + (size_t)n * a.in_nstride : nullptr;
-        const float* ib = has_ab ? a.in_b + (size_t)n * a.in_nstride : nullptr;
+        const float* xn = uniform_ptr(a.x + (size_t)n * a.H * a.W * a.Cin);
+        const float* ia = has_ab ? uniform_ptr(a.in_a + (size_t)n * a.in_nstride) : nullptr;
+        const float* ib = has_ab ? uniform_ptr(a.in_b + (size_t)n * a.in_nstride) : nullptr;
         if (xvec) {
             for (int e0 = tid; e0 < ne_x; e0 += XB * 256) {
                 float4 xv[XB];
@@ -343,17 +351,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #endif
     // ---- write this workgroup's partial slab ----
     float* slab = a.slabs + (((size_t)blockIdx.z * p.n_wg + blockIdx.x) * wsplit + ws) * (size_t)p.K * a.Cout;
+    // everything this wave owns inside K x Cout (the usual case): no per-element predicate, 32-bit offsets
+    const bool whole = (kb0 + KWV) * 32 <= p.K && co_g0 + nbw * 32 <= a.Cout && nbw == NWV;
+    if (whole) {
+        const int base = (kb0 * 32 + 4 * (lane >> 5)) * a.Cout + co_g0 + lm;
 #pragma unroll
-    for (int q = 0; q < KWV; ++q) {
-        if (kb0 + q >= p.KB) continue;
+        for (int q = 0; q < KWV; ++q)
 #pragma unroll
-        for (int j = 0; j < NWV; ++j) {
-            if (j >= nbw) continue;
-            const int co = co_g0 + j * 32 + lm;
+            for (int j = 0; j < NWV; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = (kb0 + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (kk < p.K && co < a.Cout) slab[(size_t)kk * a.Cout + co] = acc[q][j][r];
+                for (int r = 0; r < 16; ++r)
+                    slab[base + (q * 32 + (r & 3) + 8 * (r >> 2)) * a.Cout + j * 32] = acc[q][j][r];
+    } else {
+#pragma unroll
+        for (int q = 0; q < KWV; ++q) {
+            if (kb0 + q >= p.KB) continue;
+#pragma unroll
+            for (int j = 0; j < NWV; ++j) {
+                if (j >= nbw) continue;
+                const int co = co_g0 + j * 32 + lm;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kk = (kb0 + q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (kk < p.K && co < a.Cout) slab[(size_t)kk * a.Cout + co] = acc[q][j][r];
+                }
             }
         }
     }
