@@ -1,10 +1,10 @@
-echo "=== wgrad trace"
-FASTSTYLE_HIP_LIB=exp/libtrace.so timeout 300 python tools/wgrad_trace.py res_n4 s2_16_32 fold_like gram1_2 2>&1 | grep -v amdgpu.ids
-echo "=== conv trace"
-FASTSTYLE_HIP_LIB=exp/libtrace.so timeout 300 python tools/conv_trace.py res_n4 2>&1 | grep -v amdgpu.ids
-echo "=== micro wgrad"
-ITERS=30 timeout 300 python tools/micro_wgrad.py 2>&1 | grep -v amdgpu.ids
-echo "=== tests"
-timeout 900 python -m pytest tests/test_kernels_parity.py tests/test_path_parity.py -x -q -m gpu 2>&1 | tail -3
-echo "=== bench"
-timeout 300 python bench.py --steps 20 --warmup 3 --no-stylize 2>&1 | grep -v amdgpu.ids | cut -c1-200
+for v in -1 0 3 4; do
+  echo "=== variant $v"
+  FS_CONV_VARIANT=$v ITERS=30 timeout 300 python tools/micro_conv.py res_n4 vgg4_2_n4 vgg4_1_n4 vgg3_2_n4 2>&1 | grep -v amdgpu.ids
+  FS_CONV_VARIANT=$v STATS=1 ITERS=30 timeout 300 python tools/micro_conv.py res_n4 2>&1 | grep -v amdgpu.ids
+done
+for m in 256 384; do
+  echo "=== min_wgs $m"
+  FS_CONV_MIN_WGS=$m ITERS=30 timeout 300 python tools/micro_conv.py res_n4 vgg4_2_n4 vgg4_1_n4 vgg3_2_n4 2>&1 | grep -v amdgpu.ids
+  FS_CONV_MIN_WGS=$m timeout 300 python bench.py --steps 20 --warmup 3 --no-stylize 2>&1 | grep -v amdgpu.ids | cut -c1-200
+done
