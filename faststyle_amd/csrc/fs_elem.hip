@@ -354,6 +354,151 @@ __global__ __launch_bounds__(256) void in_bwd_final_kernel(const float* partial,
     }
 }
 
+// C % 4 == 0: a thread owns 4 channels; the C/4 threads of a pixel read it as consecutive float4, a workgroup covers
+// 1024/C pixels per pass and keeps UNR passes of loads in flight (the scalar kernel above waits for every pixel).
+__global__ __launch_bounds__(256) void in_bwd_partial4_kernel(const float* __restrict__ gin, const float* __restrict__ z,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ a, const float* __restrict__ b, int mode,
+                                                              float* __restrict__ partial, int HW, int C, int chunk_px) {
+    __shared__ float sh[2 * 256 * 4];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int c4n = C >> 2;            // threads per pixel (<= 64)
+    const int rows = 256 / c4n;        // pixels per pass
+    const int row = threadIdx.x / c4n, c = (threadIdx.x - row * c4n) * 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < rows) {
+        const float4 mu = *reinterpret_cast<const float4*>(mean + n * C + c), r = *reinterpret_cast<const float4*>(rstd + n * C + c);
+        const float4 ca = *reinterpret_cast<const float4*>(a + n * C + c), cb = *reinterpret_cast<const float4*>(b + n * C + c);
+        const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rv[4] = {r.x, r.y, r.z, r.w};
+        const float av[4] = {ca.x, ca.y, ca.z, ca.w}, bv[4] = {cb.x, cb.y, cb.z, cb.w};
+        const int p0 = chunk * chunk_px, p1 = min(HW, p0 + chunk_px);
+        const float* zb = z + (size_t)n * HW * C + c;
+        const float* gb = gin + (size_t)n * HW * C + c;
+        constexpr int UNR = 4;
+        for (int pb = p0 + row; pb < p1; pb += UNR * rows) {
+            float4 zz[UNR], gg[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int p = pb + u * rows;
+                const int pc = p < p1 ? p : p0;   // clamped: a valid address, the value is discarded below
+                zz[u] = *reinterpret_cast<const float4*>(zb + pc * C);
+                gg[u] = *reinterpret_cast<const float4*>(gb + pc * C);
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (pb + u * rows >= p1) continue;
+                const float zv[4] = {zz[u].x, zz[u].y, zz[u].z, zz[u].w}, gv[4] = {gg[u].x, gg[u].y, gg[u].z, gg[u].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float g = in_bwd_g(gv[q], zv[q], av[q], bv[q], mode);
+                    s1[q] += g;
+                    s2[q] += g * ((zv[q] - muv[q]) * rv[q]);
+                }
+            }
+        }
+    }
+    // sh[which][row][C]
+    if (row < rows) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sh[row * C + c + q] = s1[q];
+            sh[1024 + row * C + c + q] = s2[q];
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int r2 = 0; r2 < rows; ++r2) {
+            t1 += sh[r2 * C + threadIdx.x];
+            t2 += sh[1024 + r2 * C + threadIdx.x];
+        }
+        *reinterpret_cast<float2*>(partial + (((size_t)n * gridDim.x + chunk) * C + threadIdx.x) * 2) = make_float2(t1, t2);
+    }
+}
+
+// S[n][c][2] = sum over chunks for EVERY sample, and dbeta[c] = sum_n S1, dgamma[c] = sum_n S2, in one launch:
+// one block per 16 channels, 16 lanes per channel stride over the chunk list (fixed-order combine: deterministic).
+__global__ __launch_bounds__(256) void in_bwd_final_all_kernel(const float* __restrict__ partial, int N, int chunks, int C,
+                                                               float* __restrict__ S, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+    __shared__ float sh[512];
+    const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float g1 = 0.f, g2 = 0.f;
+    for (int n = 0; n < N; ++n) {
+        float t1 = 0.f, t2 = 0.f;
+        if (c < C) {
+            const float* pn = partial + ((size_t)n * chunks * C + c) * 2;
+            int k = tl;
+            for (; k + 48 < chunks; k += 64) {   // four loads in flight
+                const float2 v0 = *reinterpret_cast<const float2*>(pn + (size_t)k * C * 2);
+                const float2 v1 = *reinterpret_cast<const float2*>(pn + (size_t)(k + 16) * C * 2);
+                const float2 v2 = *reinterpret_cast<const float2*>(pn + (size_t)(k + 32) * C * 2);
+                const float2 v3 = *reinterpret_cast<const float2*>(pn + (size_t)(k + 48) * C * 2);
+                t1 += (v0.x + v1.x) + (v2.x + v3.x);
+                t2 += (v0.y + v1.y) + (v2.y + v3.y);
+            }
+            for (; k < chunks; k += 16) {
+                const float2 v = *reinterpret_cast<const float2*>(pn + (size_t)k * C * 2);
+                t1 += v.x;
+                t2 += v.y;
+            }
+        }
+        __syncthreads();
+        sh[threadIdx.x] = t1;
+        sh[256 + threadIdx.x] = t2;
+        __syncthreads();
+        if (tl == 0 && c < C) {
+            float u1 = 0.f, u2 = 0.f;
+            for (int j = 0; j < 16; ++j) {
+                u1 += sh[j * 16 + cl];
+                u2 += sh[256 + j * 16 + cl];
+            }
+            *reinterpret_cast<float2*>(S + (n * C + c) * 2) = make_float2(u1, u2);
+            g1 += u1;
+            g2 += u2;
+        }
+    }
+    if (tl == 0 && c < C) {
+        dbeta[c] = g1;
+        dgamma[c] = g2;
+    }
+}
+
+// dz for C % 4 == 0 (see in_bwd_apply_kernel): every per-channel parameter comes in as one float4, the channel index by a
+// mask when C is a power of two (cmask = C - 1, else -1).  dgamma / dbeta are written by in_bwd_final_all_kernel.
+__global__ __launch_bounds__(256) void in_bwd_apply4_kernel(const float* __restrict__ gin, const float* __restrict__ z,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ a, const float* __restrict__ b, int mode,
+                                                            const float* __restrict__ S, float* __restrict__ dz, int HW, int C,
+                                                            int cmask) {
+    const float inv = 1.0f / (float)HW;
+    const int n = blockIdx.y;
+    const int per = HW * C;
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j >= per) return;
+    const int c = cmask >= 0 ? (j & cmask) : j % C;
+    const int k = n * C + c;
+    const size_t base = (size_t)n * per;
+    const float4 zz = *reinterpret_cast<const float4*>(z + base + j);
+    const float4 gg = *reinterpret_cast<const float4*>(gin + base + j);
+    const float4 a4 = *reinterpret_cast<const float4*>(a + k), b4 = *reinterpret_cast<const float4*>(b + k);
+    const float4 m4 = *reinterpret_cast<const float4*>(mean + k), r4 = *reinterpret_cast<const float4*>(rstd + k);
+    const float4 sA = *reinterpret_cast<const float4*>(S + 2 * k), sB = *reinterpret_cast<const float4*>(S + 2 * k + 4);
+    const float zv[4] = {zz.x, zz.y, zz.z, zz.w}, gv[4] = {gg.x, gg.y, gg.z, gg.w};
+    const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+    const float mv[4] = {m4.x, m4.y, m4.z, m4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+    const float s1v[4] = {sA.x, sA.z, sB.x, sB.z}, s2v[4] = {sA.y, sA.w, sB.y, sB.w};
+    float o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float g = in_bwd_g(gv[q], zv[q], av[q], bv[q], mode);
+        const float xh = (zv[q] - mv[q]) * rv[q];
+        o[q] = av[q] * (g - s1v[q] * inv - xh * s2v[q] * inv);
+    }
+    *reinterpret_cast<float4*>(dz + base + j) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // dz = a * (g - S1/HW - xhat * S2/HW).  Grid (blocks over one sample, N): the sample comes from blockIdx.y and the
 // index inside it is 32-bit, so the per-element cost is one 32-bit remainder instead of two 64-bit divisions; when
 // C % 4 == 0 a thread handles 4 channels of one pixel with float4 loads.
@@ -413,16 +558,21 @@ int in_bwd(const float* gin, const float* z, const float* mean, const float* rst
     const int chunks = cdiv(HW, chunk_px);
     float* partial = scratch;
     float* S = scratch + (size_t)N * chunks * C * 2;
+    if (C % 4 == 0) {
+        hipLaunchKernelGGL(in_bwd_partial4_kernel, dim3(chunks, N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, partial, HW,
+                           C, chunk_px);
+        hipLaunchKernelGGL(in_bwd_final_all_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partial, N, chunks, C, S, dgamma, dbeta);
+        const int per = HW * C;
+        hipLaunchKernelGGL(in_bwd_apply4_kernel, dim3(cdiv(per / 4, 256), N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode,
+                           S, dz, HW, C, (C & (C - 1)) == 0 ? C - 1 : -1);
+        return 0;
+    }
     hipLaunchKernelGGL(in_bwd_partial_kernel, dim3(chunks, N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, partial, HW,
                        C, chunk_px);
     hipLaunchKernelGGL(in_bwd_final_kernel, dim3(cdiv(C, 16), N), dim3(256), 0, s, partial, N, chunks, C, S, dgamma, dbeta);
     const int per = HW * C;
-    if (C % 4 == 0)
-        hipLaunchKernelGGL(in_bwd_apply_kernel<true>, dim3(cdiv(per / 4, 256), N), dim3(256), 0, s, gin, z, mean, rstd, a, b,
-                           mode, S, dz, HW, C, N, dgamma, dbeta);
-    else
-        hipLaunchKernelGGL(in_bwd_apply_kernel<false>, dim3(min(2048, cdiv(per, 256)), N), dim3(256), 0, s, gin, z, mean, rstd,
-                           a, b, mode, S, dz, HW, C, N, dgamma, dbeta);
+    hipLaunchKernelGGL(in_bwd_apply_kernel<false>, dim3(min(2048, cdiv(per, 256)), N), dim3(256), 0, s, gin, z, mean, rstd,
+                       a, b, mode, S, dz, HW, C, N, dgamma, dbeta);
     return 0;
 }
 size_t in_bwd_scratch_floats(int N, int HW, int C) { return (size_t)N * cdiv(HW, 64) * C * 2 + (size_t)N * C * 2; }
