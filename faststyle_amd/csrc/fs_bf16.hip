@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void conv_bf16_chunked_kernel(ConvBArgs a) {
     const int tile_px = p.TH * p.TW;
     const int G = C4 ? a.KH : a.KH * a.KW;
     const int WP = C4 ? 56 : PP;                   // filter row pitch (elements)
-    const int patch_elems = (PH * PW * (C4 ? 4 : PP) + 7) & ~7;
+    const int patch_elems = (PH * PW * (C4 ? 4 : PP) + 15) & ~7;
     unsigned short* patch = smem;
     unsigned short* wl = smem + patch_elems;
     float* abl = reinterpret_cast<float*>(smem + patch_elems + G * BN * WP);  // [2][Cin] on-load affine
@@ -343,58 +343,78 @@ __global__ __launch_bounds__(256) void conv_bf16_chunked_kernel(ConvBArgs a) {
         const int g8sh = g8n == 2 ? 1 : 2;
         const int ne_p = PH * PW * g8n, ne_w = G * BN * g8n;
         const int cpad = a.p.cout_pad;
-        int goff[PMAX];  // >= 0: element offset of the granule in the image; -1 zero padding; -2 none
+        // Branch-free staging, as in fs_conv.hip: global reads go through buffer resources, and a granule that is
+        // zero padding or not this thread's gets the offset kOOB -- the hardware range check returns zeros for it.
+        // Granules the thread does not own are written (as zeros) to the eight slack elements behind the patch.
+        constexpr unsigned kOOB = 0x80000000u;
+        const int slack = patch_elems - 8;
+        unsigned gvo[PMAX];  // byte offset of the granule in the image (chunk 0), or kOOB
+        int pdst[PMAX];      // LDS element offset
 #pragma unroll
         for (int i = 0; i < PMAX; ++i) {
             const int e = tid + i * 256;
-            goff[i] = -2;
+            gvo[i] = kOOB;
+            pdst[i] = slack;
             if (e < ne_p) {
                 const int pix = e >> g8sh, g8 = e & (g8n - 1);
                 const int py = pix / PW, px = pix - py * PW;
                 int sy, sx;
                 const bool ok = bsrc_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) && bsrc_coord(a.src_mode, a.refl, vx0 + px, a.W, sx);
-                goff[i] = ok ? (sy * a.W + sx) * a.Cin + g8 * 8 : -1;
+                if (ok) gvo[i] = (unsigned)((sy * a.W + sx) * a.Cin + g8 * 8) * 2u;
+                pdst[i] = pix * PP + g8 * 8;
             }
         }
-        int woff[WMAX];
+        unsigned wvo[WMAX];
+        int wdst[WMAX];
 #pragma unroll
         for (int i = 0; i < WMAX; ++i) {
             const int e = tid + i * 256;
-            woff[i] = -1;
+            wvo[i] = kOOB;
+            wdst[i] = slack - (int)(wl - patch);  // relative to the filter area
             if (e < ne_w) {
                 const int row = e >> g8sh, g8 = e & (g8n - 1);
                 const int g = row / BN, col = row - g * BN;
-                woff[i] = (g * cpad + co0 + col) * a.Cin + g8 * 8;
+                wvo[i] = (unsigned)((g * cpad + co0 + col) * a.Cin + g8 * 8) * 2u;
+                wdst[i] = row * WP + g8 * 8;
             }
         }
+        const unsigned x_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * a.Cin) * 2u);
+        const unsigned w_bytes = __builtin_amdgcn_readfirstlane((unsigned)(G * cpad * a.Cin) * 2u);
+        auto uniform_ptr = [](const unsigned short* ptr) {
+            const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            return reinterpret_cast<unsigned short*>(((unsigned long long)hi << 32) | lo);
+        };
         uint4 pv[PMAX], wv[WMAX];
         auto issue = [&](int c0) {
+            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(xn), 0, x_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.w), 0, w_bytes, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < PMAX; ++i) {
-                pv[i] = make_uint4(0u, 0u, 0u, 0u);
-                if (goff[i] >= 0) pv[i] = *reinterpret_cast<const uint4*>(xn + goff[i] + c0);
-            }
+            for (int i = 0; i < PMAX; ++i)
+                pv[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, gvo[i], c0 * 2, 0));
 #pragma unroll
-            for (int i = 0; i < WMAX; ++i) {
-                wv[i] = make_uint4(0u, 0u, 0u, 0u);
-                if (woff[i] >= 0) wv[i] = *reinterpret_cast<const uint4*>(a.w + woff[i] + c0);
-            }
+            for (int i = 0; i < WMAX; ++i)
+                wv[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wr, wvo[i], c0 * 2, 0));
         };
-        auto commit = [&](int c0) {
+        auto commit_as = [&](auto AB, int c0) {
 #pragma unroll
             for (int i = 0; i < PMAX; ++i) {
-                if (goff[i] == -2) continue;
-                const int e = tid + i * 256;
-                const int pix = e >> g8sh, g8 = e & (g8n - 1);
                 uint4 v = pv[i];
-                if (goff[i] >= 0 && has_ab) {
+                if (decltype(AB)::value) {
+                    const int g8 = (tid + i * 256) & (g8n - 1);
                     const float* pa = abl + c0 + g8 * 8;
                     const float* pb = pa + a.Cin;
+                    // padding arrives as 0 and must stay 0: clear the shift with a bit mask (fma(0, a, 0) = 0)
+                    const unsigned okm = gvo[i] != kOOB ? 0xFFFFFFFFu : 0u;
+                    const float4 sa0 = *reinterpret_cast<const float4*>(pa), sa1 = *reinterpret_cast<const float4*>(pa + 4);
+                    const uint4 sb0 = *reinterpret_cast<const uint4*>(pb), sb1 = *reinterpret_cast<const uint4*>(pb + 4);
+                    const float sc[8] = {sa0.x, sa0.y, sa0.z, sa0.w, sa1.x, sa1.y, sa1.z, sa1.w};
+                    const unsigned sh[8] = {sb0.x, sb0.y, sb0.z, sb0.w, sb1.x, sb1.y, sb1.z, sb1.w};
                     unsigned* w32 = reinterpret_cast<unsigned*>(&v);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        float lo = fmaf(bf2f((unsigned short)(w32[k] & 0xFFFFu)), pa[2 * k], pb[2 * k]);
-                        float hi = fmaf(bf2f((unsigned short)(w32[k] >> 16)), pa[2 * k + 1], pb[2 * k + 1]);
+                        float lo = fmaf(bf2f((unsigned short)(w32[k] & 0xFFFFu)), sc[2 * k], __uint_as_float(sh[2 * k] & okm));
+                        float hi = fmaf(bf2f((unsigned short)(w32[k] >> 16)), sc[2 * k + 1], __uint_as_float(sh[2 * k + 1] & okm));
                         if (a.in_relu) {
                             lo = fmaxf(lo, 0.f);
                             hi = fmaxf(hi, 0.f);
@@ -402,16 +422,16 @@ __global__ __launch_bounds__(256) void conv_bf16_chunked_kernel(ConvBArgs a) {
                         w32[k] = pack2(lo, hi);
                     }
                 }
-                *reinterpret_cast<uint4*>(patch + pix * PP + g8 * 8) = v;
+                *reinterpret_cast<uint4*>(patch + pdst[i]) = v;
             }
 #pragma unroll
-            for (int i = 0; i < WMAX; ++i) {
-                const int e = tid + i * 256;
-                if (e < ne_w) {
-                    const int row = e >> g8sh, g8 = e & (g8n - 1);
-                    *reinterpret_cast<uint4*>(wl + row * WP + g8 * 8) = wv[i];
-                }
-            }
+            for (int i = 0; i < WMAX; ++i) *reinterpret_cast<uint4*>(wl + wdst[i]) = wv[i];
+        };
+        auto commit = [&](int c0) {
+            if (has_ab)
+                commit_as(std::true_type{}, c0);
+            else
+                commit_as(std::false_type{}, c0);
         };
         const int nks = CC >> 4;
         issue(0);
@@ -455,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_resident_kernel(ConvBArgs a)
     const int tile_px = p.TH * p.TW;
     const int G = C4 ? a.KH : a.KH * a.KW;
     const int WP = C4 ? 56 : PP;  // filter row pitch (elements)
-    const int patch_elems = (PH * PW * (C4 ? 4 : PP) + 7) & ~7;
+    const int patch_elems = (PH * PW * (C4 ? 4 : PP) + 15) & ~7;
     unsigned short* patch = smem;
     unsigned short* wl = smem + patch_elems;
     float* abl = reinterpret_cast<float*>(smem + patch_elems + G * BN * WP);  // [2][Cin] on-load affine
@@ -693,7 +713,7 @@ ConvBPlan conv_bf16_plan(const ConvBArgs& a) {
         bool fits = false;
         for (p.CC = p.c4 ? 4 : (a.Cin % 32 == 0 ? 32 : 16); p.CC >= (p.c4 ? 4 : 16); p.CC >>= 1) {
             p.PP = p.CC + 8;
-            const int patch_elems = (p.PH * p.PW * (p.c4 ? 4 : p.PP) + 7) & ~7;
+            const int patch_elems = (p.PH * p.PW * (p.c4 ? 4 : p.PP) + 15) & ~7;
             const bool resident = p.c4 || a.Cin == p.CC;
             const int stage_bytes = max_px * p.BN * (a.y_f32 ? 4 : 2);
             const int main_bytes = 2 * (patch_elems + G * p.BN * (p.c4 ? 56 : p.PP)) + 8 * a.Cin;
