@@ -175,48 +175,58 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     auto sweep = [&](const float* patch, const float* wl) {
         // LG is a whole number of 2-k-step groups for MT = 32 (4, 8, 16, 32) and, for MT = 16, unless CC = 4
         if (!FLAT && (MT == 32 || (LG & 7) == 0)) {
-            const int gpt = LG / (2 * KSTEP);
-            const int ngroups = G * gpt;
-            const float* pb = wl + laneB;
-            int kh = 0, kw = 0, kkg = 0, qload = 0;
-            float a0[2][WM], b0[2][WN], a1[2][WM], b1[2][WN];
-            auto load = [&](float (&av)[2][WM], float (&bv)[2][WN]) {
-                const int aoff = (kh * PW + kw * a.dil_x) * S + kkg * 2 * KSTEP;
-                const float* pa = patch + aoff;
-                const float* pq = pb + qload * 2 * KSTEP * BN;
+            // Group size: two k-steps for the wide register tiles (>= 4 MFMAs per k-step); four for the narrow ones,
+            // whose two-step groups hold only 2-4 matrix instructions -- less than the LDS latency the prefetch of
+            // the next group has to cover, so a wave alone on its SIMD (small launches) idled between groups.
+            auto run = [&](auto UC) {
+                constexpr int U = decltype(UC)::value;
+                const int gpt = LG / (U * KSTEP);
+                const int ngroups = G * gpt;
+                const float* pb = wl + laneB;
+                int kh = 0, kw = 0, kkg = 0, qload = 0;
+                float a0[U][WM], b0[U][WN], a1[U][WM], b1[U][WN];
+                auto load = [&](float (&av)[U][WM], float (&bv)[U][WN]) {
+                    const int aoff = (kh * PW + kw * a.dil_x) * S + kkg * U * KSTEP;
+                    const float* pa = patch + aoff;
+                    const float* pq = pb + qload * U * KSTEP * BN;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < U; ++u) {
 #pragma unroll
-                    for (int m = 0; m < WM; ++m) av[u][m] = pa[laneA[m] + u * KSTEP];
+                        for (int m = 0; m < WM; ++m) av[u][m] = pa[laneA[m] + u * KSTEP];
 #pragma unroll
-                    for (int nn = 0; nn < WN; ++nn) bv[u][nn] = pq[u * KSTEP * BN + nn * MT];
-                }
-                ++qload;
-                if (++kkg == gpt) {
-                    kkg = 0;
-                    if (++kw == a.KW) {
-                        kw = 0;
-                        ++kh;
+                        for (int nn = 0; nn < WN; ++nn) bv[u][nn] = pq[u * KSTEP * BN + nn * MT];
                     }
+                    ++qload;
+                    if (++kkg == gpt) {
+                        kkg = 0;
+                        if (++kw == a.KW) {
+                            kw = 0;
+                            ++kh;
+                        }
+                    }
+                };
+                auto mma = [&](float (&av)[U][WM], float (&bv)[U][WN]) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int m = 0; m < WM; ++m)
+#pragma unroll
+                            for (int nn = 0; nn < WN; ++nn) acc[m][nn] = F::mma(av[u][m], bv[u][nn], acc[m][nn]);
+                };
+                load(a0, b0);
+                int q = 0;
+                for (; q + 2 <= ngroups; q += 2) {
+                    load(a1, b1);
+                    mma(a0, b0);
+                    if (q + 2 < ngroups) load(a0, b0);
+                    mma(a1, b1);
                 }
+                if (q < ngroups) mma(a0, b0);
             };
-            auto mma = [&](float (&av)[2][WM], float (&bv)[2][WN]) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int m = 0; m < WM; ++m)
-#pragma unroll
-                        for (int nn = 0; nn < WN; ++nn) acc[m][nn] = F::mma(av[u][m], bv[u][nn], acc[m][nn]);
-            };
-            load(a0, b0);
-            int q = 0;
-            for (; q + 2 <= ngroups; q += 2) {
-                load(a1, b1);
-                mma(a0, b0);
-                if (q + 2 < ngroups) load(a0, b0);
-                mma(a1, b1);
-            }
-            if (q < ngroups) mma(a0, b0);
+            if (WM * WN < 4 && (LG % (4 * KSTEP)) == 0)
+                run(std::integral_constant<int, 4>{});
+            else
+                run(std::integral_constant<int, 2>{});
         } else {
             // General path (the flat Cin == 3 layout; CC = 4 with the 16-row MFMA): one k-step per stage, software-
             // pipelined through two register sets like the fast path -- without it the compiler emits
