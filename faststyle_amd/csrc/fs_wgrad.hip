@@ -130,6 +130,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const float inv_tw = 1.0f / (float)p.TW, inv_cs = 1.0f / (float)CS, inv_cr = 1.0f / (float)Cr;
     const float inv_tiles = 1.0f / (float)tiles, inv_tx = 1.0f / (float)p.tiles_x;
 
+    // fast staging paths (power-of-two channel-quad counts: every layer of this network)
+    constexpr unsigned kOOB = 0x80000000u;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    const bool fastx = xvec && pow2(c4n) && c4n <= 256;
+    const bool fastd = dvec && pow2(j4n) && j4n <= 256;
+    auto ilog2 = [](int v) {
+        int sh = 0;
+        while ((1 << sh) < v) ++sh;
+        return sh;
+    };
+    const int c4sh = ilog2(c4n > 0 ? c4n : 1), j4sh = ilog2(j4n);
+    const int ppi = 256 >> c4sh, dpy = ppi / PW, dpx = ppi - dpy * PW;            // pixel step of the x elements
+    const int ppi_d = 256 >> j4sh, dpy_d = ppi_d / p.TW, dpx_d = ppi_d - dpy_d * p.TW;
+    const unsigned x_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * a.Cin) * 4u);
+    const unsigned d_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.Ho * a.Wo * a.Cout) * 4u);
     auto uniform_ptr = [](const float* ptr) {  // a wave-uniform pointer, pinned to scalar registers
         const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -147,7 +162,70 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         const float* xn = uniform_ptr(a.x + (size_t)n * a.H * a.W * a.Cin);
         const float* ia = has_ab ? uniform_ptr(a.in_a + (size_t)n * a.in_nstride) : nullptr;
         const float* ib = has_ab ? uniform_ptr(a.in_b + (size_t)n * a.in_nstride) : nullptr;
-        if (xvec) {
+        if (fastx) {
+            // Thread <-> (pixel slot, channel quad) with the channel quad FIXED per thread (c4n is a power of two):
+            // the pixel advances by 256/c4n per element, so (py, px) and the LDS position move by additions, the
+            // instance-norm parameters of the thread's four channels are read once per tile, and the global reads
+            // are buffer loads whose out-of-image / out-of-patch offset kOOB returns zeros (no branches at all).
+            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(xn), 0, x_bytes, 0x00020000);
+            const int c4 = tid & (c4n - 1);
+            const int ch = cA + c4 * 4;
+            float4 va = make_float4(1.f, 1.f, 1.f, 1.f);
+            uint4 vb = make_uint4(0u, 0u, 0u, 0u);
+            if (has_ab) {
+                va = *reinterpret_cast<const float4*>(ia + ch);
+                vb = *reinterpret_cast<const uint4*>(ib + ch);
+            }
+            const int npix = PH * PW;
+            int pix_i = tid >> c4sh;                                   // issue-side counters
+            int py = fdiv(pix_i, inv_pw), px = pix_i - py * PW;
+            int pix_c = pix_i, dst = pix_i * S + c4 * 4;              // commit-side counters
+            for (int e0 = 0; e0 < ne_x; e0 += XB * 256) {
+                float4 xv[XB];
+                unsigned valid = 0;
+#pragma unroll
+                for (int i = 0; i < XB; ++i) {
+                    int sy, sx;
+                    const bool ok = pix_i < npix && wsrc_coord(a.src_mode, a.refl, vy0 + py, a.H, sy) &&
+                                    wsrc_coord(a.src_mode, a.refl, vx0 + px, a.W, sx);
+                    const unsigned vo = ok ? (unsigned)((sy * a.W + sx) * a.Cin + ch) * 4u : kOOB;
+                    xv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0, 0));
+                    valid |= ok ? 1u << i : 0u;
+                    pix_i += ppi;
+                    px += dpx;
+                    py += dpy;
+                    if (px >= PW) {
+                        px -= PW;
+                        ++py;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < XB; ++i) {
+                    float4 v = xv[i];
+                    if (has_ab) {  // padding arrives as 0 and stays 0: the shift is cleared by a bit mask
+                        const unsigned okm = (valid >> i) & 1u ? 0xFFFFFFFFu : 0u;
+                        v.x = fmaf(v.x, va.x, __uint_as_float(vb.x & okm));
+                        v.y = fmaf(v.y, va.y, __uint_as_float(vb.y & okm));
+                        v.z = fmaf(v.z, va.z, __uint_as_float(vb.z & okm));
+                        v.w = fmaf(v.w, va.w, __uint_as_float(vb.w & okm));
+                    }
+                    if (a.in_relu) {
+                        v.x = fmaxf(v.x, 0.f);
+                        v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f);
+                        v.w = fmaxf(v.w, 0.f);
+                    }
+                    float* d = patch + (pix_c < npix ? dst : npix * S);  // beyond the patch: the zero slack
+                    d[0] = v.x;
+                    d[1] = v.y;
+                    d[2] = v.z;
+                    d[3] = v.w;
+                    pix_c += ppi;
+                    dst += ppi * S;
+                }
+            }
+        } else if (xvec) {
             for (int e0 = tid; e0 < ne_x; e0 += XB * 256) {
                 float4 xv[XB];
                 unsigned valid = 0;
@@ -213,7 +291,70 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             }
         }
         if (tid < 4) patch[PH * PW * S + tid] = 0.f;
-        if (dvec) {
+        if (fastd) {
+            // same scheme for the dY tile: the thread's channel quad (and with it the pixel-unshuffle phase and the
+            // on-load affine of the deconv units) is fixed, pixels advance by 256/j4n
+            const float* dyn = uniform_ptr(a.dy + (size_t)n * a.Ho * a.Wo * a.Cout);
+            const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(dyn), 0, d_bytes, 0x00020000);
+            const int j4 = tid & (j4n - 1);
+            const int co = co_g0 + j4 * 4;
+            int cbase = co, ystep = a.Wo * a.Cout, xstep = a.Cout;   // element offset = oy*ystep + ox*xstep + cbase
+            if (a.dy_unshuffle) {
+                const int q = fdiv(co, inv_cr), cr = co - q * Cr;
+                cbase = ((q >> 1) * 2 * a.Wo + (q & 1)) * Cr + cr;
+                ystep = 4 * a.Wo * Cr;
+                xstep = 2 * Cr;
+            }
+            float4 va = make_float4(1.f, 1.f, 1.f, 1.f);
+            uint4 vb = make_uint4(0u, 0u, 0u, 0u);
+            if (a.dy_a) {
+                va = *reinterpret_cast<const float4*>(a.dy_a + (size_t)n * a.dy_nstride + co);
+                vb = *reinterpret_cast<const uint4*>(a.dy_b + (size_t)n * a.dy_nstride + co);
+            }
+            const int npix = p.TH * p.TW;
+            int pix_i = tid >> j4sh;
+            int py = fdiv(pix_i, inv_tw), px = pix_i - py * p.TW;
+            int e_c = tid;
+            for (int e0 = 0; e0 < ne_d; e0 += XB * 256) {
+                float4 dv[XB];
+                unsigned valid = 0;
+#pragma unroll
+                for (int i = 0; i < XB; ++i) {
+                    const int oy = ty0 + py, ox = tx0 + px;
+                    const bool ok = pix_i < npix && oy < a.Ho && ox < a.Wo;
+                    const unsigned vo = ok ? (unsigned)(oy * ystep + ox * xstep + cbase) * 4u : kOOB;
+                    dv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(dr, vo, 0, 0));
+                    valid |= ok ? 1u << i : 0u;
+                    pix_i += ppi_d;
+                    px += dpx_d;
+                    py += dpy_d;
+                    if (px >= p.TW) {
+                        px -= p.TW;
+                        ++py;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < XB; ++i) {
+                    float4 v = dv[i];
+                    if (a.dy_a) {
+                        const unsigned okm = (valid >> i) & 1u ? 0xFFFFFFFFu : 0u;
+                        v.x = fmaf(v.x, va.x, __uint_as_float(vb.x & okm));
+                        v.y = fmaf(v.y, va.y, __uint_as_float(vb.y & okm));
+                        v.z = fmaf(v.z, va.z, __uint_as_float(vb.z & okm));
+                        v.w = fmaf(v.w, va.w, __uint_as_float(vb.w & okm));
+                    }
+                    if (a.dy_relu) {
+                        v.x = fmaxf(v.x, 0.f);
+                        v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f);
+                        v.w = fmaxf(v.w, 0.f);
+                    }
+                    if (e_c < ne_d) *reinterpret_cast<float4*>(dyl + e_c * 4) = v;
+                    e_c += 256;
+                }
+            }
+        } else if (dvec) {
             for (int e0 = tid; e0 < ne_d; e0 += XB * 256) {
                 float4 dv[XB];
 #pragma unroll
