@@ -518,54 +518,55 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             }
     };
     if (a.stats) {
-        float s1[WN];
+        // Per-tile statistics in ONE pass over the accumulators: sums of (x - c) and (x - c)^2 around a per-channel
+        // shift c taken from the tile itself (its first pixel, always valid), so that M2 = S2 - S1^2/n has no
+        // cancellation to speak of (|mean - c| is of the order of the standard deviation).  Two barriers instead
+        // of four and one sweep over the registers instead of two.
+        float* red = smem;                 // [4 waves][2][BN]
+        float* shiftl = smem + 8 * BN;     // [BN]
+        if constexpr (FLAT) __syncthreads();  // (the chunked loop ends on a barrier; the flat path's sweep does not)
+        if (wave == 0 && kq == 0)
 #pragma unroll
-        for (int nn = 0; nn < WN; ++nn) s1[nn] = 0.f;
-        for_rows([&](int m, int r, bool ok, int, int) {
-#pragma unroll
-            for (int nn = 0; nn < WN; ++nn) s1[nn] += ok ? acc[m][nn][r] : 0.f;
-        });
+            for (int nn = 0; nn < WN; ++nn) shiftl[nn * MT + lm] = acc[0][nn][0];
+        __syncthreads();
+        float cs[WN], s1[WN], s2[WN];
 #pragma unroll
         for (int nn = 0; nn < WN; ++nn) {
-            s1[nn] += __shfl_xor(s1[nn], 32);
-            if (MT == 16) s1[nn] += __shfl_xor(s1[nn], 16);
-        }
-        __syncthreads();
-        float* red = smem;          // [4][BN]
-        float* meanl = smem + 4 * BN;  // [BN]
-        if (lane < MT)
-#pragma unroll
-            for (int nn = 0; nn < WN; ++nn) red[wave * BN + nn * MT + lane] = s1[nn];
-        __syncthreads();
-        const float cnt = (float)(th_valid * tw_valid);
-        if (tid < BN) meanl[tid] = (red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid]) / cnt;
-        __syncthreads();
-        float mu[WN], s2[WN];
-#pragma unroll
-        for (int nn = 0; nn < WN; ++nn) {
-            mu[nn] = meanl[nn * MT + lm];
+            cs[nn] = shiftl[nn * MT + lm];
+            s1[nn] = 0.f;
             s2[nn] = 0.f;
         }
         for_rows([&](int m, int r, bool ok, int, int) {
 #pragma unroll
             for (int nn = 0; nn < WN; ++nn) {
-                const float d = acc[m][nn][r] - mu[nn];
-                s2[nn] += ok ? d * d : 0.f;
+                const float d = ok ? acc[m][nn][r] - cs[nn] : 0.f;
+                s1[nn] += d;
+                s2[nn] = fmaf(d, d, s2[nn]);
             }
         });
 #pragma unroll
         for (int nn = 0; nn < WN; ++nn) {
+            s1[nn] += __shfl_xor(s1[nn], 32);
             s2[nn] += __shfl_xor(s2[nn], 32);
-            if (MT == 16) s2[nn] += __shfl_xor(s2[nn], 16);
+            if (MT == 16) {
+                s1[nn] += __shfl_xor(s1[nn], 16);
+                s2[nn] += __shfl_xor(s2[nn], 16);
+            }
         }
         if (lane < MT)
 #pragma unroll
-            for (int nn = 0; nn < WN; ++nn) red[wave * BN + nn * MT + lane] = s2[nn];
+            for (int nn = 0; nn < WN; ++nn) {
+                red[(wave * 2 + 0) * BN + nn * MT + lane] = s1[nn];
+                red[(wave * 2 + 1) * BN + nn * MT + lane] = s2[nn];
+            }
         __syncthreads();
         if (tid < BN && co0 + tid < a.Cout) {
+            const float cnt = (float)(th_valid * tw_valid);
+            const float S1 = (red[0 * BN + tid] + red[2 * BN + tid]) + (red[4 * BN + tid] + red[6 * BN + tid]);
+            const float S2 = (red[1 * BN + tid] + red[3 * BN + tid]) + (red[5 * BN + tid] + red[7 * BN + tid]);
             float* st = a.stats + ((size_t)tile_id * a.Cout + co0 + tid) * 3;
-            st[0] = meanl[tid];
-            st[1] = red[tid] + red[BN + tid] + red[2 * BN + tid] + red[3 * BN + tid];
+            st[0] = shiftl[tid] + S1 / cnt;
+            st[1] = fmaxf(S2 - S1 * S1 / cnt, 0.f);
             st[2] = cnt;
         }
     }
@@ -836,7 +837,7 @@ static void plan_variant(const ConvArgs& a, int variant, ConvPlan* out) {
         p.lds_bytes = chosen_bytes;
         if (chosen) break;
     }
-    if (p.lds_bytes < 4 * 5 * p.BN) p.lds_bytes = 4 * 5 * p.BN;  // stats scratch
+    if (p.lds_bytes < 4 * 9 * p.BN) p.lds_bytes = 4 * 9 * p.BN;  // stats scratch
     p.ksplit = 1;
     p.xcd_swizzle = env_int("FS_CONV_XCD", 1);
     p.skew = env_int("FS_CONV_SKEW", 0);
