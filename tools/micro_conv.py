@@ -22,6 +22,9 @@ CASES = {
     "vgg4_d1_n4": (4, 32, 32, 512, 256, 3, 1, "SAME"),
     "res_n4": (4, 80, 80, 64, 64, 3, 1, "VALID"),
     "final9x9": (4, 256, 256, 16, 3, 9, 1, "SAME"),
+    "first9x9": (4, 336, 336, 3, 16, 9, 1, "VALID"),
+    "first9x9_720p": (1, 800, 1360, 3, 16, 9, 1, "VALID"),
+    "final9x9_720p": (1, 720, 1280, 16, 3, 9, 1, "SAME"),
     "res_720p": (1, 196, 336, 64, 64, 3, 1, "VALID"),
 }
 
