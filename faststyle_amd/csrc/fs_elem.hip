@@ -261,9 +261,68 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     }
 }
 
+// count % 4 == 0 and many slabs: a thread owns 4 consecutive elements (one float4 per slab), 8 threads cover a 128-byte
+// line, the 32 slab groups of a workgroup keep all of a thread's loads in flight (<= 8 per pass)
+__global__ __launch_bounds__(256) void reduce_slabs4_kernel(const float* __restrict__ slabs, int n_wg, size_t count, float scale,
+                                                            float* __restrict__ out) {
+    constexpr int EL4 = 8, SG = 32;
+    __shared__ float4 sh[256];
+    const size_t g = blockIdx.y;
+    const int el = threadIdx.x & (EL4 - 1), sg = threadIdx.x >> 3;
+    const size_t i = ((size_t)blockIdx.x * EL4 + el) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < count) {
+        const float* p = slabs + g * n_wg * count + i;
+        int w = sg;
+        for (; w + 7 * SG < n_wg; w += 8 * SG) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(w + u * SG) * count);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc.x += v[u].x;
+                acc.y += v[u].y;
+                acc.z += v[u].z;
+                acc.w += v[u].w;
+            }
+        }
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {   // tail: clamped slab index, contribution masked (keeps the loads unconditional)
+            const int ww = w + u * SG;
+            v[u] = *reinterpret_cast<const float4*>(p + (size_t)(ww < n_wg ? ww : sg) * count);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float m = (w + u * SG) < n_wg ? 1.f : 0.f;
+            acc.x = fmaf(v[u].x, m, acc.x);
+            acc.y = fmaf(v[u].y, m, acc.y);
+            acc.z = fmaf(v[u].z, m, acc.z);
+            acc.w = fmaf(v[u].w, m, acc.w);
+        }
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (sg == 0 && i < count) {
+        float4 t = sh[el];
+#pragma unroll
+        for (int k = 1; k < SG; ++k) {
+            const float4 q = sh[k * EL4 + el];
+            t.x += q.x;
+            t.y += q.y;
+            t.z += q.z;
+            t.w += q.w;
+        }
+        *reinterpret_cast<float4*>(out + g * count + i) = make_float4(t.x * scale, t.y * scale, t.z * scale, t.w * scale);
+    }
+}
+
 int reduce_slabs(const float* slabs, int groups, int n_wg, size_t count, float scale, float* out, hipStream_t s) {
     const int deep = n_wg / 8;  // slab groups only while each still owns >= 8 slabs
-    if (deep >= 16) {
+    if (count % 4 == 0 && n_wg >= 64) {
+        hipLaunchKernelGGL(reduce_slabs4_kernel, dim3((unsigned)((count / 4 + 7) / 8), groups), dim3(256), 0, s, slabs, n_wg, count,
+                           scale, out);
+    } else if (deep >= 16) {
         hipLaunchKernelGGL(reduce_slabs_kernel<16>, dim3((unsigned)((count + 15) / 16), groups), dim3(256), 0, s, slabs, n_wg, count,
                            scale, out);
     } else if (deep >= 4) {
