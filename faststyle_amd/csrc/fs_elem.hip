@@ -476,52 +476,73 @@ __global__ __launch_bounds__(256) void in_bwd_partial4_kernel(const float* __res
 }
 
 // S[n][c][2] = sum over chunks for EVERY sample, and dbeta[c] = sum_n S1, dgamma[c] = sum_n S2, in one launch:
-// one block per 16 channels, 16 lanes per channel stride over the chunk list (fixed-order combine: deterministic).
+// one block per 16 channels; the 16 lanes of a channel are dealt to the samples (16/N lanes each, N | 16), each lane
+// strides over its sample's chunk list with 8 loads in flight; fixed-order combines through LDS (deterministic).
 __global__ __launch_bounds__(256) void in_bwd_final_all_kernel(const float* __restrict__ partial, int N, int chunks, int C,
                                                                float* __restrict__ S, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta) {
     __shared__ float sh[512];
     const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    float g1 = 0.f, g2 = 0.f;
-    for (int n = 0; n < N; ++n) {
-        float t1 = 0.f, t2 = 0.f;
-        if (c < C) {
-            const float* pn = partial + ((size_t)n * chunks * C + c) * 2;
-            int k = tl;
-            for (; k + 48 < chunks; k += 64) {   // four loads in flight
-                const float2 v0 = *reinterpret_cast<const float2*>(pn + (size_t)k * C * 2);
-                const float2 v1 = *reinterpret_cast<const float2*>(pn + (size_t)(k + 16) * C * 2);
-                const float2 v2 = *reinterpret_cast<const float2*>(pn + (size_t)(k + 32) * C * 2);
-                const float2 v3 = *reinterpret_cast<const float2*>(pn + (size_t)(k + 48) * C * 2);
-                t1 += (v0.x + v1.x) + (v2.x + v3.x);
-                t2 += (v0.y + v1.y) + (v2.y + v3.y);
-            }
-            for (; k < chunks; k += 16) {
-                const float2 v = *reinterpret_cast<const float2*>(pn + (size_t)k * C * 2);
-                t1 += v.x;
-                t2 += v.y;
+    const int L = 16 / N;            // lanes per sample
+    const int n = tl / L, j = tl - n * L;
+    float t1 = 0.f, t2 = 0.f;
+    if (c < C) {
+        const float* pn = partial + ((size_t)n * chunks * C + c) * 2;
+        int k = j;
+        for (; k + 7 * L < chunks; k += 8 * L) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(pn + (size_t)(k + u * L) * C * 2);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                t1 += v[u].x;
+                t2 += v[u].y;
             }
         }
-        __syncthreads();
-        sh[threadIdx.x] = t1;
-        sh[256 + threadIdx.x] = t2;
-        __syncthreads();
-        if (tl == 0 && c < C) {
-            float u1 = 0.f, u2 = 0.f;
-            for (int j = 0; j < 16; ++j) {
-                u1 += sh[j * 16 + cl];
-                u2 += sh[256 + j * 16 + cl];
-            }
-            *reinterpret_cast<float2*>(S + (n * C + c) * 2) = make_float2(u1, u2);
-            g1 += u1;
-            g2 += u2;
+        for (; k < chunks; k += L) {
+            const float2 v = *reinterpret_cast<const float2*>(pn + (size_t)k * C * 2);
+            t1 += v.x;
+            t2 += v.y;
         }
     }
+    sh[threadIdx.x] = t1;
+    sh[256 + threadIdx.x] = t2;
+    __syncthreads();
+    if (tl < N && c < C) {           // thread (tl = sample, cl): combine the sample's L lanes
+        float u1 = 0.f, u2 = 0.f;
+        for (int q = 0; q < L; ++q) {
+            u1 += sh[(tl * L + q) * 16 + cl];
+            u2 += sh[256 + (tl * L + q) * 16 + cl];
+        }
+        *reinterpret_cast<float2*>(S + (tl * C + c) * 2) = make_float2(u1, u2);
+        sh[(tl * L) * 16 + cl] = u1;   // (own slot: no other thread reads it before the barrier)
+        sh[256 + (tl * L) * 16 + cl] = u2;
+    }
+    __syncthreads();
     if (tl == 0 && c < C) {
+        float g1 = 0.f, g2 = 0.f;
+        for (int m = 0; m < N; ++m) {
+            g1 += sh[(m * L) * 16 + cl];
+            g2 += sh[256 + (m * L) * 16 + cl];
+        }
         dbeta[c] = g1;
         dgamma[c] = g2;
     }
+}
+
+// dbeta[c] = sum_n S1, dgamma[c] = sum_n S2 (fixed order) -- the batch sizes in_bwd_final_all_kernel does not take
+__global__ __launch_bounds__(256) void in_bwd_dparams_kernel(const float* __restrict__ S, int N, int C, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float g1 = 0.f, g2 = 0.f;
+    for (int m = 0; m < N; ++m) {
+        g1 += S[(m * C + c) * 2];
+        g2 += S[(m * C + c) * 2 + 1];
+    }
+    dbeta[c] = g1;
+    dgamma[c] = g2;
 }
 
 // dz for C % 4 == 0 (see in_bwd_apply_kernel): every per-channel parameter comes in as one float4, the channel index by a
@@ -620,7 +641,12 @@ int in_bwd(const float* gin, const float* z, const float* mean, const float* rst
     if (C % 4 == 0) {
         hipLaunchKernelGGL(in_bwd_partial4_kernel, dim3(chunks, N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, partial, HW,
                            C, chunk_px);
-        hipLaunchKernelGGL(in_bwd_final_all_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partial, N, chunks, C, S, dgamma, dbeta);
+        if (N <= 16 && 16 % N == 0) {
+            hipLaunchKernelGGL(in_bwd_final_all_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partial, N, chunks, C, S, dgamma, dbeta);
+        } else {
+            hipLaunchKernelGGL(in_bwd_final_kernel, dim3(cdiv(C, 16), N), dim3(256), 0, s, partial, N, chunks, C, S, dgamma, dbeta);
+            hipLaunchKernelGGL(in_bwd_dparams_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, S, N, C, dgamma, dbeta);
+        }
         const int per = HW * C;
         hipLaunchKernelGGL(in_bwd_apply4_kernel, dim3(cdiv(per / 4, 256), N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode,
                            S, dz, HW, C, (C & (C - 1)) == 0 ? C - 1 : -1);

@@ -145,12 +145,15 @@ def test_tnet_shipped_weights_forward_tight_backward_with_real_relu_masks(eng):
         np.testing.assert_allclose(g[tab["resblock_%d/INshift2" % k][0]:][:64], ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max())
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
-def test_instnorm_backward_modes(eng, mode):
+@pytest.mark.parametrize("mode,shape", [(0, (2, 13, 11, 16)), (1, (2, 13, 11, 16)), (2, (2, 13, 11, 16)),
+                                        (1, (4, 37, 41, 16)),     # 24 chunks per sample, 4 lanes per sample in the final reduce
+                                        (1, (3, 29, 23, 8)),      # batch size that does not divide 16: per-sample final + dparams
+                                        (2, (2, 19, 17, 3))])     # C % 4 != 0: the scalar kernels (the 3-channel output layer)
+def test_instnorm_backward_modes(eng, mode, shape):
     """IN backward with the three activations; pre-activations are nudged away from the ReLU kink."""
     from oracle import nnops
     rng = np.random.default_rng(3)
-    N, H, W, C = 2, 13, 11, 16
+    N, H, W, C = shape
     z = rng.standard_normal((N, H, W, C)).astype(np.float32) * 2 + 0.5
     gamma = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32)
     beta = (0.3 * rng.standard_normal(C)).astype(np.float32)
