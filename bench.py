@@ -124,7 +124,7 @@ def main():
         losses = tr.step(pool[(args.warmup + i) % len(pool)])
     sync()
     elapsed = time.perf_counter() - t0
-    prof = (ctypes.c_double * 18)()
+    prof = (ctypes.c_double * 21)()
     loss_val = float(losses[0].item())
     if graphed:
         # the timed steps replayed a hipGraph (no room for events between its nodes): time the SAME
@@ -221,10 +221,10 @@ def main():
     if rank == 0:
         n_img = args.steps * B * world
         value = n_img / elapsed
-        fam = [[prof[f * 3 + k] for k in range(3)] for f in range(6)]
+        fam = [[prof[f * 3 + k] for k in range(3)] for f in range(7)]
         names = ["conv_igemm_kernel<32,2,2>", "conv_igemm_kernel<32,2,1>", "conv_igemm_kernel<16,4,1>",
-                 "conv_wgrad_kernel", "conv_igemm_kernel<32,1,2>", "conv_igemm_kernel<32,1,1>"]
-        di = max(range(6), key=lambda f: fam[f][2])       # dominant = most GPU time in the timed region
+                 "conv_wgrad_kernel", "conv_igemm_kernel<32,1,2>", "conv_igemm_kernel<32,1,1>", "wino_conv_kernel"]
+        di = max(range(7), key=lambda f: fam[f][2])       # dominant = most GPU time in the timed region
         dom = fam[di]
         achieved = dom[1] / (dom[2] * 1e-3) / 1e12 if dom[2] > 0 else 0.0
         # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the
@@ -261,7 +261,7 @@ def main():
                          "per_kernel": {names[f]: {"launches_per_step": round(fam[f][0] / args.steps, 1),
                                                    "tflops": round(fam[f][1] / (fam[f][2] * 1e-3) / 1e12, 2),
                                                    "ms_per_step": round(fam[f][2] / args.steps, 3)}
-                                        for f in range(6) if fam[f][2] > 0}},
+                                        for f in range(7) if fam[f][2] > 0}},
             "step_tflops_as_written": round(GFLOP_PER_IMG_AS_WRITTEN * value / 1e3, 2),
             "step_frac_of_f32_mfma_peak": round(GFLOP_PER_IMG_AS_WRITTEN * value / 1e3 / world / PEAK_F32_MFMA_TFLOPS, 4),
             "final_loss": loss_val, "hip_graph": graphed,

@@ -67,7 +67,7 @@ PROTOTYPES = {
     "fs_last_error": (c_char_p, []),
     "fs_version": (c_char_p, []),
     "fs_profile_begin": (c_int, [c_void_p]),
-    "fs_profile_end": (c_int, [c_void_p, POINTER(ctypes.c_double * 18)]),
+    "fs_profile_end": (c_int, [c_void_p, POINTER(ctypes.c_double * 21)]),
     "fs_tnet_param_info": (c_int, [c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int), POINTER(c_int * 4)]),
     "fs_tnet_out_shape": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "fs_tnet_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -103,7 +103,7 @@ int fs_profile_begin(fs_ctx* ctx) {
     fs::Profiler::current() = &g_prof;
     return 0;
 }
-int fs_profile_end(fs_ctx* ctx, double out[18]) {
+int fs_profile_end(fs_ctx* ctx, double out[21]) {
     if (!ctx || !out) return fail(-1, "fs_profile_end: null argument");
     fs::Profiler::current() = nullptr;
     double tmp[fs::Profiler::kFamilies][3];
@@ -384,7 +384,27 @@ int fs_conv2d_fwd(fs_ctx* ctx, fs_conv_desc* d) {
     fs::ConvArgs a;
     if (int rc = fill_conv(d, &a)) return rc;
     if (!a.x || !a.w || !a.y) return fail(-1, "fs_conv2d_fwd: null tensor");
+    // Test / tuning hook (tests/test_kernels_parity.py, tools/micro_conv.py): FS_CONV2D_WINO=1 sends an eligible 3x3
+    // stride-1 SAME conv through the Winograd kernel with a filter transformed on the spot into a temporary buffer.
+    // The training step never takes this branch: fs_vgg_prepare transforms the frozen VGG filters once.
+    float* tmpU = nullptr;
+    const char* wenv = getenv("FS_CONV2D_WINO");
+    if (wenv && atoi(wenv)) {
+        fs::ConvArgs probe = a;
+        probe.w_wino = a.w;  // any non-null value: eligibility only looks at the shapes
+        if (fs::wino_eligible(probe)) {
+            if (hipMalloc(reinterpret_cast<void**>(&tmpU), (size_t)16 * a.Cin * a.Cout * sizeof(float)) != hipSuccess)
+                return fail(-5, "fs_conv2d_fwd: no memory for the Winograd filter");
+            fs::wt_wino(a.w, tmpU, a.Cin, a.Cout, ctx->stream);
+            a.w_wino = tmpU;
+            a.p = fs::conv_plan(a);
+        }
+    }
     const int rc = fs::conv_launch(a, ctx->stream);
+    if (tmpU) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tmpU);
+    }
     return rc ? fail(rc, "fs_conv2d_fwd: launch failed (%d)", rc) : 0;
 }
 

@@ -846,6 +846,10 @@ static void plan_variant(const ConvArgs& a, int variant, ConvPlan* out) {
 
 ConvPlan conv_plan(const ConvArgs& a) {
     ConvPlan p;
+    if (wino_eligible(a) && env_int("FS_CONV_WINO", 1)) {
+        wino_plan(a, &p);
+        return p;
+    }
     if (a.Cout <= 16 || a.Cin == 3) {  // narrow outputs, and the flat Cin==3 path, have one variant each
         plan_variant(a, a.Cout <= 16 ? 2 : 0, &p);
         return p;
@@ -947,6 +951,12 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
     reinterpret_cast<float4*>(y)[i] = v;
 }
 
+#define FS_TRY_(x)           \
+    do {                     \
+        int rc_ = (x);       \
+        if (rc_) return rc_; \
+    } while (0)
+
 int conv_launch(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     if (env_int("FS_CONV_DEBUG", 0))  // tuning aid: one line per launch with the chosen plan
@@ -972,6 +982,8 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
         double fl = 2.0 * a.N * a.Ho * a.Wo * (double)a.KH * a.KW * a.Cin * a.Cout;
         if (a.src_mode == SRC_DILATE2) fl *= 0.25;
         if (a.shuffle) fl *= 9.0 / 16.0;  // phase-collapsed resize-conv / stride-2 dgrad: 9 of the 16 tap-parity slots are non-zero
+        // Winograd F(2x2,3x3): 16 products per 2x2 output tile instead of 36 -- the FLOPs actually executed
+        if (p.variant == 5) fl = 2.0 * a.N * cdiv(a.Ho, 2) * cdiv(a.Wo, 2) * 16.0 * a.Cin * a.Cout;
         prof->begin(p.variant < 3 ? p.variant : p.variant + 1, fl, s);
     }
 #define FS_LAUNCH(MT_, WM_, WN_, FL_)                                                                              \
@@ -984,7 +996,10 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
         }                                                                                                          \
         hipLaunchKernelGGL((conv_igemm_kernel<MT_, WM_, WN_, FL_>), grid, dim3(256), (size_t)p.lds_bytes, s, a);   \
     } while (0)
-    if (p.flat) {
+    if (p.variant == 5) {
+        if (!wino_eligible(a_in)) return -7;
+        FS_TRY_(wino_launch(a, s));
+    } else if (p.flat) {
         if (p.variant == 0)
             FS_LAUNCH(32, 2, 2, true);
         else if (p.variant == 2)

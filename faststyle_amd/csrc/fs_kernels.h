@@ -20,7 +20,7 @@ enum SrcMode {
 };
 
 struct ConvPlan {
-    int variant;  // conv_igemm_kernel<MT,WM,WN>: 0 <32,2,2>  1 <32,2,1>  2 <16,4,1>  3 <32,1,2>  4 <32,1,1>
+    int variant;  // conv_igemm_kernel<MT,WM,WN>: 0 <32,2,2>  1 <32,2,1>  2 <16,4,1>  3 <32,1,2>  4 <32,1,1>;  5 wino_conv_kernel
     int BN;       // output channels per workgroup
     int flat;     // Cin==3: K runs over (kw,ci) contiguously per kernel row
     int CC;       // input channels staged per chunk
@@ -37,6 +37,7 @@ struct ConvPlan {
 struct ConvArgs {
     const float* x;  // [N,H,W,Cin]
     const float* w;  // [KH*KW, Cin, Cout] (HWIO); + n*w_nstride for per-sample weights
+    const float* w_wino;  // optional: the same filter Winograd-transformed, [16][Cin][Cout] (fs::wt_wino); enables variant 5
     float* y;        // [N,Ho,Wo,Cout], or [N,2Ho,2Wo,Cout/4] when shuffle
     int N, H, W, Cin;
     int Ho, Wo, Cout;
@@ -111,6 +112,11 @@ int apply_res(const float* z, const float* a, const float* b, const float* skip,
 int apply_tanh(const float* z, const float* a, const float* b, float* y, int N, int HW, int C, hipStream_t s);
 int reduce_slabs(const float* slabs, int groups, int n_wg, size_t count, float scale, float* out, hipStream_t s);
 // output-pixel tile (TH x TW <= max_px) with the best fill / halo trade-off for an Ho x Wo image (fs_conv.hip)
+// Winograd F(2x2,3x3) path (fs_wino.hip)
+int wt_wino(const float* w, float* U, int Cin, int Cout, hipStream_t s);
+bool wino_eligible(const ConvArgs& a);
+void wino_plan(const ConvArgs& a, ConvPlan* out);
+int wino_launch(const ConvArgs& a, hipStream_t s);
 void plan_tile(int Ho, int Wo, int KH, int KW, int stride, int max_px, int* TH, int* TW);
 // thread-local message behind fs_last_error(); returns `code` (fs_api.hip)
 int set_error(int code, const char* fmt, ...);
@@ -170,7 +176,7 @@ namespace fs {
 // Optional HIP-event profiler around the MFMA kernels (bench.py's roofline leg): per kernel
 // family it accumulates launches, algorithmic FLOPs and the event-measured duration.
 struct Profiler {
-    static const int kFamilies = 6;  // conv variants 0..2, wgrad/gram 3, conv variants 3..4 -> 4..5
+    static const int kFamilies = 7;  // conv variants 0..2, wgrad/gram 3, conv variants 3..4 -> 4..5, Winograd conv 6
     struct Rec { hipEvent_t a, b; int fam; double flops; };
     Rec* recs = nullptr;
     int n = 0, cap = 0;

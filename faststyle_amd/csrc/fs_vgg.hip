@@ -26,11 +26,25 @@ static inline int pool_index(int l) { return l == 1 ? 0 : (l == 3 ? 1 : 2); }
         if (rc_) return rc_; \
     } while (0)
 
-size_t vgg_prepared_floats() {
+// prepared buffer: [flip-transposed filters of every layer (dgrad)] [Winograd-transformed forward filters, layers 1..]
+// [Winograd-transformed flip-transposed filters, layers 1..]; the frozen weights are transformed once (fs_vgg_prepare)
+static size_t flipt_floats() {
     size_t n = 0;
     for (int l = 0; l < FS_VGG_NLAYERS; ++l) n += ((size_t)9 * kCin[l] * kCout[l] + 63) & ~(size_t)63;
     return n;
 }
+static size_t wino_offset(int l, bool dgrad) {  // l >= 1
+    size_t n = flipt_floats();
+    for (int i = 1; i < FS_VGG_NLAYERS; ++i) {
+        const size_t sz = ((size_t)16 * kCin[i] * kCout[i] + 63) & ~(size_t)63;
+        if (i == l && !dgrad) return n;
+        n += sz;
+        if (i == l && dgrad) return n;
+        n += sz;
+    }
+    return n;
+}
+size_t vgg_prepared_floats() { return wino_offset(FS_VGG_NLAYERS, false); }
 static size_t prepared_offset(int l) {
     size_t n = 0;
     for (int i = 0; i < l; ++i) n += ((size_t)9 * kCin[i] * kCout[i] + 63) & ~(size_t)63;
@@ -40,6 +54,10 @@ static size_t prepared_offset(int l) {
 int vgg_prepare(const float* const w[FS_VGG_NLAYERS], float* prepared, hipStream_t s) {
     for (int l = 0; l < FS_VGG_NLAYERS; ++l)
         FS_TRY(wt_flip_transpose(w[l], prepared + prepared_offset(l), 3, 3, kCin[l], kCout[l], s));
+    for (int l = 1; l < FS_VGG_NLAYERS; ++l) {
+        FS_TRY(wt_wino(w[l], prepared + wino_offset(l, false), kCin[l], kCout[l], s));
+        FS_TRY(wt_wino(prepared + prepared_offset(l), prepared + wino_offset(l, true), kCout[l], kCin[l], s));  // [3][3][Cout][Cin]
+    }
     return 0;
 }
 
@@ -139,11 +157,12 @@ void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, 
     L->total_floats = b.off;
 }
 
-static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, const float* bias, const float* ab, float* y,
-                    float* split_ws, size_t split_ws_floats, hipStream_t s) {
+static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, const float* w_wino, const float* bias, const float* ab,
+                    float* y, float* split_ws, size_t split_ws_floats, hipStream_t s) {
     ConvArgs a{};
     a.x = x;
     a.w = w;
+    a.w_wino = w_wino;
     a.y = y;
     a.N = N;
     a.H = a.Ho = H;
@@ -166,13 +185,15 @@ static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, 
 }
 
 // forward through layers [0..lmax]; samples [0,N) go all the way, [N,NB) stop after cmax
+// prepared: the buffer of fs_vgg_prepare (Winograd-transformed filters) or nullptr (direct convolutions only)
 static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
-                       float* ws, hipStream_t s) {
+                       const float* prepared, float* ws, hipStream_t s) {
     FS_TRY(vgg_consts(ws + L.ab, s));
     const float* src = ws + L.xin;
     for (int l = 0; l <= L.lmax; ++l) {
         const int nb = l <= L.cmax ? L.NB : L.N;
-        FS_TRY(vgg_conv(src, nb, L.Hl[l], L.Wl[l], l, w[l], b[l], ws + L.ab, ws + L.act[l], ws + L.splitws, L.splitws_floats, s));
+        FS_TRY(vgg_conv(src, nb, L.Hl[l], L.Wl[l], l, w[l], (prepared && l >= 1) ? prepared + wino_offset(l, false) : nullptr, b[l],
+                        ws + L.ab, ws + L.act[l], ws + L.splitws, L.splitws_floats, s));
         src = ws + L.act[l];
         if (pool_after(l) && l < L.lmax) {
             FS_TRY(maxpool(ws + L.act[l], ws + L.pool[pool_index(l)], nb, L.Hl[l], L.Wl[l], kCout[l], s));
@@ -197,7 +218,7 @@ int vgg_features(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const
                  int n_layers, const int* layers, float* const* out, float* ws, hipStream_t s) {
     if (hipMemcpyAsync(ws + L.xin, x, (size_t)L.N * L.H * L.W * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return -10;
-    FS_TRY(vgg_forward(L, w, b, ws, s));
+    FS_TRY(vgg_forward(L, w, b, nullptr, ws, s));
     for (int i = 0; i < n_layers; ++i) {
         const int l = layers[i];
         const size_t bytes = (size_t)L.N * L.Hl[l] * L.Wl[l] * kCout[l] * sizeof(float);
@@ -215,7 +236,7 @@ int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], cons
     for (int i = 0; i < cfg.n_style; ++i)
         if (cfg.style_layer[i] > lmax) lmax = cfg.style_layer[i];
     L2.lmax = lmax;
-    FS_TRY(vgg_forward(L2, w, b, ws, s));
+    FS_TRY(vgg_forward(L2, w, b, nullptr, ws, s));
     for (int i = 0; i < cfg.n_style; ++i) FS_TRY(gram_forward(L2, cfg.style_layer[i], ws + L2.act[cfg.style_layer[i]], grams[i], ws, s));
     return 0;
 }
@@ -230,7 +251,7 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         hipMemcpyAsync(ws + L.xin + img, content, img * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return -10;
     if (hipMemsetAsync(losses, 0, 4 * sizeof(float), s) != hipSuccess) return -10;
-    FS_TRY(vgg_forward(L, w, b, ws, s));
+    FS_TRY(vgg_forward(L, w, b, prepared, ws, s));
 
     // ---- losses ----
     for (int i = 0; i < cfg.n_style; ++i) {
@@ -296,6 +317,7 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         ConvArgs a{};
         a.x = pre_cur;
         a.w = prepared + prepared_offset(l);
+        a.w_wino = l >= 1 ? prepared + wino_offset(l, true) : nullptr;
         a.N = N;
         a.H = a.Ho = H;
         a.W = a.Wo = W;

@@ -1,0 +1,329 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix cores: the 3x3 stride-1 SAME convolutions of VGG16
+// (reference libs/vgg16.py:36-220, forward, and their input gradients in the training step).
+//
+//   Y = A^T [ (G g G^T) . (B^T d B) ] A        (Lavin & Gray; cross-correlation form, as tf.nn.conv2d)
+//
+// A 4x4 input tile d (stride 2) yields a 2x2 output tile from 16 element-wise products instead of 36
+// multiply-adds; summed over input channels the 16 products are 16 independent GEMMs
+// [tiles x Cin] x [Cin x Cout] -- 2.25x less matrix work than the direct form, still fp32 throughout (the
+// transforms only add, subtract and halve).  It is NOT bit-identical to the fmaf chain of the direct kernel:
+// rounding differs at the 1e-7 level (tests hold both paths to the same tolerance against the fp64 oracle).
+//
+// Mapping.  512 threads (8 waves, two per SIMD).  A workgroup owns 8x8 tiles (16x16 output pixels) x 64 output
+// channels and walks the input channels in chunks of 8:
+//   * the 18x18 input patch of the chunk is staged in LDS ([pixel][8+1]), one thread transforms one (tile, channel)
+//     4x4 block into V[16][64 tiles][8+1];
+//   * the pre-transformed filter chunk U[16][8][64] (fs::wt_wino, built once per weight set) is staged beside it;
+//   * wave w multiplies positions 2w and 2w+1: M = 64 tiles (2 MFMA row blocks), N = 64 channels (2 column blocks),
+//     K = the chunk -- 8 accumulator blocks of v_mfma_f32_32x32x2_f32 per wave, 32 MFMAs per chunk and wave;
+//   * the next chunk's global loads are in flight during the sweep (registers), two barriers per chunk;
+//   * epilogue: the 16 position planes are exchanged through LDS 16 channels at a time, one thread applies
+//     A^T . A to a (tile, channel) pair and stores the 2x2 pixels (bias / ReLU / consumer mask, or raw split-K partials).
+#include "fs_kernels.h"
+
+#include <cstdlib>
+
+namespace fs {
+
+namespace {
+constexpr int kTT = 8;              // tiles per side of a workgroup block
+constexpr int kPT = 2 * kTT + 2;    // patch side (18)
+constexpr int kCC = 8;              // input channels per chunk
+constexpr int kPS = kCC + 1;        // LDS pitch of patch pixels and of V rows
+constexpr int kBN = 64;             // output channels per workgroup
+constexpr int kNT = kTT * kTT;      // tiles per workgroup (64)
+constexpr int kPatchFloats = (kPT * kPT * kPS + 7) & ~7;   // 2920 (+4 slack used as the zero sink)
+constexpr int kVFloats = 16 * kNT * kPS;                   // 9216
+constexpr int kUFloats = 16 * kCC * kBN;                   // 8192
+constexpr int kMPitch = 17;                                // exchange buffer [16][64][16+1] == kVFloats + kUFloats
+}  // namespace
+
+// U[pos][ci][co] = (G g G^T)[pos] for g = w[:, :, ci, co]   (w HWIO [3][3][Cin][Cout])
+__global__ __launch_bounds__(256) void wt_wino_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t cc = (size_t)Cin * Cout;
+    if (i >= cc) return;
+    float g[3][3], t[4][3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) g[kh][kw] = w[(size_t)(kh * 3 + kw) * cc + i];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        t[0][kw] = g[0][kw];
+        t[1][kw] = 0.5f * (g[0][kw] + g[1][kw] + g[2][kw]);
+        t[2][kw] = 0.5f * (g[0][kw] - g[1][kw] + g[2][kw]);
+        t[3][kw] = g[2][kw];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        U[(size_t)(r * 4 + 0) * cc + i] = t[r][0];
+        U[(size_t)(r * 4 + 1) * cc + i] = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
+        U[(size_t)(r * 4 + 2) * cc + i] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
+        U[(size_t)(r * 4 + 3) * cc + i] = t[r][2];
+    }
+}
+
+int wt_wino(const float* w, float* U, int Cin, int Cout, hipStream_t s) {
+    const size_t cc = (size_t)Cin * Cout;
+    hipLaunchKernelGGL(wt_wino_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, w, U, Cin, Cout);
+    return 0;
+}
+
+__global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* patch = smem;
+    float* Vl = smem + kPatchFloats;
+    float* Ul = Vl + kVFloats;
+    const ConvPlan& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 31, kq = lane >> 5;
+    auto fdiv = [](int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); };
+    const int blocks = p.tiles_y * p.tiles_x;
+    const int n = __builtin_amdgcn_readfirstlane(fdiv((int)blockIdx.x, 1.0f / (float)blocks));
+    const int br = (int)blockIdx.x - n * blocks;
+    const int byi = __builtin_amdgcn_readfirstlane(fdiv(br, 1.0f / (float)p.tiles_x));
+    const int oy0 = byi * 2 * kTT, ox0 = (br - byi * p.tiles_x) * 2 * kTT;   // first output pixel of the block
+    const int co0 = (int)blockIdx.y * kBN;
+    auto uniform_ptr = [](const float* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    };
+    const float* xn = uniform_ptr(a.x + (size_t)n * a.H * a.W * a.Cin);
+    const float* ub = uniform_ptr(a.w_wino);
+    const unsigned x_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * a.Cin) * 4u);
+    const unsigned u_bytes = __builtin_amdgcn_readfirstlane((unsigned)(16 * a.Cin * a.Cout) * 4u);
+    constexpr unsigned kOOB = 0x80000000u;
+
+    // ---- staging descriptors (chunk-invariant) ----
+    // patch: 18*18 pixels x 2 float4 = 648 elements, <= 2 per thread; zero padding / unowned -> kOOB (loads zeros)
+    unsigned gvo[2];
+    int pdst[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * 512;
+        gvo[i] = kOOB;
+        pdst[i] = kPT * kPT * kPS;  // slack
+        if (e < kPT * kPT * 2) {
+            const int pix = e >> 1, c4 = e & 1;
+            const int py = fdiv(pix, 1.0f / (float)kPT), px = pix - py * kPT;
+            const int sy = oy0 - 1 + py, sx = ox0 - 1 + px;
+            if (sy >= 0 && sy < a.H && sx >= 0 && sx < a.W) gvo[i] = (unsigned)((sy * a.W + sx) * a.Cin + c4 * 4) * 4u;
+            pdst[i] = pix * kPS + c4 * 4;
+        }
+    }
+    // filter: 16 positions x 8 rows x 16 float4 = 2048 elements, 4 per thread; LDS position = element index
+    unsigned uvo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * 512;
+        const int pos = e >> 7, k = (e >> 4) & 7, c4 = e & 15;
+        uvo[i] = (unsigned)((pos * a.Cin + k) * a.Cout + co0 + c4 * 4) * 4u;
+    }
+    float4 pv[2], uv[4];
+    auto issue = [&](int chunk) {
+        const int ci0 = chunk * kCC;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(xn)), 0, x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(ub)), 0, u_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, gvo[i], ci0 * 4, 0));
+        const int uso = ci0 * a.Cout * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) uv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, uvo[i], uso, 0));
+    };
+    auto commit_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float* d = patch + pdst[i];
+            d[0] = pv[i].x;
+            d[1] = pv[i].y;
+            d[2] = pv[i].z;
+            d[3] = pv[i].w;
+        }
+    };
+    auto commit_filter = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(Ul + (tid + i * 512) * 4) = uv[i];
+    };
+    // input transform: thread = (tile, channel of the chunk);  V = B^T d B
+    const int tt = tid >> 3, tk = tid & 7;
+    const int tty = tt >> 3, ttx = tt & 7;
+    auto transform = [&]() {
+        const float* src = patch + ((2 * tty) * kPT + 2 * ttx) * kPS + tk;
+        float d[4][4], r[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[i][j] = src[(i * kPT + j) * kPS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // B^T d  (rows)
+            r[0][j] = d[0][j] - d[2][j];
+            r[1][j] = d[1][j] + d[2][j];
+            r[2][j] = d[2][j] - d[1][j];
+            r[3][j] = d[1][j] - d[3][j];
+        }
+        float* dst = Vl + tt * kPS + tk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // (.) B  (columns)
+            dst[(i * 4 + 0) * kNT * kPS] = r[i][0] - r[i][2];
+            dst[(i * 4 + 1) * kNT * kPS] = r[i][1] + r[i][2];
+            dst[(i * 4 + 2) * kNT * kPS] = r[i][2] - r[i][1];
+            dst[(i * 4 + 3) * kNT * kPS] = r[i][1] - r[i][3];
+        }
+    };
+
+    f32x16 acc[2][2][2];  // [position of the wave][tile block][channel block]
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pp][m][nn][r] = 0.f;
+
+    auto sweep = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < kCC / 2; ++ks) {
+            const int k = ks * 2 + kq;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int pos = wave * 2 + pp;
+                const float* pa = Vl + (pos * kNT + lm) * kPS + k;
+                const float* pb = Ul + (pos * kCC + k) * kBN + lm;
+                const float a0 = pa[0], a1 = pa[32 * kPS];
+                const float b0 = pb[0], b1 = pb[32];
+                acc[pp][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[pp][0][0], 0, 0, 0);
+                acc[pp][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[pp][0][1], 0, 0, 0);
+                acc[pp][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[pp][1][0], 0, 0, 0);
+                acc[pp][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[pp][1][1], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nchunks = a.Cin / kCC;
+    const int cbeg = __builtin_amdgcn_readfirstlane(p.ksplit > 1 ? (int)blockIdx.z * nchunks / p.ksplit : 0);
+    const int cend = __builtin_amdgcn_readfirstlane(p.ksplit > 1 ? ((int)blockIdx.z + 1) * nchunks / p.ksplit : nchunks);
+    issue(cbeg);
+    commit_patch();
+    __syncthreads();
+    transform();
+    commit_filter();
+    __syncthreads();
+    for (int chunk = cbeg; chunk < cend; ++chunk) {
+        const bool more = chunk + 1 < cend;
+        if (more) issue(chunk + 1);
+        sweep();
+        if (more) commit_patch();   // the sweep does not read the patch
+        __syncthreads();            // every wave is done with V and U of this chunk
+        if (more) {
+            transform();
+            commit_filter();
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: exchange the 16 position planes 16 channels at a time, output transform, store ----
+    float* Ml = Vl;  // [16][64 tiles][16 + 1]
+    const float* bias = a.bias;
+    const bool relu_out = a.out_relu != 0;
+    float* yn = a.y + ((size_t)n + (p.ksplit > 1 ? (size_t)blockIdx.z * a.N : 0)) * a.Ho * a.Wo * a.Cout;
+    const float* msn = a.mask_src ? a.mask_src + (size_t)n * a.Ho * a.Wo * a.Cout : nullptr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // accumulator element r of lane l: tile row (r&3) + 8*(r>>2) + 4*kq of its block, channel lm of its block
+        if ((lm >> 4) == (q & 1)) {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int t = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+                        Ml[((wave * 2 + pp) * kNT + t) * kMPitch + (lm & 15)] = acc[pp][m][q >> 1][r];
+                    }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * 512;
+            const int c16 = e & 15, t = e >> 4;
+            const int ty = t >> 3, tx = t & 7;
+            float mm[4][4];
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) mm[pos >> 2][pos & 3] = Ml[(pos * kNT + t) * kMPitch + c16];
+            float s[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {   // A^T M
+                s[0][j] = mm[0][j] + mm[1][j] + mm[2][j];
+                s[1][j] = mm[1][j] - mm[2][j] - mm[3][j];
+            }
+            const int co = co0 + q * 16 + c16;
+            const float bs = bias ? bias[co] : 0.f;
+#pragma unroll
+            for (int ai = 0; ai < 2; ++ai) {
+                const float y0 = s[ai][0] + s[ai][1] + s[ai][2];
+                const float y1 = s[ai][1] - s[ai][2] - s[ai][3];
+                const int oy = oy0 + 2 * ty + ai;
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi) {
+                    const int ox = ox0 + 2 * tx + bi;
+                    if (oy < a.Ho && ox < a.Wo) {
+                        const int o = (oy * a.Wo + ox) * a.Cout + co;
+                        float v = (bi ? y1 : y0) + bs;
+                        v = relu_out ? fmaxf(v, 0.f) : v;
+                        if (msn) v = msn[o] > 0.f ? v : 0.f;
+                        yn[o] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+bool wino_eligible(const ConvArgs& a) {
+    return a.w_wino && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_t == 1 && a.pad_l == 1 && a.src_mode == SRC_PLAIN &&
+           a.Ho == a.H && a.Wo == a.W && a.Cin % kCC == 0 && a.Cout % kBN == 0 && !a.stats && !a.shuffle && !a.add_src &&
+           !a.in_a && a.w_nstride == 0 && (a.dil_x <= 1);
+}
+
+// plan: 16x16-pixel blocks; split the channel chunks over blockIdx.z while the launch cannot fill the CUs (one
+// workgroup of 8 waves per CU) and scratch for the partials is available
+void wino_plan(const ConvArgs& a, ConvPlan* out) {
+    ConvPlan p{};
+    p.variant = 5;
+    p.BN = kBN;
+    p.CC = kCC;
+    p.TH = p.TW = 2 * kTT;
+    p.tiles_y = cdiv(a.Ho, 2 * kTT);
+    p.tiles_x = cdiv(a.Wo, 2 * kTT);
+    p.lds_bytes = 4 * (kPatchFloats + kVFloats + kUFloats);
+    p.ksplit = 1;
+    const long wgs = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / kBN);
+    const int nchunks = a.Cin / kCC;
+    if (a.split_ws) {
+        int ks = 1;
+        while (ks < 4 && wgs * ks < 256 && nchunks / (ks * 2) >= 8 &&
+               (size_t)(ks * 2) * a.N * a.Ho * a.Wo * a.Cout <= a.split_ws_floats)
+            ks *= 2;
+        p.ksplit = ks;
+    }
+    *out = p;
+}
+
+int wino_launch(const ConvArgs& a, hipStream_t s) {
+    const ConvPlan& p = a.p;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)(a.N * p.tiles_y * p.tiles_x), (unsigned)(a.Cout / kBN), (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
+    hipLaunchKernelGGL(wino_conv_kernel, grid, dim3(512), (size_t)p.lds_bytes, s, a);
+    return 0;
+}
+
+}  // namespace fs

@@ -34,9 +34,9 @@ const char* fs_version(void);
 /* ---- measurement hook (bench.py): HIP events around every MFMA-kernel launch on the ctx stream.
  * out[f*3+{0,1,2}] = {launches, algorithmic FLOPs, milliseconds} for kernel family f:
  * 0 conv_igemm<32,2,2>, 1 conv_igemm<32,2,1>, 2 conv_igemm<16,4,1>, 3 conv_wgrad (incl. Gram),
- * 4 conv_igemm<32,1,2>, 5 conv_igemm<32,1,1>. */
+ * 4 conv_igemm<32,1,2>, 5 conv_igemm<32,1,1>, 6 wino_conv (Winograd F(2x2,3x3); FLOPs = those executed). */
 int fs_profile_begin(fs_ctx* ctx);
-int fs_profile_end(fs_ctx* ctx, double out[18]);
+int fs_profile_end(fs_ctx* ctx, double out[21]);
 
 /* ---- image-transform net: reference im_transf_net.py:14-75 (create_net) ------------------ */
 #define FS_TNET_NPARAMS 424102 /* 48 fp32 tensors, sorted-key (= checkpoint) order */

@@ -52,6 +52,36 @@ def test_conv2d_matches_oracle(eng, case):
     assert rel(y, want) < TOL
 
 
+WINO_CASES = [
+    # name, x shape, Cout, bias/relu epilogue
+    ("one_block", (1, 16, 16, 16), 64, False),
+    ("ragged_2img", (2, 21, 37, 8), 64, True),         # odd extents: partial 16x16 blocks, odd last tile row/column
+    ("two_coblocks", (1, 9, 33, 24), 128, True),
+    ("tiny", (1, 3, 1, 8), 64, False),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
+def test_winograd_conv_matches_oracle(eng, case, monkeypatch):
+    """wino_conv_kernel (F(2x2,3x3), the VGG 3x3 convs of the training step) through the conv2d C-ABI test hook:
+    same fp64 oracle and tolerance as the direct kernel; also checked against the direct kernel itself."""
+    _, xs, cout, epi = case
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(xs).astype(np.float32)
+    w = (rng.standard_normal((3, 3, xs[3], cout)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32) if epi else None
+    kw = dict(bias=up(eng, bias), out_relu=1) if epi else {}
+    direct = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME", **kw))
+    monkeypatch.setenv("FS_CONV2D_WINO", "1")
+    y = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME", **kw))
+    want = nnops.conv2d(x.astype(np.float64), w.astype(np.float64), 1, "SAME")
+    if epi:
+        want = np.maximum(want + bias, 0.0)
+    assert y.shape == want.shape
+    assert rel(y, want) < TOL
+    assert rel(y, direct) < TOL and not np.array_equal(y, direct)      # really the other algorithm
+
+
 def test_conv_reflect_pad_fused(eng):
     rng = np.random.default_rng(2)
     x = rng.uniform(0, 255, (1, 45, 50, 3)).astype(np.float32)
