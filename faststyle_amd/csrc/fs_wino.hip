@@ -35,7 +35,6 @@ constexpr int kNT = kTT * kTT;      // tiles per workgroup (64)
 constexpr int kPatchFloats = (kPT * kPT * kPS + 7) & ~7;   // 2920 (+4 slack used as the zero sink)
 constexpr int kVFloats = 16 * kNT * kPS;                   // 9216
 constexpr int kUFloats = 16 * kCC * kBN;                   // 8192
-constexpr int kMPitch = 17;                                // exchange buffer [16][64][16+1] == kVFloats + kUFloats
 }  // namespace
 
 // U[pos][ci][co] = (G g G^T)[pos] for g = w[:, :, ci, co]   (w HWIO [3][3][Cin][Cout])
@@ -70,11 +69,21 @@ int wt_wino(const float* w, float* U, int Cin, int Cout, hipStream_t s) {
     return 0;
 }
 
+#ifdef FS_CONV_TRACE
+extern __device__ long long g_conv_trace[4096 * 8];   // fs_conv.hip (tools/conv_trace.py)
+#define FS_WINO_NOW() ((long long)__builtin_readcyclecounter())
+#endif
+
 __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
     HIP_DYNAMIC_SHARED(float, smem)
-    float* patch = smem;
-    float* Vl = smem + kPatchFloats;
-    float* Ul = Vl + kVFloats;
+#ifdef FS_CONV_TRACE
+    const long long tr_t0 = FS_WINO_NOW();
+    long long tr_sweep = 0, tr_commit = 0, tr_bar = 0;
+#endif
+    // two stages each of patch | V | U (162,624 bytes of the CU's 160 KiB); the epilogue's exchange buffer overlays V
+    float* patch0 = smem;
+    float* Vl0 = smem + 2 * kPatchFloats;
+    float* Ul0 = Vl0 + 2 * kVFloats;
     const ConvPlan& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lm = lane & 31, kq = lane >> 5;
@@ -122,17 +131,18 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
         uvo[i] = (unsigned)((pos * a.Cin + k) * a.Cout + co0 + c4 * 4) * 4u;
     }
     float4 pv[2], uv[4];
-    auto issue = [&](int chunk) {
-        const int ci0 = chunk * kCC;
+    auto issue_patch = [&](int chunk) {
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(xn)), 0, x_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(ub)), 0, u_bytes, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, gvo[i], ci0 * 4, 0));
-        const int uso = ci0 * a.Cout * 4;
+        for (int i = 0; i < 2; ++i) pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, gvo[i], chunk * kCC * 4, 0));
+    };
+    auto issue_filter = [&](int chunk) {
+        const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(ub)), 0, u_bytes, 0x00020000);
+        const int uso = chunk * kCC * a.Cout * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) uv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, uvo[i], uso, 0));
     };
-    auto commit_patch = [&]() {
+    auto commit_patch = [&](float* patch) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float* d = patch + pdst[i];
@@ -142,14 +152,14 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
             d[3] = pv[i].w;
         }
     };
-    auto commit_filter = [&]() {
+    auto commit_filter = [&](float* Ul) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(Ul + (tid + i * 512) * 4) = uv[i];
     };
     // input transform: thread = (tile, channel of the chunk);  V = B^T d B
     const int tt = tid >> 3, tk = tid & 7;
     const int tty = tt >> 3, ttx = tt & 7;
-    auto transform = [&]() {
+    auto transform = [&](const float* patch, float* Vl) {
         const float* src = patch + ((2 * tty) * kPT + 2 * ttx) * kPS + tk;
         float d[4][4], r[4][4];
 #pragma unroll
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[pp][m][nn][r] = 0.f;
 
-    auto sweep = [&]() {
+    auto sweep = [&](const float* Vl, const float* Ul) {
 #pragma unroll
         for (int ks = 0; ks < kCC / 2; ++ks) {
             const int k = ks * 2 + kq;
@@ -205,61 +215,101 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
     const int nchunks = a.Cin / kCC;
     const int cbeg = __builtin_amdgcn_readfirstlane(p.ksplit > 1 ? (int)blockIdx.z * nchunks / p.ksplit : 0);
     const int cend = __builtin_amdgcn_readfirstlane(p.ksplit > 1 ? ((int)blockIdx.z + 1) * nchunks / p.ksplit : nchunks);
-    issue(cbeg);
-    commit_patch();
-    __syncthreads();
-    transform();
-    commit_filter();
-    __syncthreads();
-    for (int chunk = cbeg; chunk < cend; ++chunk) {
-        const bool more = chunk + 1 < cend;
-        if (more) issue(chunk + 1);
-        sweep();
-        if (more) commit_patch();   // the sweep does not read the patch
-        __syncthreads();            // every wave is done with V and U of this chunk
-        if (more) {
-            transform();
-            commit_filter();
-        }
-        __syncthreads();
+    // Pipeline.  Chunk j is multiplied out of stage j&1 while chunk j+1 is prepared (patch -> V transform, filter
+    // commit) into the other stage and the global loads of chunk j+2 are in flight; one barrier per chunk.
+    // (Measured: letting the two waves of a SIMD do "multiply" and "prepare" in opposite order changes nothing --
+    // with two waves per SIMD, MFMA issue and the other wave's VALU work do not overlap; what counts is the number
+    // of non-MFMA instructions per chunk.)
+    const int nloc = cend - cbeg;
+    issue_patch(cbeg);
+    issue_filter(cbeg);
+    commit_patch(patch0);
+    commit_filter(Ul0);
+    if (nloc > 1) {
+        issue_patch(cbeg + 1);
+        issue_filter(cbeg + 1);   // stays in registers until the first iteration prepares chunk 1
     }
+    __syncthreads();
+    transform(patch0, Vl0);
+    if (nloc > 1) commit_patch(patch0 + kPatchFloats);
+    __syncthreads();
+#ifdef FS_CONV_TRACE
+    const long long tr_pro = FS_WINO_NOW();
+#endif
+    for (int j = 0; j < nloc; ++j) {
+        const int cur = j & 1, nxt = cur ^ 1;
+        const bool has1 = j + 1 < nloc, has2 = j + 2 < nloc;
+        const float* Vc = Vl0 + cur * kVFloats;
+        const float* Uc = Ul0 + cur * kUFloats;
+        float* Vn = Vl0 + nxt * kVFloats;
+        float* Un = Ul0 + nxt * kUFloats;
+#ifdef FS_CONV_TRACE
+        const long long q0 = FS_WINO_NOW();
+#endif
+        if (has2) issue_patch(cbeg + j + 2);
+        sweep(Vc, Uc);
+#ifdef FS_CONV_TRACE
+        tr_sweep += FS_WINO_NOW() - q0;
+#endif
+        if (has1) {
+            transform(patch0 + nxt * kPatchFloats, Vn);
+            commit_filter(Un);
+        }
+        if (has2) {
+            issue_filter(cbeg + j + 2);
+            commit_patch(patch0 + cur * kPatchFloats);
+        }
+#ifdef FS_CONV_TRACE
+        const long long q4 = FS_WINO_NOW();
+#endif
+        __syncthreads();
+#ifdef FS_CONV_TRACE
+        const long long q5 = FS_WINO_NOW();
+        tr_commit += q4 - q0;
+        tr_bar += q5 - q4;
+#endif
+    }
+#ifdef FS_CONV_TRACE
+    tr_commit -= tr_sweep;
+    const long long tr_main = FS_WINO_NOW();
+#endif
 
-    // ---- epilogue: exchange the 16 position planes 16 channels at a time, output transform, store ----
-    float* Ml = Vl;  // [16][64 tiles][16 + 1]
+    // ---- epilogue: exchange the 16 position planes through LDS 32 channels at a time ([16][64 tiles][32+1] floats
+    // over the V and U stages), output transform A^T M A per (tile, channel), store ----
+    constexpr int kMP = 33;
+    float* Ml = Vl0;
     const float* bias = a.bias;
     const bool relu_out = a.out_relu != 0;
     float* yn = a.y + ((size_t)n + (p.ksplit > 1 ? (size_t)blockIdx.z * a.N : 0)) * a.Ho * a.Wo * a.Cout;
     const float* msn = a.mask_src ? a.mask_src + (size_t)n * a.Ho * a.Wo * a.Cout : nullptr;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        // accumulator element r of lane l: tile row (r&3) + 8*(r>>2) + 4*kq of its block, channel lm of its block
-        if ((lm >> 4) == (q & 1)) {
+    for (int q = 0; q < 2; ++q) {
+        // accumulator element r of lane l: tile row (r&3) + 8*(r>>2) + 4*kq of its block, channel lm of block q
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp)
+        for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int t = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
-                        Ml[((wave * 2 + pp) * kNT + t) * kMPitch + (lm & 15)] = acc[pp][m][q >> 1][r];
-                    }
-        }
+                for (int r = 0; r < 16; ++r) {
+                    const int t = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+                    Ml[((wave * 2 + pp) * kNT + t) * kMP + lm] = acc[pp][m][q][r];
+                }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int e = tid + i * 512;
-            const int c16 = e & 15, t = e >> 4;
+            const int c32 = e & 31, t = e >> 5;
             const int ty = t >> 3, tx = t & 7;
             float mm[4][4];
 #pragma unroll
-            for (int pos = 0; pos < 16; ++pos) mm[pos >> 2][pos & 3] = Ml[(pos * kNT + t) * kMPitch + c16];
+            for (int pos = 0; pos < 16; ++pos) mm[pos >> 2][pos & 3] = Ml[(pos * kNT + t) * kMP + c32];
             float s[2][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {   // A^T M
                 s[0][j] = mm[0][j] + mm[1][j] + mm[2][j];
                 s[1][j] = mm[1][j] - mm[2][j] - mm[3][j];
             }
-            const int co = co0 + q * 16 + c16;
+            const int co = co0 + q * 32 + c32;
             const float bs = bias ? bias[co] : 0.f;
 #pragma unroll
             for (int ai = 0; ai < 2; ++ai) {
@@ -279,8 +329,25 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
                 }
             }
         }
-        __syncthreads();
+        if (q == 0) __syncthreads();
     }
+#ifdef FS_CONV_TRACE
+    {
+        const long long tr_end = FS_WINO_NOW();
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (tid == 0 && lin < 4096) {
+            long long* t = g_conv_trace + lin * 8;
+            t[0] = tr_t0;
+            t[1] = tr_pro - tr_t0;
+            t[2] = tr_sweep;
+            t[3] = tr_commit;
+            t[4] = tr_bar;
+            t[5] = tr_end - tr_main;
+            t[6] = tr_end;
+            t[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        }
+    }
+#endif
 }
 
 bool wino_eligible(const ConvArgs& a) {
@@ -299,7 +366,7 @@ void wino_plan(const ConvArgs& a, ConvPlan* out) {
     p.TH = p.TW = 2 * kTT;
     p.tiles_y = cdiv(a.Ho, 2 * kTT);
     p.tiles_x = cdiv(a.Wo, 2 * kTT);
-    p.lds_bytes = 4 * (kPatchFloats + kVFloats + kUFloats);
+    p.lds_bytes = 4 * 2 * (kPatchFloats + kVFloats + kUFloats);
     p.ksplit = 1;
     const long wgs = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / kBN);
     const int nchunks = a.Cin / kCC;
