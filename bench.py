@@ -248,12 +248,16 @@ def main():
                                    "conv3_3 content loss, resize-conv transform net, TF-Adam" % B,
                        "global_batch": B * world, "image_size": [S, S], "parallelism": "dp%d" % world,
                        "style_image": "starry_night_crop.jpg 640x938"},
-            "roofline": {"bound": "mfma", "kernel": names[di] + " (fp32 MFMA implicit-GEMM conv)",
+            "roofline": {"bound": "mfma",
+                         "kernel": names[di] + (" (fp32 MFMA, Winograd F(2x2,3x3) 3x3 conv; achieved = FLOPs EXECUTED, "
+                                                "16 products per 2x2 outputs instead of 36)" if di == 6
+                                                else " (fp32 MFMA implicit-GEMM conv)"),
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE, KiB counters)", "traffic_source": traffic_src,
                          "timed_with": "HIP events on the launch stream, " + ("eager pass of the same K steps right after "
                                        "the hipGraph-replayed timed region" if graphed else "inside the timed region"),
+                         "direct_form_equivalent_tflops": round(achieved * 2.25, 2) if di == 6 else None,
                          "launches_per_step": round(dom[0] / args.steps, 1),
                          "avg_launch_us": round(1e3 * dom[2] / dom[0], 2) if dom[0] else None,
                          "all_mfma_kernels_tflops": round(mfma_flops / (mfma_ms * 1e-3) / 1e12, 2) if mfma_ms else None,

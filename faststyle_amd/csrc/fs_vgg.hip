@@ -11,6 +11,8 @@
 //   with per-sample filters) -> 3x3 dgrad conv with the pre-flipped filters -> ... -> dy (+ beta*dTV)
 #include "fs_vgg.h"
 
+#include <cstdlib>
+
 #include <cstring>
 
 namespace fs {
@@ -45,6 +47,12 @@ static size_t wino_offset(int l, bool dgrad) {  // l >= 1
     return n;
 }
 size_t vgg_prepared_floats() { return wino_offset(FS_VGG_NLAYERS, false); }
+// debugging aid: FS_VGG_WINO_MASK selects the layers that may take the Winograd kernel (bit l: forward of layer l,
+// bit 16+l: its input gradient); default all
+static bool wino_layer_on(int bit) {
+    const char* v = getenv("FS_VGG_WINO_MASK");
+    return !v || ((strtoul(v, nullptr, 0) >> bit) & 1u);
+}
 static size_t prepared_offset(int l) {
     size_t n = 0;
     for (int i = 0; i < l; ++i) n += ((size_t)9 * kCin[i] * kCout[i] + 63) & ~(size_t)63;
@@ -192,7 +200,7 @@ static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS],
     const float* src = ws + L.xin;
     for (int l = 0; l <= L.lmax; ++l) {
         const int nb = l <= L.cmax ? L.NB : L.N;
-        FS_TRY(vgg_conv(src, nb, L.Hl[l], L.Wl[l], l, w[l], (prepared && l >= 1) ? prepared + wino_offset(l, false) : nullptr, b[l],
+        FS_TRY(vgg_conv(src, nb, L.Hl[l], L.Wl[l], l, w[l], (prepared && l >= 1 && wino_layer_on(l)) ? prepared + wino_offset(l, false) : nullptr, b[l],
                         ws + L.ab, ws + L.act[l], ws + L.splitws, L.splitws_floats, s));
         src = ws + L.act[l];
         if (pool_after(l) && l < L.lmax) {
@@ -317,7 +325,7 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         ConvArgs a{};
         a.x = pre_cur;
         a.w = prepared + prepared_offset(l);
-        a.w_wino = l >= 1 ? prepared + wino_offset(l, true) : nullptr;
+        a.w_wino = (l >= 1 && wino_layer_on(16 + l)) ? prepared + wino_offset(l, true) : nullptr;
         a.N = N;
         a.H = a.Ho = H;
         a.W = a.Wo = W;

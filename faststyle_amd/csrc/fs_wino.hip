@@ -370,9 +370,10 @@ void wino_plan(const ConvArgs& a, ConvPlan* out) {
     p.ksplit = 1;
     const long wgs = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / kBN);
     const int nchunks = a.Cin / kCC;
+    const int max_ks = getenv("FS_WINO_KSPLIT") ? atoi(getenv("FS_WINO_KSPLIT")) : 4;  // tuning / debugging aid
     if (a.split_ws) {
         int ks = 1;
-        while (ks < 4 && wgs * ks < 256 && nchunks / (ks * 2) >= 8 &&
+        while (ks < max_ks && wgs * ks < 256 && nchunks / (ks * 2) >= 8 &&
                (size_t)(ks * 2) * a.N * a.Ho * a.Wo * a.Cout <= a.split_ws_floats)
             ks *= 2;
         p.ksplit = ks;
