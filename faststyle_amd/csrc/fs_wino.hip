@@ -193,22 +193,29 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[pp][m][nn][r] = 0.f;
 
+    // 8 groups (k-step, position) of 4 MFMAs each; the LDS reads of group g+1 are issued before the MFMAs of group g
+    // (two register sets), so that a wave does not sit on ds_read latency between matrix instructions
     auto sweep = [&](const float* Vl, const float* Ul) {
+        float av[2][2], bv[2][2];
+        auto load = [&](int g, float (&a2)[2], float (&b2)[2]) {
+            const int ks = g >> 1, pp = g & 1;
+            const int k = ks * 2 + kq, pos = wave * 2 + pp;
+            const float* pa = Vl + (pos * kNT + lm) * kPS + k;
+            const float* pb = Ul + (pos * kCC + k) * kBN + lm;
+            a2[0] = pa[0];
+            a2[1] = pa[32 * kPS];
+            b2[0] = pb[0];
+            b2[1] = pb[32];
+        };
+        load(0, av[0], bv[0]);
 #pragma unroll
-        for (int ks = 0; ks < kCC / 2; ++ks) {
-            const int k = ks * 2 + kq;
-#pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const int pos = wave * 2 + pp;
-                const float* pa = Vl + (pos * kNT + lm) * kPS + k;
-                const float* pb = Ul + (pos * kCC + k) * kBN + lm;
-                const float a0 = pa[0], a1 = pa[32 * kPS];
-                const float b0 = pb[0], b1 = pb[32];
-                acc[pp][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[pp][0][0], 0, 0, 0);
-                acc[pp][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[pp][0][1], 0, 0, 0);
-                acc[pp][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[pp][1][0], 0, 0, 0);
-                acc[pp][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[pp][1][1], 0, 0, 0);
-            }
+        for (int g = 0; g < kCC; ++g) {   // kCC/2 k-steps x 2 positions
+            if (g + 1 < kCC) load(g + 1, av[(g + 1) & 1], bv[(g + 1) & 1]);
+            const int pp = g & 1, c = g & 1;
+            acc[pp][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][0], bv[c][0], acc[pp][0][0], 0, 0, 0);
+            acc[pp][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][0], bv[c][1], acc[pp][0][1], 0, 0, 0);
+            acc[pp][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][1], bv[c][0], acc[pp][1][0], 0, 0, 0);
+            acc[pp][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][1], bv[c][1], acc[pp][1][1], 0, 0, 0);
         }
     };
 
