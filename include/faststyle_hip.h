@@ -67,11 +67,13 @@ int fs_tnet_backward(fs_ctx* ctx, const float* params, const float* x, const flo
 
 /* ---- VGG16 + Gram + losses: reference libs/vgg16.py:36-220, utils.py:66-83, losses.py ------ */
 #define FS_VGG_NLAYERS 10 /* conv1_1 .. conv4_3 (conv5_x is never fetched: train.py:55-59) */
-/* floats needed for the dgrad re-layout of the 10 frozen filters */
+/* floats needed for the derived forms of the 10 frozen filters: flip-transposed (input-gradient convs) and, for
+ * conv1_2 .. conv4_3, Winograd F(2x2,3x3)-transformed [16][Cin][Cout] in both orientations (about 35 M floats) */
 size_t fs_vgg_prepared_floats(void);
 /* w[i], b[i]: conv1_1,conv1_2,conv2_1,...,conv4_3 in the npz convention of vgg16.load_weights
  * (vgg16.py:257-266: HWIO [3,3,Cin,Cout] kernels, [Cout] biases).  Fills `prepared` with the
- * flipped/transposed filters the input-gradient convs use (VGG is frozen: train.py:198-199). */
+ * flipped/transposed filters the input-gradient convs use and the Winograd-transformed filters of the 3x3
+ * stride-1 convs (VGG is frozen: train.py:198-199, so this runs once per weight set). */
 int fs_vgg_prepare(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], float* prepared);
 
 typedef struct {
