@@ -22,6 +22,7 @@
 #include "fs_kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace fs {
 
@@ -222,6 +223,83 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
     const int nchunks = a.Cin / kCC;
     const int cbeg = __builtin_amdgcn_readfirstlane(p.ksplit > 1 ? (int)blockIdx.z * nchunks / p.ksplit : 0);
     const int cend = __builtin_amdgcn_readfirstlane(p.ksplit > 1 ? ((int)blockIdx.z + 1) * nchunks / p.ksplit : nchunks);
+    // sweep(chunk j) with the transform of chunk j+1 threaded through it: the wave's own VALU / LDS instructions issue
+    // in the shadow of its own matrix instructions (another wave's do not: MFMA issue is in order and a streaming wave
+    // leaves its SIMD partner almost no issue slots).  sched_barrier pins the interleaving.
+    auto sweep_fused = [&](auto PREP, const float* Vl, const float* Ul, const float* patch, float* Vn, float* Un) {
+        constexpr bool prep = decltype(PREP)::value;
+        float av[2][2], bv[2][2];
+        auto load_a = [&](int g, float (&a2)[2]) {
+            const int k = (g >> 1) * 2 + kq, pos = wave * 2 + (g & 1);
+            const float* pa = Vl + (pos * kNT + lm) * kPS + k;
+            a2[0] = pa[0];
+            a2[1] = pa[32 * kPS];
+        };
+        auto load_b = [&](int g, float (&b2)[2]) {
+            const int k = (g >> 1) * 2 + kq, pos = wave * 2 + (g & 1);
+            const float* pb = Ul + (pos * kCC + k) * kBN + lm;
+            b2[0] = pb[0];
+            b2[1] = pb[32];
+        };
+        float d[4][4], r[4][4];
+        const float* src = patch + ((2 * tty) * kPT + 2 * ttx) * kPS + tk;
+        float* dst = Vn + tt * kPS + tk;
+        // one slice of the next chunk's preparation per MFMA slot (g = group 0..7, h = 0: after the 3rd MFMA of the group,
+        // h = 1: after the 4th); every slice is a handful of instructions, about what one 64-cycle MFMA covers
+        auto slice = [&](int g, int h) {
+            if (!prep) return;
+            if (g == 0) {                                     // the 4x4 block of the next chunk
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    d[i][2 * h] = src[(i * kPT + 2 * h) * kPS];
+                    d[i][2 * h + 1] = src[(i * kPT + 2 * h + 1) * kPS];
+                }
+            } else if (g == 1) {                              // B^T d (rows), two columns per slice
+#pragma unroll
+                for (int j = 2 * h; j < 2 * h + 2; ++j) {
+                    r[0][j] = d[0][j] - d[2][j];
+                    r[1][j] = d[1][j] + d[2][j];
+                    r[2][j] = d[2][j] - d[1][j];
+                    r[3][j] = d[1][j] - d[3][j];
+                }
+            } else if (g <= 5) {                              // (.) B (columns): row i of positions, two outputs per slice
+                const int i = g - 2;
+                if (h == 0) {
+                    dst[(i * 4 + 0) * kNT * kPS] = r[i][0] - r[i][2];
+                    dst[(i * 4 + 1) * kNT * kPS] = r[i][1] + r[i][2];
+                } else {
+                    dst[(i * 4 + 2) * kNT * kPS] = r[i][2] - r[i][1];
+                    dst[(i * 4 + 3) * kNT * kPS] = r[i][1] - r[i][3];
+                }
+            } else if (g == 6) {                              // the next chunk's filter
+                *reinterpret_cast<float4*>(Un + (tid + (2 * h) * 512) * 4) = uv[2 * h];
+                *reinterpret_cast<float4*>(Un + (tid + (2 * h + 1) * 512) * 4) = uv[2 * h + 1];
+            }
+        };
+        load_a(0, av[0]);
+        load_b(0, bv[0]);
+#pragma unroll
+        for (int g = 0; g < kCC; ++g) {
+            const int pp = g & 1, c = g & 1, nx = (g + 1) & 1;
+            acc[pp][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][0], bv[c][0], acc[pp][0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < kCC) load_a(g + 1, av[nx]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pp][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][0], bv[c][1], acc[pp][0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < kCC) load_b(g + 1, bv[nx]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pp][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][1], bv[c][0], acc[pp][1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            slice(g, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pp][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][1], bv[c][1], acc[pp][1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            slice(g, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     // Pipeline.  Chunk j is multiplied out of stage j&1 while chunk j+1 is prepared (patch -> V transform, filter
     // commit) into the other stage and the global loads of chunk j+2 are in flight; one barrier per chunk.
     // (Measured: letting the two waves of a SIMD do "multiply" and "prepare" in opposite order changes nothing --
@@ -254,14 +332,12 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
         const long long q0 = FS_WINO_NOW();
 #endif
         if (has2) issue_patch(cbeg + j + 2);
-        sweep(Vc, Uc);
+        // (also on the last chunk, where the prepared stage is never read: a second, transform-free instantiation
+        // makes the register allocator copy the 128 accumulators at the join and spill)
+        sweep_fused(std::true_type{}, Vc, Uc, patch0 + nxt * kPatchFloats, Vn, Un);
 #ifdef FS_CONV_TRACE
         tr_sweep += FS_WINO_NOW() - q0;
 #endif
-        if (has1) {
-            transform(patch0 + nxt * kPatchFloats, Vn);
-            commit_filter(Un);
-        }
         if (has2) {
             issue_filter(cbeg + j + 2);
             commit_patch(patch0 + cur * kPatchFloats);

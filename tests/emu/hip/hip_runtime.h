@@ -325,6 +325,7 @@ static inline float fmed3f(float a, float b, float c) {
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 #define __builtin_amdgcn_s_sleep(imm) ((void)0)
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)   /* only ever applied to wave-uniform values */
 
 static inline float __shfl_xor(float v, int mask, int width = 64) { (void)width; return fsemu::shfl_idx(v, fsemu::blk().cur->lane ^ mask); }
