@@ -377,38 +377,52 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
                     const int t = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
                     Ml[((wave * 2 + pp) * kNT + t) * kMP + lm] = acc[pp][m][q][r];
                 }
+        // this thread's 4 (tile, channel) pairs x 2x2 pixels: offsets first, and ALL consumer-mask loads issued before
+        // the barrier (unconditional, clamped to element 0 for pixels outside the image) -- per-element
+        // "load, wait, store" chains would cost a global-memory latency each
+        const int c32 = tid & 31;
+        const int co = co0 + q * 32 + c32;
+        const float bs = bias ? bias[co] : 0.f;
+        int off[4][4];
+        float mk[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = (tid >> 5) + i * 16;
+            const int oy = oy0 + 2 * (t >> 3), ox = ox0 + 2 * (t & 7);
+            const int o00 = (oy * a.Wo + ox) * a.Cout + co;
+            const bool y0 = oy < a.Ho, y1 = oy + 1 < a.Ho, x0 = ox < a.Wo, x1 = ox + 1 < a.Wo;
+            off[i][0] = (y0 && x0) ? o00 : -1;
+            off[i][1] = (y0 && x1) ? o00 + a.Cout : -1;
+            off[i][2] = (y1 && x0) ? o00 + a.Wo * a.Cout : -1;
+            off[i][3] = (y1 && x1) ? o00 + (a.Wo + 1) * a.Cout : -1;
+            if (msn) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mk[i][k] = msn[off[i][k] >= 0 ? off[i][k] : 0];
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int e = tid + i * 512;
-            const int c32 = e & 31, t = e >> 5;
-            const int ty = t >> 3, tx = t & 7;
+            const int t = (tid >> 5) + i * 16;
             float mm[4][4];
 #pragma unroll
             for (int pos = 0; pos < 16; ++pos) mm[pos >> 2][pos & 3] = Ml[(pos * kNT + t) * kMP + c32];
-            float s[2][4];
+            float s4[2][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {   // A^T M
-                s[0][j] = mm[0][j] + mm[1][j] + mm[2][j];
-                s[1][j] = mm[1][j] - mm[2][j] - mm[3][j];
+                s4[0][j] = mm[0][j] + mm[1][j] + mm[2][j];
+                s4[1][j] = mm[1][j] - mm[2][j] - mm[3][j];
             }
-            const int co = co0 + q * 32 + c32;
-            const float bs = bias ? bias[co] : 0.f;
 #pragma unroll
             for (int ai = 0; ai < 2; ++ai) {
-                const float y0 = s[ai][0] + s[ai][1] + s[ai][2];
-                const float y1 = s[ai][1] - s[ai][2] - s[ai][3];
-                const int oy = oy0 + 2 * ty + ai;
+                const float yv[2] = {s4[ai][0] + s4[ai][1] + s4[ai][2], s4[ai][1] - s4[ai][2] - s4[ai][3]};
 #pragma unroll
                 for (int bi = 0; bi < 2; ++bi) {
-                    const int ox = ox0 + 2 * tx + bi;
-                    if (oy < a.Ho && ox < a.Wo) {
-                        const int o = (oy * a.Wo + ox) * a.Cout + co;
-                        float v = (bi ? y1 : y0) + bs;
-                        v = relu_out ? fmaxf(v, 0.f) : v;
-                        if (msn) v = msn[o] > 0.f ? v : 0.f;
-                        yn[o] = v;
-                    }
+                    const int k = ai * 2 + bi;
+                    float v = yv[bi] + bs;
+                    v = relu_out ? fmaxf(v, 0.f) : v;
+                    if (msn) v = mk[i][k] > 0.f ? v : 0.f;
+                    if (off[i][k] >= 0) yn[off[i][k]] = v;
                 }
             }
         }
