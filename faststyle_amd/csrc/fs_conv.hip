@@ -661,6 +661,52 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             else
                 run(std::false_type{}, std::false_type{});
         }
+    } else if (!a.shuffle && !msn) {
+        // residual-gradient add (the W1 dgrads of the residual blocks): the cropped addend is loaded for a batch of
+        // rows before the first store, like the consumer mask above
+        const int row_stride = a.Wo * a.Cout;
+        constexpr int RB = NACC < 8 ? NACC : 8;
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int r0 = 0; r0 < NACC; r0 += RB) {
+                int off[RB], aof[RB];  // output / addend element offsets of the row's pixel (channel 0); -1: none
+#pragma unroll
+                for (int rg = 0; rg < RB; rg += 4) {
+                    const int t = (wave * WM + m) * MT + F::row(r0 + rg, lane);
+                    int py = (int)(((float)t + 0.5f) * inv_tw), px = t - py * p.TW;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = t + j < tile_px && py < th_valid && px < tw_valid;
+                        const int oy = ty0 + py, ox = tx0 + px;
+                        const bool inner = ok && oy >= ap && oy < a.Ho - ap && ox >= ap && ox < a.Wo - ap;
+                        off[rg + j] = ok ? oy * row_stride + ox * a.Cout : -1;
+                        aof[rg + j] = inner ? ((oy - ap) * aW + (ox - ap)) * a.Cout : -1;
+                        ++px;
+                        if (px == p.TW) {
+                            px = 0;
+                            ++py;
+                        }
+                    }
+                }
+                float ad[RB][WN];
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int nn = 0; nn < WN; ++nn) ad[i][nn] = asn[(aof[i] >= 0 && cok[nn]) ? aof[i] + cof[nn] : 0];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    if (off[i] < 0) continue;
+#pragma unroll
+                    for (int nn = 0; nn < WN; ++nn) {
+                        if (!cok[nn]) continue;
+                        float v = acc[m][nn][r0 + i] + bs[nn];
+                        v = relu_out ? fmaxf(v, 0.f) : v;
+                        if (aof[i] >= 0) v += ad[i][nn];
+                        yn[off[i] + cof[nn]] = v;
+                    }
+                }
+            }
     } else {
         for_rows([&](int m, int r, bool ok, int py, int px) {
             if (!ok) return;
