@@ -134,7 +134,8 @@ int fs_tnet_out_shape(int H, int W, int* Ho, int* Wo) {
 
 static const fs::TnetLayout* get_layout(fs_ctx* ctx, int N, int H, int W, int flags) {
     const int deconv = (flags & FS_FLAG_UPSAMPLE_DECONV) ? 1 : 0;
-    if (!ctx->tnet_valid || ctx->tnet.N != N || ctx->tnet.H != H || ctx->tnet.W != W || ctx->tnet.deconv != deconv) {
+    if (!ctx->tnet_valid || ctx->tnet.N != N || ctx->tnet.H != H || ctx->tnet.W != W || ctx->tnet.deconv != deconv ||
+        ctx->tnet.wino_mode != fs::tnet_wino_mode()) {
         fs::tnet_layout(N, H, W, deconv, &ctx->tnet);
         ctx->tnet_valid = true;
     }
@@ -375,6 +376,11 @@ static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
 int fs_conv2d_plan(fs_conv_desc* d, int* tiles_per_image) {
     fs::ConvArgs a;
     if (int rc = fill_conv(d, &a)) return rc;
+    const char* wenv = getenv("FS_CONV2D_WINO");   // the test hook of fs_conv2d_fwd plans with the Winograd kernel: say so here
+    if (wenv && atoi(wenv)) {
+        a.w_wino = a.w;
+        if (fs::wino_eligible(a)) a.p = fs::conv_plan(a);
+    }
     if (tiles_per_image) *tiles_per_image = a.p.tiles_y * a.p.tiles_x;
     return 0;
 }

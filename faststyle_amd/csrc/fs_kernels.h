@@ -114,6 +114,12 @@ int reduce_slabs(const float* slabs, int groups, int n_wg, size_t count, float s
 // output-pixel tile (TH x TW <= max_px) with the best fill / halo trade-off for an Ho x Wo image (fs_conv.hip)
 // Winograd F(2x2,3x3) path (fs_wino.hip)
 int wt_wino(const float* w, float* U, int Cin, int Cout, hipStream_t s);
+struct WinoBatch {  // several filters of one shape in one launch (the 10 residual convs of the transform net)
+    const float* w[12];
+    float* U[12];
+    int n;
+};
+int wt_wino_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s);
 bool wino_eligible(const ConvArgs& a);
 void wino_plan(const ConvArgs& a, ConvPlan* out);
 int wino_launch(const ConvArgs& a, hipStream_t s);

@@ -30,6 +30,8 @@ struct Unit {
     int w_off, g_off, b_off;  // offsets into the flat parameter buffer
     size_t z, stats, mean, rstd, a, b;  // workspace offsets (floats)
     int tiles;
+    int wino;        // forward through wino_conv_kernel (3x3 VALID residual convs on grids that fill the chip)
+    size_t wino_u;   // its transformed filter [16][Cin][Cout] in the workspace
     ConvPlan plan;
     WgradPlan wplan;
 };
@@ -37,6 +39,7 @@ struct Unit {
 struct TnetLayout {
     int N, H, W, Hy, Wy;
     int deconv;       // upsample_method == 'deconv'
+    int wino_mode;    // FS_TNET_WINO at layout time (0 off, 1 auto, 2 forced): part of the layout's identity
     Unit u[16];
     size_t h[5];      // residual block outputs
     size_t weff[2];   // collapsed resize-conv filters
@@ -48,6 +51,7 @@ struct TnetLayout {
 };
 
 void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L);
+int tnet_wino_mode();  // current FS_TNET_WINO
 WgradArgs unit_wgrad_args(const Unit& u, int N);
 int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s);
 // Optional second stream + events: the filter gradients of unit i only need dz_i, so they run concurrently

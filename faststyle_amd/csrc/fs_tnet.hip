@@ -4,6 +4,8 @@
 // the consumer's load) and the hand-derived backward sequence.  No allocation, no sync.
 #include "fs_tnet.h"
 
+#include <cstdlib>
+
 #include <cstring>
 
 namespace fs {
@@ -105,9 +107,15 @@ static ConvArgs unit_args(const Unit& u, int N) {
     return a;
 }
 
+int tnet_wino_mode() {
+    const char* tv = getenv("FS_TNET_WINO");
+    return tv ? atoi(tv) : 1;
+}
+
 void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
     memset(L, 0, sizeof(*L));
     L->deconv = deconv;
+    L->wino_mode = tnet_wino_mode();
     L->N = N;
     L->H = H;
     L->W = W;
@@ -231,7 +239,21 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
     for (int i = 0; i < 16; ++i) {
         Unit& u = L->u[i];
         ConvArgs a = unit_args(u, N);
+        // Residual convs (3x3 VALID, 64 -> 64) go through the Winograd kernel when its 16x16-pixel blocks fill the
+        // chip (720p / 1080p frames: 240-290 blocks per image); at 256x256 batch 4 they are 100 blocks for 256 CUs and
+        // the direct kernel stays.  FS_TNET_WINO=0 disables, =2 forces (tests).
+        u.wino = 0;
+        {
+            const int mode = L->wino_mode;
+            a.w_wino = reinterpret_cast<const float*>(16);   // eligibility looks at the shapes only
+            a.stats = reinterpret_cast<float*>(16);
+            const long blocks = (long)N * cdiv(u.Hc, 16) * cdiv(u.Wc, 16) * (u.Cc / 64 > 0 ? u.Cc / 64 : 1);
+            if (mode && u.kind == 0 && i >= 3 && i <= 12 && wino_eligible(a) && (mode == 2 || blocks >= 200)) u.wino = 1;
+            if (!u.wino) a.w_wino = nullptr;
+            a.stats = nullptr;
+        }
         u.plan = conv_plan(a);
+        u.wino_u = u.wino ? b.take((size_t)16 * u.Cin * u.Cc) : 0;
         u.tiles = u.kind == 2 ? cdiv(u.Hout * u.Wout, 256) : u.plan.tiles_y * u.plan.tiles_x;
         const size_t act = (size_t)N * u.Hout * u.Wout * u.Cout;
         u.z = b.take(act);
@@ -333,6 +355,16 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
         wb.add(WT_FOLD5FWD, params + L.u[15].w_off, ws + L.wfold, 9, 9, 16, 3);
     }
     FS_TRY(wt_batch(wb, s));
+    {   // Winograd-transformed filters of the residual convs that use wino_conv_kernel (one launch)
+        WinoBatch nb{};
+        for (int i = 3; i <= 12; ++i)
+            if (L.u[i].wino) {
+                nb.w[nb.n] = params + L.u[i].w_off;
+                nb.U[nb.n] = ws + L.u[i].wino_u;
+                ++nb.n;
+            }
+        FS_TRY(wt_wino_batch(nb, 64, 64, s));
+    }
     const float* src = x;
     const float* src_a = nullptr;
     const float* src_b = nullptr;
@@ -346,6 +378,7 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
         a.in_nstride = src_a ? u.Cin : 0;
         a.in_relu = src_a ? 1 : 0;
         a.w = (u.kind == 1 || (u.kind == 3 && i < 15)) ? ws + L.weff[i - 13] : ((u.kind == 2 || u.kind == 3) ? ws + L.wfold : params + u.w_off);
+        a.w_wino = u.wino ? ws + u.wino_u : nullptr;
         a.y = u.kind == 2 ? ws + L.zfold : ws + u.z;
         a.stats = u.kind == 2 ? nullptr : ws + u.stats;
         FS_TRY(conv_launch(a, s));

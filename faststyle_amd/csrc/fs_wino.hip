@@ -64,6 +64,40 @@ __global__ __launch_bounds__(256) void wt_wino_kernel(const float* __restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void wt_wino_batch_kernel(WinoBatch b, int Cin, int Cout) {
+    const float* __restrict__ w = b.w[blockIdx.y];
+    float* __restrict__ U = b.U[blockIdx.y];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t cc = (size_t)Cin * Cout;
+    if (i >= cc) return;
+    float g[3][3], t[4][3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) g[kh][kw] = w[(size_t)(kh * 3 + kw) * cc + i];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        t[0][kw] = g[0][kw];
+        t[1][kw] = 0.5f * (g[0][kw] + g[1][kw] + g[2][kw]);
+        t[2][kw] = 0.5f * (g[0][kw] - g[1][kw] + g[2][kw]);
+        t[3][kw] = g[2][kw];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        U[(size_t)(r * 4 + 0) * cc + i] = t[r][0];
+        U[(size_t)(r * 4 + 1) * cc + i] = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
+        U[(size_t)(r * 4 + 2) * cc + i] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
+        U[(size_t)(r * 4 + 3) * cc + i] = t[r][2];
+    }
+}
+
+int wt_wino_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s) {
+    if (b.n <= 0) return 0;
+    const size_t cc = (size_t)Cin * Cout;
+    hipLaunchKernelGGL(wt_wino_batch_kernel, dim3((unsigned)((cc + 255) / 256), (unsigned)b.n), dim3(256), 0, s, b, Cin, Cout);
+    return 0;
+}
+
 int wt_wino(const float* w, float* U, int Cin, int Cout, hipStream_t s) {
     const size_t cc = (size_t)Cin * Cout;
     hipLaunchKernelGGL(wt_wino_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, w, U, Cin, Cout);
@@ -118,7 +152,7 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
         if (e < kPT * kPT * 2) {
             const int pix = e >> 1, c4 = e & 1;
             const int py = fdiv(pix, 1.0f / (float)kPT), px = pix - py * kPT;
-            const int sy = oy0 - 1 + py, sx = ox0 - 1 + px;
+            const int sy = oy0 - a.pad_t + py, sx = ox0 - a.pad_l + px;
             if (sy >= 0 && sy < a.H && sx >= 0 && sx < a.W) gvo[i] = (unsigned)((sy * a.W + sx) * a.Cin + c4 * 4) * 4u;
             pdst[i] = pix * kPS + c4 * 4;
         }
@@ -132,10 +166,21 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
         uvo[i] = (unsigned)((pos * a.Cin + k) * a.Cout + co0 + c4 * 4) * 4u;
     }
     float4 pv[2], uv[4];
+    // producer instance norm + ReLU folded into the load (transform-net convs; VALID padding only, so every patch pixel
+    // that reaches a stored output is a real pixel and padding needs no masking).  Both elements of a thread belong
+    // to the same channel quad (tid & 1), so one float4 of scales and of shifts per chunk.
+    const bool has_ab = a.in_a != nullptr;
+    const float* ian = has_ab ? uniform_ptr(a.in_a + (size_t)n * a.in_nstride) : nullptr;
+    const float* ibn = has_ab ? uniform_ptr(a.in_b + (size_t)n * a.in_nstride) : nullptr;
+    float4 va = make_float4(1.f, 1.f, 1.f, 1.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
     auto issue_patch = [&](int chunk) {
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(xn)), 0, x_bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 2; ++i) pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, gvo[i], chunk * kCC * 4, 0));
+        if (has_ab) {
+            va = *reinterpret_cast<const float4*>(ian + chunk * kCC + (tid & 1) * 4);
+            vb = *reinterpret_cast<const float4*>(ibn + chunk * kCC + (tid & 1) * 4);
+        }
     };
     auto issue_filter = [&](int chunk) {
         const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(ub)), 0, u_bytes, 0x00020000);
@@ -146,11 +191,24 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
     auto commit_patch = [&](float* patch) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            float4 v = pv[i];
+            if (has_ab) {
+                v.x = fmaf(v.x, va.x, vb.x);
+                v.y = fmaf(v.y, va.y, vb.y);
+                v.z = fmaf(v.z, va.z, vb.z);
+                v.w = fmaf(v.w, va.w, vb.w);
+                if (a.in_relu) {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+            }
             float* d = patch + pdst[i];
-            d[0] = pv[i].x;
-            d[1] = pv[i].y;
-            d[2] = pv[i].z;
-            d[3] = pv[i].w;
+            d[0] = v.x;
+            d[1] = v.y;
+            d[2] = v.z;
+            d[3] = v.w;
         }
     };
     auto commit_filter = [&](float* Ul) {
@@ -401,6 +459,7 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
             }
         }
         __syncthreads();
+        float vals[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int t = (tid >> 5) + i * 16;
@@ -415,17 +474,54 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
             }
 #pragma unroll
             for (int ai = 0; ai < 2; ++ai) {
-                const float yv[2] = {s4[ai][0] + s4[ai][1] + s4[ai][2], s4[ai][1] - s4[ai][2] - s4[ai][3]};
-#pragma unroll
-                for (int bi = 0; bi < 2; ++bi) {
-                    const int k = ai * 2 + bi;
-                    float v = yv[bi] + bs;
-                    v = relu_out ? fmaxf(v, 0.f) : v;
-                    if (msn) v = mk[i][k] > 0.f ? v : 0.f;
-                    if (off[i][k] >= 0) yn[off[i][k]] = v;
-                }
+                vals[i][ai * 2 + 0] = s4[ai][0] + s4[ai][1] + s4[ai][2];
+                vals[i][ai * 2 + 1] = s4[ai][1] - s4[ai][2] - s4[ai][3];
             }
         }
+        if (a.stats) {
+            // per-block instance-norm partials of the RAW conv output (mean, M2, count), one pass around a shift taken
+            // from the block's first pixel -- same record the direct kernel writes (fs_conv.hip)
+            float* shiftl = patch0;            // [32]   (the patch stages are free by now)
+            float* red = patch0 + 32;          // [16][32][2]
+            if ((tid >> 5) == 0) shiftl[c32] = vals[0][0];
+            __syncthreads();
+            const float cs = shiftl[c32];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dv = off[i][k] >= 0 ? vals[i][k] - cs : 0.f;
+                    s1 += dv;
+                    s2 = fmaf(dv, dv, s2);
+                }
+            red[((tid >> 5) * 32 + c32) * 2] = s1;
+            red[((tid >> 5) * 32 + c32) * 2 + 1] = s2;
+            __syncthreads();
+            if (tid < 32) {
+                float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    S1 += red[(g * 32 + tid) * 2];
+                    S2 += red[(g * 32 + tid) * 2 + 1];
+                }
+                const int th_valid = min(2 * kTT, a.Ho - oy0), tw_valid = min(2 * kTT, a.Wo - ox0);
+                const float cnt = (float)(th_valid * tw_valid);
+                float* st = a.stats + ((size_t)blockIdx.x * a.Cout + co0 + q * 32 + tid) * 3;
+                st[0] = cs + S1 / cnt;
+                st[1] = fmaxf(S2 - S1 * S1 / cnt, 0.f);
+                st[2] = cnt;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v = vals[i][k] + bs;
+                v = relu_out ? fmaxf(v, 0.f) : v;
+                if (msn) v = mk[i][k] > 0.f ? v : 0.f;
+                if (off[i][k] >= 0) yn[off[i][k]] = v;
+            }
         if (q == 0) __syncthreads();
     }
 #ifdef FS_CONV_TRACE
@@ -448,9 +544,12 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
 }
 
 bool wino_eligible(const ConvArgs& a) {
-    return a.w_wino && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_t == 1 && a.pad_l == 1 && a.src_mode == SRC_PLAIN &&
-           a.Ho == a.H && a.Wo == a.W && a.Cin % kCC == 0 && a.Cout % kBN == 0 && !a.stats && !a.shuffle && !a.add_src &&
-           !a.in_a && a.w_nstride == 0 && (a.dil_x <= 1);
+    // SAME (pad 1, the VGG convs) or VALID (pad 0, the residual convs of the transform net); the on-load affine needs
+    // pad 0; statistics only without split-K (the plan takes care of that)
+    const bool pad_ok = a.pad_t == a.pad_l && (a.pad_t == 0 || a.pad_t == 1) && a.Ho == a.H + 2 * a.pad_t - 2 &&
+                        a.Wo == a.W + 2 * a.pad_l - 2;
+    return a.w_wino && a.KH == 3 && a.KW == 3 && a.stride == 1 && pad_ok && a.src_mode == SRC_PLAIN && a.Cin % kCC == 0 &&
+           a.Cout % kBN == 0 && !a.shuffle && !a.add_src && (!a.in_a || a.pad_t == 0) && a.w_nstride == 0 && (a.dil_x <= 1);
 }
 
 // plan: 16x16-pixel blocks; split the channel chunks over blockIdx.z while the launch cannot fill the CUs (one
@@ -468,7 +567,7 @@ void wino_plan(const ConvArgs& a, ConvPlan* out) {
     const long wgs = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / kBN);
     const int nchunks = a.Cin / kCC;
     const int max_ks = getenv("FS_WINO_KSPLIT") ? atoi(getenv("FS_WINO_KSPLIT")) : 4;  // tuning / debugging aid
-    if (a.split_ws) {
+    if (a.split_ws && !a.stats) {
         int ks = 1;
         while (ks < max_ks && wgs * ks < 256 && nchunks / (ks * 2) >= 8 &&
                (size_t)(ks * 2) * a.N * a.Ho * a.Wo * a.Cout <= a.split_ws_floats)

@@ -6,6 +6,7 @@ injectable (``mem``) so the parity tests can drive the very same code with host 
 the kernel emulator build; the product always uses ``TorchMem`` on a ROCm device.
 """
 import ctypes
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -140,7 +141,7 @@ class Engine(object):
         return ho.value, wo.value
 
     def _tnet_workspace(self, N, H, W, bf16=False):
-        key = (N, H, W, bf16)
+        key = (N, H, W, bf16, os.environ.get("FS_TNET_WINO", ""))   # (the layout depends on this tuning knob)
         if key not in self._tnet_ws:
             nbytes = self.lib.fs_tnet_workspace_bytes(N, H, W, L.FS_FLAG_BF16 if bf16 else L.FS_FLAG_SAVE_FOR_BWD)
             if nbytes == 0:

@@ -82,6 +82,30 @@ def test_winograd_conv_matches_oracle(eng, case, monkeypatch):
     assert rel(y, direct) < TOL and not np.array_equal(y, direct)      # really the other algorithm
 
 
+def test_winograd_valid_conv_with_affine_on_load_and_tile_statistics(eng, monkeypatch):
+    """The residual-block form of the Winograd kernel (transform net, im_transf_net.py:250-276): VALID padding, the
+    producer's instance norm + ReLU applied on load, per-block statistics of the raw output -> instnorm_finalize."""
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal((2, 37, 41, 64)).astype(np.float32) + 0.5        # 35x39 outputs: ragged 16x16 blocks
+    w1 = (rng.standard_normal((3, 3, 64, 64)) * 0.1).astype(np.float32)
+    w2 = (rng.standard_normal((3, 3, 64, 64)) * 0.1).astype(np.float32)
+    gamma = (1 + 0.3 * rng.standard_normal(64)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(64)).astype(np.float32)
+    monkeypatch.setenv("FS_CONV2D_WINO", "1")
+    z, stats, tiles = eng.conv2d(up(eng, x), up(eng, w1), 1, "VALID", want_stats=True)
+    assert tiles == 3 * 3                                                    # 16x16 blocks of the Winograd plan
+    mean, rstd, a, b = eng.instnorm_finalize(stats, tiles, 64, 1, up(eng, gamma), up(eng, beta))
+    y = down(eng, eng.conv2d(z, up(eng, w2), 1, "VALID", in_a=a, in_b=b, in_per_sample=1, in_relu=1))
+    z64 = nnops.conv2d(x.astype(np.float64), w1.astype(np.float64), 1, "VALID")
+    n64, (xhat, rs, _) = nnops.inst_norm(z64, gamma.astype(np.float64), beta.astype(np.float64))
+    assert rel(down(eng, z), z64) < TOL
+    assert rel(down(eng, mean), z64.mean(axis=(1, 2))) < TOL
+    assert rel(down(eng, rstd), rs[:, 0, 0, :]) < TOL
+    want = nnops.conv2d(nnops.relu(n64), w2.astype(np.float64), 1, "VALID")
+    assert y.shape == want.shape == (2, 33, 37, 64)
+    assert rel(y, want) < 5e-5
+
+
 def test_conv_reflect_pad_fused(eng):
     rng = np.random.default_rng(2)
     x = rng.uniform(0, 255, (1, 45, 50, 3)).astype(np.float32)

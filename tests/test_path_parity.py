@@ -110,6 +110,24 @@ def test_tnet_forward_with_two_level_statistics_merge(eng, monkeypatch):
     assert np.abs(y - yo).max() / 255.0 < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 48, 56), (1, 45, 67)])
+def test_tnet_residual_convs_through_the_winograd_kernel(eng, shape, monkeypatch):
+    """FS_TNET_WINO=2 forces what 720p / 1080p frames (and large training batches) select by themselves: the ten 3x3
+    VALID residual convs through wino_conv_kernel -- producer instance norm + ReLU on load, per-block statistics --
+    forward against the oracle with the shipped weights, and the backward pass on top of that forward."""
+    monkeypatch.setenv("FS_TNET_WINO", "2")
+    rng = np.random.default_rng(9)
+    P = tnet.strip_scope(starry())
+    flat = eng.mem.from_numpy(eng.flatten_params(P, scope=""))
+    x = rng.uniform(0, 255, shape + (3,)).astype(np.float32)
+    y = eng.mem.to_numpy(eng.tnet_forward(flat, eng.mem.from_numpy(x)))
+    yo = tnet.create_net(x.astype(np.float64), f64(P))
+    assert np.abs(y - yo).max() / 255.0 < 2e-5
+    yk, yok, g, want = run_fwd_bwd(eng, kink_free_params(), shape, seed=0)
+    assert np.abs(yk - yok).max() / 255.0 < 2e-5
+    assert grads_close(eng, g, want, 2e-4) == []
+
+
 @pytest.mark.parametrize("shape", [(2, 48, 56), (1, 41, 41), (1, 45, 67)])
 def test_tnet_forward_matches_oracle_and_backward_tight_when_kink_free(eng, shape):
     """Smallest legal size (41: REFLECT needs pad < dim), odd sizes (asymmetric SAME padding of
