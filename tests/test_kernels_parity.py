@@ -82,6 +82,20 @@ def test_winograd_conv_matches_oracle(eng, case, monkeypatch):
     assert rel(y, direct) < TOL and not np.array_equal(y, direct)      # really the other algorithm
 
 
+def test_winograd_accuracy_is_that_of_the_direct_kernel(eng, monkeypatch):
+    """F(2x2,3x3) only adds / subtracts / halves in its transforms: on post-ReLU-like data with a deep reduction
+    (256 input channels) its error against the fp64 oracle stays within 2x of the direct fp32 kernel's."""
+    rng = np.random.default_rng(17)
+    x = (np.maximum(rng.standard_normal((1, 16, 16, 256)), 0) * 50).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 256, 64)) * 0.02).astype(np.float32)
+    want = nnops.conv2d(x.astype(np.float64), w.astype(np.float64), 1, "SAME")
+    direct = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME"))
+    monkeypatch.setenv("FS_CONV2D_WINO", "1")
+    wino = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME"))
+    e_d, e_w = rel(direct, want), rel(wino, want)
+    assert e_w < 3e-6 and e_w < 2.0 * e_d + 1e-7, (e_d, e_w)
+
+
 def test_winograd_valid_conv_with_affine_on_load_and_tile_statistics(eng, monkeypatch):
     """The residual-block form of the Winograd kernel (transform net, im_transf_net.py:250-276): VALID padding, the
     producer's instance norm + ReLU applied on load, per-block statistics of the raw output -> instnorm_finalize."""
