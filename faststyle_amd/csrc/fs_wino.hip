@@ -16,9 +16,14 @@
 //   * the pre-transformed filter chunk U[16][8][64] (fs::wt_wino, built once per weight set) is staged beside it;
 //   * wave w multiplies positions 2w and 2w+1: M = 64 tiles (2 MFMA row blocks), N = 64 channels (2 column blocks),
 //     K = the chunk -- 8 accumulator blocks of v_mfma_f32_32x32x2_f32 per wave, 32 MFMAs per chunk and wave;
-//   * the next chunk's global loads are in flight during the sweep (registers), two barriers per chunk;
-//   * epilogue: the 16 position planes are exchanged through LDS 16 channels at a time, one thread applies
-//     A^T . A to a (tile, channel) pair and stores the 2x2 pixels (bias / ReLU / consumer mask, or raw split-K partials).
+//   * two LDS stages: chunk j is multiplied while chunk j+1 is transformed / committed into the other stage -- one
+//     slice of that work per MFMA slot of the sweep -- and the global loads of chunk j+2 are in flight (registers); one
+//     barrier per chunk;
+//   * epilogue: the 16 position planes are exchanged through LDS 32 channels at a time, one thread applies
+//     A^T . A to four (tile, channel) pairs and stores their 2x2 pixels (bias / ReLU / consumer mask, raw split-K
+//     partials, or -- transform-net form -- per-block instance-norm statistics);
+//   * variants by argument: SAME padding (VGG16) or VALID padding with the producer's instance norm + ReLU applied
+//     on load (residual convs of the transform net, reference im_transf_net.py:250-276).
 #include "fs_kernels.h"
 
 #include <cstdlib>
@@ -252,35 +257,10 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[pp][m][nn][r] = 0.f;
 
-    // 8 groups (k-step, position) of 4 MFMAs each; the LDS reads of group g+1 are issued before the MFMAs of group g
-    // (two register sets), so that a wave does not sit on ds_read latency between matrix instructions
-    auto sweep = [&](const float* Vl, const float* Ul) {
-        float av[2][2], bv[2][2];
-        auto load = [&](int g, float (&a2)[2], float (&b2)[2]) {
-            const int ks = g >> 1, pp = g & 1;
-            const int k = ks * 2 + kq, pos = wave * 2 + pp;
-            const float* pa = Vl + (pos * kNT + lm) * kPS + k;
-            const float* pb = Ul + (pos * kCC + k) * kBN + lm;
-            a2[0] = pa[0];
-            a2[1] = pa[32 * kPS];
-            b2[0] = pb[0];
-            b2[1] = pb[32];
-        };
-        load(0, av[0], bv[0]);
-#pragma unroll
-        for (int g = 0; g < kCC; ++g) {   // kCC/2 k-steps x 2 positions
-            if (g + 1 < kCC) load(g + 1, av[(g + 1) & 1], bv[(g + 1) & 1]);
-            const int pp = g & 1, c = g & 1;
-            acc[pp][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][0], bv[c][0], acc[pp][0][0], 0, 0, 0);
-            acc[pp][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][0], bv[c][1], acc[pp][0][1], 0, 0, 0);
-            acc[pp][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][1], bv[c][0], acc[pp][1][0], 0, 0, 0);
-            acc[pp][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][1], bv[c][1], acc[pp][1][1], 0, 0, 0);
-        }
-    };
-
     const int nchunks = a.Cin / kCC;
     const int cbeg = __builtin_amdgcn_readfirstlane(p.ksplit > 1 ? (int)blockIdx.z * nchunks / p.ksplit : 0);
     const int cend = __builtin_amdgcn_readfirstlane(p.ksplit > 1 ? ((int)blockIdx.z + 1) * nchunks / p.ksplit : nchunks);
+
     // sweep(chunk j) with the transform of chunk j+1 threaded through it: the wave's own VALU / LDS instructions issue
     // in the shadow of its own matrix instructions (another wave's do not: MFMA issue is in order and a streaming wave
     // leaves its SIMD partner almost no issue slots).  sched_barrier pins the interleaving.
