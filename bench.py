@@ -2,27 +2,33 @@
 """Headline benchmark of the faststyle hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...;
+   `--nproc-per-node 1` is supported too and runs the RCCL all-reduce at world size 1)
 
-A "step" is one full train.py loop body (reference train.py:245-275) on a synthetic 256x256 batch
-of 4 images per GPU (the reference's --batch_size 4; global batch 4N, 32 at N=8 = BASELINE.json's
-"256x256 b32"): content-target VGG pass, transform-net forward, VGG16+Gram+losses, full backward,
-one RCCL all-reduce (SUM) of the 424,102 gradients, TF-Adam.  fp32 end to end (the reference's
-dtype); every convolution / Gram contraction runs on the fp32 matrix cores.
+A "step" is one full train.py loop body (reference train.py:245-275) on a synthetic 256x256 batch: content-target VGG
+pass, transform-net forward, VGG16 + Gram + losses, full backward, ONE RCCL all-reduce (SUM) of the 424,102 gradients
+when launched under torch.distributed, TF-Adam.  fp32 end to end (the reference's dtype); every convolution / Gram
+contraction runs on the fp32 matrix cores.  Forward + backward replay one hipGraph per step.
 
-Prints ONE JSON line on rank 0 (contract: see the task statement); extra keys:
-  roofline      dominant kernel (conv_igemm<32,2,2>, the VGG16 / residual 3x3 convs): algorithmic
-                FLOP / HIP-event time, measured live on the launch stream during the timed steps
-  cpu_baseline  the numpy oracle (a port of the reference path; TF1 itself cannot be installed)
-                timed on this box's host cores on a bounded sample, rank 0 / N=1 only
-  train_b32_one_gpu_images_per_sec  the same train step at batch 32 on ONE GPU (N=1 runs only; eager launches)
-  stylize_720p_fps  config[1]: im_transf_net forward on a 720p frame, batch 1, fp32
-  stylize_1080p_b8_bf16_fps / _fp32_fps  config[4]: 1080p, batch 8 per GPU, the bf16 mixed-precision path
-                (bf16 MFMA, fp32 statistics; NOT the parity path) beside the fp32 path on the same input
+  value                the step at batch 32 PER GPU -- BASELINE.json's metric configuration ("256x256 b32") on one GPU;
+                       weak scaling: global batch 32 N
+  train_b4_per_gpu     the same step at batch 4 per GPU (BASELINE configs[2]; at N=8 this is configs[3], global batch 32),
+                       also hipGraph-replayed, with its own per-kernel table
+  roofline             dominant kernel of the b32 step: FLOPs EXECUTED / HIP-event time on the launch stream (an eager
+                       pass of the same step right after the timed region -- a replayed hipGraph has no room for events
+                       between its nodes), per-kernel table, HBM bytes per launch from profiles/ (rocprofv3 PMC passes)
+  gram                 Gram forward (F^T F, utils.py:76-82) + backward GFLOP/s and % of the fp32 MFMA peak
+  vgg_gram_substep     fs_perceptual_loss as a whole (VGG16 forward incl. the content-target half, Grams, losses, VGG
+                       input gradients): wall time of the section by HIP events, FLOPs executed and as written
+  cpu_baseline         BASELINE.md section 3: the numpy oracle (as-written algorithm) and a torch-CPU (oneDNN) restatement
+                       on this box's host cores, warm-up + >= 5 timed runs, median/min; a 1-core figure; the 720p forward
+  stylize_*            configs[1] (720p, batch 1, fp32) and configs[4] (1080p, batch 8 per GPU, bf16) forward rates
 """
 import argparse
+import ctypes
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -31,66 +37,153 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# SURVEY.md §8d algorithmic work (FLOP = 2*MAC, convs/Grams only), per image at 256x256
-GFLOP_PER_IMG_AS_WRITTEN = 121.94
+# algorithmic work per image at 256x256 (FLOP = 2*MAC, convs / Grams only), AS WRITTEN
+GF_TNET_FWD, GF_TNET_BWD, GF_VGG_CONTENT, GF_VGG_FWD, GF_VGG_DGRAD, GF_GRAM = 7.069, 13.260, 24.386, 36.465, 36.465, 4.295
+GF_STEP = GF_TNET_FWD + GF_TNET_BWD + GF_VGG_CONTENT + GF_VGG_FWD + GF_VGG_DGRAD + GF_GRAM          # 121.94
+GF_VGG_GRAM = GF_VGG_CONTENT + GF_VGG_FWD + GF_VGG_DGRAD + GF_GRAM                                   # 101.61
+# transform-net forward: executed (phase-collapsed resize-conv) GFLOP and minimum fp32 HBM traffic (MB) per image
+FWD_WORK = {(720, 1280): (70.756, 83.496, 1524.6), (1080, 1920): (155.023, 183.688, 3335.5), (256, 256): (6.163, 7.069, 134.4)}
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_TBS = 8.0                    # spec; 6.29 measured (float4 copy)
+TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic_pmc.json")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-per-gpu", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--b4-steps", type=int, default=200, help="timed steps of the batch-4-per-GPU leg")
+    ap.add_argument("--profile-steps", type=int, default=5, help="eager steps of the per-kernel / per-section pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-quick", action="store_true", help="one warm-up + one timed run per CPU figure (contract test)")
     ap.add_argument("--no-stylize", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=3)
+    ap.add_argument("--no-b4", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     return ap.parse_args()
 
 
-def cpu_baseline(n_images, size):
-    """Oracle (numpy float32 port of the reference path, as-written algorithm) train-step rate."""
-    from oracle import perceptual, tnet            # allowed here: the CPU-baseline leg only
+# ----------------------------------------------------------------------------------------------- CPU baseline
+_QUICK = False
+
+
+def _timed(fn, warm, n, what=""):
+    if _QUICK:
+        warm, n = min(warm, 1), 1
+    t_start = time.perf_counter()
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    print("bench: cpu_baseline %s: %d+%d runs in %.1f s" % (what, warm, n, time.perf_counter() - t_start), file=sys.stderr, flush=True)
+    return statistics.median(ts), min(ts)
+
+
+def cpu_baseline(size):
+    """BASELINE.md section 3.  TF1 cannot be installed here or on the GPU box: the figures are the build's own CPU
+    restatements of the reference path (kind "port"), timed on the host cores of this box."""
+    import torch
+    from threadpoolctl import threadpool_limits
+    from oracle import perceptual, tnet, torch_ref           # allowed here: the CPU-baseline leg only
+    ncpu = os.cpu_count() or 1
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        ncores = len(os.sched_getaffinity(0))
     except Exception:
-        threads = os.cpu_count() or 1
+        ncores = ncpu
     rng = np.random.default_rng(1)
     P = tnet.init_params(0)
     Wv = perceptual.synthetic_vgg_weights(3)
-    style = rng.uniform(0, 255, (1, 128, 128, 3)).astype(np.float32)
-    tg = perceptual.target_grams(style, Wv, ("conv1_2", "conv2_2", "conv3_3", "conv4_3"))
-    t0 = time.perf_counter()
-    for _ in range(n_images):
-        x = rng.uniform(0, 255, (1, size, size, 3)).astype(np.float32)
-        perceptual.train_step(P, x, tg, Wv)
-    dt = time.perf_counter() - t0
-    return {"value": round(n_images / dt, 4), "unit": "images/sec", "cores": int(threads), "kind": "port",
-            "sample": "%d train steps of 1x%dx%dx3 (fwd+bwd, no Adam), numpy/OpenBLAS float32 oracle of the "
-                      "reference path; host has %d logical cores" % (n_images, size, size, os.cpu_count() or 0)}
+    style = np.random.default_rng(2).uniform(0, 255, (1, 128, 128, 3)).astype(np.float32)
+    layers = ("conv1_2", "conv2_2", "conv3_3", "conv4_3")
+    tg = perceptual.target_grams(style, Wv, layers)
+    x1 = rng.uniform(0, 255, (1, size, size, 3)).astype(np.float32)
+    x4 = rng.uniform(0, 255, (4, size, size, 3)).astype(np.float32)
+    x720 = np.random.default_rng(0).uniform(0, 255, (1, 720, 1280, 3)).astype(np.float32)
+
+    # (i) numpy/OpenBLAS oracle, the as-written algorithm (materialised x4 upsample, unfused instance norm), all cores
+    med, mn = _timed(lambda: perceptual.train_step(P, x1, tg, Wv), 2, 5, "numpy train step")
+    out = {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": int(ncores), "kind": "port",
+           "sample": "train step (fwd+bwd, no Adam) of 1x%dx%dx3, numpy/OpenBLAS float32 oracle of the reference path "
+                     "(as-written algorithm); 2 warm-up + 5 timed runs, median; host has %d logical CPUs" % (size, size, ncpu),
+           "min_time_value": round(1.0 / mn, 4)}
+
+    # (ii) torch-CPU (oneDNN) float32 + autograd: the "strong CPU" figure, batch 4 as train.py's default
+    Pt = dict((k, torch.tensor(v, requires_grad=True)) for k, v in P.items())
+    Wt = dict((k, torch.tensor(v)) for k, v in Wv.items())
+    tgt = [torch.tensor(g) for g in tg]
+    # torch's CPU convolutions stop scaling early on this class of host (measured on the 256-thread GPU box: batch-4 step
+    # 1.05 s with 16 threads, 1.43 s with 32, 2.1 s with 64, 6.1 s with 128, > 40 s with 256): use the fastest setting
+    tthreads = min(ncores, 16)
+    torch.set_num_threads(tthreads)
+    xt4, xt1, xt720 = torch.tensor(x4), torch.tensor(x1), torch.tensor(x720)
+    med, mn = _timed(lambda: torch_ref.train_step(Pt, xt4, tgt, Wt), 3, 5, "torch train step b4")
+    out["torch_cpu"] = {"value": round(4.0 / med, 3), "min_time_value": round(4.0 / mn, 3), "unit": "images/sec", "cores": int(tthreads),
+                        "sample": "train step of 4x%dx%dx3, torch %s CPU (oneDNN) float32 autograd restatement, %d threads (more "
+                                  "threads are slower on this host); 3 warm-up + 5 timed, median" % (size, size, torch.__version__, tthreads)}
+    # (iii) one core, for per-core normalisation
+    torch.set_num_threads(1)
+    with threadpool_limits(limits=1):
+        med, mn = _timed(lambda: torch_ref.train_step(Pt, xt1, tgt, Wt), 1, 3, "torch train step 1 core")
+    out["one_core"] = {"value": round(1.0 / med, 4), "min_time_value": round(1.0 / mn, 4), "unit": "images/sec", "cores": 1,
+                       "sample": "train step of 1x%dx%dx3, torch CPU float32, 1 thread; 1 warm-up + 3 timed, median" % (size, size)}
+    torch.set_num_threads(tthreads)
+    # (iv) 720p forward (configs[1])
+    with torch.no_grad():
+        Pn = dict((k, v.detach()) for k, v in Pt.items())
+        med, mn = _timed(lambda: torch_ref.tnet(xt720, Pn), 3, 5, "torch 720p forward")
+    s720 = {"torch_cpu_fps": round(1.0 / med, 3), "torch_cpu_min_time_fps": round(1.0 / mn, 3), "torch_cpu_cores": int(tthreads),
+            "numpy_oracle_cores": int(ncores),
+            "sample": "create_net forward of 1x720x1280x3; torch CPU float32 3 warm-up + 5 timed; numpy oracle 1 + 3; median"}
+    med, mn = _timed(lambda: tnet.create_net(x720, P), 1, 3, "numpy 720p forward")
+    s720["numpy_oracle_fps"] = round(1.0 / med, 3)
+    s720["numpy_oracle_min_time_fps"] = round(1.0 / mn, 3)
+    out["stylize_720p"] = s720
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- helpers
+def fam_table(prof, steps, names):
+    """fs_profile_end output -> {kernel: {launches_per_step, gflop_per_step, tflops, ms_per_step, frac}}"""
+    tab = {}
+    for f, nm in enumerate(names):
+        n, fl, ms = prof[3 * f], prof[3 * f + 1], prof[3 * f + 2]
+        if ms > 0:
+            tf = fl / (ms * 1e-3) / 1e12
+            tab[nm] = {"launches_per_step": round(n / steps, 1), "gflop_per_step": round(fl / steps / 1e9, 2),
+                       "ms_per_step": round(ms / steps, 3), "avg_launch_us": round(1e3 * ms / n, 1),
+                       "tflops": round(tf, 2), "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+    return tab
 
 
 def main():
+    global _QUICK
     args = parse()
+    _QUICK = args.cpu_quick
     import torch
     import torch.distributed as dist
-    from faststyle_amd import engine, im_transf_net, trainer, utils, vgg16
+    from faststyle_amd import _lib, engine, im_transf_net, trainer, utils, vgg16
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                             % (args.gpus, args.gpus))
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ       # under torch.distributed.run (any world size)
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                         % (args.gpus, args.gpus))
     torch.cuda.set_device(local)
-    if world > 1:
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    ddist = dist if launched else None
     eng = engine.Engine(engine.TorchMem("cuda:%d" % local))
+    lib = eng.lib
+    NF = _lib.FS_PROFILE_FAMILIES
+    names = _lib.PROFILE_FAMILY_NAMES
 
     B, S = args.batch_per_gpu, args.size
     params = eng.flatten_params(im_transf_net.initial_variables(seed=0), scope="")
@@ -98,188 +191,248 @@ def main():
     real_vgg = os.path.exists(npz)
     vgg_w = vgg16.load_weights(npz) if real_vgg else vgg16.synthetic_weights(seed=3)
     style = utils.imread(os.path.join(ROOT, "style_images", "starry_night_crop.jpg")).astype(np.float32)[None]
-    tr = trainer.Trainer(eng, params, vgg_w, style, learn_rate=1e-3, dist=dist if world > 1 else None,
-                         use_graph=not args.no_graph)
 
-    # synthetic COCO: uniform [0,255) float32 batches, pre-generated on the device, fresh per step
     g = torch.Generator(device="cuda")
     g.manual_seed(100 + rank)
-    pool = [torch.rand((B, S, S, 3), device="cuda", generator=g) * 255.0 for _ in range(8)]
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if launched:
             dist.barrier()
             torch.cuda.synchronize()
 
-    import ctypes
-    for i in range(args.warmup):
-        tr.step(pool[i % len(pool)])
-    sync()
-    graphed = bool(tr.use_graph and tr.graph is not None)
-    if not graphed:
-        eng.lib.fs_profile_begin(eng.ctx)      # HIP events around every MFMA launch of the timed steps
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        losses = tr.step(pool[(args.warmup + i) % len(pool)])
-    sync()
-    elapsed = time.perf_counter() - t0
-    prof = (ctypes.c_double * 21)()
-    loss_val = float(losses[0].item())
-    if graphed:
-        # the timed steps replayed a hipGraph (no room for events between its nodes): time the SAME
-        # kernels with HIP events on the launch stream in an eager pass of the same K steps
-        tr.use_graph = False
-        eng.lib.fs_profile_begin(eng.ctx)
-        for i in range(args.steps):
-            tr.step(pool[(args.warmup + i) % len(pool)])
-        sync()
-        tr.use_graph = True
-    eng.lib.fs_profile_end(eng.ctx, ctypes.byref(prof))
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def max_over_ranks(v):
+        if world > 1:
+            t = torch.tensor([v], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return v
 
-    # the metric's "b32" on ONE GPU (N=1 only; at N=8 the timed region above already is global batch 32)
-    b32 = None
-    if world == 1 and not args.no_stylize and B != 32:
-        big = [torch.rand((32, S, S, 3), device="cuda", generator=g) * 255.0 for _ in range(2)]
-        tr.use_graph = False
-        for i in range(2):
-            tr.step(big[i % 2])
+    def train_leg(batch, steps, warmup, tr):
+        """Timed region + the eager per-section / per-kernel passes of one batch size."""
+        pool = [torch.rand((batch, S, S, 3), device="cuda", generator=g) * 255.0 for _ in range(4)]
+        for i in range(max(warmup, 2 if tr.use_graph else 1)):      # (graph mode: first step captures, second replays)
+            tr.step(pool[i % len(pool)])
         sync()
-        tb = time.perf_counter()
-        for i in range(6):
-            tr.step(big[i % 2])
+        graphed = bool(tr.use_graph and tr.graph is not None)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            losses = tr.step(pool[(warmup + i) % len(pool)])
         sync()
-        b32 = 6 * 32 / (time.perf_counter() - tb)
-        tr.use_graph = not args.no_graph
-        del big
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        res = {"elapsed": elapsed, "graphed": graphed, "loss": float(losses[0].item())}
+        # ---- eager passes of the same step: (1) section wall times by HIP events on the launch stream, no per-kernel events
+        e, P = tr.eng, args.profile_steps
+        secs = ["tnet_forward", "perceptual_loss", "tnet_backward", "allreduce_adam"]
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(P)]
 
-    # config[1]: 720p stylize, batch 1 per GPU, independent frames (no collective)
-    fps = None
+        def sections(i, hook_begin=None, hook_end=None):
+            x = pool[i % len(pool)]
+            out = []
+            for k in range(4):
+                if hook_begin:
+                    hook_begin()
+                else:
+                    ev[i][k].record()
+                if k == 0:
+                    y = e.tnet_forward(tr.params, x, save_for_bwd=True)
+                elif k == 1:
+                    _, dy = e.perceptual_loss(y, x, tr.target_grams, tr.cfg)
+                elif k == 2:
+                    e.tnet_backward(tr.params, x, dy, grads=tr.grads)
+                else:
+                    if tr._dist_on():
+                        tr.dist.all_reduce(tr.grads, op=tr.dist.ReduceOp.SUM)
+                    tr.global_step += 1
+                    e.adam_tf_step(tr.params, tr.grads, tr.m, tr.v, tr.global_step, lr=tr.lr)
+                if hook_end:
+                    out.append(hook_end())
+            if not hook_begin:
+                ev[i][4].record()
+            return out
+        for i in range(P):
+            sections(i)
+        sync()
+        res["sections_ms"] = dict((secs[k], round(sum(ev[i][k].elapsed_time(ev[i][k + 1]) for i in range(P)) / P, 3)) for k in range(4))
+        # (2) per-kernel: HIP events around every MFMA launch, collected per section
+        acc = np.zeros((4, 3 * NF))
+
+        def hb():
+            lib.fs_profile_begin(e.ctx)
+
+        def he():
+            buf = (ctypes.c_double * (3 * NF))()
+            lib.fs_profile_end(e.ctx, ctypes.byref(buf))
+            return np.array(buf[:])
+        for i in range(P):
+            for k, v in enumerate(sections(i, hb, he)):
+                acc[k] += v
+        sync()
+        res["prof"] = acc
+        res["psteps"] = P
+        del pool
+        return res
+
+    # ------------------------------------------------------------------ the metric's configuration: batch 32 per GPU
+    tr = trainer.Trainer(eng, params, vgg_w, style, learn_rate=1e-3, dist=ddist, use_graph=not args.no_graph)
+    main_leg = train_leg(B, args.steps, args.warmup, tr)
+    b4_leg = None
+    if not args.no_b4 and B != 4:
+        tr4 = trainer.Trainer(eng, params, None, style, learn_rate=1e-3, dist=ddist, use_graph=not args.no_graph)
+        b4_leg = train_leg(4, args.b4_steps, args.warmup, tr4)
+        del tr4
+    del tr
+
+    # ------------------------------------------------------------------ configs[1] / configs[4]: forward only, independent frames
+    fwd = {}
     if not args.no_stylize:
         from faststyle_amd import ckpt
-        W = ckpt.load_checkpoint(os.path.join(ROOT, "models", "starry_final.ckpt"))
-        flat = eng.mem.from_numpy(eng.flatten_params(W))
-        frame = torch.rand((1, 720, 1280, 3), device="cuda", generator=g) * 255.0
-        for _ in range(3):
-            eng.tnet_forward(flat, frame)
-        sync()
-        # one hipGraph per frame, as the streaming driver does (faststyle_amd/stream.py): a batch-1 frame is ~45 short
-        # launches and the host's launch rate should not be part of the number
-        run_frame = lambda: eng.tnet_forward(flat, frame)
-        if not args.no_graph:
-            try:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    eng.tnet_forward(flat, frame)
-                torch.cuda.current_stream().wait_stream(side)
-                sync()
-                fg = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(fg, capture_error_mode="thread_local"):
-                    eng.tnet_forward(flat, frame)
-                run_frame = fg.replay
-            except Exception as ex:
-                print("bench: frame graph capture failed (%s); eager launches" % ex, file=sys.stderr)
-        run_frame()
-        sync()
-        t1 = time.perf_counter()
-        iters = 20
-        for _ in range(iters):
-            run_frame()
-        sync()
-        dt = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        fps = world * iters / dt
+        Wc = ckpt.load_checkpoint(os.path.join(ROOT, "models", "starry_final.ckpt"))
+        flat = eng.mem.from_numpy(eng.flatten_params(Wc))
 
-        # config[4]: bf16 mixed-precision 1080p inference, batch 8 per GPU, independent frames (no collective)
-        def timed_fwd(x, bf16, iters):
-            for _ in range(2):
-                eng.tnet_forward(flat, x, bf16=bf16)
+        def fwd_leg(shape, bf16, warm, iters, graph):
+            x = torch.rand(shape, device="cuda", generator=g) * 255.0
+            run = lambda: eng.tnet_forward(flat, x, bf16=bf16)
+            for _ in range(warm):
+                run()
             sync()
+            if graph and not args.no_graph:
+                # one hipGraph per frame, as the streaming driver does (faststyle_amd/stream.py): a batch-1 frame is ~45
+                # short launches and the host's launch rate should not be part of the number
+                try:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        run()
+                    torch.cuda.current_stream().wait_stream(side)
+                    sync()
+                    fg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(fg, capture_error_mode="thread_local"):
+                        run()
+                    run = fg.replay
+                    run()
+                    sync()
+                except Exception as ex:
+                    print("bench: frame graph capture failed (%s); eager launches" % ex, file=sys.stderr)
             t0 = time.perf_counter()
             for _ in range(iters):
-                eng.tnet_forward(flat, x, bf16=bf16)
+                run()
             sync()
-            d = time.perf_counter() - t0
-            if world > 1:
-                tt = torch.tensor([d], device="cuda", dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                d = float(tt.item())
-            return world * iters * x.shape[0] / d
-        hd = torch.rand((8, 1080, 1920, 3), device="cuda", generator=g) * 255.0
-        fps_1080_bf16 = timed_fwd(hd, True, 10)
-        fps_1080_f32 = timed_fwd(hd, False, 5)
-        del hd
+            dt = max_over_ranks(time.perf_counter() - t0)
+            n = shape[0]
+            fps = world * iters * n / dt
+            gf_exec, gf_written, mb = FWD_WORK[(shape[1], shape[2])]
+            if bf16:
+                mb = mb / 2
+            per_gpu = fps / world
+            return {"fps": round(fps, 1), "ms_per_batch": round(1e3 * dt / iters, 3), "batch_per_gpu": n, "iters": iters,
+                    "tflops_executed": round(gf_exec * per_gpu / 1e3, 2), "tflops_as_written": round(gf_written * per_gpu / 1e3, 2),
+                    "frac_f32_mfma_peak_executed": None if bf16 else round(gf_exec * per_gpu / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+                    "min_traffic_TBps": round(mb * per_gpu / 1e6, 3), "frac_hbm_peak_min_traffic": round(mb * per_gpu / 1e6 / PEAK_HBM_TBS, 4),
+                    "hip_graph": bool(graph and not args.no_graph)}
+        fwd["stylize_720p"] = fwd_leg((1, 720, 1280, 3), False, 10, 50, True)
+        fwd["stylize_1080p_b8_bf16"] = fwd_leg((8, 1080, 1920, 3), True, 3, 20, False)
+        fwd["stylize_1080p_b8_fp32"] = fwd_leg((8, 1080, 1920, 3), False, 2, 8, False)
 
     if rank == 0:
-        n_img = args.steps * B * world
-        value = n_img / elapsed
-        fam = [[prof[f * 3 + k] for k in range(3)] for f in range(7)]
-        names = ["conv_igemm_kernel<32,2,2>", "conv_igemm_kernel<32,2,1>", "conv_igemm_kernel<16,4,1>",
-                 "conv_wgrad_kernel", "conv_igemm_kernel<32,1,2>", "conv_igemm_kernel<32,1,1>", "wino_conv_kernel"]
-        di = max(range(7), key=lambda f: fam[f][2])       # dominant = most GPU time in the timed region
-        dom = fam[di]
-        achieved = dom[1] / (dom[2] * 1e-3) / 1e12 if dom[2] > 0 else 0.0
-        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the
-        # figure comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+        def leg_report(leg, batch, steps):
+            n_img = steps * batch * world
+            value = n_img / leg["elapsed"]
+            P = leg["psteps"]
+            acc = leg["prof"]
+            tot = acc.sum(axis=0)
+            per_kernel = fam_table(tot, P, names)
+            fams = [(tot[3 * f + 2], f) for f in range(NF)]
+            di = max(fams)[1]                                              # dominant = most GPU time
+            exec_gflop = sum(tot[3 * f + 1] for f in range(NF)) / P / 1e9     # FLOPs executed per step (all MFMA kernels)
+            mfma_ms = sum(tot[3 * f + 2] for f in range(NF)) / P
+            step_s = leg["elapsed"] / steps
+            pl = acc[1]
+            perc_gflop = sum(pl[3 * f + 1] for f in range(NF)) / P / 1e9
+            perc_ms = leg["sections_ms"]["perceptual_loss"]
+            gram_fl = (pl[3 * 7 + 1] + pl[3 * 8 + 1]) / P
+            gram_ms = (pl[3 * 7 + 2] + pl[3 * 8 + 2]) / P
+            rep = {
+                "images_per_sec": round(value, 2), "ms_per_step": round(1e3 * step_s, 3), "steps": steps, "batch_per_gpu": batch,
+                "global_batch": batch * world, "hip_graph": leg["graphed"], "final_loss": leg["loss"],
+                "sections_ms_eager": leg["sections_ms"],
+                "step_tflops_as_written": round(GF_STEP * value / 1e3, 2),
+                "step_frac_as_written": round(GF_STEP * value / 1e3 / world / PEAK_F32_MFMA_TFLOPS, 4),
+                "step_gflop_executed": round(exec_gflop, 1),
+                "step_tflops_executed": round(exec_gflop / step_s / 1e3, 2),
+                "step_frac_executed": round(exec_gflop / step_s / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+                "all_mfma_kernels_tflops": round(exec_gflop / mfma_ms, 2) if mfma_ms else None,
+                "mfma_kernel_ms_per_step": round(mfma_ms, 3),
+                "gram": {"gflop_per_step": round(gram_fl / 1e9, 2), "ms_per_step": round(gram_ms, 3),
+                         "tflops": round(gram_fl / (gram_ms * 1e-3) / 1e12, 2) if gram_ms else None,
+                         "frac_of_f32_mfma_peak": round(gram_fl / (gram_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if gram_ms else None,
+                         "forward_tflops": per_kernel.get(names[7], {}).get("tflops"),
+                         "backward_tflops": per_kernel.get(names[8], {}).get("tflops"),
+                         "note": "G = F^T F/(hwc) per sample on 4 layers (utils.py:66-83) and dF = F (dG+dG^T); 4.295 GFLOP/img as written"},
+                "vgg_gram_substep": {"ms": perc_ms, "gflop_executed": round(perc_gflop, 1),
+                                     "tflops_executed": round(perc_gflop / perc_ms, 2),
+                                     "frac_executed": round(perc_gflop / perc_ms / PEAK_F32_MFMA_TFLOPS, 4),
+                                     "gflop_as_written": round(GF_VGG_GRAM * batch, 1),
+                                     "frac_as_written": round(GF_VGG_GRAM * batch / perc_ms / PEAK_F32_MFMA_TFLOPS, 4),
+                                     "note": "fs_perceptual_loss: VGG16 fwd on [y;content], 4 Grams, losses, VGG input gradients; wall "
+                                             "time of the section by HIP events in an eager pass (every kernel of it, not only MFMA ones)"},
+                "per_kernel": per_kernel,
+            }
+            return rep, di, per_kernel
+        rep, di, per_kernel = leg_report(main_leg, B, args.steps)
+        dom = per_kernel[names[di]]
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
+        tpath = os.path.join(ROOT, TRAFFIC_FILE)
         if os.path.exists(tpath):
-            k = json.load(open(tpath)).get("kernels", {}).get(names[di])
-            if k:
-                traffic, traffic_src = k["traffic_bytes_per_launch"], "profiles/r01_hbm_traffic_pmc.json"
-        mfma_flops = sum(f[1] for f in fam)
-        mfma_ms = sum(f[2] for f in fam)
+            tj = json.load(open(tpath))
+            k = tj.get("kernels", {}).get(names[di])
+            if k and tj.get("batch_per_gpu") == B:
+                traffic, traffic_src = k["traffic_bytes_per_launch"], TRAFFIC_FILE
         out = {
-            "metric": "images/sec train-step 256x256 (global batch 4/GPU x N; b32 at N=8)",
-            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "metric": "images/sec train-step 256x256 b32 (+ Gram GFLOPs % MFMA peak); 720p stylize fps",
+            "value": rep["images_per_sec"], "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": rep["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (uniform[0,255) images; %s VGG16 weights; random-init transform net)"
                     % ("real" if real_vgg else "synthetic He-normal"),
-            "config": {"workload": "train.py step: 256x256, batch %d/GPU, VGG16 conv1_2/2_2/3_3/4_3 Gram style loss + "
-                                   "conv3_3 content loss, resize-conv transform net, TF-Adam" % B,
-                       "global_batch": B * world, "image_size": [S, S], "parallelism": "dp%d" % world,
+            "config": {"workload": "train.py step: %dx%d, batch %d per GPU (BASELINE metric 'b32' on one GPU; global batch %d), VGG16 "
+                                   "conv1_2/2_2/3_3/4_3 Gram style loss + conv3_3 content loss, resize-conv transform net, TF-Adam, "
+                                   "hipGraph-replayed; secondary line train_b4_per_gpu = the same step at batch 4 per GPU "
+                                   "(BASELINE configs[2]; configs[3] at N=8)" % (S, S, B, B * world),
+                       "global_batch": B * world, "batch_per_gpu": B, "image_size": [S, S], "parallelism": "dp%d" % world,
+                       "collective": ("one RCCL all-reduce(SUM) of 1,696,408 B per step (world size %d)" % world) if launched else "none (single process)",
                        "style_image": "starry_night_crop.jpg 640x938"},
             "roofline": {"bound": "mfma",
-                         "kernel": names[di] + (" (fp32 MFMA, Winograd F(2x2,3x3) 3x3 conv; achieved = FLOPs EXECUTED, "
-                                                "16 products per 2x2 outputs instead of 36)" if di == 6
-                                                else " (fp32 MFMA implicit-GEMM conv)"),
-                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE, KiB counters)", "traffic_source": traffic_src,
-                         "timed_with": "HIP events on the launch stream, " + ("eager pass of the same K steps right after "
-                                       "the hipGraph-replayed timed region" if graphed else "inside the timed region"),
-                         "direct_form_equivalent_tflops": round(achieved * 2.25, 2) if di == 6 else None,
-                         "launches_per_step": round(dom[0] / args.steps, 1),
-                         "avg_launch_us": round(1e3 * dom[2] / dom[0], 2) if dom[0] else None,
-                         "all_mfma_kernels_tflops": round(mfma_flops / (mfma_ms * 1e-3) / 1e12, 2) if mfma_ms else None,
-                         "mfma_kernel_ms_per_step": round(mfma_ms / args.steps, 3),
-                         "per_kernel": {names[f]: {"launches_per_step": round(fam[f][0] / args.steps, 1),
-                                                   "tflops": round(fam[f][1] / (fam[f][2] * 1e-3) / 1e12, 2),
-                                                   "ms_per_step": round(fam[f][2] / args.steps, 3)}
-                                        for f in range(7) if fam[f][2] > 0}},
-            "step_tflops_as_written": round(GFLOP_PER_IMG_AS_WRITTEN * value / 1e3, 2),
-            "step_frac_of_f32_mfma_peak": round(GFLOP_PER_IMG_AS_WRITTEN * value / 1e3 / world / PEAK_F32_MFMA_TFLOPS, 4),
-            "final_loss": loss_val, "hip_graph": graphed,
+                         "kernel": names[di] + (" (fp32 MFMA, Winograd F(2x2,3x3) 3x3 conv; achieved = FLOPs EXECUTED, 16 products per "
+                                                "2x2 outputs instead of 36)" if di == 6 else " (fp32 MFMA)"),
+                         "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE, KiB counters)",
+                         "traffic_source": traffic_src,
+                         "timed_with": "HIP events on the launch stream, eager pass of %d steps right after the timed region" % args.profile_steps,
+                         "direct_form_equivalent_tflops": round(dom["tflops"] * 2.25, 2) if di == 6 else None,
+                         "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
+                         "per_kernel": per_kernel},
+            "gram": rep["gram"], "vgg_gram_substep": rep["vgg_gram_substep"],
+            "step_tflops_as_written": rep["step_tflops_as_written"], "step_frac_of_f32_mfma_peak": rep["step_frac_as_written"],
+            "step_gflop_executed": rep["step_gflop_executed"], "step_tflops_executed": rep["step_tflops_executed"],
+            "step_frac_executed": rep["step_frac_executed"], "all_mfma_kernels_tflops": rep["all_mfma_kernels_tflops"],
+            "mfma_kernel_ms_per_step": rep["mfma_kernel_ms_per_step"], "sections_ms_eager": rep["sections_ms_eager"],
+            "final_loss": rep["final_loss"], "hip_graph": rep["hip_graph"],
         }
-        if b32 is not None:
-            out["train_b32_one_gpu_images_per_sec"] = round(b32, 1)      # same step at batch 32 on this one GPU
-        if fps is not None:
-            out["stylize_720p_fps"] = round(fps, 2)
-            out["stylize_1080p_b8_bf16_fps"] = round(fps_1080_bf16, 1)     # FS_FLAG_BF16: ~52 dB PSNR vs the fp32 path
-            out["stylize_1080p_b8_fp32_fps"] = round(fps_1080_f32, 1)
+        if b4_leg is not None:
+            r4, d4, pk4 = leg_report(b4_leg, 4, args.b4_steps)
+            r4["dominant_kernel"] = names[d4]
+            out["train_b4_per_gpu"] = r4
+        for k, v in fwd.items():
+            out[k] = v
+        if fwd:
+            out["stylize_720p_fps"] = fwd["stylize_720p"]["fps"]
+            out["stylize_1080p_b8_bf16_fps"] = fwd["stylize_1080p_b8_bf16"]["fps"]     # FS_FLAG_BF16: ~52 dB PSNR vs the fp32 path
+            out["stylize_1080p_b8_fp32_fps"] = fwd["stylize_1080p_b8_fp32"]["fps"]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_images, S)
+            out["cpu_baseline"] = cpu_baseline(S)
         print(json.dumps(out))
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

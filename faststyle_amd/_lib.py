@@ -20,6 +20,10 @@ FS_FLAG_UPSAMPLE_DECONV = 2
 FS_FLAG_BF16 = 4
 FS_PAD_SAME, FS_PAD_VALID, FS_PAD_EXPLICIT = 0, 1, 2
 FS_SRC_PLAIN, FS_SRC_REFLECT, FS_SRC_DILATE2 = 0, 1, 2
+FS_PROFILE_FAMILIES = 9
+PROFILE_FAMILY_NAMES = ["conv_igemm_kernel<32,2,2>", "conv_igemm_kernel<32,2,1>", "conv_igemm_kernel<16,4,1>", "conv_wgrad_kernel",
+                        "conv_igemm_kernel<32,1,2>", "conv_igemm_kernel<32,1,1>", "wino_conv_kernel",
+                        "conv_wgrad_kernel (Gram forward)", "conv_igemm_kernel (Gram backward)"]
 
 VGG_LAYER_NAMES = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3",
                    "conv4_1", "conv4_2", "conv4_3"]
@@ -43,7 +47,7 @@ class fs_conv_desc(Structure):
                 ("src_mode", c_int), ("refl", c_int),
                 ("in_a", c_void_p), ("in_b", c_void_p), ("in_per_sample", c_int), ("in_relu", c_int),
                 ("bias", c_void_p), ("out_relu", c_int), ("shuffle", c_int), ("stats", c_void_p),
-                ("add_src", c_void_p), ("add_pad", c_int), ("w_nstride", c_longlong)]
+                ("add_src", c_void_p), ("add_pad", c_int), ("w_nstride", c_longlong), ("w_wino", c_void_p)]
 
 
 class fs_wgrad_desc(Structure):
@@ -67,7 +71,7 @@ PROTOTYPES = {
     "fs_last_error": (c_char_p, []),
     "fs_version": (c_char_p, []),
     "fs_profile_begin": (c_int, [c_void_p]),
-    "fs_profile_end": (c_int, [c_void_p, POINTER(ctypes.c_double * 21)]),
+    "fs_profile_end": (c_int, [c_void_p, POINTER(ctypes.c_double * (3 * FS_PROFILE_FAMILIES))]),
     "fs_tnet_param_info": (c_int, [c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int), POINTER(c_int * 4)]),
     "fs_tnet_out_shape": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "fs_tnet_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -91,6 +95,7 @@ PROTOTYPES = {
                                 c_float, c_longlong]),
     "fs_conv2d_fwd": (c_int, [c_void_p, POINTER(fs_conv_desc)]),
     "fs_conv2d_plan": (c_int, [POINTER(fs_conv_desc), POINTER(c_int)]),
+    "fs_wino_transform_filter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fs_instnorm_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "fs_instnorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -128,6 +133,8 @@ def bind(cdll):
         fn.argtypes = args
     if missing:
         raise FaststyleError("shared library lacks C-ABI symbols: %s" % ", ".join(missing))
+    cdll.fs_debug_reload_env.restype = None       # tests / tuning scripts only (not declared in include/*.h)
+    cdll.fs_debug_reload_env.argtypes = []
     return cdll
 
 

@@ -1,31 +1,60 @@
-"""Build libfaststyle_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libfaststyle_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Every .hip source is compiled to its own object under faststyle_amd/build/ (in parallel, re-used
+while neither the source nor any header changed), then linked into the shared library."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["fs_conv.hip", "fs_wino.hip", "fs_wgrad.hip", "fs_elem.hip", "fs_fold.hip", "fs_io.hip", "fs_tnet.hip", "fs_bf16.hip", "fs_vgg.hip", "fs_api.hip"]
 OUT = os.path.join(HERE, "libfaststyle_hip.so")
+OBJDIR = os.path.join(HERE, "build")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed"]
 
 
 def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=(), out=None, objdir=None):
+    out = out or OUT
+    objdir = objdir or OBJDIR
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + \
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + \
         [os.path.join(os.path.dirname(HERE), "include", "faststyle_hip.h")]
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= _newest(deps):
-        return OUT
+    hdr_time = _newest(headers + [os.path.abspath(__file__)])
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
-           "-Wno-pass-failed", "-I", CSRC] + srcs + ["-o", OUT]
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
+            jobs.append([hipcc] + FLAGS + list(extra_flags) + ["-I", CSRC, "-c", s, "-o", o])
+    if not jobs and os.path.exists(out) and os.path.getmtime(out) >= _newest(objs):
+        return out
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        return r.returncode, r.stdout.decode(errors="replace"), cmd
+
+    with ThreadPoolExecutor(max_workers=min(len(jobs) or 1, os.cpu_count() or 4)) as ex:
+        for rc, log, cmd in ex.map(run, jobs):
+            if log.strip():
+                sys.stderr.write(log)
+            if rc != 0:
+                raise subprocess.CalledProcessError(rc, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return OUT
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
+    return out
 
 
 if __name__ == "__main__":

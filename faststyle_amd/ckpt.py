@@ -286,7 +286,13 @@ def save_checkpoint(prefix, tensors):
               _put_varint(idx_off) + _put_varint(len(idx_block)))
     footer += b"\x00" * (40 - len(footer)) + _MAGIC
     out += footer
-    with open(prefix + ".data-00000-of-00001", "wb") as f:
-        f.write(bytes(blob))
-    with open(prefix + ".index", "wb") as f:
-        f.write(bytes(out))
+    # each file goes to "<file>.tmp" and is renamed into place, the data file first and the index -- the file a reader
+    # opens first -- last (as TF's BundleWriter does): a crash mid-save never leaves a truncated bundle behind the
+    # prefix that --resume_from would be pointed at
+    for suffix, payload in ((".data-00000-of-00001", bytes(blob)), (".index", bytes(out))):
+        tmp = prefix + suffix + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(payload)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, prefix + suffix)

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "fs_bf16.h"
 #include "fs_tnet.h"
@@ -33,6 +34,34 @@ static int fail(int code, const char* fmt, ...) {
 }
 
 namespace fs {
+namespace {
+struct TuneEntry {
+    char name[48];
+    bool present;
+    int val;
+};
+TuneEntry g_tune[64];
+int g_ntune = 0;
+std::mutex g_tune_mu;
+}  // namespace
+int tune_int(const char* name, int unset) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    for (int i = 0; i < g_ntune; ++i)
+        if (!strcmp(g_tune[i].name, name)) return g_tune[i].present ? g_tune[i].val : unset;
+    const char* v = getenv(name);
+    if (g_ntune < 64) {
+        TuneEntry& e = g_tune[g_ntune++];
+        strncpy(e.name, name, sizeof(e.name) - 1);
+        e.name[sizeof(e.name) - 1] = 0;
+        e.present = v != nullptr;
+        e.val = v ? (int)strtol(v, nullptr, 0) : 0;
+    }
+    return v ? (int)strtol(v, nullptr, 0) : unset;
+}
+void tune_reload() {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_ntune = 0;
+}
 int set_error(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -61,6 +90,8 @@ int fs_f32_to_u8(fs_ctx* ctx, const float* src, size_t npix, int swap_rb, unsign
     return fs::f32_to_u8(src, dst, npix, swap_rb, ctx->stream) ? fail(-3, "fs_f32_to_u8: launch failed") : 0;
 }
 
+// tests / tuning scripts: re-read the FS_* knobs after changing the environment (not part of the product ABI)
+void fs_debug_reload_env(void) { fs::tune_reload(); }
 const char* fs_last_error(void) { return g_err; }
 const char* fs_version(void) { return "faststyle_hip 0.1 (gfx950, fp32 MFMA)"; }
 
@@ -73,7 +104,7 @@ int fs_ctx_create(int device, void* hip_stream, fs_ctx** out) {
     c->tnet_valid = false;
     c->btnet = nullptr;
     c->have_side = false;
-    if (!getenv("FS_NO_SIDE_STREAM") && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess) {
+    if (!fs::tune_int("FS_NO_SIDE_STREAM", 0) && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess) {
         c->have_side = true;
         for (int i = 0; i < 34; ++i)
             if (hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming) != hipSuccess) c->have_side = false;
@@ -103,9 +134,10 @@ int fs_profile_begin(fs_ctx* ctx) {
     fs::Profiler::current() = &g_prof;
     return 0;
 }
-int fs_profile_end(fs_ctx* ctx, double out[21]) {
+int fs_profile_end(fs_ctx* ctx, double out[3 * FS_PROFILE_FAMILIES]) {
     if (!ctx || !out) return fail(-1, "fs_profile_end: null argument");
     fs::Profiler::current() = nullptr;
+    static_assert(fs::Profiler::kFamilies == FS_PROFILE_FAMILIES, "header and profiler disagree");
     double tmp[fs::Profiler::kFamilies][3];
     if (g_prof.collect(tmp)) return fail(-4, "fs_profile_end: event query failed");
     memcpy(out, tmp, sizeof(tmp));
@@ -369,6 +401,8 @@ static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
     a->add_src = d->add_src;
     a->add_pad = d->add_pad;
     a->w_nstride = d->w_nstride;
+    a->w_wino = d->w_wino;
+    if (a->w_wino && !fs::wino_eligible(*a)) a->w_wino = nullptr;   // (not a 3x3 stride-1 conv of the supported shapes: direct kernel)
     a->p = fs::conv_plan(*a);
     return 0;
 }
@@ -376,11 +410,6 @@ static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
 int fs_conv2d_plan(fs_conv_desc* d, int* tiles_per_image) {
     fs::ConvArgs a;
     if (int rc = fill_conv(d, &a)) return rc;
-    const char* wenv = getenv("FS_CONV2D_WINO");   // the test hook of fs_conv2d_fwd plans with the Winograd kernel: say so here
-    if (wenv && atoi(wenv)) {
-        a.w_wino = a.w;
-        if (fs::wino_eligible(a)) a.p = fs::conv_plan(a);
-    }
     if (tiles_per_image) *tiles_per_image = a.p.tiles_y * a.p.tiles_x;
     return 0;
 }
@@ -390,45 +419,15 @@ int fs_conv2d_fwd(fs_ctx* ctx, fs_conv_desc* d) {
     fs::ConvArgs a;
     if (int rc = fill_conv(d, &a)) return rc;
     if (!a.x || !a.w || !a.y) return fail(-1, "fs_conv2d_fwd: null tensor");
-    // Test / tuning hook (tests/test_kernels_parity.py, tools/micro_conv.py): FS_CONV2D_WINO=1 sends an eligible 3x3
-    // stride-1 SAME conv through the Winograd kernel with a filter transformed on the spot into a temporary buffer.
-    // The training step never takes this branch: fs_vgg_prepare transforms the frozen VGG filters once.
-    float* tmpU = nullptr;
-    const char* wenv = getenv("FS_CONV2D_WINO");
-    if (wenv && atoi(wenv)) {
-        fs::ConvArgs probe = a;
-        probe.w_wino = a.w;  // any non-null value: eligibility only looks at the shapes
-        if (fs::wino_eligible(probe)) {
-            // mode 2 (micro-benchmarks): keep the transformed filter of the last (pointer, shape) instead of rebuilding it
-            static float* cacheU = nullptr;
-            static const float* cache_w = nullptr;
-            static int cache_ci = 0, cache_co = 0;
-            const bool cached = atoi(wenv) == 2;
-            if (cached && cacheU && cache_w == a.w && cache_ci == a.Cin && cache_co == a.Cout) {
-                a.w_wino = cacheU;
-            } else {
-                if (hipMalloc(reinterpret_cast<void**>(&tmpU), (size_t)16 * a.Cin * a.Cout * sizeof(float)) != hipSuccess)
-                    return fail(-5, "fs_conv2d_fwd: no memory for the Winograd filter");
-                fs::wt_wino(a.w, tmpU, a.Cin, a.Cout, ctx->stream);
-                a.w_wino = tmpU;
-                if (cached) {
-                    if (cacheU) (void)hipFree(cacheU);
-                    cacheU = tmpU;
-                    cache_w = a.w;
-                    cache_ci = a.Cin;
-                    cache_co = a.Cout;
-                    tmpU = nullptr;
-                }
-            }
-            a.p = fs::conv_plan(a);
-        }
-    }
     const int rc = fs::conv_launch(a, ctx->stream);
-    if (tmpU) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(tmpU);
-    }
     return rc ? fail(rc, "fs_conv2d_fwd: launch failed (%d)", rc) : 0;
+}
+
+int fs_wino_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, float* U) {
+    if (!ctx || !w || !U) return fail(-1, "fs_wino_transform_filter: null argument");
+    if (Cin < 1 || Cout < 1) return fail(-2, "fs_wino_transform_filter: bad shape %dx%d", Cin, Cout);
+    const int rc = fs::wt_wino(w, U, Cin, Cout, ctx->stream);
+    return rc ? fail(rc, "fs_wino_transform_filter: launch failed (%d)", rc) : 0;
 }
 
 int fs_instnorm_finalize(fs_ctx* ctx, const float* stats, int N, int tiles, int C, int groups, const float* gamma,

@@ -697,11 +697,11 @@ ConvBPlan conv_bf16_plan(const ConvBArgs& a) {
     const int G = p.c4 ? a.KH : a.KH * a.KW;
     // widest pixel tile / deepest channel chunk whose staging fits the per-thread register budget; the narrower
     // tile when the launch could not fill the chip
-    const char* wm_env = getenv("FS_BF16_WM");  // tuning aid: cap the pixel tile (1: 128 pixels)
+    const int wm_env = tune_int("FS_BF16_WM", 0);  // tuning aid: cap the pixel tile (1: 128 pixels)
     // the resident kernel with 64 output channels and the 256-pixel tile does not fit the register file (it spills
     // ~1 KB per lane and measures 1.5x slower than the 128-pixel tile): start it at WM = 1
     const bool single_chunk = p.c4 || a.Cin <= 32;
-    const int wm0 = wm_env ? atoi(wm_env) : (single_chunk && p.BN == 64 ? 1 : 2);
+    const int wm0 = wm_env > 0 ? wm_env : (single_chunk && p.BN == 64 ? 1 : 2);
     for (p.WM = wm0; p.WM >= 1; --p.WM) {
         const int max_px = 4 * p.WM * 32;
         plan_tile(a.Ho, a.Wo, a.KH, p.c4 ? 12 : a.KW, a.stride, max_px, &p.TH, &p.TW);
@@ -751,18 +751,13 @@ int conv_bf16_launch(const ConvBArgs& a_in, hipStream_t s) {
     // resident kernels walk a strided list of tiles: cap the grid at a few waves of workgroups per CU so that the
     // resident filter is amortised over many tiles
     const long total_tiles = (long)a.N * p.tiles_y * p.tiles_x;
-    const char* cap_env = getenv("FS_BF16_GRID");  // (tests shrink it to force the multi-tile walk on small images)
-    const int cap = cap_env ? atoi(cap_env) : 2048;
+    const int cap = tune_int("FS_BF16_GRID", 2048);  // (tests shrink it to force the multi-tile walk on small images)
     const bool resident = p.c4 || a.Cin == p.CC;
     dim3 grid((unsigned)(resident && total_tiles > cap ? cap : total_tiles), (unsigned)(p.cout_pad / p.BN));
 #define FS_BLAUNCH_K(KERNEL_)                                                                                             \
     do {                                                                                                                  \
-        static bool attr_done = false;                                                                                    \
-        if (!attr_done) {                                                                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL_), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      160 * 1024);                                                                        \
-            attr_done = true;                                                                                             \
-        }                                                                                                                 \
+        static BigLds lds_attr;                                                                                           \
+        lds_attr.ensure(reinterpret_cast<const void*>(KERNEL_));                                                          \
         hipLaunchKernelGGL(KERNEL_, grid, dim3(256), (size_t)p.lds_bytes, s, a);                                          \
     } while (0)
 #define FS_BLAUNCH(WM_, WN_, C4_)                                        \

@@ -806,10 +806,7 @@ Profiler::~Profiler() {
     free(recs);
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+static int env_int(const char* name, int dflt) { return tune_int(name, dflt); }
 
 void plan_tile(int Ho, int Wo, int KH, int KW, int stride, int max_px, int* TH, int* TW) {
     double best = -1;
@@ -1030,16 +1027,12 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
         if (a.shuffle) fl *= 9.0 / 16.0;  // phase-collapsed resize-conv / stride-2 dgrad: 9 of the 16 tap-parity slots are non-zero
         // Winograd F(2x2,3x3): 16 products per 2x2 output tile instead of 36 -- the FLOPs actually executed
         if (p.variant == 5) fl = 2.0 * a.N * cdiv(a.Ho, 2) * cdiv(a.Wo, 2) * 16.0 * a.Cin * a.Cout;
-        prof->begin(p.variant < 3 ? p.variant : p.variant + 1, fl, s);
+        prof->begin(a.w_nstride ? 8 : (p.variant < 3 ? p.variant : p.variant + 1), fl, s);
     }
 #define FS_LAUNCH(MT_, WM_, WN_, FL_)                                                                              \
     do {                                                                                                           \
-        static bool attr_done = false;                                                                             \
-        if (!attr_done) { /* allow > 64 KiB of dynamic LDS (gfx950: 160 KiB per CU) */                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<MT_, WM_, WN_, FL_>),        \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
-            attr_done = true;                                                                                      \
-        }                                                                                                          \
+        static BigLds lds_attr; /* > 64 KiB of dynamic LDS */                                                      \
+        lds_attr.ensure(reinterpret_cast<const void*>(conv_igemm_kernel<MT_, WM_, WN_, FL_>));                       \
         hipLaunchKernelGGL((conv_igemm_kernel<MT_, WM_, WN_, FL_>), grid, dim3(256), (size_t)p.lds_bytes, s, a);   \
     } while (0)
     if (p.variant == 5) {

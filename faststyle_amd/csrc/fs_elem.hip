@@ -9,6 +9,10 @@
 
 namespace fs {
 
+// every launcher reports a failed launch (bad configuration, missing code object) instead of returning success
+static inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : -3; }
+
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -146,8 +150,8 @@ __global__ __launch_bounds__(256) void in_prereduce_kernel(const float* __restri
 int in_finalize(const float* stats, int N, int T, int C, int groups, const float* gamma, const float* beta, float eps,
                 float* mean, float* rstd, float* a, float* b, hipStream_t s, float* scratch) {
     const int Cv = C * groups;
-    const char* mt = getenv("FS_FINALIZE_MIN_T");  // (tests lower it so small images take the two-level path)
-    const int min_t = mt ? atoi(mt) : 16 * kFinalizeSplit;  // 1024 tiles: 720p and up; training sizes stay single-level
+    // (tests lower FS_FINALIZE_MIN_T so small images take the two-level path)
+    const int min_t = tune_int("FS_FINALIZE_MIN_T", 16 * kFinalizeSplit);  // 1024 tiles: 720p and up; training sizes stay single-level
     if (scratch && T * groups > min_t && T > kFinalizeSplit && Cv <= 256) {  // scratch: N * kFinalizeSplit * Cv * 3 floats
         hipLaunchKernelGGL(in_prereduce_kernel, dim3(kFinalizeSplit, N), dim3(256), 0, s, stats, T, Cv, kFinalizeSplit, scratch);
         stats = scratch;
@@ -159,7 +163,7 @@ int in_finalize(const float* stats, int N, int T, int C, int groups, const float
     else
         hipLaunchKernelGGL(in_finalize_kernel<64>, dim3(N, cdiv(C, 4)), dim3(256), 0, s, stats, T, C, groups, gamma, beta,
                            eps, mean, rstd, a, b);
-    return 0;
+    return launch_status();
 }
 
 // ---------------------------------------------------------------- residual add / tanh
@@ -200,7 +204,7 @@ int apply_res(const float* z, const float* a, const float* b, const float* skip,
     if (C % 4) return -1;
     hipLaunchKernelGGL(apply_res_kernel, dim3(cdiv(W * (C / 4), 256), H, N), dim3(256), 0, s, z, a, b, skip, sa, sb, skip_relu,
                        out, H, W, C);
-    return 0;
+    return launch_status();
 }
 
 // y = (255*tanh(a z + b) + 255)/2   reference im_transf_net.py:202-215
@@ -218,7 +222,7 @@ int apply_tanh(const float* z, const float* a, const float* b, float* y, int N, 
     const size_t total = (size_t)N * HW * C;
     hipLaunchKernelGGL(apply_tanh_kernel, dim3((unsigned)min((size_t)2048, (total + 255) / 256)), dim3(256), 0, s, z, a, b,
                        y, HW, C, total);
-    return 0;
+    return launch_status();
 }
 
 // ---------------------------------------------------------------- slab reduction
@@ -332,7 +336,7 @@ int reduce_slabs(const float* slabs, int groups, int n_wg, size_t count, float s
         hipLaunchKernelGGL(reduce_slabs_kernel<256>, dim3((unsigned)((count + 255) / 256), groups), dim3(256), 0, s, slabs, n_wg,
                            count, scale, out);
     }
-    return 0;
+    return launch_status();
 }
 
 // ---------------------------------------------------------------- instance-norm backward
@@ -637,8 +641,8 @@ int in_bwd(const float* gin, const float* z, const float* mean, const float* rst
     int chunk_px = cdiv(HW * N, 2048);
     if (chunk_px < 128) chunk_px = 128;
     {   // tuning aid: pixels per partial-sum block (multiples of 64 only: the scratch is sized for 64)
-        const char* v = getenv("FS_INBWD_CHUNK");
-        if (v && atoi(v) >= 64) chunk_px = atoi(v);
+        const int v = tune_int("FS_INBWD_CHUNK", 0);
+        if (v >= 64) chunk_px = v;
     }
     const int chunks = cdiv(HW, chunk_px);
     float* partial = scratch;
@@ -655,7 +659,7 @@ int in_bwd(const float* gin, const float* z, const float* mean, const float* rst
         const int per = HW * C;
         hipLaunchKernelGGL(in_bwd_apply4_kernel, dim3(cdiv(per / 4, 256), N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode,
                            S, dz, HW, C, (C & (C - 1)) == 0 ? C - 1 : -1);
-        return 0;
+        return launch_status();
     }
     hipLaunchKernelGGL(in_bwd_partial_kernel, dim3(chunks, N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, partial, HW,
                        C, chunk_px);
@@ -663,7 +667,7 @@ int in_bwd(const float* gin, const float* z, const float* mean, const float* rst
     const int per = HW * C;
     hipLaunchKernelGGL(in_bwd_apply_kernel<false>, dim3(min(2048, cdiv(per, 256)), N), dim3(256), 0, s, gin, z, mean, rstd,
                        a, b, mode, S, dz, HW, C, N, dgamma, dbeta);
-    return 0;
+    return launch_status();
 }
 size_t in_bwd_scratch_floats(int N, int HW, int C) { return (size_t)N * cdiv(HW, 64) * C * 2 + (size_t)N * C * 2; }
 
@@ -699,7 +703,7 @@ int maxpool(const float* x, float* y, int N, int H, int W, int C, hipStream_t s)
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     if (C % 4) return -1;
     hipLaunchKernelGGL(maxpool_kernel, dim3(cdiv(Wo * (C / 4), 256), Ho, N), dim3(256), 0, s, x, y, H, W, C, Ho, Wo);
-    return 0;
+    return launch_status();
 }
 
 // d_pre[n,y,x,c] = (route(d_above) + d_tap) * (out > 0)
@@ -763,7 +767,7 @@ int vgg_bwd_route(const float* out, const float* d_above, const float* d_tap, in
     if (C % 4) return -1;
     hipLaunchKernelGGL(vgg_bwd_route_kernel, dim3(cdiv(W * (C / 4), 256), H, N), dim3(256), 0, s, out, d_above, d_tap, pooled,
                        d_pre, H, W, C);
-    return 0;
+    return launch_status();
 }
 
 // ---------------------------------------------------------------- losses
@@ -803,7 +807,7 @@ int sqdiff_loss(const float* x, const float* t, size_t t_period, size_t total, f
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(sqdiff_kernel, dim3(bx, periods), dim3(256), 0, s, x, t, t_period, gscale, grad, scratch);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, scratch, bx * periods, lscale, loss_out, accumulate);
-    return 0;
+    return launch_status();
 }
 
 // TV loss (reference losses.py:70-97): sum of squared forward differences along H and W, and
@@ -843,7 +847,7 @@ int tv_loss(const float* x, int N, int H, int W, int C, float lscale, float gsca
     const int blocks = (int)min((size_t)1024, (total + 255) / 256);
     hipLaunchKernelGGL(tv_kernel, dim3(blocks), dim3(256), 0, s, x, H, W, C, total, gscale, grad, scratch);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, scratch, blocks, lscale, loss_out, 0);
-    return 0;
+    return launch_status();
 }
 
 // out = alpha * (x - t[i % period])     (style: S = coef*(G - Gt), the filter of the Gram backward)
@@ -854,7 +858,7 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* x, const float*
 
 int axpby(const float* x, const float* y, float a, float b, float* out, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)min((size_t)4096, (n + 255) / 256)), dim3(256), 0, s, x, y, a, b, out, n);
-    return 0;
+    return launch_status();
 }
 
 // ---------------------------------------------------------------- TF-style Adam
@@ -875,7 +879,7 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* p, const float* g, 
 int adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s) {
     hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)min((size_t)2048, (n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr_t,
                        b1, b2, eps);
-    return 0;
+    return launch_status();
 }
 
 // ---------------------------------------------------------------- filter re-layouts
@@ -894,7 +898,7 @@ __global__ __launch_bounds__(256) void wt_flip_transpose_kernel(const float* w, 
 
 int wt_flip_transpose(const float* w, float* out, int KH, int KW, int Ci, int Co, hipStream_t s) {
     hipLaunchKernelGGL(wt_flip_transpose_kernel, dim3(cdiv(KH * KW * Ci * Co, 256)), dim3(256), 0, s, w, out, KH, KW, Ci, Co);
-    return 0;
+    return launch_status();
 }
 
 // Phase-collapsed resize-conv (reference im_transf_net.py:122-155: NEAREST x4 then 3x3 stride-2
@@ -1028,20 +1032,20 @@ int wt_batch(const WtBatch& b, hipStream_t s) {
     for (int k = 0; k < b.n; ++k)
         if (b.j[k].total > mx) mx = b.j[k].total;
     hipLaunchKernelGGL(wt_batch_kernel, dim3(cdiv(mx, 256), b.n), dim3(256), 0, s, b);
-    return 0;
+    return launch_status();
 }
 
 int wt_upconv_fwd(const float* w, float* weff, int Ci, int Co, hipStream_t s) {
     hipLaunchKernelGGL(wt_upconv_fwd_kernel, dim3(cdiv(16 * Ci * Co, 256)), dim3(256), 0, s, w, weff, Ci, Co);
-    return 0;
+    return launch_status();
 }
 int wt_upconv_dgrad(const float* w, float* v, int Ci, int Co, hipStream_t s) {
     hipLaunchKernelGGL(wt_upconv_dgrad_kernel, dim3(cdiv(9 * Ci * Co, 256)), dim3(256), 0, s, w, v, Ci, Co);
-    return 0;
+    return launch_status();
 }
 int wt_upconv_wgrad_fold(const float* dweff, float* dw, int Ci, int Co, hipStream_t s) {
     hipLaunchKernelGGL(wt_upconv_wgrad_fold_kernel, dim3(cdiv(9 * Ci * Co, 256)), dim3(256), 0, s, dweff, dw, Ci, Co);
-    return 0;
+    return launch_status();
 }
 
 }  // namespace fs
@@ -1060,7 +1064,7 @@ __global__ void vgg_consts_kernel(float* ab) {
 }
 int vgg_consts(float* ab, hipStream_t s) {
     hipLaunchKernelGGL(vgg_consts_kernel, dim3(1), dim3(64), 0, s, ab);
-    return 0;
+    return launch_status();
 }
 // losses = {total, content, style, beta*tv}   (reference train.py:184)
 __global__ void loss_total_kernel(float* l) {
@@ -1068,6 +1072,6 @@ __global__ void loss_total_kernel(float* l) {
 }
 int loss_total(float* losses, hipStream_t s) {
     hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, s, losses);
-    return 0;
+    return launch_status();
 }
 }  // namespace fs

@@ -12,6 +12,10 @@
 
 namespace fs {
 
+// every launcher reports a failed launch (bad configuration, missing code object) instead of returning success
+static inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : -3; }
+
+
 // wf[kh][b][ci][16] from w[9][9][Ci][3]
 __global__ __launch_bounds__(256) void wt_fold5_fwd_kernel(const float* w, float* wf, int Ci) {
     const int total = 9 * 2 * Ci * 16;
@@ -118,25 +122,25 @@ __global__ __launch_bounds__(256) void unfold5_kernel(const float* dz, float* dy
 
 int wt_fold5_fwd(const float* w, float* wf, int Ci, hipStream_t s) {
     hipLaunchKernelGGL(wt_fold5_fwd_kernel, dim3(cdiv(18 * Ci * 16, 256)), dim3(256), 0, s, w, wf, Ci);
-    return 0;
+    return launch_status();
 }
 int wt_fold5_back(const float* dwf, float* dw, int Ci, hipStream_t s) {
     hipLaunchKernelGGL(wt_fold5_back_kernel, dim3(cdiv(81 * Ci * 3, 256)), dim3(256), 0, s, dwf, dw, Ci);
-    return 0;
+    return launch_status();
 }
 int fold5_fwd(const float* Z, float* z, float* stats, int N, int Ho, int Wo, hipStream_t s) {
     hipLaunchKernelGGL(fold5_fwd_kernel<float>, dim3(cdiv(Ho * Wo, 256), N), dim3(256), 0, s, Z, z, stats, Ho * Wo, Wo);
-    return 0;
+    return launch_status();
 }
 int fold5_fwd_bf16(const unsigned short* Z, float* z, float* stats, int N, int Ho, int Wo, hipStream_t s) {
     hipLaunchKernelGGL(fold5_fwd_kernel<unsigned short>, dim3(cdiv(Ho * Wo, 256), N), dim3(256), 0, s, Z, z, stats, Ho * Wo, Wo);
-    return 0;
+    return launch_status();
 }
 int unfold5(const float* dz, float* dys, int N, int Ho, int Wo, hipStream_t s) {
     const size_t total = (size_t)N * Ho * (Wo + 4);
     hipLaunchKernelGGL(unfold5_kernel, dim3((unsigned)min((size_t)8192, (total + 255) / 256)), dim3(256), 0, s, dz, dys, Ho,
                        Wo, total);
-    return 0;
+    return launch_status();
 }
 
 }  // namespace fs

@@ -5,6 +5,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -100,6 +101,17 @@ int wgrad_launch(const WgradArgs& a, hipStream_t s);
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// More than 64 KiB of dynamic LDS (gfx950: 160 KiB per CU) needs hipFuncAttributeMaxDynamicSharedMemorySize, once per
+// kernel AND device (one static BigLds per kernel instantiation; thread-safe).
+struct BigLds {
+    std::once_flag once[16];
+    void ensure(const void* fn) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::call_once(once[dev & 15], [fn] { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    }
+};
+
 }  // namespace fs
 
 namespace fs {
@@ -124,6 +136,11 @@ bool wino_eligible(const ConvArgs& a);
 void wino_plan(const ConvArgs& a, ConvPlan* out);
 int wino_launch(const ConvArgs& a, hipStream_t s);
 void plan_tile(int Ho, int Wo, int KH, int KW, int stride, int max_px, int* TH, int* TW);
+// Tuning / debugging knobs come from the environment ONCE: the first lookup of a name reads and caches it,
+// so no launch or planning path calls getenv() afterwards.  fs_debug_reload_env() (tests) drops the cache.  `unset` is
+// returned when the variable is absent.  (fs_api.hip)
+int tune_int(const char* name, int unset);
+void tune_reload();
 // thread-local message behind fs_last_error(); returns `code` (fs_api.hip)
 int set_error(int code, const char* fmt, ...);
 // tf.image.resize_images(method=2) of TF 1.0 on device u8 [H,W,3] -> f32 [Ho,Wo,3] (fs_io.hip)
@@ -182,7 +199,8 @@ namespace fs {
 // Optional HIP-event profiler around the MFMA kernels (bench.py's roofline leg): per kernel
 // family it accumulates launches, algorithmic FLOPs and the event-measured duration.
 struct Profiler {
-    static const int kFamilies = 7;  // conv variants 0..2, wgrad/gram 3, conv variants 3..4 -> 4..5, Winograd conv 6
+    static const int kFamilies = 9;  // conv variants 0..2, filter gradients 3, conv variants 3..4 -> 4..5, Winograd conv 6,
+                                     // Gram forward (per-sample F^T F) 7, Gram backward (1x1 conv with per-sample filters) 8
     struct Rec { hipEvent_t a, b; int fam; double flops; };
     Rec* recs = nullptr;
     int n = 0, cap = 0;

@@ -108,8 +108,7 @@ static ConvArgs unit_args(const Unit& u, int N) {
 }
 
 int tnet_wino_mode() {
-    const char* tv = getenv("FS_TNET_WINO");
-    return tv ? atoi(tv) : 1;
+    return tune_int("FS_TNET_WINO", 1);
 }
 
 void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {

@@ -50,8 +50,7 @@ size_t vgg_prepared_floats() { return wino_offset(FS_VGG_NLAYERS, false); }
 // debugging aid: FS_VGG_WINO_MASK selects the layers that may take the Winograd kernel (bit l: forward of layer l,
 // bit 16+l: its input gradient); default all
 static bool wino_layer_on(int bit) {
-    const char* v = getenv("FS_VGG_WINO_MASK");
-    return !v || ((strtoul(v, nullptr, 0) >> bit) & 1u);
+    return ((unsigned)tune_int("FS_VGG_WINO_MASK", -1) >> bit) & 1u;
 }
 static size_t prepared_offset(int l) {
     size_t n = 0;

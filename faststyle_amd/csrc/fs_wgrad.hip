@@ -538,10 +538,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #endif
 }
 
-static int env_int2(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+static int env_int2(const char* name, int dflt) { return tune_int(name, dflt); }
 
 WgradPlan wgrad_plan(const WgradArgs& a) {
     WgradPlan p{};
@@ -621,12 +618,8 @@ WgradPlan wgrad_plan(const WgradArgs& a) {
 
 template <int KWV, int NWV>
 static void launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KWV, NWV>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static BigLds lds_attr;
+    lds_attr.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<KWV, NWV>));
     hipLaunchKernelGGL((conv_wgrad_kernel<KWV, NWV>), grid, dim3(256), (size_t)a.p.lds_bytes, s, a);
 }
 
@@ -639,7 +632,7 @@ int wgrad_launch(const WgradArgs& a_in, hipStream_t s) {
     const int NWV = p.NWV;
     dim3 grid((unsigned)p.n_wg, (unsigned)(cdiv(p.KB, p.waves_k * p.KWV) * cdiv(p.NB, NWV)), (unsigned)(a.per_sample ? a.N : 1));
     Profiler* prof = Profiler::current();
-    if (prof) prof->begin(3, 2.0 * a.N * a.Ho * a.Wo * (double)p.K * a.Cout, s);
+    if (prof) prof->begin(a.per_sample ? 7 : 3, 2.0 * a.N * a.Ho * a.Wo * (double)p.K * a.Cout, s);
     if (p.KWV == 1)
         launch_wgrad<1, 4>(a, grid, s);
     else if (p.KWV == 2)

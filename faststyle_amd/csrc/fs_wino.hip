@@ -27,6 +27,7 @@
 #include "fs_kernels.h"
 
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace fs {
@@ -43,32 +44,7 @@ constexpr int kVFloats = 16 * kNT * kPS;                   // 9216
 constexpr int kUFloats = 16 * kCC * kBN;                   // 8192
 }  // namespace
 
-// U[pos][ci][co] = (G g G^T)[pos] for g = w[:, :, ci, co]   (w HWIO [3][3][Cin][Cout])
-__global__ __launch_bounds__(256) void wt_wino_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t cc = (size_t)Cin * Cout;
-    if (i >= cc) return;
-    float g[3][3], t[4][3];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) g[kh][kw] = w[(size_t)(kh * 3 + kw) * cc + i];
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-        t[0][kw] = g[0][kw];
-        t[1][kw] = 0.5f * (g[0][kw] + g[1][kw] + g[2][kw]);
-        t[2][kw] = 0.5f * (g[0][kw] - g[1][kw] + g[2][kw]);
-        t[3][kw] = g[2][kw];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        U[(size_t)(r * 4 + 0) * cc + i] = t[r][0];
-        U[(size_t)(r * 4 + 1) * cc + i] = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
-        U[(size_t)(r * 4 + 2) * cc + i] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
-        U[(size_t)(r * 4 + 3) * cc + i] = t[r][2];
-    }
-}
-
+// U[pos][ci][co] = (G g G^T)[pos] for g = w[:, :, ci, co]   (w HWIO [3][3][Cin][Cout]); blockIdx.y = filter of the batch
 __global__ __launch_bounds__(256) void wt_wino_batch_kernel(WinoBatch b, int Cin, int Cout) {
     const float* __restrict__ w = b.w[blockIdx.y];
     float* __restrict__ U = b.U[blockIdx.y];
@@ -100,13 +76,15 @@ int wt_wino_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s) {
     if (b.n <= 0) return 0;
     const size_t cc = (size_t)Cin * Cout;
     hipLaunchKernelGGL(wt_wino_batch_kernel, dim3((unsigned)((cc + 255) / 256), (unsigned)b.n), dim3(256), 0, s, b, Cin, Cout);
-    return 0;
+    return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 int wt_wino(const float* w, float* U, int Cin, int Cout, hipStream_t s) {
-    const size_t cc = (size_t)Cin * Cout;
-    hipLaunchKernelGGL(wt_wino_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, w, U, Cin, Cout);
-    return 0;
+    WinoBatch b{};
+    b.w[0] = w;
+    b.U[0] = U;
+    b.n = 1;
+    return wt_wino_batch(b, Cin, Cout, s);
 }
 
 #ifdef FS_CONV_TRACE
@@ -546,7 +524,7 @@ void wino_plan(const ConvArgs& a, ConvPlan* out) {
     p.ksplit = 1;
     const long wgs = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / kBN);
     const int nchunks = a.Cin / kCC;
-    const int max_ks = getenv("FS_WINO_KSPLIT") ? atoi(getenv("FS_WINO_KSPLIT")) : 4;  // tuning / debugging aid
+    const int max_ks = tune_int("FS_WINO_KSPLIT", 4);  // tuning / debugging aid
     if (a.split_ws && !a.stats) {
         int ks = 1;
         while (ks < max_ks && wgs * ks < 256 && nchunks / (ks * 2) >= 8 &&
@@ -559,15 +537,12 @@ void wino_plan(const ConvArgs& a, ConvPlan* out) {
 
 int wino_launch(const ConvArgs& a, hipStream_t s) {
     const ConvPlan& p = a.p;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr_done = true;
-    }
+    // > 64 KiB of dynamic LDS needs the attribute once per device (a per-function property of the loaded code object)
+    static BigLds lds_attr;
+    lds_attr.ensure(reinterpret_cast<const void*>(wino_conv_kernel));
     dim3 grid((unsigned)(a.N * p.tiles_y * p.tiles_x), (unsigned)(a.Cout / kBN), (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
     hipLaunchKernelGGL(wino_conv_kernel, grid, dim3(512), (size_t)p.lds_bytes, s, a);
-    return 0;
+    return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 }  // namespace fs

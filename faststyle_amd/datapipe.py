@@ -119,6 +119,8 @@ def batcher(filenames, batch_size, resize_shape=None, num_epochs=None, min_after
         raise L.FaststyleError("datapipe.batcher needs the Engine that owns the device (no CPU resize path)")
     if resize_shape is None:
         raise L.FaststyleError("batching needs a static image shape: pass resize_shape (train.py --preprocess_size)")
+    if max_batches is not None and max_batches <= 0:       # (checked before anything is read: a zero cap yields nothing)
+        return
     files = sorted(filenames)[rank::world]
     if not files:
         raise L.FaststyleError("rank %d of %d has no TFRecord shard (%d files)" % (rank, world, len(filenames)))

@@ -1,6 +1,6 @@
 """Thin Python driver over the C ABI: owns a context, workspaces and the pointer plumbing.
 
-Device memory, streams and (in ``parallel.py``) ``torch.distributed`` come from PyTorch-ROCm --
+Device memory, streams and (in ``trainer.py``) ``torch.distributed`` come from PyTorch-ROCm --
 plumbing only; every FLOP of the path runs in libfaststyle_hip.so.  The memory provider is
 injectable (``mem``) so the parity tests can drive the very same code with host arrays against
 the kernel emulator build; the product always uses ``TorchMem`` on a ROCm device.
@@ -75,6 +75,8 @@ def default_loss_cfg():
 
 
 class Engine(object):
+    MAX_CACHED_SHAPES = 8          # workspaces kept per (batch, size, mode) key
+
     def __init__(self, mem=None, lib=None):
         self.mem = mem if mem is not None else TorchMem()      # initialises the HIP runtime PyTorch ships
         self.lib = lib if lib is not None else L.load()
@@ -146,7 +148,13 @@ class Engine(object):
             nbytes = self.lib.fs_tnet_workspace_bytes(N, H, W, L.FS_FLAG_BF16 if bf16 else L.FS_FLAG_SAVE_FOR_BWD)
             if nbytes == 0:
                 raise L.FaststyleError("bad transform-net shape %s" % (key,))
-            self._tnet_ws = {key: (self.mem.empty((nbytes // 4,)), nbytes)}   # keep only the latest shape
+            # a few shapes stay resident (a captured hipGraph holds raw pointers into its workspace, and a backward
+            # must find the workspace its forward filled); least-recently-used beyond that
+            while len(self._tnet_ws) >= self.MAX_CACHED_SHAPES:
+                self._tnet_ws.pop(next(iter(self._tnet_ws)))
+            self._tnet_ws[key] = (self.mem.empty((nbytes // 4,)), nbytes)
+        else:
+            self._tnet_ws[key] = self._tnet_ws.pop(key)                      # mark as most recently used
         return self._tnet_ws[key]
 
     @staticmethod
@@ -174,6 +182,8 @@ class Engine(object):
         """Gradient of the 48 tensors given dL/dy; must follow tnet_forward(save_for_bwd=True)."""
         self._sync_stream()
         N, H, W, _ = (int(s) for s in x.shape)
+        if (N, H, W, False, os.environ.get("FS_TNET_WINO", "")) not in self._tnet_ws:
+            raise L.FaststyleError("tnet_backward(%dx%dx%d) without a tnet_forward(save_for_bwd=True) of that shape" % (N, H, W))
         ws, nbytes = self._tnet_workspace(N, H, W)
         if grads is None:
             grads = self.mem.empty((L.FS_TNET_NPARAMS,))
@@ -203,6 +213,10 @@ class Engine(object):
 
     def _cfg(self, cfg, target_grams=None):
         c = L.fs_loss_cfg()
+        # the reference asserts equal lengths (losses.py:28, :58 iterate by index over both lists)
+        if len(cfg["content_layers"]) != len(cfg["content_weights"]) or len(cfg["style_layers"]) != len(cfg["style_weights"]):
+            raise L.FaststyleError("loss layers and weights differ in length: %s / %s, %s / %s" % (
+                cfg["content_layers"], cfg["content_weights"], cfg["style_layers"], cfg["style_weights"]))
         c.n_content = len(cfg["content_layers"])
         for i, (n, w) in enumerate(zip(cfg["content_layers"], cfg["content_weights"])):
             c.content_layer[i] = L.VGG_LAYER_NAMES.index(n)
@@ -244,7 +258,12 @@ class Engine(object):
         key = (N, H, W, tuple(cfg["content_layers"]), tuple(cfg["style_layers"]))
         nbytes = self.lib.fs_perceptual_workspace_bytes(N, H, W, ctypes.byref(c))
         if key not in self._perc_ws or self._perc_ws[key][1] != nbytes:
-            self._perc_ws = {key: (self.mem.empty((nbytes // 4,)), nbytes)}
+            self._perc_ws.pop(key, None)
+            while len(self._perc_ws) >= self.MAX_CACHED_SHAPES:
+                self._perc_ws.pop(next(iter(self._perc_ws)))
+            self._perc_ws[key] = (self.mem.empty((nbytes // 4,)), nbytes)
+        else:
+            self._perc_ws[key] = self._perc_ws.pop(key)
         ws, nbytes = self._perc_ws[key]
         losses = self.mem.empty((4,))
         dy = self.mem.empty((N, H, W, 3))
@@ -355,6 +374,11 @@ class Engine(object):
         d.shuffle = int(kw.get("shuffle", 0))
         d.add_pad = int(kw.get("add_pad", 0))
         d.w_nstride = int(kw.get("w_nstride", 0))
+        if kw.get("winograd"):     # F(2x2,3x3): transform the filter into a caller-owned buffer, hand it over with the conv
+            U = self.mem.empty((16, Cin, Cout))
+            L.check(self.lib, self.lib.fs_wino_transform_filter(self.ctx, p(w), Cin, Cout, p(U)), "fs_wino_transform_filter")
+            d.w_wino = p(U)
+            self._keep = [U]
         tiles = ctypes.c_int()
         L.check(self.lib, self.lib.fs_conv2d_plan(ctypes.byref(d), ctypes.byref(tiles)), "fs_conv2d_plan")
         if d.shuffle:

@@ -33,7 +33,8 @@ class Trainer(object):
         self.m = mem.zeros(self.params.shape)
         self.v = mem.zeros(self.params.shape)
         self.global_step = 0
-        eng.vgg_load(vgg_weights)
+        if vgg_weights is not None:          # None: the engine already holds this weight set (a second Trainer on it)
+            eng.vgg_load(vgg_weights)
         # train.py:144-151: target Grams of the style image, computed once
         self.target_grams = eng.style_targets(mem.from_numpy(style_img), self.cfg)
         self.use_graph = use_graph
@@ -41,9 +42,12 @@ class Trainer(object):
         self._static_in = None
         self._static_losses = None
 
-    def _world(self):
+    def _dist_on(self):
         d = self.dist
-        return d.get_world_size() if (d is not None and d.is_initialized()) else 1
+        return d is not None and d.is_initialized()
+
+    def _world(self):
+        return self.dist.get_world_size() if self._dist_on() else 1
 
     def _forward_backward(self, batch):
         e = self.eng
@@ -69,6 +73,9 @@ class Trainer(object):
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._static_losses = self._forward_backward(self._static_in)
         self.graph = g
+        # the graph replays raw pointers into the engine's workspaces: keep them alive for as long as the graph lives,
+        # whatever the engine's per-shape cache does meanwhile
+        self._graph_keepalive = [dict(self.eng._tnet_ws), dict(self.eng._perc_ws)]
 
     def step(self, batch):
         """batch: device tensor [B,H,W,3] float32 RGB 0..255 (train.py:158-160).
@@ -89,7 +96,7 @@ class Trainer(object):
             losses = self._static_losses
         else:
             losses = self._forward_backward(batch)
-        if self._world() > 1:
+        if self._dist_on():       # also at world_size 1 (torchrun --nproc-per-node 1): the RCCL path is then exercised as is
             self.dist.all_reduce(self.grads, op=self.dist.ReduceOp.SUM)   # 1,696,408 B, once per step
         self.global_step += 1
         e.adam_tf_step(self.params, self.grads, self.m, self.v, self.global_step, lr=self.lr)

@@ -33,10 +33,12 @@ const char* fs_version(void);
 
 /* ---- measurement hook (bench.py): HIP events around every MFMA-kernel launch on the ctx stream.
  * out[f*3+{0,1,2}] = {launches, algorithmic FLOPs, milliseconds} for kernel family f:
- * 0 conv_igemm<32,2,2>, 1 conv_igemm<32,2,1>, 2 conv_igemm<16,4,1>, 3 conv_wgrad (incl. Gram),
- * 4 conv_igemm<32,1,2>, 5 conv_igemm<32,1,1>, 6 wino_conv (Winograd F(2x2,3x3); FLOPs = those executed). */
+ * 0 conv_igemm<32,2,2>, 1 conv_igemm<32,2,1>, 2 conv_igemm<16,4,1>, 3 conv_wgrad (filter gradients),
+ * 4 conv_igemm<32,1,2>, 5 conv_igemm<32,1,1>, 6 wino_conv (Winograd F(2x2,3x3); FLOPs = those executed),
+ * 7 Gram forward (conv_wgrad, per-sample F^T F: utils.py:76-82), 8 Gram backward (conv_igemm, 1x1 with per-sample filters). */
+#define FS_PROFILE_FAMILIES 9
 int fs_profile_begin(fs_ctx* ctx);
-int fs_profile_end(fs_ctx* ctx, double out[21]);
+int fs_profile_end(fs_ctx* ctx, double out[3 * FS_PROFILE_FAMILIES]);
 
 /* ---- image-transform net: reference im_transf_net.py:14-75 (create_net) ------------------ */
 #define FS_TNET_NPARAMS 424102 /* 48 fp32 tensors, sorted-key (= checkpoint) order */
@@ -146,7 +148,13 @@ typedef struct {
     const float* add_src;
     int add_pad;
     long long w_nstride; /* per-sample filter stride in floats (0: shared) */
+    const float* w_wino; /* optional: the same filter transformed by fs_wino_transform_filter ([16][Cin][Cout]); an
+                          * eligible conv (3x3, stride 1, SAME or VALID, Cin % 8 == 0, Cout % 64 == 0) then runs on the
+                          * Winograd F(2x2,3x3) kernel -- the path the VGG16 convs of fs_perceptual_loss take */
 } fs_conv_desc;
+/* U[16][Cin][Cout] = G g G^T for every (ci, co) filter g = w[:, :, ci, co] of a 3x3 HWIO filter (Lavin & Gray F(2x2,3x3));
+ * the caller owns U (16*Cin*Cout floats).  fs_vgg_prepare does this once for the frozen VGG16 filters. */
+int fs_wino_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, float* U);
 /* tf.nn.conv2d (im_transf_net.py:115, vgg16.py:47) on the matrix cores. */
 int fs_conv2d_fwd(fs_ctx* ctx, fs_conv_desc* d);
 /* resolves Ho/Wo/pads and returns the per-image tile count the launch will use */

@@ -1,7 +1,9 @@
-"""Independent torch-CPU float64 restatement of the same maths (F.conv2d / autograd).
+"""Independent torch-CPU restatement of the same maths (F.conv2d / autograd; dtype follows the inputs).
 
-A SECOND implementation used only to cross-check the numpy oracle's hand-written
-backward passes (SURVEY.md §8c "independent cross-checks").  Not the oracle of record.
+TEST INFRASTRUCTURE.  A SECOND implementation used (i) in float64 to cross-check the numpy oracle's
+hand-written backward passes (tests/test_oracle_backward.py; SURVEY.md §8c "independent
+cross-checks") and (ii) in float32 as the "strong CPU" (oneDNN) figure of bench.py's
+``cpu_baseline`` leg.  Not the oracle of record; never imported by faststyle_amd.
 """
 import torch
 import torch.nn.functional as TF
@@ -98,3 +100,15 @@ def loss(y_nhwc, content_targets_nchw, tgt_grams, W, beta=0.0,
         sl = sl + w * ((g - t) ** 2).sum() / (g.shape[1] * g.shape[2])
     tv = ((y_nhwc[:, :-1] - y_nhwc[:, 1:]) ** 2).sum() + ((y_nhwc[:, :, :-1] - y_nhwc[:, :, 1:]) ** 2).sum()
     return cl + sl + beta * tv, cl, sl, tv
+
+
+def train_step(P, x_nhwc, tgt_grams, W, beta=0.0):
+    """One train.py loop body (train.py:245-275) without the optimiser update: content-target VGG pass on the raw
+    batch (train.py:250-251), transform net, perceptual loss, gradients of the 48 tensors.  P: dict of leaf tensors
+    with requires_grad; returns (loss tensor, [grads])."""
+    with torch.no_grad():
+        ct = [vgg(x_nhwc, W)["conv3_3"]]
+    y = tnet(x_nhwc, P)
+    L, _, _, _ = loss(y, ct, tgt_grams, W, beta=beta)
+    names = sorted(P)
+    return L, torch.autograd.grad(L, [P[n] for n in names])

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_json_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
-                          "--cpu-images", "1"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+                          "--b4-steps", "5", "--profile-steps", "2", "--cpu-quick"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -24,10 +24,22 @@ def test_bench_json_contract():
     assert "vs_baseline" in d and d["vs_baseline"] is None            # BASELINE.md publishes no number for this metric
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f32"
     assert d["higher_is_better"] is True and "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] - 4 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-2
+    assert d["config"]["batch_per_gpu"] == 32 and d["config"]["global_batch"] == 32      # the metric's "b32" on one GPU
+    assert abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-2
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 1.0
     assert r["traffic"] is None or r["traffic"] > 1e6
+    assert set(r["per_kernel"]) >= {"wino_conv_kernel", "conv_wgrad_kernel", "conv_wgrad_kernel (Gram forward)",
+                                    "conv_igemm_kernel (Gram backward)"}
+    g = d["gram"]
+    assert 0.0 < g["frac_of_f32_mfma_peak"] < 1.0 and abs(g["gflop_per_step"] - 4.295 * 32) / (4.295 * 32) < 0.02
+    v = d["vgg_gram_substep"]
+    assert 0.0 < v["frac_executed"] < 1.0 and v["ms"] < d["ms_per_step"] * 1.2
+    assert 0.0 < d["step_frac_executed"] < d["step_frac_of_f32_mfma_peak"]
+    b4 = d["train_b4_per_gpu"]
+    assert b4["batch_per_gpu"] == 4 and b4["hip_graph"] is True and b4["images_per_sec"] > 0
+    assert d["stylize_720p"]["fps"] > 0 and d["stylize_1080p_b8_bf16"]["fps"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["torch_cpu"]["value"] > 0 and c["one_core"]["cores"] == 1 and c["stylize_720p"]["torch_cpu_fps"] > 0

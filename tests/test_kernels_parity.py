@@ -62,8 +62,8 @@ WINO_CASES = [
 
 
 @pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
-def test_winograd_conv_matches_oracle(eng, case, monkeypatch):
-    """wino_conv_kernel (F(2x2,3x3), the VGG 3x3 convs of the training step) through the conv2d C-ABI test hook:
+def test_winograd_conv_matches_oracle(eng, case):
+    """wino_conv_kernel (F(2x2,3x3), the VGG 3x3 convs of the training step) through fs_conv2d_fwd with a caller-transformed filter (fs_wino_transform_filter):
     same fp64 oracle and tolerance as the direct kernel; also checked against the direct kernel itself."""
     _, xs, cout, epi = case
     rng = np.random.default_rng(11)
@@ -72,8 +72,7 @@ def test_winograd_conv_matches_oracle(eng, case, monkeypatch):
     bias = rng.standard_normal(cout).astype(np.float32) if epi else None
     kw = dict(bias=up(eng, bias), out_relu=1) if epi else {}
     direct = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME", **kw))
-    monkeypatch.setenv("FS_CONV2D_WINO", "1")
-    y = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME", **kw))
+    y = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME", winograd=True, **kw))
     want = nnops.conv2d(x.astype(np.float64), w.astype(np.float64), 1, "SAME")
     if epi:
         want = np.maximum(want + bias, 0.0)
@@ -82,7 +81,7 @@ def test_winograd_conv_matches_oracle(eng, case, monkeypatch):
     assert rel(y, direct) < TOL and not np.array_equal(y, direct)      # really the other algorithm
 
 
-def test_winograd_accuracy_is_that_of_the_direct_kernel(eng, monkeypatch):
+def test_winograd_accuracy_is_that_of_the_direct_kernel(eng):
     """F(2x2,3x3) only adds / subtracts / halves in its transforms: on post-ReLU-like data with a deep reduction
     (256 input channels) its error against the fp64 oracle stays within 2x of the direct fp32 kernel's."""
     rng = np.random.default_rng(17)
@@ -90,13 +89,12 @@ def test_winograd_accuracy_is_that_of_the_direct_kernel(eng, monkeypatch):
     w = (rng.standard_normal((3, 3, 256, 64)) * 0.02).astype(np.float32)
     want = nnops.conv2d(x.astype(np.float64), w.astype(np.float64), 1, "SAME")
     direct = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME"))
-    monkeypatch.setenv("FS_CONV2D_WINO", "1")
-    wino = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME"))
+    wino = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME", winograd=True))
     e_d, e_w = rel(direct, want), rel(wino, want)
     assert e_w < 3e-6 and e_w < 2.0 * e_d + 1e-7, (e_d, e_w)
 
 
-def test_winograd_valid_conv_with_affine_on_load_and_tile_statistics(eng, monkeypatch):
+def test_winograd_valid_conv_with_affine_on_load_and_tile_statistics(eng):
     """The residual-block form of the Winograd kernel (transform net, im_transf_net.py:250-276): VALID padding, the
     producer's instance norm + ReLU applied on load, per-block statistics of the raw output -> instnorm_finalize."""
     rng = np.random.default_rng(13)
@@ -105,11 +103,10 @@ def test_winograd_valid_conv_with_affine_on_load_and_tile_statistics(eng, monkey
     w2 = (rng.standard_normal((3, 3, 64, 64)) * 0.1).astype(np.float32)
     gamma = (1 + 0.3 * rng.standard_normal(64)).astype(np.float32)
     beta = (0.2 * rng.standard_normal(64)).astype(np.float32)
-    monkeypatch.setenv("FS_CONV2D_WINO", "1")
-    z, stats, tiles = eng.conv2d(up(eng, x), up(eng, w1), 1, "VALID", want_stats=True)
+    z, stats, tiles = eng.conv2d(up(eng, x), up(eng, w1), 1, "VALID", want_stats=True, winograd=True)
     assert tiles == 3 * 3                                                    # 16x16 blocks of the Winograd plan
     mean, rstd, a, b = eng.instnorm_finalize(stats, tiles, 64, 1, up(eng, gamma), up(eng, beta))
-    y = down(eng, eng.conv2d(z, up(eng, w2), 1, "VALID", in_a=a, in_b=b, in_per_sample=1, in_relu=1))
+    y = down(eng, eng.conv2d(z, up(eng, w2), 1, "VALID", in_a=a, in_b=b, in_per_sample=1, in_relu=1, winograd=True))
     z64 = nnops.conv2d(x.astype(np.float64), w1.astype(np.float64), 1, "VALID")
     n64, (xhat, rs, _) = nnops.inst_norm(z64, gamma.astype(np.float64), beta.astype(np.float64))
     assert rel(down(eng, z), z64) < TOL

@@ -1,11 +1,11 @@
 """Cross-check the numpy oracle (forward AND hand-written backward) against an independent
-torch-CPU float64 autograd restatement (tests/torch_ref.py)."""
+torch-CPU float64 autograd restatement (oracle/torch_ref.py)."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import nnops, perceptual, tnet
-from tests import torch_ref
+from oracle import torch_ref
 
 
 def _t(d):

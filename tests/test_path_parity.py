@@ -20,6 +20,18 @@ def eng(request):
     return get_engine(request.param)
 
 
+@pytest.fixture
+def knob(monkeypatch, eng):
+    """Set an FS_* tuning knob for one test: the library caches the environment at first use, so it is told to re-read
+    it now and again once monkeypatch has restored the environment."""
+    def set_knob(name, value):
+        monkeypatch.setenv(name, str(value))
+        eng.lib.fs_debug_reload_env()
+    yield set_knob
+    monkeypatch.undo()
+    eng.lib.fs_debug_reload_env()
+
+
 def f64(d):
     return {k: np.asarray(v, np.float64) for k, v in d.items()}
 
@@ -97,10 +109,10 @@ def run_fwd_bwd(eng, P_named, shape, seed, method="resize"):
     return y, yo, g, want
 
 
-def test_tnet_forward_with_two_level_statistics_merge(eng, monkeypatch):
+def test_tnet_forward_with_two_level_statistics_merge(eng, knob):
     """Large images pre-reduce the per-tile instance-norm records (in_prereduce_kernel); force that path at a
     small size: T > 1 tiles -> 64 ranges -> finalize."""
-    monkeypatch.setenv("FS_FINALIZE_MIN_T", "1")
+    knob("FS_FINALIZE_MIN_T", 1)
     rng = np.random.default_rng(6)
     P = tnet.strip_scope(starry())
     flat = eng.mem.from_numpy(eng.flatten_params(P, scope=""))
@@ -111,11 +123,11 @@ def test_tnet_forward_with_two_level_statistics_merge(eng, monkeypatch):
 
 
 @pytest.mark.parametrize("shape", [(2, 48, 56), (1, 45, 67)])
-def test_tnet_residual_convs_through_the_winograd_kernel(eng, shape, monkeypatch):
+def test_tnet_residual_convs_through_the_winograd_kernel(eng, shape, knob):
     """FS_TNET_WINO=2 forces what 720p / 1080p frames (and large training batches) select by themselves: the ten 3x3
     VALID residual convs through wino_conv_kernel -- producer instance norm + ReLU on load, per-block statistics --
     forward against the oracle with the shipped weights, and the backward pass on top of that forward."""
-    monkeypatch.setenv("FS_TNET_WINO", "2")
+    knob("FS_TNET_WINO", 2)
     rng = np.random.default_rng(9)
     P = tnet.strip_scope(starry())
     flat = eng.mem.from_numpy(eng.flatten_params(P, scope=""))
@@ -198,11 +210,11 @@ def test_instnorm_backward_modes(eng, mode, shape):
 
 
 @pytest.mark.parametrize("force_ksplit", [0, 3])
-def test_perceptual_loss_and_gradient_match_oracle(eng, monkeypatch, force_ksplit):
+def test_perceptual_loss_and_gradient_match_oracle(eng, knob, force_ksplit):
     """force_ksplit=3 drives every eligible VGG conv (forward and dgrad) through the split-K kernel path +
     splitk_epilogue_kernel (bias/ReLU, tap add + ReLU mask), which otherwise only triggers at 256x256."""
     if force_ksplit:
-        monkeypatch.setenv("FS_CONV_FORCE_KSPLIT", str(force_ksplit))
+        knob("FS_CONV_FORCE_KSPLIT", force_ksplit)
     rng = np.random.default_rng(1)
     Wv = perceptual.synthetic_vgg_weights(seed=3)
     eng.vgg_load(Wv)
@@ -316,12 +328,12 @@ def test_bf16_rounding_helper_known_answers():
 
 
 @pytest.mark.parametrize("shape,grid_cap", [((2, 48, 56), None), ((1, 45, 67), None), ((2, 48, 56), 3)])
-def test_tnet_bf16_forward_against_bf16_restatement_and_fp32_oracle(eng, shape, grid_cap, monkeypatch):
+def test_tnet_bf16_forward_against_bf16_restatement_and_fp32_oracle(eng, shape, grid_cap, knob):
     """FS_FLAG_BF16 against (a) the numpy restatement with the same rounding points -- differences are
     accumulation-order noise flipping an occasional bf16 rounding -- and (b) the fp32/fp64 oracle, where
     the error is the precision of bfloat16 itself (~1e-2 of the range; reported, not held to 1e-3)."""
     if grid_cap:      # persistent workgroups: 3 workgroups walk all the tiles of the single-chunk layers (crossing images)
-        monkeypatch.setenv("FS_BF16_GRID", str(grid_cap))
+        knob("FS_BF16_GRID", grid_cap)
     rng = np.random.default_rng(4)
     P = tnet.strip_scope(starry())
     flat = eng.mem.from_numpy(eng.flatten_params(P, scope=""))

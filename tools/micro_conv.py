@@ -41,6 +41,8 @@ def main():
             x.zero_()
             w.zero_()
         kw = {"want_stats": True} if os.environ.get("STATS") else {}
+        if os.environ.get("WINO"):            # eligible 3x3 convs through the Winograd kernel
+            kw["winograd"] = True
         y = e.conv2d(x, w, s, pad, **kw)
         torch.cuda.synchronize()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -15,10 +15,9 @@ for (N, H, W, Ci, Co) in [(2, 16, 20, 64, 64), (1, 16, 20, 64, 64), (2, 16, 20, 
         x = np.maximum(rng.standard_normal((N, H, W, Ci)), 0).astype(np.float32) * scale
         w = (rng.standard_normal((3, 3, Ci, Co)) * 0.05).astype(np.float32)
         b = rng.standard_normal(Co).astype(np.float32)
-        os.environ.pop("FS_CONV2D_WINO", None)
         d = eng.mem.to_numpy(eng.conv2d(eng.mem.from_numpy(x), eng.mem.from_numpy(w), 1, "SAME", bias=eng.mem.from_numpy(b), out_relu=1))
-        os.environ["FS_CONV2D_WINO"] = "1"
-        y = eng.mem.to_numpy(eng.conv2d(eng.mem.from_numpy(x), eng.mem.from_numpy(w), 1, "SAME", bias=eng.mem.from_numpy(b), out_relu=1))
+        y = eng.mem.to_numpy(eng.conv2d(eng.mem.from_numpy(x), eng.mem.from_numpy(w), 1, "SAME", bias=eng.mem.from_numpy(b), out_relu=1,
+                                        winograd=True))
         e = np.abs(y - d)
         print("N%d %dx%d %d->%d x%g: max diff %.3e (rel %.2e) at %s; mask flips %d" % (
             N, H, W, Ci, Co, scale, e.max(), e.max() / np.abs(d).max(), np.unravel_index(e.argmax(), e.shape),

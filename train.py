@@ -17,6 +17,7 @@ Differences from the reference that are forced by the environment and stated, no
     train.py:185-189, 260-272; no graph definition in it) the same values go to ``scalars.jsonl``.
 """
 import glob
+import itertools
 import json
 import os
 import sys
@@ -106,20 +107,17 @@ def main(args):
     tr = trainer.Trainer(eng, params, vgg_w, style_img, cfg, learn_rate=args.learn_rate,
                          dist=dist if world > 1 else None, upsample_method=method)
 
-    # Setup subdirectory for this run's logs (train.py:207-217).
+    # Log directory of this run (behaviour of train.py:207-217): --run_name when given, otherwise the first
+    # "<model_name><k>", k = 0, 1, 2, ..., that is not yet a directory under summaries/train/.
     run_name = args.run_name
     if rank == 0:
-        if not os.path.exists('./summaries/train/'):
-            os.makedirs('./summaries/train/')
+        base = os.path.join('.', 'summaries', 'train')
+        os.makedirs(base, exist_ok=True)
         if run_name is None:
-            current_dirs = [name for name in os.listdir('./summaries/train/')
-                            if os.path.isdir('./summaries/train/' + name)]
-            name = args.model_name + '0'
-            count = 0
-            while name in current_dirs:
-                count += 1
-                name = args.model_name + '{}'.format(count)
-            run_name = name
+            k = 0
+            while os.path.isdir(os.path.join(base, '%s%d' % (args.model_name, k))):
+                k += 1
+            run_name = '%s%d' % (args.model_name, k)
         for d in ('./training', './models', './summaries/train/' + run_name):
             if not os.path.exists(d):
                 os.makedirs(d)
@@ -137,19 +135,32 @@ def main(args):
 
     # Input pipeline (train.py:192-196): TFRecord shards train-* when present
     shards = sorted(glob.glob(os.path.join(args.train_dir, 'train-*'))) if args.train_dir != 'synthetic' else []
+
+    def common_step_count(n_local):
+        """Ranks read disjoint shards / files of unequal size: every rank must run the SAME number of steps, or the
+        ones with a batch left over block forever in the gradient all-reduce of a peer that already left."""
+        if world == 1:
+            return n_local
+        t = torch.tensor([n_local], device="cuda:%d" % local_rank, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
+
     if shards:
-        cap = None
-        if world > 1:   # ranks read disjoint shards of unequal size: agree on the common number of steps
-            n_local = datapipe.count_records(shards[rank::world]) * args.n_epochs // args.batch_size
-            t = torch.tensor([n_local], device="cuda:%d" % local_rank, dtype=torch.int64)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            cap = int(t.item())
+        if len(shards) < world:            # identical on every rank (same directory listing): all leave together, no collective pending
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit("--train_dir holds %d train-* shards for %d ranks: every rank needs at least one" % (len(shards), world))
+        cap = common_step_count(datapipe.count_records(shards[rank::world]) * args.n_epochs // args.batch_size)
         batches = datapipe.batcher(shards, args.batch_size, args.preprocess_size, args.n_epochs,
                                    args.num_pipe_buffer, engine=eng, seed=1234, rank=rank, world=world,
                                    max_batches=cap)
     else:
-        batches = (eng.mem.from_numpy(b) for b in batcher(args.train_dir, args.batch_size, args.preprocess_size,
-                                                          args.n_epochs, args.num_pipe_buffer, 1234, rank, world))
+        gen = batcher(args.train_dir, args.batch_size, args.preprocess_size, args.n_epochs, args.num_pipe_buffer, 1234, rank, world)
+        if args.train_dir != 'synthetic':   # a directory of image files, dealt files[rank::world]: counts differ by up to one image
+            n_files = len([f for f in os.listdir(args.train_dir) if f.lower().endswith((".jpg", ".jpeg", ".png"))])
+            n_mine = len(range(rank, n_files, world))
+            gen = itertools.islice(gen, common_step_count(n_mine * args.n_epochs // args.batch_size))
+        batches = (eng.mem.from_numpy(b) for b in gen)
     if rank == 0:
         print('Starting training...')
     try:
@@ -178,11 +189,19 @@ def main(args):
                 print('Done training.')
     finally:
         # Save the model (the image transformation network) for later usage (train.py:283-286)
-        if rank == 0:
-            save('models/' + args.model_name + '_final.ckpt', full=False)
-            train_writer.close()
-        if world > 1:
-            dist.destroy_process_group()
+        try:
+            if rank == 0:
+                save('models/' + args.model_name + '_final.ckpt', full=False)
+                train_writer.close()
+        finally:
+            if world > 1:
+                # leave together: a rank that tears the process group down while a peer still sits in a collective
+                # turns that peer's exit into a watchdog abort (and rank 0's final save above must not depend on it)
+                try:
+                    dist.barrier()
+                except Exception as ex:      # a peer died: nothing left to wait for
+                    print('train.py: barrier before shutdown failed (%s)' % ex, file=sys.stderr)
+                dist.destroy_process_group()
 
 
 if __name__ == "__main__":
