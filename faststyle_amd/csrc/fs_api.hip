@@ -483,6 +483,8 @@ static int fill_wgrad(fs_wgrad_desc* d, fs::WgradArgs* a) {
 size_t fs_conv2d_wgrad_workspace_bytes(fs_wgrad_desc* d) {
     fs::WgradArgs a;
     if (fill_wgrad(d, &a)) return 0;
+    fs::Wg2Args w2;
+    if (const size_t f = fs::wgrad2_plan(&a, 1, &w2)) return f * sizeof(float);   // second-generation kernel (fs_wgrad2.hip)
     return (size_t)(a.per_sample ? a.N : 1) * a.p.n_slabs * a.p.K * a.Cout * sizeof(float);
 }
 
@@ -490,6 +492,14 @@ int fs_conv2d_wgrad(fs_ctx* ctx, fs_wgrad_desc* d, void* ws, size_t ws_bytes) {
     if (!ctx || !ws) return fail(-1, "fs_conv2d_wgrad: null argument");
     fs::WgradArgs a;
     if (int rc = fill_wgrad(d, &a)) return rc;
+    if (!a.x || !a.dy || !d->dw) return fail(-1, "fs_conv2d_wgrad: null tensor");
+    fs::Wg2Args w2;
+    if (const size_t f = fs::wgrad2_plan(&a, 1, &w2)) {
+        if (ws_bytes < f * sizeof(float)) return fail(-3, "fs_conv2d_wgrad: workspace too small");
+        float* out[1] = {d->dw};
+        const int rc2 = fs::wgrad2_run(w2, (float*)ws, out, d->scale, ctx->stream);
+        return rc2 ? fail(rc2, "fs_conv2d_wgrad: launch failed (%d)", rc2) : 0;
+    }
     const size_t need = (size_t)(a.per_sample ? a.N : 1) * a.p.n_slabs * a.p.K * a.Cout * sizeof(float);
     if (ws_bytes < need) return fail(-3, "fs_conv2d_wgrad: workspace too small");
     a.slabs = (float*)ws;

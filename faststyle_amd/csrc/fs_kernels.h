@@ -94,12 +94,66 @@ struct WgradArgs {
     WgradPlan p;
 };
 
+// ---- second-generation filter gradients (fs_wgrad2.hip): persistent workgroups, 16x16x4 MFMA, batched problems
+constexpr int kW2MaxProb = 10;
+struct Wg2Plan {
+    int TH, TW, PH, PW;   // pixel tile and its input patch
+    int S, DP;            // LDS pitches (floats) of a patch pixel / a dY pixel
+    int K, KB, NB;        // KH*KW*Cin, its 16-row blocks, 16-channel blocks of Cout
+    int KM, KN;           // blocks per wave (kernel instantiation)
+    int waves_k;          // waves tiling the k dimension; the other 4/waves_k split the tile's pixel rows
+    int patch_floats, stage_floats, lds_bytes;
+    int xn, dn;           // 16-byte loads per thread and tile: patch / dY
+};
+struct Wg2Prob {
+    const float* x;       // [N,H,W,Cin] (virtual via src_mode)
+    const float* dy;      // [N,Ho,Wo,Cout]
+    const float* in_a;    // optional [N,Cin] on-load affine of x (+ ReLU): the producer's instance norm
+    const float* in_b;
+    const float* dy_a;    // optional on-load affine of dy (conv2d_transpose units)
+    const float* dy_b;
+    float* slabs;         // [wg_count * 4/waves_k][K][Cout]
+    size_t slab_off;      // offset of `slabs` inside the launch's scratch (floats)
+    int N, H, W, Ho, Wo, tiles_y, tiles_x;
+    int wg_begin, wg_count;
+};
+struct Wg2Args {
+    int Cin, Cout, KH, KW, stride, pad_t, pad_l, dil_x, src_mode, refl;
+    int in_nstride, in_relu, dy_nstride, dy_relu, dy_unshuffle;
+    int nprob, n_wg;
+    int debug;   // FS_WGRAD2_DEBUG (timing experiments)
+    Wg2Plan p;
+    Wg2Prob prob[kW2MaxProb];
+};
+struct Wg2Reduce {
+    struct Job {
+        const float* slabs;
+        float* out;
+        size_t count;
+        int n_slabs;
+    } job[kW2MaxProb];
+    float scale;
+    int n;
+};
+bool wgrad2_eligible(const WgradArgs& a);
+size_t wgrad2_plan(const WgradArgs* probs, int n, Wg2Args* out);   // returns the slab scratch in floats (0: not eligible)
+int wgrad2_run(const Wg2Args& planned, float* slabs, float* const* dw, float scale, hipStream_t s);
+
 ConvPlan conv_plan(const ConvArgs& a);
 int conv_launch(const ConvArgs& a, hipStream_t s);
 WgradPlan wgrad_plan(const WgradArgs& a);
 int wgrad_launch(const WgradArgs& a, hipStream_t s);
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Address of a kernel's (single, by-value) argument struct in the kernel-argument segment, for kernels that index a
+// table inside it at run time.  (Host passes -- the launch stub, the CPU emulator of tests/ -- take the parameter's own
+// address.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FS_KERNARG_PTR(T, param) (reinterpret_cast<const T*>(__builtin_amdgcn_kernarg_segment_ptr()))
+#else
+#define FS_KERNARG_PTR(T, param) (&(param))
+#endif
 
 // More than 64 KiB of dynamic LDS (gfx950: 160 KiB per CU) needs hipFuncAttributeMaxDynamicSharedMemorySize, once per
 // kernel AND device (one static BigLds per kernel instantiation; thread-safe).

@@ -291,8 +291,20 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
         Unit& u = L->u[i];
         WgradArgs wa = unit_wgrad_args(u, N);
         u.wplan = wgrad_plan(wa);
-        const size_t sl = (size_t)u.wplan.n_slabs * u.wplan.K * wa.Cout;
+        size_t sl = (size_t)u.wplan.n_slabs * u.wplan.K * wa.Cout;
+        Wg2Args w2;
+        if (const size_t f2 = wgrad2_plan(&wa, 1, &w2)) sl = f2;   // second-generation kernel where eligible (fs_wgrad2.hip)
         if (sl > max_slab) max_slab = sl;
+    }
+    {   // the ten residual filter gradients as one launch: every dz is kept until the last one exists
+        WgradArgs probs[10];
+        for (int i = 3; i <= 12; ++i) probs[i - 3] = unit_wgrad_args(L->u[i], N);
+        Wg2Args w2;
+        const size_t f2 = tune_int("FS_TNET_WGRAD_BATCH", 1) ? wgrad2_plan(probs, 10, &w2) : 0;
+        L->res_batch = f2 > 0;
+        if (f2 > max_slab) max_slab = f2;
+        for (int i = 3; i <= 12; ++i)
+            L->dzres[i - 3] = L->res_batch ? b.take((size_t)N * L->u[i].Hout * L->u[i].Wout * L->u[i].Cout) : 0;
     }
     L->slabs = b.take(max_slab);
     L->total_floats = b.off;
@@ -481,8 +493,10 @@ static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, c
     return conv_launch(a, s);
 }
 
-static int unit_wgrad(const TnetLayout& L, const Unit& u, const float* xin, const float* xa, const float* xb,
-                      const float* dz, float* grads, float* ws, hipStream_t s) {
+// Filter gradient of one unit.  Problem description first (which tensor plays 'x', which 'dy', on-load affines), then the
+// kernel: the persistent second-generation kernel where the shape is eligible, else the first-generation one.
+static void unit_wgrad_problem(const TnetLayout& L, const Unit& u, const float* xin, const float* xa, const float* xb,
+                               const float* dz, float* ws, WgradArgs* out) {
     WgradArgs a = unit_wgrad_args(u, L.N);
     a.p = u.wplan;
     if (u.kind == 3) {  // dW[K,K,Cout,Cin] = conv2d_bwd_filter(input = dz, grad = the unit's input activation)
@@ -492,32 +506,37 @@ static int unit_wgrad(const TnetLayout& L, const Unit& u, const float* xin, cons
         a.dy_b = xb;
         a.dy_nstride = xa ? u.Cin : 0;
         a.dy_relu = xa ? 1 : 0;
-        a.slabs = ws + L.slabs;
-        FS_TRY(wgrad_launch(a, s));
-        return reduce_slabs(ws + L.slabs, 1, a.p.n_slabs, (size_t)a.p.K * a.Cout, 1.0f, grads + u.w_off, s);
-    }
-    a.x = xin;
-    a.in_a = xa;
-    a.in_b = xb;
-    a.in_nstride = xa ? u.Cin : 0;
-    a.in_relu = xa ? 1 : 0;
-    a.dy = dz;
-    if (u.kind == 2) {  // unfold dY to [q][(v,co)] (fs_fold.hip); the Z buffer of the forward is free by now
-        FS_TRY(unfold5(dz, ws + L.zfold, L.N, u.Hout, u.Wout, s));
-        a.dy = ws + L.zfold;
+    } else {
+        a.x = xin;
+        a.in_a = xa;
+        a.in_b = xb;
+        a.in_nstride = xa ? u.Cin : 0;
+        a.in_relu = xa ? 1 : 0;
+        a.dy = u.kind == 2 ? ws + L.zfold : dz;   // kind 2: dY unfolded to [q][(v,co)] by unfold5 (fs_fold.hip)
     }
     a.slabs = ws + L.slabs;
-    FS_TRY(wgrad_launch(a, s));
-    const size_t count = (size_t)a.p.K * a.Cout;
-    if (u.kind == 2) {
-        FS_TRY(reduce_slabs(ws + L.slabs, 1, a.p.n_slabs, count, 1.0f, ws + L.dwfold, s));
-        return wt_fold5_back(ws + L.dwfold, grads + u.w_off, u.Cin, s);
+    *out = a;
+}
+
+static int unit_wgrad(const TnetLayout& L, const Unit& u, const float* xin, const float* xa, const float* xb,
+                      const float* dz, float* grads, float* ws, hipStream_t s) {
+    WgradArgs a;
+    unit_wgrad_problem(L, u, xin, xa, xb, dz, ws, &a);
+    if (u.kind == 2)  // the Z buffer of the forward is free by now
+        FS_TRY(unfold5(dz, ws + L.zfold, L.N, u.Hout, u.Wout, s));
+    // where the reduced gradient goes: the parameter-gradient buffer, or a scratch the unit's filter re-layout reads
+    float* dst = u.kind == 2 ? ws + L.dwfold : (u.kind == 1 ? ws + L.dweff : grads + u.w_off);
+    Wg2Args w2;
+    if (wgrad2_plan(&a, 1, &w2)) {
+        float* out[1] = {dst};
+        FS_TRY(wgrad2_run(w2, ws + L.slabs, out, 1.0f, s));
+    } else {
+        FS_TRY(wgrad_launch(a, s));
+        FS_TRY(reduce_slabs(ws + L.slabs, 1, a.p.n_slabs, (size_t)a.p.K * a.Cout, 1.0f, dst, s));
     }
-    if (u.kind == 1) {
-        FS_TRY(reduce_slabs(ws + L.slabs, 1, a.p.n_slabs, count, 1.0f, ws + L.dweff, s));
-        return wt_upconv_wgrad_fold(ws + L.dweff, grads + u.w_off, u.Cin, u.Cout, s);
-    }
-    return reduce_slabs(ws + L.slabs, 1, a.p.n_slabs, count, 1.0f, grads + u.w_off, s);
+    if (u.kind == 2) return wt_fold5_back(ws + L.dwfold, grads + u.w_off, u.Cin, s);
+    if (u.kind == 1) return wt_upconv_wgrad_fold(ws + L.dweff, grads + u.w_off, u.Cin, u.Cout, s);
+    return 0;
 }
 
 int tnet_backward(const TnetLayout& L, const float* params, const float* x, const float* dy, float* grads, float* ws,
@@ -540,11 +559,14 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
     }
     const float* g = dy;         // gradient wrt the current unit's output activation (or h_k)
     const float* res_g = nullptr;  // d h_k, kept alive until the block's first conv adds it to its dgrad
+    int dz_reader[2] = {-1, -1};   // event (side stream) of the last filter gradient that read dz[0] / dz[1]
+    WgradArgs res_probs[10];       // the residual units' filter-gradient problems, launched together after unit 3
     for (int i = 15; i >= 0; --i) {
         const Unit& u = L.u[i];
-        float* dz = ws + L.dz[i & 1];
-        // dz[i&1] was last read by the filter gradient of unit i+2 on the side stream
-        if (fork && i + 2 <= 15 && hipStreamWaitEvent(s, aux->ev[16 + i + 2], 0) != hipSuccess) return -20;
+        const bool batched = L.res_batch && i >= 3 && i <= 12;
+        float* dz = batched ? ws + L.dzres[i - 3] : ws + L.dz[i & 1];
+        // dz[i&1] was last read by a filter gradient on the side stream
+        if (fork && !batched && dz_reader[i & 1] >= 0 && hipStreamWaitEvent(s, aux->ev[dz_reader[i & 1]], 0) != hipSuccess) return -20;
         const bool res2 = i >= 4 && i <= 12 && ((i - 3) & 1);       // second conv of a block (no activation)
         const bool res1 = i >= 3 && i <= 11 && ((i - 3) & 1) == 0;  // first conv of a block
         if (res2) res_g = g;
@@ -570,11 +592,28 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
             xa = ws + L.u[i - 1].a;
             xb = ws + L.u[i - 1].b;
         }
-        if (fork) {  // dz_i ready -> side stream computes dW_i while this stream continues with the input gradient
-            if (hipEventRecord(aux->ev[i], s) != hipSuccess || hipStreamWaitEvent(ws_stream, aux->ev[i], 0) != hipSuccess) return -20;
+        if (batched) {
+            unit_wgrad_problem(L, u, xin, xa, xb, dz, ws, &res_probs[i - 3]);
+            if (i == 3) {   // every residual dz exists: ten filter gradients, one launch + one reduction
+                if (fork && (hipEventRecord(aux->ev[i], s) != hipSuccess || hipStreamWaitEvent(ws_stream, aux->ev[i], 0) != hipSuccess))
+                    return -20;
+                Wg2Args w2;
+                if (!wgrad2_plan(res_probs, 10, &w2)) return -21;
+                float* outs[10];
+                for (int k = 0; k < 10; ++k) outs[k] = grads + L.u[3 + k].w_off;
+                FS_TRY(wgrad2_run(w2, ws + L.slabs, outs, 1.0f, ws_stream));
+                if (fork && hipEventRecord(aux->ev[16 + i], ws_stream) != hipSuccess) return -20;
+            }
+        } else {
+            if (fork) {  // dz_i ready -> side stream computes dW_i while this stream continues with the input gradient
+                if (hipEventRecord(aux->ev[i], s) != hipSuccess || hipStreamWaitEvent(ws_stream, aux->ev[i], 0) != hipSuccess) return -20;
+            }
+            FS_TRY(unit_wgrad(L, u, xin, xa, xb, dz, grads, ws, ws_stream));
+            if (fork) {
+                if (hipEventRecord(aux->ev[16 + i], ws_stream) != hipSuccess) return -20;
+                dz_reader[i & 1] = 16 + i;
+            }
         }
-        FS_TRY(unit_wgrad(L, u, xin, xa, xb, dz, grads, ws, ws_stream));
-        if (fork && hipEventRecord(aux->ev[16 + i], ws_stream) != hipSuccess) return -20;
         if (i == 0) break;
         float* dst = nullptr;
         for (int k = 0; k < 3; ++k) {

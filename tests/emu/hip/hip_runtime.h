@@ -312,6 +312,13 @@ static inline uint4 raw_buffer_load_b128(buffer_rsrc r, unsigned voff, unsigned 
     else if (voff < 0x80000000u) { fprintf(stderr, "emu: buffer load out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
     return v;
 }
+static inline unsigned raw_buffer_load_b32(buffer_rsrc r, unsigned voff, unsigned soff) {
+    unsigned v = 0u;
+    const unsigned long long end = (unsigned long long)voff + soff + 4ull;
+    if (voff < 0x80000000u && end <= r.nbytes) memcpy(&v, r.base + voff + soff, 4);
+    else if (voff < 0x80000000u) { fprintf(stderr, "emu: buffer load out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
+    return v;
+}
 static inline float fmed3f(float a, float b, float c) {
     const float lo = a < b ? a : b, hi = a < b ? b : a;
     return c < lo ? lo : (c > hi ? hi : c);
@@ -321,11 +328,13 @@ static inline float fmed3f(float a, float b, float c) {
 #define __builtin_amdgcn_make_buffer_rsrc(ptr, stride, nbytes, flags) \
     fsemu::buffer_rsrc{reinterpret_cast<const unsigned char*>(ptr), (unsigned)(nbytes)}
 #define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) fsemu::raw_buffer_load_b128((r), (unsigned)(voff), (unsigned)(soff))
+#define __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, aux) fsemu::raw_buffer_load_b32((r), (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_fmed3f(a, b, c) fsemu::fmed3f((a), (b), (c))
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 #define __builtin_amdgcn_s_sleep(imm) ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)   /* only ever applied to wave-uniform values */
 
 static inline float __shfl_xor(float v, int mask, int width = 64) { (void)width; return fsemu::shfl_idx(v, fsemu::blk().cur->lane ^ mask); }

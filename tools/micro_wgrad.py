@@ -17,6 +17,14 @@ CASES = {
     "s2_16_32": (4, 336, 336, 16, 32, 3, 2, "SAME", False),
     "first9x9": (4, 336, 336, 3, 16, 9, 1, "SAME", False),
     "fold_like": (4, 256, 256, 16, 16, 9, 1, "SAME", False),
+    # the transform-net filter gradients of a 256x256 step (batch from the BATCH environment variable, default 32)
+    "t_res": (0, 78, 78, 64, 64, 3, 1, "VALID", False),
+    "t_init1": (0, 336, 336, 16, 32, 3, 2, "SAME", False),
+    "t_init2": (0, 168, 168, 32, 64, 3, 2, "SAME", False),
+    "t_init0": (0, 336, 336, 3, 16, 9, 1, "SAME", False),
+    "t_up0": (0, 64, 64, 64, 128, 2, 1, (0, 0, 64, 64), False),
+    "t_up1": (0, 128, 128, 32, 64, 2, 1, (0, 0, 128, 128), False),
+    "t_out3x3": (0, 256, 256, 16, 16, 3, 1, "SAME", False),
 }
 
 
@@ -26,8 +34,11 @@ def main():
     iters = int(os.environ.get("ITERS", "20"))
     for nm in names:
         N, H, W, Ci, Co, K, s, pad, ps = CASES[nm]
+        N = N or int(os.environ.get("BATCH", "32"))
         x = torch.randn(N, H, W, Ci, device="cuda")
-        if pad == "VALID":
+        if not isinstance(pad, str):
+            Ho, Wo = pad[2], pad[3]
+        elif pad == "VALID":
             Ho, Wo = H - K + 1, W - K + 1
         else:
             Ho, Wo = -(-H // s), -(-W // s)
