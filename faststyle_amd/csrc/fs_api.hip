@@ -401,8 +401,13 @@ static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
     a->add_src = d->add_src;
     a->add_pad = d->add_pad;
     a->w_nstride = d->w_nstride;
-    a->w_wino = d->w_wino;
-    if (a->w_wino && !fs::wino_eligible(*a)) a->w_wino = nullptr;   // (not a 3x3 stride-1 conv of the supported shapes: direct kernel)
+    if (fs::tune_int("FS_WINO_V", 2) >= 2) {   // the filter layout fs_wino_transform_filter produced (see there)
+        a->w_wino2 = d->w_wino;
+        if (a->w_wino2 && !fs::wino2_eligible(*a)) a->w_wino2 = nullptr;   // (not a 3x3 stride-1 conv of the supported shapes: direct kernel)
+    } else {
+        a->w_wino = d->w_wino;
+        if (a->w_wino && !fs::wino_eligible(*a)) a->w_wino = nullptr;
+    }
     a->p = fs::conv_plan(*a);
     return 0;
 }
@@ -426,7 +431,8 @@ int fs_conv2d_fwd(fs_ctx* ctx, fs_conv_desc* d) {
 int fs_wino_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, float* U) {
     if (!ctx || !w || !U) return fail(-1, "fs_wino_transform_filter: null argument");
     if (Cin < 1 || Cout < 1) return fail(-2, "fs_wino_transform_filter: bad shape %dx%d", Cin, Cout);
-    const int rc = fs::wt_wino(w, U, Cin, Cout, ctx->stream);
+    if (Cin % 8) return fail(-2, "fs_wino_transform_filter: Cin must be a multiple of 8 (got %d)", Cin);
+    const int rc = fs::tune_int("FS_WINO_V", 2) >= 2 ? fs::wt_wino2(w, U, Cin, Cout, ctx->stream) : fs::wt_wino(w, U, Cin, Cout, ctx->stream);
     return rc ? fail(rc, "fs_wino_transform_filter: launch failed (%d)", rc) : 0;
 }
 

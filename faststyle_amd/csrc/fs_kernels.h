@@ -21,7 +21,7 @@ enum SrcMode {
 };
 
 struct ConvPlan {
-    int variant;  // conv_igemm_kernel<MT,WM,WN>: 0 <32,2,2>  1 <32,2,1>  2 <16,4,1>  3 <32,1,2>  4 <32,1,1>;  5 wino_conv_kernel
+    int variant;  // conv_igemm_kernel<MT,WM,WN>: 0 <32,2,2>  1 <32,2,1>  2 <16,4,1>  3 <32,1,2>  4 <32,1,1>;  5 wino_conv_kernel;  6 wino2_conv_kernel
     int BN;       // output channels per workgroup
     int flat;     // Cin==3: K runs over (kw,ci) contiguously per kernel row
     int CC;       // input channels staged per chunk
@@ -39,6 +39,7 @@ struct ConvArgs {
     const float* x;  // [N,H,W,Cin]
     const float* w;  // [KH*KW, Cin, Cout] (HWIO); + n*w_nstride for per-sample weights
     const float* w_wino;  // optional: the same filter Winograd-transformed, [16][Cin][Cout] (fs::wt_wino); enables variant 5
+    const float* w_wino2; // optional: ... in the K-contiguous order [16][Cin/8][Cout][8] (fs::wt_wino2); enables variant 6
     float* y;        // [N,Ho,Wo,Cout], or [N,2Ho,2Wo,Cout/4] when shuffle
     int N, H, W, Cin;
     int Ho, Wo, Cout;
@@ -149,6 +150,18 @@ __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // Address of a kernel's (single, by-value) argument struct in the kernel-argument segment, for kernels that index a
 // table inside it at run time.  (Host passes -- the launch stub, the CPU emulator of tests/ -- take the parameter's own
 // address.)
+// One element of an MFMA accumulator moved to an ordinary vector register at THIS point of the program (the "a" constraint
+// keeps the operand in the accumulator file, `volatile` keeps the read where it is written).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float fs_acc_read(float v) {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(v));
+    return x;
+}
+#define FS_ACC_READ(e) fs_acc_read(e)
+#else
+#define FS_ACC_READ(e) (e)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FS_KERNARG_PTR(T, param) (reinterpret_cast<const T*>(__builtin_amdgcn_kernarg_segment_ptr()))
 #else
@@ -186,6 +199,11 @@ struct WinoBatch {  // several filters of one shape in one launch (the 10 residu
     int n;
 };
 int wt_wino_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s);
+int wt_wino2(const float* w, float* U, int Cin, int Cout, hipStream_t s);                      // fs_wino2.hip
+int wt_wino2_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s);
+bool wino2_eligible(const ConvArgs& a);
+void wino2_plan(const ConvArgs& a, ConvPlan* out);
+int wino2_launch(const ConvArgs& a, hipStream_t s);
 bool wino_eligible(const ConvArgs& a);
 void wino_plan(const ConvArgs& a, ConvPlan* out);
 int wino_launch(const ConvArgs& a, hipStream_t s);

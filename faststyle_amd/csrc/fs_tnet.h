@@ -47,6 +47,7 @@ struct TnetLayout {
     size_t fwd_floats;
     size_t wTu[16];   // per-unit input-gradient filters (flip+transpose / collapsed), all built by one wt_batch launch
     size_t g[3], dz[2], wT, dweff, inbwd, slabs;  // backward scratch (dz double-buffered: filter gradients run on a side stream)
+    size_t wino_d[10]; // Winograd-transformed input-gradient filters of the residual convs (0: direct kernel)
     size_t dzres[10]; // dz of the ten residual convs, kept until their filter gradients run as ONE launch (fs_wgrad2.hip)
     int res_batch;    // 1: that batched launch is planned (shapes eligible)
     size_t total_floats;

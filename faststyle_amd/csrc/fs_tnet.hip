@@ -245,10 +245,11 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
         {
             const int mode = L->wino_mode;
             a.w_wino = reinterpret_cast<const float*>(16);   // eligibility looks at the shapes only
+            a.w_wino2 = a.w_wino;
             a.stats = reinterpret_cast<float*>(16);
             const long blocks = (long)N * cdiv(u.Hc, 16) * cdiv(u.Wc, 16) * (u.Cc / 64 > 0 ? u.Cc / 64 : 1);
-            if (mode && u.kind == 0 && i >= 3 && i <= 12 && wino_eligible(a) && (mode == 2 || blocks >= 200)) u.wino = 1;
-            if (!u.wino) a.w_wino = nullptr;
+            if (mode && u.kind == 0 && i >= 3 && i <= 12 && (wino_eligible(a) || wino2_eligible(a)) && (mode == 2 || blocks >= 200)) u.wino = 1;
+            if (!u.wino) a.w_wino = a.w_wino2 = nullptr;
             a.stats = nullptr;
         }
         u.plan = conv_plan(a);
@@ -286,6 +287,12 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
                                       : b.take((size_t)(L->u[i].kind == 1 ? 9 : (L->u[i].stride == 2 ? 16 : L->u[i].K * L->u[i].K)) *
                                                L->u[i].Cin * L->u[i].Cout);
     L->dweff = b.take(4 * 64 * 128);
+    for (int i = 3; i <= 12; ++i) {   // residual input gradients (3x3 'full' convs of dz) through the Winograd kernel when its blocks fill the chip
+        const Unit& u = L->u[i];
+        const long blocks = (long)N * cdiv(u.Hin, 16) * cdiv(u.Win, 16);
+        const bool on = L->wino_mode && tune_int("FS_WINO_V", 2) >= 2 && (L->wino_mode == 2 || blocks >= 200);
+        L->wino_d[i - 3] = on ? b.take((size_t)16 * 64 * 64) : 0;
+    }
     L->inbwd = b.take(max_inbwd);
     for (int i = 0; i < 16; ++i) {
         Unit& u = L->u[i];
@@ -374,7 +381,7 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
                 nb.U[nb.n] = ws + L.u[i].wino_u;
                 ++nb.n;
             }
-        FS_TRY(wt_wino_batch(nb, 64, 64, s));
+        FS_TRY(tune_int("FS_WINO_V", 2) >= 2 ? wt_wino2_batch(nb, 64, 64, s) : wt_wino_batch(nb, 64, 64, s));
     }
     const float* src = x;
     const float* src_a = nullptr;
@@ -389,7 +396,8 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
         a.in_nstride = src_a ? u.Cin : 0;
         a.in_relu = src_a ? 1 : 0;
         a.w = (u.kind == 1 || (u.kind == 3 && i < 15)) ? ws + L.weff[i - 13] : ((u.kind == 2 || u.kind == 3) ? ws + L.wfold : params + u.w_off);
-        a.w_wino = u.wino ? ws + u.wino_u : nullptr;
+        a.w_wino = (u.wino && tune_int("FS_WINO_V", 2) < 2) ? ws + u.wino_u : nullptr;
+        a.w_wino2 = (u.wino && tune_int("FS_WINO_V", 2) >= 2) ? ws + u.wino_u : nullptr;
         a.y = u.kind == 2 ? ws + L.zfold : ws + u.z;
         a.stats = u.kind == 2 ? nullptr : ws + u.stats;
         FS_TRY(conv_launch(a, s));
@@ -432,6 +440,10 @@ static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, c
     a.x = dz;
     a.y = dst;
     a.w = ws + L.wTu[&u - L.u];  // built at the start of tnet_backward
+    {
+        const int ui = (int)(&u - L.u);
+        if (ui >= 3 && ui <= 12 && L.wino_d[ui - 3]) a.w_wino2 = ws + L.wino_d[ui - 3];
+    }
     a.add_src = add_src;
     a.add_pad = add_src ? 2 : 0;
     if (u.kind == 3) {  // adjoint of conv2d_transpose = the plain strided conv with the stored filter
@@ -556,6 +568,14 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
                 wb.add(u.kind == 1 ? WT_UPDGRAD : WT_FLIPT, params + u.w_off, ws + L.wTu[i], K, K, u.Cin, u.Cout);
         }
         FS_TRY(wt_batch(wb, s));
+        WinoBatch nb{};   // ... and the Winograd transforms of the residual ones ([3][3][Cout][Cin] as the kernel's HWIO)
+        for (int i = 3; i <= 12; ++i)
+            if (L.wino_d[i - 3]) {
+                nb.w[nb.n] = ws + L.wTu[i];
+                nb.U[nb.n] = ws + L.wino_d[i - 3];
+                ++nb.n;
+            }
+        FS_TRY(wt_wino2_batch(nb, 64, 64, s));
     }
     const float* g = dy;         // gradient wrt the current unit's output activation (or h_k)
     const float* res_g = nullptr;  // d h_k, kept alive until the block's first conv adds it to its dgrad

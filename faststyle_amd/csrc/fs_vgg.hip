@@ -46,7 +46,10 @@ static size_t wino_offset(int l, bool dgrad) {  // l >= 1
     }
     return n;
 }
-size_t vgg_prepared_floats() { return wino_offset(FS_VGG_NLAYERS, false); }
+static size_t wino_region_floats() { return wino_offset(FS_VGG_NLAYERS, false) - flipt_floats(); }
+// (the same transformed filters once more in the K-contiguous order of the second-generation kernel, fs_wino2.hip)
+static size_t wino2_offset(int l, bool dgrad) { return wino_offset(l, dgrad) + wino_region_floats(); }
+size_t vgg_prepared_floats() { return wino_offset(FS_VGG_NLAYERS, false) + wino_region_floats(); }
 // debugging aid: FS_VGG_WINO_MASK selects the layers that may take the Winograd kernel (bit l: forward of layer l,
 // bit 16+l: its input gradient); default all
 static bool wino_layer_on(int bit) {
@@ -64,6 +67,8 @@ int vgg_prepare(const float* const w[FS_VGG_NLAYERS], float* prepared, hipStream
     for (int l = 1; l < FS_VGG_NLAYERS; ++l) {
         FS_TRY(wt_wino(w[l], prepared + wino_offset(l, false), kCin[l], kCout[l], s));
         FS_TRY(wt_wino(prepared + prepared_offset(l), prepared + wino_offset(l, true), kCout[l], kCin[l], s));  // [3][3][Cout][Cin]
+        FS_TRY(wt_wino2(w[l], prepared + wino2_offset(l, false), kCin[l], kCout[l], s));
+        FS_TRY(wt_wino2(prepared + prepared_offset(l), prepared + wino2_offset(l, true), kCout[l], kCin[l], s));
     }
     return 0;
 }
@@ -164,12 +169,13 @@ void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, 
     L->total_floats = b.off;
 }
 
-static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, const float* w_wino, const float* bias, const float* ab,
+static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, const float* w_wino, const float* w_wino2, const float* bias, const float* ab,
                     float* y, float* split_ws, size_t split_ws_floats, hipStream_t s) {
     ConvArgs a{};
     a.x = x;
     a.w = w;
     a.w_wino = w_wino;
+    a.w_wino2 = w_wino2;
     a.y = y;
     a.N = N;
     a.H = a.Ho = H;
@@ -199,7 +205,9 @@ static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS],
     const float* src = ws + L.xin;
     for (int l = 0; l <= L.lmax; ++l) {
         const int nb = l <= L.cmax ? L.NB : L.N;
-        FS_TRY(vgg_conv(src, nb, L.Hl[l], L.Wl[l], l, w[l], (prepared && l >= 1 && wino_layer_on(l)) ? prepared + wino_offset(l, false) : nullptr, b[l],
+        const bool wl = prepared && l >= 1 && wino_layer_on(l);
+        FS_TRY(vgg_conv(src, nb, L.Hl[l], L.Wl[l], l, w[l], wl ? prepared + wino_offset(l, false) : nullptr,
+                        wl ? prepared + wino2_offset(l, false) : nullptr, b[l],
                         ws + L.ab, ws + L.act[l], ws + L.splitws, L.splitws_floats, s));
         src = ws + L.act[l];
         if (pool_after(l) && l < L.lmax) {
@@ -325,6 +333,7 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         a.x = pre_cur;
         a.w = prepared + prepared_offset(l);
         a.w_wino = (l >= 1 && wino_layer_on(16 + l)) ? prepared + wino_offset(l, true) : nullptr;
+        a.w_wino2 = (l >= 1 && wino_layer_on(16 + l)) ? prepared + wino2_offset(l, true) : nullptr;
         a.N = N;
         a.H = a.Ho = H;
         a.W = a.Wo = W;

@@ -1,0 +1,639 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix cores, second generation (same arithmetic as fs_wino.hip:
+// Y = A^T [ (G g G^T) . (B^T d B) ] A, Lavin & Gray, cross-correlation form as tf.nn.conv2d; reference
+// libs/vgg16.py:36-220 forward and input gradients, im_transf_net.py:250-276 residual convs).
+//
+// What changed against the first kernel, and why (measured there: a fixed cost of ~27k cycles per 16x16-pixel block --
+// prologue + the LDS exchange of the 16 position planes in the epilogue -- against ~5.5k cycles per 8-channel chunk, i.e.
+// 38 % of the lifetime of a block on the 64-channel layers):
+//   * ONE wave per SIMD (256 threads, up to 512 registers): a wave owns a 32-tile x 32-channel block of the result for
+//     ALL 16 Winograd positions (256 accumulator registers), so the output transform A^T M A runs in registers -- no
+//     exchange through LDS, no barriers in the epilogue, 128-byte coalesced stores straight from the accumulators;
+//   * PERSISTENT workgroups walk a strided list of (block, channel-block) items and the staging pipeline (global loads
+//     two chunks ahead, patch -> V transform one chunk ahead) runs across item boundaries: the prologue of the next
+//     block is hidden behind the last chunks of the current one;
+//   * operands are laid out K-CONTIGUOUS in LDS (V[pos][tile][8], U[pos][co][8]; lane half kq multiplies channels
+//     4kq..4kq+3 of the chunk): one 16-byte LDS read feeds four matrix instructions (8 reads per chunk and position
+//     pair instead of 32), conflict-free without padding; the transformed filters are stored in that order in HBM
+//     (fs::wt_wino2: [pos][Cin/8][Cout][8]) so their staging is a straight 16-byte copy.
+#include "fs_kernels.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace fs {
+
+namespace {
+constexpr int kTT = 8;               // tiles per side of a block (16x16 output pixels)
+constexpr int kPT = 2 * kTT + 2;     // patch side (18)
+constexpr int kCC = 8;               // input channels per chunk
+constexpr int kPS = kCC + 1;         // patch pixel pitch (odd: the transform's reads of a tile row spread over the banks)
+constexpr int kBN = 64;              // output channels per item
+constexpr int kNT = kTT * kTT;       // tiles per block
+constexpr int kPatchF = ((kPT * kPT * kPS + 8 + 3) & ~3);   // 2924 -> patch + 8 floats of sink
+constexpr int kVF = 16 * kNT * kCC;  // 8192
+constexpr int kUF = 16 * kBN * kCC;  // 8192
+constexpr int kStageF = kPatchF + kVF + kUF;
+constexpr int kRedF = 64 * 2 * 4 + 64;   // statistics scratch: [4 contributors][64][2] + shift[64]
+constexpr unsigned kOOB = 0x80000000u;
+}  // namespace
+
+// U2[pos][ci/8][co][ci%8] = (G g G^T)[pos] for g = w[:, :, ci, co]   (w HWIO [3][3][Cin][Cout]); blockIdx.y = filter of the batch
+__global__ __launch_bounds__(256) void wt_wino2_batch_kernel(WinoBatch b, int Cin, int Cout) {
+    const float* __restrict__ w = b.w[blockIdx.y];
+    float* __restrict__ U = b.U[blockIdx.y];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t cc = (size_t)Cin * Cout;
+    if (i >= cc) return;
+    const int ci = (int)(i / Cout), co = (int)(i - (size_t)ci * Cout);
+    float g[3][3], t[4][3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) g[kh][kw] = w[(size_t)(kh * 3 + kw) * cc + i];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        t[0][kw] = g[0][kw];
+        t[1][kw] = 0.5f * (g[0][kw] + g[1][kw] + g[2][kw]);
+        t[2][kw] = 0.5f * (g[0][kw] - g[1][kw] + g[2][kw]);
+        t[3][kw] = g[2][kw];
+    }
+    const size_t pos_stride = cc;   // floats per position plane
+    float* dst = U + ((size_t)(ci >> 3) * Cout + co) * 8 + (ci & 7);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        dst[(size_t)(r * 4 + 0) * pos_stride] = t[r][0];
+        dst[(size_t)(r * 4 + 1) * pos_stride] = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
+        dst[(size_t)(r * 4 + 2) * pos_stride] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
+        dst[(size_t)(r * 4 + 3) * pos_stride] = t[r][2];
+    }
+}
+
+int wt_wino2_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s) {
+    if (b.n <= 0) return 0;
+    const size_t cc = (size_t)Cin * Cout;
+    hipLaunchKernelGGL(wt_wino2_batch_kernel, dim3((unsigned)((cc + 255) / 256), (unsigned)b.n), dim3(256), 0, s, b, Cin, Cout);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int wt_wino2(const float* w, float* U, int Cin, int Cout, hipStream_t s) {
+    WinoBatch b{};
+    b.w[0] = w;
+    b.U[0] = U;
+    b.n = 1;
+    return wt_wino2_batch(b, Cin, Cout, s);
+}
+
+#ifdef FS_WINO2_TRACE
+// debug build only (tools/conv_trace.py --wino2): per-workgroup phase cycle counts of the last launch
+__device__ long long g_wino2_trace[4096 * 8];
+extern "C" int fs_debug_conv_trace(long long* out, int n_wg) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wino2_trace), sizeof(long long) * 8 * (size_t)n_wg, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int fs_debug_conv_trace_reset() {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wino2_trace)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(long long) * 8 * 4096);
+}
+#define FS_W2_NOW() ((long long)__builtin_readcyclecounter())
+#endif
+
+__global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+#ifdef FS_WINO2_TRACE
+    const long long tr_t0 = FS_W2_NOW();
+    long long tr_sweep = 0, tr_post = 0, tr_bar = 0, tr_epi = 0, tr_pro = 0;
+#endif
+    const ConvPlan& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 31, kq = lane >> 5;
+    const int mb = wave & 1, nb = wave >> 1;   // this wave's 32-tile block / 32-channel block of the 64 x 64 item
+    auto fdiv = [](int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); };
+    auto uniform_ptr = [](const float* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    };
+    float* red = smem + 2 * kStageF;   // statistics scratch (transform-net form only)
+
+
+    // ---- the item list of this workgroup: item = ((n * blocks + block) * ncob + channel block) * ksplit + z
+    const int blocks = p.tiles_y * p.tiles_x;
+    const int ncob = a.Cout / kBN;
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    const int nchunks_all = a.Cin / kCC;
+    const int total_items = a.N * blocks * ncob * ks;
+    const int G = (int)gridDim.x;
+    const int my_items = ((int)blockIdx.x < total_items) ? (total_items - 1 - (int)blockIdx.x) / G + 1 : 0;
+    const float inv_ks = 1.0f / (float)ks, inv_ncob = 1.0f / (float)ncob, inv_blocks = 1.0f / (float)blocks, inv_tx = 1.0f / (float)p.tiles_x;
+    struct Item {
+        int n, oy0, ox0, co0, cbeg, cend, z, tile_lin;
+    };
+    auto decode = [&](int it) {
+        Item r;
+        const int lin = (int)blockIdx.x + it * G;
+        const int t1 = fdiv(lin, inv_ks);
+        r.z = lin - t1 * ks;
+        const int t2 = fdiv(t1, inv_ncob);
+        const int cob = t1 - t2 * ncob;
+        r.tile_lin = t2;
+        r.n = fdiv(t2, inv_blocks);
+        const int br = t2 - r.n * blocks;
+        const int byi = fdiv(br, inv_tx);
+        r.oy0 = byi * 2 * kTT;
+        r.ox0 = (br - byi * p.tiles_x) * 2 * kTT;
+        r.co0 = cob * kBN;
+        r.cbeg = ks > 1 ? r.z * nchunks_all / ks : 0;
+        r.cend = ks > 1 ? (r.z + 1) * nchunks_all / ks : nchunks_all;
+        r.n = __builtin_amdgcn_readfirstlane(r.n);
+        r.oy0 = __builtin_amdgcn_readfirstlane(r.oy0);
+        r.ox0 = __builtin_amdgcn_readfirstlane(r.ox0);
+        r.co0 = __builtin_amdgcn_readfirstlane(r.co0);
+        r.cbeg = __builtin_amdgcn_readfirstlane(r.cbeg);
+        r.cend = __builtin_amdgcn_readfirstlane(r.cend);
+        r.z = __builtin_amdgcn_readfirstlane(r.z);
+        r.tile_lin = __builtin_amdgcn_readfirstlane(r.tile_lin);
+        return r;
+    };
+
+    // ---- staging descriptors
+    // patch: 18*18 pixels x 2 float4 = 648 elements, <= 3 per thread; element -> (py << 8 | px), channel quad c4
+    int pq[3], pdst[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int e = tid + i * 256;
+        pq[i] = -1;
+        pdst[i] = kPT * kPT * kPS;   // sink
+        if (e < kPT * kPT * 2) {
+            const int pix = e >> 1, c4 = e & 1;
+            const int py = pix / kPT, px = pix - py * kPT;
+            pq[i] = (py << 8) | px;
+            pdst[i] = pix * kPS + c4 * 4;
+        }
+    }
+    const int pc4 = (tid & 1) * 4;     // every element of a thread has the same channel quad (256 is even)
+    const unsigned x_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * a.Cin) * 4u);
+    const unsigned u_bytes = __builtin_amdgcn_readfirstlane((unsigned)(16 * a.Cin * a.Cout) * 4u);
+    const bool has_ab = a.in_a != nullptr;
+    const float* ub = uniform_ptr(a.w_wino2);
+    float4 pv[3], uv[8];
+    float4 va = make_float4(1.f, 1.f, 1.f, 1.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned gvo[3];
+
+    auto item_offsets = [&](const Item& I) {   // global offsets of the thread's patch elements for this item
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int py = pq[i] >> 8, px = pq[i] & 255;
+            const int sy = I.oy0 - a.pad_t + py, sx = I.ox0 - a.pad_l + px;
+            const bool ok = pq[i] >= 0 && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W;
+            gvo[i] = ok ? (unsigned)((sy * a.W + sx) * a.Cin + pc4) * 4u : kOOB;
+        }
+    };
+    auto issue_patch = [&](const Item& I, int chunk) {
+        const float* xn = uniform_ptr(a.x + (size_t)I.n * a.H * a.W * a.Cin);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, x_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, gvo[i], chunk * kCC * 4, 0));
+        if (has_ab) {
+            va = *reinterpret_cast<const float4*>(a.in_a + (size_t)I.n * a.in_nstride + chunk * kCC + pc4);
+            vb = *reinterpret_cast<const float4*>(a.in_b + (size_t)I.n * a.in_nstride + chunk * kCC + pc4);
+        }
+    };
+    auto issue_filter = [&](const Item& I, int chunk) {
+        // U2[pos][chunk][co][8]: for a position the 64 channels x 8 of the item are 2 KB contiguous; element e of the
+        // thread = (pos = e >> 7, float4 index inside that run = e & 127), LDS position = e
+        const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ub), 0, u_bytes, 0x00020000);
+        const unsigned so = (unsigned)((chunk * a.Cout + I.co0) * 8) * 4u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + i * 256;
+            const unsigned vo = (unsigned)((e >> 7) * a.Cin * a.Cout + (e & 127) * 4) * 4u;
+            uv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, vo, so, 0));
+        }
+    };
+    auto issue_filter_pair = [&](const Item& I, int chunk, int i0) {   // elements i0, i0+1 of issue_filter (one sweep slot)
+        const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ub), 0, u_bytes, 0x00020000);
+        const unsigned so = (unsigned)((chunk * a.Cout + I.co0) * 8) * 4u;
+#pragma unroll
+        for (int i = i0; i < i0 + 2; ++i) {
+            const int e = tid + i * 256;
+            const unsigned vo = (unsigned)((e >> 7) * a.Cin * a.Cout + (e & 127) * 4) * 4u;
+            uv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, vo, so, 0));
+        }
+    };
+    auto commit_patch = [&](float* patch) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float4 v = pv[i];
+            if (has_ab) {   // (VALID padding only: every patch pixel that reaches a stored output is a real pixel)
+                v.x = fmaf(v.x, va.x, vb.x);
+                v.y = fmaf(v.y, va.y, vb.y);
+                v.z = fmaf(v.z, va.z, vb.z);
+                v.w = fmaf(v.w, va.w, vb.w);
+                if (a.in_relu) {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+            }
+            float* d = patch + pdst[i];
+            d[0] = v.x;
+            d[1] = v.y;
+            d[2] = v.z;
+            d[3] = v.w;
+        }
+    };
+    auto commit_filter = [&](float* Ul) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(Ul + (tid + i * 256) * 4) = uv[i];
+    };
+    // input transform V = B^T d B: a thread does two (tile, channel) pairs per chunk
+    auto transform_pair = [&](const float* patch, float* Vl, int pidx) {
+        const int tt = pidx >> 3, tk = pidx & 7;
+        const int tty = tt >> 3, ttx = tt & 7;
+        const float* src = patch + ((2 * tty) * kPT + 2 * ttx) * kPS + tk;
+        float d[4][4], r[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[i][j] = src[(i * kPT + j) * kPS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[0][j] = d[0][j] - d[2][j];
+            r[1][j] = d[1][j] + d[2][j];
+            r[2][j] = d[2][j] - d[1][j];
+            r[3][j] = d[1][j] - d[3][j];
+        }
+        float* dst = Vl + tt * kCC + tk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dst[(i * 4 + 0) * kNT * kCC] = r[i][0] - r[i][2];
+            dst[(i * 4 + 1) * kNT * kCC] = r[i][1] + r[i][2];
+            dst[(i * 4 + 2) * kNT * kCC] = r[i][2] - r[i][1];
+            dst[(i * 4 + 3) * kNT * kCC] = r[i][1] - r[i][3];
+        }
+    };
+
+    f32x16 acc[16];   // one 32x32 block per Winograd position
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[pos][r] = 0.f;
+    };
+    zero_acc();
+
+    // sweep of one chunk: per position one 16-byte read of A (tiles) and of B (channels), four matrix instructions
+    // (channels 4kq..4kq+3 of the chunk in lane half kq); the reads of position pos+1 are issued behind the first matrix
+    // instruction of position pos.  The preparation of the NEXT step (input transform of the thread's two (tile, channel)
+    // pairs, filter commit) is threaded through the sweep in small slices -- three slots per position, pinned with
+    // sched_barrier: with one wave per SIMD nothing else covers that work, and left to itself the compiler emits each
+    // transform as one block of ~60 instructions and LDS round trips during which the matrix pipe idles.
+    float td[4][4], tr[4][4];   // the transform in flight (one pair at a time)
+    // loop state the slices touch (the load stream runs inside the sweep: nothing but the barrier stands between two sweeps)
+    bool has1 = false, has2 = false, load_live = false;
+    Item L = decode(0);          // cursor of the load stream: the step whose loads were issued last
+    int l_it = 0, l_chunk = L.cbeg;
+    auto advance_load = [&]() {   // returns false when the stream is exhausted
+        if (++l_chunk < L.cend) return true;
+        if (++l_it >= my_items) return false;
+        L = decode(l_it);
+        l_chunk = L.cbeg;
+        item_offsets(L);
+        return true;
+    };
+    auto slice = [&](int sl, const float* patch_n, float* Vn, float* Un) {
+        // 48 slots per sweep.  0-3: global loads of the filter of step q+1; 4: the load cursor moves to step q+2 and its
+        // patch loads go out; 5-16: input transform of pair `tid` (4 slots of reads, 2 idle while they land, 2 of row sums,
+        // 4 of column sums + stores); 17-28: pair `tid + 256`; 40-47: the filter commit, as late as its loads allow
+        if (sl < 4) {
+            if (has1) issue_filter_pair(L, l_chunk, 2 * sl);
+            return;
+        }
+        if (sl == 4) {
+            has2 = false;
+            if (has1 && load_live) {
+                has2 = advance_load();
+                load_live = has2;
+                if (has2) issue_patch(L, l_chunk);
+            }
+            return;
+        }
+        if (sl >= 40) {
+            const int i0 = sl - 40;
+            *reinterpret_cast<float4*>(Un + (tid + i0 * 256) * 4) = uv[i0];
+            return;
+        }
+        const int half = sl >= 17 ? 1 : 0, k = sl - 5 - half * 12;
+        if (sl >= 29 || k == 4 || k == 5) return;
+        const int pidx = tid + half * 256;
+        const int tt = pidx >> 3, tk = pidx & 7;
+        const float* src = patch_n + ((2 * (tt >> 3)) * kPT + 2 * (tt & 7)) * kPS + tk;
+        float* dst = Vn + tt * kCC + tk;
+        if (k < 4) {                 // 4 rows of the 4x4 input block, one per slot
+#pragma unroll
+            for (int j = 0; j < 4; ++j) td[k][j] = src[(k * kPT + j) * kPS];
+        } else if (k < 8) {          // B^T d (rows), two columns per slot
+#pragma unroll
+            for (int j = 2 * (k - 6); j < 2 * (k - 6) + 2; ++j) {
+                tr[0][j] = td[0][j] - td[2][j];
+                tr[1][j] = td[1][j] + td[2][j];
+                tr[2][j] = td[2][j] - td[1][j];
+                tr[3][j] = td[1][j] - td[3][j];
+            }
+        } else {                     // (.) B (columns) of row i and its four stores
+            const int i = k - 8;
+            dst[(i * 4 + 0) * kNT * kCC] = tr[i][0] - tr[i][2];
+            dst[(i * 4 + 1) * kNT * kCC] = tr[i][1] + tr[i][2];
+            dst[(i * 4 + 2) * kNT * kCC] = tr[i][2] - tr[i][1];
+            dst[(i * 4 + 3) * kNT * kCC] = tr[i][1] - tr[i][3];
+        }
+    };
+    auto sweep = [&](const float* Vl, const float* Ul, const float* patch_n, float* Vn, float* Un) {
+        const float* pa = Vl + (mb * 32 + lm) * kCC + kq * 4;
+        const float* pb = Ul + (nb * 32 + lm) * kCC + kq * 4;
+        // two positions at a time, their matrix instructions alternating: consecutive MFMAs never share an accumulator (an
+        // instruction slipped between two MFMAs on the SAME accumulator costs ~40 cycles, between independent ones ~6)
+        float4 A[2][2], B[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            A[0][h] = *reinterpret_cast<const float4*>(pa + h * kNT * kCC);
+            B[0][h] = *reinterpret_cast<const float4*>(pb + h * kBN * kCC);
+        }
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const int c = pp & 1, n = c ^ 1, p0 = 2 * pp, p1 = 2 * pp + 1;
+            const float a0[4] = {A[c][0].x, A[c][0].y, A[c][0].z, A[c][0].w}, b0[4] = {B[c][0].x, B[c][0].y, B[c][0].z, B[c][0].w};
+            const float a1[4] = {A[c][1].x, A[c][1].y, A[c][1].z, A[c][1].w}, b1[4] = {B[c][1].x, B[c][1].y, B[c][1].z, B[c][1].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[k], b0[k], acc[p0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k == 0 && pp + 1 < 8) {   // operands of the next position pair
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        A[n][h] = *reinterpret_cast<const float4*>(pa + (p0 + 2 + h) * kNT * kCC);
+                        B[n][h] = *reinterpret_cast<const float4*>(pb + (p0 + 2 + h) * kBN * kCC);
+                    }
+                } else if (k > 0) {
+                    slice(pp * 6 + (k - 1) * 2, patch_n, Vn, Un);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[k], b1[k], acc[p1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k > 0) slice(pp * 6 + (k - 1) * 2 + 1, patch_n, Vn, Un);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // ---- epilogue of one item: output transform in registers, bias / ReLU / residual add / consumer mask / statistics, store.
+    // Accumulator register r of lane (lm, kq) is tile (4 mb + (r >> 2), (r & 3) + 4 kq) of the block, channel nb*32 + lm.
+    // FULL: the 16x16-pixel block lies inside the image (no per-pixel predicates).  Every consumer-mask / residual load of
+    // the item is issued up front (clamped addresses for pixels outside the image) -- one memory latency per item, not
+    // one per pixel.
+    auto epilogue_body = [&](auto FULLT, const Item& I) {
+        constexpr bool full = decltype(FULLT)::value;
+        const int co = I.co0 + nb * 32 + lm;
+        const float bs = a.bias ? a.bias[co] : 0.f;
+        const bool relu_out = a.out_relu != 0;
+        float* yn = a.y + ((size_t)I.n + (ks > 1 ? (size_t)I.z * a.N : 0)) * a.Ho * a.Wo * a.Cout;
+        const float* msn = a.mask_src ? a.mask_src + (size_t)I.n * a.Ho * a.Wo * a.Cout : nullptr;
+        const int Ha = a.Ho - 2 * a.add_pad, Wa = a.Wo - 2 * a.add_pad;
+        const float* adn = a.add_src ? a.add_src + (size_t)I.n * Ha * Wa * a.Cout : nullptr;
+        const int oyb = I.oy0 + 8 * mb, oxb = I.ox0 + 8 * kq;     // first pixel of the lane's tiles: rows r>>2, columns r&3
+        const int rowp = a.Wo * a.Cout;
+        const int obase = (oyb * a.Wo + oxb) * a.Cout + co;
+        // buffer resources: pixels outside the image (edge blocks) get the out-of-range offset -- loads return 0, stores are
+        // dropped by the hardware range check -- so there is no branch and no saved exec mask per pixel
+        const unsigned img_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.Ho * a.Wo * a.Cout) * 4u);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(yn)), 0, img_bytes, 0x00020000);
+        float mk[16][4], ad[16][4];
+        if (msn) {
+            const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(msn)), 0, img_bytes, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int py = 2 * (r >> 2) + (k >> 1), px = 2 * (r & 3) + (k & 1);
+                    const unsigned off = (unsigned)(obase + py * rowp + px * a.Cout) * 4u;
+                    const bool ok = full || (oyb + py < a.Ho && oxb + px < a.Wo);
+                    mk[r][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mr, ok ? off : kOOB, 0, 0));
+                }
+        }
+        if (adn) {
+            const unsigned add_bytes = __builtin_amdgcn_readfirstlane((unsigned)(Ha * Wa * a.Cout) * 4u);
+            const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(adn)), 0, add_bytes, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ay = oyb + 2 * (r >> 2) + (k >> 1) - a.add_pad, ax = oxb + 2 * (r & 3) + (k & 1) - a.add_pad;
+                    const bool ok = ay >= 0 && ay < Ha && ax >= 0 && ax < Wa;
+                    ad[r][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ar, ok ? (unsigned)((ay * Wa + ax) * a.Cout + co) * 4u : kOOB, 0, 0));
+                }
+        }
+        float s1 = 0.f, s2 = 0.f, cs = 0.f;
+        if (a.stats) {   // shift of the one-pass statistics: the block's first pixel of this channel (held by tile 0: mb 0, kq 0)
+            if (mb == 0 && kq == 0) {
+                const float m00 = acc[0][0] + acc[1][0] + acc[2][0], m01 = acc[4][0] + acc[5][0] + acc[6][0],
+                            m02 = acc[8][0] + acc[9][0] + acc[10][0];
+                red[512 + nb * 32 + lm] = m00 + m01 + m02;
+            }
+            __syncthreads();
+            cs = red[512 + nb * 32 + lm];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // the 16 position values of this row leave the accumulator file HERE (FS_ACC_READ: a volatile read on the GPU): left
+            // to itself the compiler copies ~180 accumulators to ordinary registers in one block behind the chunk loop and spills
+            float m[16];
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) m[pos] = FS_ACC_READ(acc[pos][r]);
+            float s4[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {   // A^T M
+                s4[0][j] = m[0 + j] + m[4 + j] + m[8 + j];
+                s4[1][j] = m[4 + j] - m[8 + j] - m[12 + j];
+            }
+            float v[4];
+#pragma unroll
+            for (int ai = 0; ai < 2; ++ai) {
+                v[ai * 2 + 0] = s4[ai][0] + s4[ai][1] + s4[ai][2];
+                v[ai * 2 + 1] = s4[ai][1] - s4[ai][2] - s4[ai][3];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int py = 2 * (r >> 2) + (k >> 1), px = 2 * (r & 3) + (k & 1);
+                const bool ok = full || (oyb + py < a.Ho && oxb + px < a.Wo);
+                float val = v[k];
+                if (a.stats) {
+                    const float dv = ok ? val - cs : 0.f;
+                    s1 += dv;
+                    s2 = fmaf(dv, dv, s2);
+                }
+                val += bs;
+                val = relu_out ? fmaxf(val, 0.f) : val;
+                if (adn) val += ad[r][k];
+                if (msn) val = mk[r][k] > 0.f ? val : 0.f;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), yr, ok ? (unsigned)(obase + py * rowp + px * a.Cout) * 4u : kOOB, 0, 0);
+            }
+        }
+        if (a.stats) {
+            // per-block instance-norm partials of the RAW conv output (mean, M2, count) around the shift `cs`: the four
+            // contributors of a channel (2 lane halves x 2 tile blocks) meet in LDS
+            red[(((mb * 2 + kq) * 64) + nb * 32 + lm) * 2] = s1;
+            red[(((mb * 2 + kq) * 64) + nb * 32 + lm) * 2 + 1] = s2;
+            __syncthreads();
+            if (tid < 64) {
+                float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    S1 += red[(g * 64 + tid) * 2];
+                    S2 += red[(g * 64 + tid) * 2 + 1];
+                }
+                const int th_valid = min(2 * kTT, a.Ho - I.oy0), tw_valid = min(2 * kTT, a.Wo - I.ox0);
+                const float cnt = (float)(th_valid * tw_valid);
+                float* st = a.stats + ((size_t)I.tile_lin * a.Cout + I.co0 + tid) * 3;
+                const float shift = red[512 + tid];
+                st[0] = shift + S1 / cnt;
+                st[1] = fmaxf(S2 - S1 * S1 / cnt, 0.f);
+                st[2] = cnt;
+            }
+            __syncthreads();   // `red` is reused by the next item
+        }
+    };
+    auto epilogue = [&](const Item& I) {
+        if (I.oy0 + 2 * kTT <= a.Ho && I.ox0 + 2 * kTT <= a.Wo)
+            epilogue_body(std::true_type{}, I);
+        else
+            epilogue_body(std::false_type{}, I);
+        zero_acc();
+    };
+
+    // ---- the flat pipeline over (item, chunk) steps.  Step q multiplies out of stage q&1 while step q+1 is prepared
+    // (patch -> V, filter commit) into the other stage and the global loads of step q+2 are in flight.
+    if (my_items == 0) return;
+    item_offsets(L);
+    float* const st0 = smem;
+    float* const st1 = smem + kStageF;
+    // step 0: load + commit; step 1: its patch (the filter of step q+1 always travels during the sweep of step q)
+    issue_patch(L, l_chunk);
+    issue_filter(L, l_chunk);
+    commit_patch(st0);
+    commit_filter(st0 + kPatchF + kVF);
+    const bool have1 = advance_load();
+    if (have1) issue_patch(L, l_chunk);
+    __syncthreads();
+    transform_pair(st0, st0 + kPatchF, tid);
+    transform_pair(st0, st0 + kPatchF, tid + 256);
+    if (have1) commit_patch(st1);
+    __syncthreads();
+#ifdef FS_WINO2_TRACE
+    tr_pro = FS_W2_NOW() - tr_t0;
+    long long tr_last = FS_W2_NOW();
+#endif
+    load_live = have1;   // a step beyond the one whose patch is already committed may still exist
+    int q = 0;
+    // (nested item / chunk loops rather than one flat loop with a conditional epilogue: a conditional re-zeroing of the 256
+    // accumulators makes the register allocator merge two versions of them at the join -- copies and spills)
+    for (int it = 0; it < my_items; ++it) {
+        const Item cur_it = decode(it);
+        for (int chunk = cur_it.cbeg; chunk < cur_it.cend; ++chunk, ++q) {
+            float* S0 = (q & 1) ? st1 : st0;
+            float* S1 = (q & 1) ? st0 : st1;
+            // does step q+1 exist?  (its patch already sits in S1's patch area; L points at it)
+            has1 = (chunk + 1 < cur_it.cend) || (it + 1 < my_items);
+#ifdef FS_WINO2_TRACE
+            const long long q0 = FS_W2_NOW();
+#endif
+            // (the transform / filter-commit slices run unconditionally: after the last step they work on stale data that
+            // nothing reads)
+            sweep(S0 + kPatchF, S0 + kPatchF + kVF, S1, S1 + kPatchF, S1 + kPatchF + kVF);
+#ifdef FS_WINO2_TRACE
+            const long long q1 = FS_W2_NOW();
+#endif
+            if (has2) commit_patch(S0);    // S0's patch was consumed by the transform of the previous step
+#ifdef FS_WINO2_TRACE
+            const long long q2 = FS_W2_NOW();
+#endif
+            __syncthreads();
+#ifdef FS_WINO2_TRACE
+            const long long q3 = FS_W2_NOW();
+            tr_sweep += q1 - q0;
+            tr_post += q2 - q1 + (q0 - tr_last);
+            tr_bar += q3 - q2;
+            tr_last = q3;
+#endif
+        }
+#ifdef FS_WINO2_TRACE
+        const long long e0 = FS_W2_NOW();
+#endif
+        epilogue(cur_it);
+#ifdef FS_WINO2_TRACE
+        tr_last = FS_W2_NOW();
+        tr_epi += tr_last - e0;
+#endif
+    }
+#ifdef FS_WINO2_TRACE
+    if (tid == 0 && blockIdx.x < 4096) {
+        long long* t = g_wino2_trace + (size_t)blockIdx.x * 8;
+        t[0] = tr_t0;
+        t[1] = tr_pro;
+        t[2] = tr_sweep;
+        t[3] = tr_post;
+        t[4] = tr_bar;
+        t[5] = tr_epi;
+        t[6] = FS_W2_NOW();
+        t[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+#endif
+}
+
+bool wino2_eligible(const ConvArgs& a) {
+    // SAME (pad 1: the VGG convs), VALID (pad 0: residual convs of the transform net) or FULL (pad 2: their input
+    // gradients); the on-load affine needs pad 0
+    const bool pad_ok = a.pad_t == a.pad_l && a.pad_t >= 0 && a.pad_t <= 2 && a.Ho == a.H + 2 * a.pad_t - 2 && a.Wo == a.W + 2 * a.pad_l - 2;
+    // (measured: ahead of the first-generation kernel on the 64-channel layers -- 8 chunks per block, where the fixed cost of
+    // a block weighs most --, level at 128 input channels, behind it beyond: FS_WINO2_MAXCIN)
+    return a.w_wino2 && tune_int("FS_WINO_V", 2) >= 2 && a.Cin <= tune_int("FS_WINO2_MAXCIN", 128) && a.KH == 3 && a.KW == 3 && a.stride == 1 && pad_ok && a.src_mode == SRC_PLAIN && a.Cin % kCC == 0 &&
+           a.Cout % kBN == 0 && !a.shuffle && (!a.in_a || a.pad_t == 0) && a.w_nstride == 0 && (a.dil_x <= 1) &&
+           (!a.add_src || !a.stats);
+}
+
+void wino2_plan(const ConvArgs& a, ConvPlan* out) {
+    ConvPlan p{};
+    p.variant = 6;
+    p.BN = kBN;
+    p.CC = kCC;
+    p.TH = p.TW = 2 * kTT;
+    p.tiles_y = cdiv(a.Ho, 2 * kTT);
+    p.tiles_x = cdiv(a.Wo, 2 * kTT);
+    p.lds_bytes = 4 * (2 * kStageF + kRedF);
+    p.ksplit = 1;
+    const long items = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / kBN);
+    const int nchunks = a.Cin / kCC;
+    const int max_ks = tune_int("FS_WINO_KSPLIT", 4);
+    if (a.split_ws && !a.stats && !a.add_src) {
+        int ks = 1;
+        while (ks < max_ks && items * ks < 256 && nchunks / (ks * 2) >= 8 &&
+               (size_t)(ks * 2) * a.N * a.Ho * a.Wo * a.Cout <= a.split_ws_floats)
+            ks *= 2;
+        p.ksplit = ks;
+    }
+    *out = p;
+}
+
+int wino2_launch(const ConvArgs& a, hipStream_t s) {
+    const ConvPlan& p = a.p;
+    static BigLds lds_attr;
+    lds_attr.ensure(reinterpret_cast<const void*>(wino2_conv_kernel));
+    const long items = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / kBN) * (p.ksplit > 1 ? p.ksplit : 1);
+    const int wgs = tune_int("FS_WINO2_WGS", 256);
+    const long grid = items < wgs ? items : wgs;
+    hipLaunchKernelGGL(wino2_conv_kernel, dim3((unsigned)grid), dim3(256), (size_t)p.lds_bytes, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace fs

@@ -319,6 +319,11 @@ static inline unsigned raw_buffer_load_b32(buffer_rsrc r, unsigned voff, unsigne
     else if (voff < 0x80000000u) { fprintf(stderr, "emu: buffer load out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
     return v;
 }
+static inline void raw_buffer_store_b32(unsigned v, buffer_rsrc r, unsigned voff, unsigned soff) {
+    const unsigned long long end = (unsigned long long)voff + soff + 4ull;
+    if (voff < 0x80000000u && end <= r.nbytes) memcpy(const_cast<unsigned char*>(r.base) + voff + soff, &v, 4);
+    else if (voff < 0x80000000u) { fprintf(stderr, "emu: buffer store out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
+}
 static inline float fmed3f(float a, float b, float c) {
     const float lo = a < b ? a : b, hi = a < b ? b : a;
     return c < lo ? lo : (c > hi ? hi : c);
@@ -329,6 +334,7 @@ static inline float fmed3f(float a, float b, float c) {
     fsemu::buffer_rsrc{reinterpret_cast<const unsigned char*>(ptr), (unsigned)(nbytes)}
 #define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) fsemu::raw_buffer_load_b128((r), (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, aux) fsemu::raw_buffer_load_b32((r), (unsigned)(voff), (unsigned)(soff))
+#define __builtin_amdgcn_raw_buffer_store_b32(v, r, voff, soff, aux) fsemu::raw_buffer_store_b32((v), (r), (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_fmed3f(a, b, c) fsemu::fmed3f((a), (b), (c))
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }

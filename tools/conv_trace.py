@@ -18,6 +18,9 @@ from faststyle_amd import engine  # noqa: E402
 from tools.micro_conv import CASES  # noqa: E402
 
 
+KW = {"winograd": True} if os.environ.get("WINO") else {}    # WINO=1: the Winograd kernel (build with -DFS_WINO2_TRACE)
+
+
 def main():
     names = sys.argv[1:] or ["vgg1_2_n4", "vgg2_2_n4", "vgg3_2_n4", "vgg4_2_n4"]
     CASES.setdefault("vgg1_2_n4", (4, 256, 256, 64, 64, 3, 1, "SAME"))
@@ -30,18 +33,18 @@ def main():
         x = torch.randn(N, H, W, Ci, device="cuda")
         w = torch.randn(K, K, Ci, Co, device="cuda") * 0.05
         for _ in range(3):
-            y = e.conv2d(x, w, s, pad)
+            y = e.conv2d(x, w, s, pad, **KW)
         torch.cuda.synchronize()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         iters = 10
         t0.record()
         for _ in range(iters):
-            y = e.conv2d(x, w, s, pad)
+            y = e.conv2d(x, w, s, pad, **KW)
         t1.record()
         torch.cuda.synchronize()
         us = t0.elapsed_time(t1) * 1e3 / iters
         assert e.lib.fs_debug_conv_trace_reset() == 0
-        y = e.conv2d(x, w, s, pad)
+        y = e.conv2d(x, w, s, pad, **KW)
         torch.cuda.synchronize()
         buf = np.zeros((4096, 8), dtype=np.int64)
         rc = rd(buf.ctypes.data, 4096)
