@@ -177,8 +177,15 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
     const bool has_ab = a.in_a != nullptr;
     const float* ub = uniform_ptr(a.w_wino2);
     float4 pv[3], uv[8];
+    const __amdgpu_buffer_rsrc_t ur_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ub), 0, u_bytes, 0x00020000);   // kernel-constant
     float4 va = make_float4(1.f, 1.f, 1.f, 1.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned gvo[3];
+    unsigned uvo[8];   // filter element offsets (kernel-constant per thread)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + i * 256;
+        uvo[i] = (unsigned)((e >> 7) * a.Cin * a.Cout + (e & 127) * 4) * 4u;
+    }
 
     auto item_offsets = [&](const Item& I) {   // global offsets of the thread's patch elements for this item
 #pragma unroll
@@ -212,13 +219,10 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
         }
     };
     auto issue_filter_pair = [&](const Item& I, int chunk, int i0) {   // elements i0, i0+1 of issue_filter (one sweep slot)
-        const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ub), 0, u_bytes, 0x00020000);
         const unsigned so = (unsigned)((chunk * a.Cout + I.co0) * 8) * 4u;
 #pragma unroll
         for (int i = i0; i < i0 + 2; ++i) {
-            const int e = tid + i * 256;
-            const unsigned vo = (unsigned)((e >> 7) * a.Cin * a.Cout + (e & 127) * 4) * 4u;
-            uv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, vo, so, 0));
+            uv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur_k, uvo[i], so, 0));
         }
     };
     auto commit_patch = [&](float* patch) {
@@ -541,22 +545,21 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
     for (int it = 0; it < my_items; ++it) {
         const Item cur_it = decode(it);
         for (int chunk = cur_it.cbeg; chunk < cur_it.cend; ++chunk, ++q) {
-            float* S0 = (q & 1) ? st1 : st0;
-            float* S1 = (q & 1) ? st0 : st1;
-            // does step q+1 exist?  (its patch already sits in S1's patch area; L points at it)
+            // does step q+1 exist?  (its patch already sits in the other stage's patch area; L points at it)
             has1 = (chunk + 1 < cur_it.cend) || (it + 1 < my_items);
 #ifdef FS_WINO2_TRACE
             const long long q0 = FS_W2_NOW();
 #endif
-            // (the transform / filter-commit slices run unconditionally: after the last step they work on stale data that
-            // nothing reads)
-            sweep(S0 + kPatchF, S0 + kPatchF + kVF, S1, S1 + kPatchF, S1 + kPatchF + kVF);
+            // stage offsets as integers into the LDS array (selecting between two POINTERS makes them generic pointers:
+            // a null check and 64-bit arithmetic per access); ONE copy of the step body -- a second one makes the register
+            // allocator merge two versions of the 256 accumulators at the join.  The transform / filter-commit slices run
+            // unconditionally: after the last step they work on stale data that nothing reads.
+            const int o0 = (q & 1) ? kStageF : 0, o1 = kStageF - o0;
+            sweep(smem + o0 + kPatchF, smem + o0 + kPatchF + kVF, smem + o1, smem + o1 + kPatchF, smem + o1 + kPatchF + kVF);
+            if (has2) commit_patch(smem + o0);   // this stage's patch was consumed by the transform of the previous step
 #ifdef FS_WINO2_TRACE
             const long long q1 = FS_W2_NOW();
-#endif
-            if (has2) commit_patch(S0);    // S0's patch was consumed by the transform of the previous step
-#ifdef FS_WINO2_TRACE
-            const long long q2 = FS_W2_NOW();
+            const long long q2 = q1;
 #endif
             __syncthreads();
 #ifdef FS_WINO2_TRACE
