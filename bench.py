@@ -385,7 +385,7 @@ def main():
         tpath = os.path.join(ROOT, TRAFFIC_FILE)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            k = tj.get("kernels", {}).get(names[di])
+            k = tj.get("families", {}).get(names[di]) or tj.get("kernels", {}).get(names[di])
             if k and tj.get("batch_per_gpu") == B:
                 traffic, traffic_src = k["traffic_bytes_per_launch"], TRAFFIC_FILE
         out = {
@@ -403,8 +403,8 @@ def main():
                        "collective": ("one RCCL all-reduce(SUM) of 1,696,408 B per step (world size %d)" % world) if launched else "none (single process)",
                        "style_image": "starry_night_crop.jpg 640x938"},
             "roofline": {"bound": "mfma",
-                         "kernel": names[di] + (" (fp32 MFMA, Winograd F(2x2,3x3) 3x3 conv; achieved = FLOPs EXECUTED, 16 products per "
-                                                "2x2 outputs instead of 36)" if di == 6 else " (fp32 MFMA)"),
+                         "kernel": names[di] + (" (wino_conv_kernel + wino2_conv_kernel: fp32 MFMA, Winograd F(2x2,3x3) 3x3 conv; achieved = "
+                                                "FLOPs EXECUTED, 16 products per 2x2 outputs instead of 36)" if di == 6 else " (fp32 MFMA)"),
                          "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE, KiB counters)",
                          "traffic_source": traffic_src,

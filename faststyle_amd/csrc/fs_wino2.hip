@@ -11,10 +11,11 @@
 //   * PERSISTENT workgroups walk a strided list of (block, channel-block) items and the staging pipeline (global loads
 //     two chunks ahead, patch -> V transform one chunk ahead) runs across item boundaries: the prologue of the next
 //     block is hidden behind the last chunks of the current one;
-//   * operands are laid out K-CONTIGUOUS in LDS (V[pos][tile][8], U[pos][co][8]; lane half kq multiplies channels
-//     4kq..4kq+3 of the chunk): one 16-byte LDS read feeds four matrix instructions (8 reads per chunk and position
-//     pair instead of 32), conflict-free without padding; the transformed filters are stored in that order in HBM
-//     (fs::wt_wino2: [pos][Cin/8][Cout][8]) so their staging is a straight 16-byte copy.
+//   * operands are laid out K-CONTIGUOUS in LDS (V[pos][kq][tile][4], U[pos][kq][co][4]; lane half kq multiplies
+//     channels 4kq..4kq+3 of the chunk): one 16-byte LDS read feeds four matrix instructions (8 reads per chunk and
+//     position pair instead of 32) and the 32 lanes of a half read 512 contiguous bytes -- conflict-free (a 32-byte lane
+//     stride is a 2-way conflict that costs ~30 cycles per read beside the matrix instructions); the transformed filters
+//     are stored in that order in HBM (fs::wt_wino2: [pos][Cin/8][2][Cout][4]) so their staging is a straight 16-byte copy.
 #include "fs_kernels.h"
 
 #include <cstdlib>
@@ -37,7 +38,7 @@ constexpr int kRedF = 64 * 2 * 4 + 64;   // statistics scratch: [4 contributors]
 constexpr unsigned kOOB = 0x80000000u;
 }  // namespace
 
-// U2[pos][ci/8][co][ci%8] = (G g G^T)[pos] for g = w[:, :, ci, co]   (w HWIO [3][3][Cin][Cout]); blockIdx.y = filter of the batch
+// U2[pos][ci/8][(ci/4)%2][co][ci%4] = (G g G^T)[pos] for g = w[:, :, ci, co]   (w HWIO [3][3][Cin][Cout]); blockIdx.y = filter of the batch
 __global__ __launch_bounds__(256) void wt_wino2_batch_kernel(WinoBatch b, int Cin, int Cout) {
     const float* __restrict__ w = b.w[blockIdx.y];
     float* __restrict__ U = b.U[blockIdx.y];
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void wt_wino2_batch_kernel(WinoBatch b, int Ci
         t[3][kw] = g[2][kw];
     }
     const size_t pos_stride = cc;   // floats per position plane
-    float* dst = U + ((size_t)(ci >> 3) * Cout + co) * 8 + (ci & 7);
+    float* dst = U + (((size_t)(ci >> 3) * 2 + ((ci >> 2) & 1)) * Cout + co) * 4 + (ci & 3);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         dst[(size_t)(r * 4 + 0) * pos_stride] = t[r][0];
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int e = tid + i * 256;
-        uvo[i] = (unsigned)((e >> 7) * a.Cin * a.Cout + (e & 127) * 4) * 4u;
+        uvo[i] = (unsigned)((e >> 7) * a.Cin * a.Cout + ((e >> 6) & 1) * a.Cout * 4 + (e & 63) * 4) * 4u;
     }
 
     auto item_offsets = [&](const Item& I) {   // global offsets of the thread's patch elements for this item
@@ -207,19 +208,17 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
         }
     };
     auto issue_filter = [&](const Item& I, int chunk) {
-        // U2[pos][chunk][co][8]: for a position the 64 channels x 8 of the item are 2 KB contiguous; element e of the
-        // thread = (pos = e >> 7, float4 index inside that run = e & 127), LDS position = e
+        // U2[pos][chunk][kq][co][4]: per (position, lane half) the 64 channels of the item are 1 KB contiguous; element e of
+        // the thread = (pos = e >> 7, kq = (e >> 6) & 1, channel = e & 63), LDS position = e
         const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ub), 0, u_bytes, 0x00020000);
-        const unsigned so = (unsigned)((chunk * a.Cout + I.co0) * 8) * 4u;
+        const unsigned so = (unsigned)((chunk * 2 * a.Cout + I.co0) * 4) * 4u;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int e = tid + i * 256;
-            const unsigned vo = (unsigned)((e >> 7) * a.Cin * a.Cout + (e & 127) * 4) * 4u;
-            uv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, vo, so, 0));
+            uv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, uvo[i], so, 0));
         }
     };
     auto issue_filter_pair = [&](const Item& I, int chunk, int i0) {   // elements i0, i0+1 of issue_filter (one sweep slot)
-        const unsigned so = (unsigned)((chunk * a.Cout + I.co0) * 8) * 4u;
+        const unsigned so = (unsigned)((chunk * 2 * a.Cout + I.co0) * 4) * 4u;
 #pragma unroll
         for (int i = i0; i < i0 + 2; ++i) {
             uv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur_k, uvo[i], so, 0));
@@ -269,7 +268,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
             r[2][j] = d[2][j] - d[1][j];
             r[3][j] = d[1][j] - d[3][j];
         }
-        float* dst = Vl + tt * kCC + tk;
+        float* dst = Vl + (tk >> 2) * (kNT * 4) + tt * 4 + (tk & 3);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             dst[(i * 4 + 0) * kNT * kCC] = r[i][0] - r[i][2];
@@ -294,7 +293,11 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
     // pairs, filter commit) is threaded through the sweep in small slices -- three slots per position, pinned with
     // sched_barrier: with one wave per SIMD nothing else covers that work, and left to itself the compiler emits each
     // transform as one block of ~60 instructions and LDS round trips during which the matrix pipe idles.
-    float td[4][4], tr[4][4];   // the transform in flight (one pair at a time)
+    // Measured on gfx950 (exp/mfma_overlap.hip, one wave per SIMD): the fp32 matrix instruction and the vector ALU exclude
+    // each other -- every VALU instruction between two v_mfma_f32_32x32x2_f32 adds ~6.5 cycles, plus ~10 for the first one
+    // of a gap; scalar instructions are free (up to ~8 per MFMA), LDS reads nearly so.  Hence: LDS reads and global loads
+    // are spread over the gaps, the VALU work of the input transform is bunched into TWO gaps.
+    float td[2][4][4];   // the 4x4 input blocks of the thread's two (tile, channel) pairs
     // loop state the slices touch (the load stream runs inside the sweep: nothing but the barrier stands between two sweeps)
     bool has1 = false, has2 = false, load_live = false;
     Item L = decode(0);          // cursor of the load stream: the step whose loads were issued last
@@ -307,12 +310,15 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
         item_offsets(L);
         return true;
     };
+#ifndef FS_W2_ABL
+#define FS_W2_ABL 0   /* timing experiments (tools/conv_trace.py): 1 no input transform, 2 no filter commit, 4 no global loads, 8 no operand reads */
+#endif
     auto slice = [&](int sl, const float* patch_n, float* Vn, float* Un) {
         // 48 slots per sweep.  0-3: global loads of the filter of step q+1; 4: the load cursor moves to step q+2 and its
-        // patch loads go out; 5-16: input transform of pair `tid` (4 slots of reads, 2 idle while they land, 2 of row sums,
-        // 4 of column sums + stores); 17-28: pair `tid + 256`; 40-47: the filter commit, as late as its loads allow
+        // patch loads go out; 5-12: LDS reads of the two 4x4 input blocks (one row per slot); 28 / 34: the transform
+        // arithmetic + stores of pair `tid` / `tid + 256`, each in ONE gap; 40-47: the filter commit, as late as its loads allow
         if (sl < 4) {
-            if (has1) issue_filter_pair(L, l_chunk, 2 * sl);
+            if (has1 && !(FS_W2_ABL & 4)) issue_filter_pair(L, l_chunk, 2 * sl);
             return;
         }
         if (sl == 4) {
@@ -320,43 +326,51 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
             if (has1 && load_live) {
                 has2 = advance_load();
                 load_live = has2;
-                if (has2) issue_patch(L, l_chunk);
+                if (has2 && !(FS_W2_ABL & 4)) issue_patch(L, l_chunk);
             }
             return;
         }
         if (sl >= 40) {
+            if (FS_W2_ABL & 2) return;
             const int i0 = sl - 40;
             *reinterpret_cast<float4*>(Un + (tid + i0 * 256) * 4) = uv[i0];
             return;
         }
-        const int half = sl >= 17 ? 1 : 0, k = sl - 5 - half * 12;
-        if (sl >= 29 || k == 4 || k == 5) return;
-        const int pidx = tid + half * 256;
-        const int tt = pidx >> 3, tk = pidx & 7;
-        const float* src = patch_n + ((2 * (tt >> 3)) * kPT + 2 * (tt & 7)) * kPS + tk;
-        float* dst = Vn + tt * kCC + tk;
-        if (k < 4) {                 // 4 rows of the 4x4 input block, one per slot
+        if (FS_W2_ABL & 1) return;
+        if (sl >= 5 && sl < 13) {
+            const int half = (sl - 5) >> 2, k = (sl - 5) & 3;
+            const int pidx = tid + half * 256;
+            const int tt = pidx >> 3, tk = pidx & 7;
+            const float* src = patch_n + ((2 * (tt >> 3)) * kPT + 2 * (tt & 7)) * kPS + tk;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) td[k][j] = src[(k * kPT + j) * kPS];
-        } else if (k < 8) {          // B^T d (rows), two columns per slot
+            for (int j = 0; j < 4; ++j) td[half][k][j] = src[(k * kPT + j) * kPS];
+            return;
+        }
+        if (sl == 28 || sl == 34) {
+            const int half = sl == 34 ? 1 : 0;
+            const int pidx = tid + half * 256;
+            const int tt = pidx >> 3, tk = pidx & 7;
+            float* dst = Vn + (tk >> 2) * (kNT * 4) + tt * 4 + (tk & 3);
+            float tr[4][4];
 #pragma unroll
-            for (int j = 2 * (k - 6); j < 2 * (k - 6) + 2; ++j) {
-                tr[0][j] = td[0][j] - td[2][j];
-                tr[1][j] = td[1][j] + td[2][j];
-                tr[2][j] = td[2][j] - td[1][j];
-                tr[3][j] = td[1][j] - td[3][j];
+            for (int j = 0; j < 4; ++j) {   // B^T d (rows)
+                tr[0][j] = td[half][0][j] - td[half][2][j];
+                tr[1][j] = td[half][1][j] + td[half][2][j];
+                tr[2][j] = td[half][2][j] - td[half][1][j];
+                tr[3][j] = td[half][1][j] - td[half][3][j];
             }
-        } else {                     // (.) B (columns) of row i and its four stores
-            const int i = k - 8;
-            dst[(i * 4 + 0) * kNT * kCC] = tr[i][0] - tr[i][2];
-            dst[(i * 4 + 1) * kNT * kCC] = tr[i][1] + tr[i][2];
-            dst[(i * 4 + 2) * kNT * kCC] = tr[i][2] - tr[i][1];
-            dst[(i * 4 + 3) * kNT * kCC] = tr[i][1] - tr[i][3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // (.) B (columns)
+                dst[(i * 4 + 0) * kNT * kCC] = tr[i][0] - tr[i][2];
+                dst[(i * 4 + 1) * kNT * kCC] = tr[i][1] + tr[i][2];
+                dst[(i * 4 + 2) * kNT * kCC] = tr[i][2] - tr[i][1];
+                dst[(i * 4 + 3) * kNT * kCC] = tr[i][1] - tr[i][3];
+            }
         }
     };
     auto sweep = [&](const float* Vl, const float* Ul, const float* patch_n, float* Vn, float* Un) {
-        const float* pa = Vl + (mb * 32 + lm) * kCC + kq * 4;
-        const float* pb = Ul + (nb * 32 + lm) * kCC + kq * 4;
+        const float* pa = Vl + kq * (kNT * 4) + (mb * 32 + lm) * 4;
+        const float* pb = Ul + kq * (kBN * 4) + (nb * 32 + lm) * 4;
         // two positions at a time, their matrix instructions alternating: consecutive MFMAs never share an accumulator (an
         // instruction slipped between two MFMAs on the SAME accumulator costs ~40 cycles, between independent ones ~6)
         float4 A[2][2], B[2][2];
@@ -374,7 +388,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
             for (int k = 0; k < 4; ++k) {
                 acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[k], b0[k], acc[p0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (k == 0 && pp + 1 < 8) {   // operands of the next position pair
+                if (k == 0 && pp + 1 < 8 && !(FS_W2_ABL & 8)) {   // operands of the next position pair
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         A[n][h] = *reinterpret_cast<const float4*>(pa + (p0 + 2 + h) * kNT * kCC);
@@ -556,7 +570,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
             // unconditionally: after the last step they work on stale data that nothing reads.
             const int o0 = (q & 1) ? kStageF : 0, o1 = kStageF - o0;
             sweep(smem + o0 + kPatchF, smem + o0 + kPatchF + kVF, smem + o1, smem + o1 + kPatchF, smem + o1 + kPatchF + kVF);
-            if (has2) commit_patch(smem + o0);   // this stage's patch was consumed by the transform of the previous step
+            if (has2 && !(FS_W2_ABL & 4)) commit_patch(smem + o0);   // this stage's patch was consumed by the transform of the previous step
 #ifdef FS_WINO2_TRACE
             const long long q1 = FS_W2_NOW();
             const long long q2 = q1;

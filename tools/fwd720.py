@@ -15,7 +15,7 @@ W = ckpt.load_checkpoint(os.path.join(root, "models", "starry_final.ckpt"))
 flat = e.mem.from_numpy(e.flatten_params(W))
 H, Wd = (int(v) for v in (sys.argv[1:3] if len(sys.argv) > 2 else (720, 1280)))
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-BF16 = len(sys.argv) > 4 and sys.argv[4] == "bf16"
+BF16 = len(sys.argv) > 4 and sys.argv[4] == "bf16"      # ("fp32": the default path)
 x = torch.rand((N, H, Wd, 3), device="cuda") * 255
 for _ in range(3):
     e.tnet_forward(flat, x, bf16=BF16)

@@ -6,7 +6,10 @@ Units / corrections (MI355X_MICROARCH.md, HBM section): the counters are in KiB;
 reports half of the bytes of wide coalesced reads -> doubled.  The doubling is calibrated in the same run
 on maxpool_kernel, whose algorithmic bytes are known (reads its whole input once, writes a quarter).
 
-usage: pmc_traffic.py <dir_fetch> <dir_write> <out.json> [provenance text]"""
+usage: pmc_traffic.py <dir_fetch> <dir_write> <out.json> [provenance text] [batch_per_gpu]
+
+Besides the per-kernel table the output has "families": the kernel families of bench.py's roofline table (both Winograd
+generations under "wino_conv_kernel", both filter-gradient generations under "conv_wgrad_kernel"), launch-weighted."""
 import csv
 import glob
 import json
@@ -16,9 +19,10 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(conv_igemm_kernel<[^>]*>|conv_wgrad_kernel<[^>]*>|conv_bf16_\w+<[^>]*>|[a-z_0-9]+_kernel)", name)
+    m = re.search(r"(conv_igemm_kernel<[^>]*>|conv_wgrad_kernel<[^>]*>|wgrad2_kernel<[^>]*>|conv_bf16_\w+<[^>]*>|[a-z_0-9]+_kernel)", name)
     s = m.group(1) if m else name[:60]
-    return s.replace(", false", "").replace(", true", ",flat").replace(" ", "")
+    s = s.replace(" ", "")
+    return s if s.startswith("wgrad2") else s.replace(",false", "").replace(",true", ",flat")
 
 
 def collect(d, counter):
@@ -40,7 +44,19 @@ def main():
         w = sum(wr[k]) / len(wr[k])
         kernels[k] = {"launches_sampled": len(fe[k]), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
                       "traffic_bytes_per_launch": int((2 * f + w) * 1024)}
-    json.dump({"_provenance": prov, "kernels": kernels}, open(out, "w"), indent=1)
+    fams = {"wino_conv_kernel": r"^wino2?_conv_kernel$", "conv_wgrad_kernel": r"^(conv_wgrad_kernel<(?!1,4)|wgrad2_kernel<)",
+            "conv_wgrad_kernel (Gram forward)": r"^conv_wgrad_kernel<1,4>"}
+    families = {}
+    for fam, pat in fams.items():
+        ks = [k for k in kernels if re.search(pat, k)]
+        n = sum(kernels[k]["launches_sampled"] for k in ks)
+        if n:
+            families[fam] = {"kernels": ks, "launches_sampled": n,
+                             "traffic_bytes_per_launch": int(sum(kernels[k]["traffic_bytes_per_launch"] * kernels[k]["launches_sampled"] for k in ks) / n)}
+    doc = {"_provenance": prov, "kernels": kernels, "families": families}
+    if len(sys.argv) > 5:
+        doc["batch_per_gpu"] = int(sys.argv[5])
+    json.dump(doc, open(out, "w"), indent=1)
     for k, v in list(kernels.items())[:12]:
         print("%-40s %4d launches  %10.1f MB/launch" % (k, v["launches_sampled"], v["traffic_bytes_per_launch"] / 1e6))
 
