@@ -162,6 +162,17 @@ __device__ __forceinline__ float fs_acc_read(float v) {
 #else
 #define FS_ACC_READ(e) (e)
 #endif
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4): `gsrc` is the lane's own source, `lds_wave`
+// the wave-uniform destination -- lane l lands at lds_wave + 16*l bytes.  Completion is covered by vmcnt / the next barrier.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FS_GLOBAL_LOAD_LDS_B128(gsrc, lds_wave)                                                                        \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),                            \
+                                     (__attribute__((address_space(3))) void*)(lds_wave), 16, 0, 0)
+#elif defined(FS_EMULATOR)   /* tests/emu/hip/hip_runtime.h: the CPU emulator of the test suite */
+#define FS_GLOBAL_LOAD_LDS_B128(gsrc, lds_wave) fs_emu_global_load_lds_b128((gsrc), (lds_wave))
+#else                        /* host pass of hipcc: kernel bodies are parsed, never run */
+#define FS_GLOBAL_LOAD_LDS_B128(gsrc, lds_wave) ((void)0)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FS_KERNARG_PTR(T, param) (reinterpret_cast<const T*>(__builtin_amdgcn_kernarg_segment_ptr()))
 #else

@@ -310,6 +310,9 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
         item_offsets(L);
         return true;
     };
+#ifndef FS_W2_DMA
+#define FS_W2_DMA 0   /* 1: the filter chunk goes global -> LDS by DMA (global_load_lds_dwordx4) -- no staging registers, no ds_write pass, but MEASURED SLOWER (sweep 5.9k -> 6.6k cycles per chunk): kept as a recorded experiment */
+#endif
 #ifndef FS_W2_ABL
 #define FS_W2_ABL 0   /* timing experiments (tools/conv_trace.py): 1 no input transform, 2 no filter commit, 4 no global loads, 8 no operand reads */
 #endif
@@ -318,7 +321,18 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
         // patch loads go out; 5-12: LDS reads of the two 4x4 input blocks (one row per slot); 28 / 34: the transform
         // arithmetic + stores of pair `tid` / `tid + 256`, each in ONE gap; 40-47: the filter commit, as late as its loads allow
         if (sl < 4) {
-            if (has1 && !(FS_W2_ABL & 4)) issue_filter_pair(L, l_chunk, 2 * sl);
+            if (has1 && !(FS_W2_ABL & 4)) {
+                if (FS_W2_DMA) {
+                    // U2 -> LDS directly: the LDS image of a filter chunk is lane-linear (element e of the chunk at float4 slot e), so a
+                    // wave's 64 lanes write 1 KB contiguous; the barrier at the end of the sweep waits for the transfers
+                    const float* gsrc = ub + (size_t)(l_chunk * 2 * a.Cout + L.co0) * 4;
+#pragma unroll
+                    for (int i = 2 * sl; i < 2 * sl + 2; ++i)
+                        FS_GLOBAL_LOAD_LDS_B128(gsrc + (uvo[i] >> 2), Un + (wave * 64 + i * 256) * 4);
+                } else {
+                    issue_filter_pair(L, l_chunk, 2 * sl);
+                }
+            }
             return;
         }
         if (sl == 4) {
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
             return;
         }
         if (sl >= 40) {
-            if (FS_W2_ABL & 2) return;
+            if ((FS_W2_ABL & 2) || FS_W2_DMA) return;
             const int i0 = sl - 40;
             *reinterpret_cast<float4*>(Un + (tid + i0 * 256) * 4) = uv[i0];
             return;
