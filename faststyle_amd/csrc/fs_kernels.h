@@ -58,6 +58,8 @@ struct ConvArgs {
     const float* add_src;  // optional residual [N,Ho-2*add_pad,Wo-2*add_pad,Cout] added in the interior
     int add_pad;
     const float* mask_src;  // optional [N,Ho,Wo,Cout]: after the add, v = mask_src > 0 ? v : 0 (ReLU gradient of the consumer)
+    float* pool_out;        // optional [N,Ho/2,Wo/2,Cout] (Winograd kernels, even Ho/Wo, no split-K): max over every 2x2 output tile =
+                            // tf.nn.max_pool 2x2/2 of the stored result (vgg16.py:68,104,154) straight from the epilogue's registers
     long long w_nstride;
     float* split_ws;         // optional scratch for split-K partials (split_ws_floats capacity); enables ksplit plans
     size_t split_ws_floats;
@@ -92,6 +94,7 @@ struct WgradArgs {
     int dy_nstride, dy_relu;
     int per_sample;   // 1: Gram-style, one result per n; 0: summed over the batch
     int dy_unshuffle; // dy is [N,2Ho,2Wo,Cout/4]; read it as the 2x2 pixel-unshuffled [N,Ho,Wo,Cout]
+    int same_xy;      // set by wgrad_launch: Gram of <= 128 channels (x == dy, 1x1): the B operand comes from the staged x tile
     WgradPlan p;
 };
 

@@ -169,8 +169,9 @@ void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, 
     L->total_floats = b.off;
 }
 
+// pool: optional destination of the 2x2/2 max-pool of the result; *pooled tells whether the conv launch produced it
 static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, const float* w_wino, const float* w_wino2, const float* bias, const float* ab,
-                    float* y, float* split_ws, size_t split_ws_floats, hipStream_t s) {
+                    float* y, float* split_ws, size_t split_ws_floats, hipStream_t s, float* pool = nullptr, bool* pooled = nullptr) {
     ConvArgs a{};
     a.x = x;
     a.w = w;
@@ -194,6 +195,11 @@ static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, 
         a.in_b = ab + 4;
     }
     a.p = conv_plan(a);
+    if (pooled) *pooled = false;
+    if (pool && a.p.variant >= 5 && a.p.ksplit <= 1 && !(H & 1) && !(W & 1) && tune_int("FS_VGG_POOL_FUSED", 1)) {
+        a.pool_out = pool;   // the Winograd epilogues hold whole 2x2 tiles: the pooled tensor comes for one extra store per tile
+        if (pooled) *pooled = true;
+    }
     return conv_launch(a, s);
 }
 
@@ -204,14 +210,17 @@ static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS],
     FS_TRY(vgg_consts(ws + L.ab, s));
     const float* src = ws + L.xin;
     for (int l = 0; l <= L.lmax; ++l) {
+        bool pooled = false;
         const int nb = l <= L.cmax ? L.NB : L.N;
         const bool wl = prepared && l >= 1 && wino_layer_on(l);
         FS_TRY(vgg_conv(src, nb, L.Hl[l], L.Wl[l], l, w[l], wl ? prepared + wino_offset(l, false) : nullptr,
                         wl ? prepared + wino2_offset(l, false) : nullptr, b[l],
-                        ws + L.ab, ws + L.act[l], ws + L.splitws, L.splitws_floats, s));
+                        ws + L.ab, ws + L.act[l], ws + L.splitws, L.splitws_floats, s,
+                        (pool_after(l) && l < L.lmax) ? ws + L.pool[pool_index(l)] : nullptr, &pooled));
         src = ws + L.act[l];
         if (pool_after(l) && l < L.lmax) {
-            FS_TRY(maxpool(ws + L.act[l], ws + L.pool[pool_index(l)], nb, L.Hl[l], L.Wl[l], kCout[l], s));
+            if (!pooled)
+                FS_TRY(maxpool(ws + L.act[l], ws + L.pool[pool_index(l)], nb, L.Hl[l], L.Wl[l], kCout[l], s));
             src = ws + L.pool[pool_index(l)];
         }
     }

@@ -291,7 +291,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             }
         }
         if (tid < 4) patch[PH * PW * S + tid] = 0.f;
-        if (fastd) {
+        if (a.same_xy) {
+            // Gram matrix of <= 128 channels: dY IS the staged input tile (x == dy, 1x1, every channel in the patch) --
+            // nothing more to stage; the B operand is read from the patch (half the HBM traffic of the 64/128-channel Grams,
+            // which are bandwidth-bound: 537 MB of conv1_2 features per batch of 32)
+        } else if (fastd) {
             // same scheme for the dY tile: the thread's channel quad (and with it the pixel-unshuffle phase and the
             // on-load affine of the deconv units) is fixed, pixels advance by 256/j4n
             const float* dyn = uniform_ptr(a.dy + (size_t)n * a.Ho * a.Wo * a.Cout);
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                         float av[KWV], bv[NWV];
 #pragma unroll
                         for (int q = 0; q < KWV; ++q) av[q] = patch[abase[q] + amul[q] * poff];
-                        const float* pb = dyl + (py * p.TW + px) * DP + lm;
+                        const float* pb = a.same_xy ? patch + (py * PW + px) * S + co_g0 + lm : dyl + (py * p.TW + px) * DP + lm;
 #pragma unroll
                         for (int j = 0; j < NWV; ++j) bv[j] = (full || j < nbw) ? pb[j * 32] : 0.f;
 #pragma unroll
@@ -627,6 +631,9 @@ int wgrad_launch(const WgradArgs& a_in, hipStream_t s) {
     WgradArgs a = a_in;
     if (a.dil_x < 1) a.dil_x = 1;
     const WgradPlan& p = a.p;
+    a.same_xy = a.per_sample && a.x == a.dy && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.Cin == a.Cout && a.Cin <= 128 &&
+                a.Cin % 32 == 0 && !a.in_a && !a.dy_a && !a.dy_unshuffle && a.src_mode == SRC_PLAIN && a.pad_t == 0 && a.pad_l == 0 &&
+                tune_int("FS_GRAM_SAME", 1);
     if (a.Cin > 128 && a.Cin % 128) return -1;
     if (p.lds_bytes > 160 * 1024) return -2;
     const int NWV = p.NWV;

@@ -471,15 +471,24 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
                 st[2] = cnt;
             }
         }
+        float* pon = a.pool_out ? a.pool_out + (size_t)n * (a.Ho >> 1) * (a.Wo >> 1) * a.Cout : nullptr;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            float pmax = -3.0e38f;   // max of the tile's four stored values: the 2x2/2 max-pool window (tiles sit on even coordinates)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float v = vals[i][k] + bs;
                 v = relu_out ? fmaxf(v, 0.f) : v;
                 if (msn) v = mk[i][k] > 0.f ? v : 0.f;
+                pmax = fmaxf(pmax, v);
                 if (off[i][k] >= 0) yn[off[i][k]] = v;
             }
+            if (pon && off[i][0] >= 0) {
+                const int t = (tid >> 5) + i * 16;
+                const int qy = (oy0 >> 1) + (t >> 3), qx = (ox0 >> 1) + (t & 7);
+                pon[(qy * (a.Wo >> 1) + qx) * a.Cout + co] = pmax;
+            }
+        }
         if (q == 0) __syncthreads();
     }
 #ifdef FS_CONV_TRACE

@@ -466,6 +466,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
                     ad[r][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ar, ok ? (unsigned)((ay * Wa + ax) * a.Cout + co) * 4u : kOOB, 0, 0));
                 }
         }
+        float* pon = a.pool_out ? a.pool_out + (size_t)I.n * (a.Ho >> 1) * (a.Wo >> 1) * a.Cout : nullptr;
         float s1 = 0.f, s2 = 0.f, cs = 0.f;
         if (a.stats) {   // shift of the one-pass statistics: the block's first pixel of this channel (held by tile 0: mb 0, kq 0)
             if (mb == 0 && kq == 0) {
@@ -495,6 +496,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
                 v[ai * 2 + 0] = s4[ai][0] + s4[ai][1] + s4[ai][2];
                 v[ai * 2 + 1] = s4[ai][1] - s4[ai][2] - s4[ai][3];
             }
+            float pmax = -3.0e38f;   // max of the tile's four stored values: the 2x2/2 max-pool window (tiles sit on even coordinates)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int py = 2 * (r >> 2) + (k >> 1), px = 2 * (r & 3) + (k & 1);
@@ -509,7 +511,12 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
                 val = relu_out ? fmaxf(val, 0.f) : val;
                 if (adn) val += ad[r][k];
                 if (msn) val = mk[r][k] > 0.f ? val : 0.f;
+                pmax = fmaxf(pmax, val);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), yr, ok ? (unsigned)(obase + py * rowp + px * a.Cout) * 4u : kOOB, 0, 0);
+            }
+            if (pon) {
+                const int qy = (oyb >> 1) + (r >> 2), qx = (oxb >> 1) + (r & 3);
+                if (full || (2 * qy < a.Ho && 2 * qx < a.Wo)) pon[(qy * (a.Wo >> 1) + qx) * a.Cout + co] = pmax;
             }
         }
         if (a.stats) {

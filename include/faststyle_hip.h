@@ -148,12 +148,14 @@ typedef struct {
     const float* add_src;
     int add_pad;
     long long w_nstride; /* per-sample filter stride in floats (0: shared) */
-    const float* w_wino; /* optional: the same filter transformed by fs_wino_transform_filter ([16][Cin][Cout]); an
-                          * eligible conv (3x3, stride 1, SAME or VALID, Cin % 8 == 0, Cout % 64 == 0) then runs on the
-                          * Winograd F(2x2,3x3) kernel -- the path the VGG16 convs of fs_perceptual_loss take */
+    const float* w_wino; /* optional: the same filter as transformed by fs_wino_transform_filter (16*Cin*Cout floats, layout
+                          * private to the library); an eligible conv (3x3, stride 1, SAME / VALID / 'full' padding, Cin % 8 == 0,
+                          * Cout % 64 == 0) then runs on a Winograd F(2x2,3x3) kernel -- the path the VGG16 convs of
+                          * fs_perceptual_loss and the residual convs of the transform net take */
 } fs_conv_desc;
-/* U[16][Cin][Cout] = G g G^T for every (ci, co) filter g = w[:, :, ci, co] of a 3x3 HWIO filter (Lavin & Gray F(2x2,3x3));
- * the caller owns U (16*Cin*Cout floats).  fs_vgg_prepare does this once for the frozen VGG16 filters. */
+/* U = G g G^T for every (ci, co) filter g = w[:, :, ci, co] of a 3x3 HWIO filter (Lavin & Gray F(2x2,3x3)), 16 values per
+ * filter, in the order the Winograd kernels stage them; the caller owns U (16*Cin*Cout floats; Cin % 8 == 0).
+ * fs_vgg_prepare does this once for the frozen VGG16 filters. */
 int fs_wino_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, float* U);
 /* tf.nn.conv2d (im_transf_net.py:115, vgg16.py:47) on the matrix cores. */
 int fs_conv2d_fwd(fs_ctx* ctx, fs_conv_desc* d);
