@@ -218,6 +218,8 @@ int wt_wino2_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s);
 bool wino2_eligible(const ConvArgs& a);
 void wino2_plan(const ConvArgs& a, ConvPlan* out);
 int wino2_launch(const ConvArgs& a, hipStream_t s);
+bool conv3x3_to3_eligible(const ConvArgs& a);                                                 // fs_c3.hip
+int conv3x3_to3_launch(const ConvArgs& a, hipStream_t s);
 bool wino_eligible(const ConvArgs& a);
 void wino_plan(const ConvArgs& a, ConvPlan* out);
 int wino_launch(const ConvArgs& a, hipStream_t s);

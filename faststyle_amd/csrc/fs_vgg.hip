@@ -355,6 +355,10 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         a.split_ws_floats = L.splitws_floats;
         if (l == 0) {
             a.y = dy;
+            if (conv3x3_to3_eligible(a)) {   // 64 -> 3 channels: vector-ALU kernel (fs_c3.hip), no padded MFMA columns
+                FS_TRY(conv3x3_to3_launch(a, s));
+                break;
+            }
             a.p = conv_plan(a);
             FS_TRY(conv_launch(a, s));
             break;
