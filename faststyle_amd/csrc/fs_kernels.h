@@ -165,6 +165,57 @@ __device__ __forceinline__ float fs_acc_read(float v) {
 #else
 #define FS_ACC_READ(e) (e)
 #endif
+// The column stage of the Winograd input transform on packed fp32.  With t01 = {t0, t1}, t23 = {t2, t3} (one row of B^T d):
+//   cols01 = {t0 - t2, t1 + t2},  cols23 = {t2 - t1, t1 - t3}
+// Each is ONE v_pk_add_f32: op_sel / op_sel_hi pick the low or high dword of a source for the low / high result, neg_lo /
+// neg_hi negate it -- no register moves (left to the compiler the shuffles become v_mov + v_xor and nothing is saved).
+// -DFS_NO_PK_ASM builds the plain-C form (what the emulator and the host pass see).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fs_wino_cols01(f32x2 t01, f32x2 t23) {   // {t0 - t2, t1 + t2}
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_PK_ASM)
+    f32x2 o;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(o) : "v"(t01), "v"(t23));
+    return o;
+#else
+    f32x2 o;
+    o.x = t01.x - t23.x;
+    o.y = t01.y + t23.x;
+    return o;
+#endif
+}
+__device__ __forceinline__ f32x2 fs_wino_cols23(f32x2 t01, f32x2 t23) {   // {t2 - t1, t1 - t3}
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_PK_ASM)
+    f32x2 o;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(o) : "v"(t01), "v"(t23));
+    return o;
+#else
+    f32x2 o;
+    o.x = t23.x - t01.y;
+    o.y = t01.y - t23.y;
+    return o;
+#endif
+}
+// a + b / a - b on two packed floats as ONE instruction.  (Written as vector arithmetic the backend un-packs v_pk_add_f32
+// next to matrix instructions, betting on co-issue; measured on gfx950 -- exp/mfma_overlap.hip -- every vector instruction
+// beside the fp32 MFMA stream costs its issue time, so fewer instructions is what counts.)
+__device__ __forceinline__ f32x2 fs_pk_add(f32x2 a, f32x2 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_PK_ASM)
+    f32x2 o;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+#else
+    return a + b;
+#endif
+}
+__device__ __forceinline__ f32x2 fs_pk_sub(f32x2 a, f32x2 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_PK_ASM)
+    f32x2 o;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+#else
+    return a - b;
+#endif
+}
 // 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4): `gsrc` is the lane's own source, `lds_wave`
 // the wave-uniform destination -- lane l lands at lds_wave + 16*l bytes.  Completion is covered by vmcnt / the next barrier.
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
             b2[0] = pb[0];
             b2[1] = pb[32];
         };
-        float d[4][4], r[4][4];
+        f32x2 d[4][2], r[4][2];   // column pairs: the arithmetic runs as packed fp32 (fs_pk_*, fs_wino_cols*: 16 instructions, not 32)
         const float* src = patch + ((2 * tty) * kPT + 2 * ttx) * kPS + tk;
         float* dst = Vn + tt * kPS + tk;
         // one slice of the next chunk's preparation per MFMA slot (g = group 0..7, h = 0: after the 3rd MFMA of the group,
@@ -267,25 +267,24 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
             if (g == 0) {                                     // the 4x4 block of the next chunk
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    d[i][2 * h] = src[(i * kPT + 2 * h) * kPS];
-                    d[i][2 * h + 1] = src[(i * kPT + 2 * h + 1) * kPS];
+                    d[i][h].x = src[(i * kPT + 2 * h) * kPS];
+                    d[i][h].y = src[(i * kPT + 2 * h + 1) * kPS];
                 }
             } else if (g == 1) {                              // B^T d (rows), two columns per slice
-#pragma unroll
-                for (int j = 2 * h; j < 2 * h + 2; ++j) {
-                    r[0][j] = d[0][j] - d[2][j];
-                    r[1][j] = d[1][j] + d[2][j];
-                    r[2][j] = d[2][j] - d[1][j];
-                    r[3][j] = d[1][j] - d[3][j];
-                }
+                r[0][h] = fs_pk_sub(d[0][h], d[2][h]);
+                r[1][h] = fs_pk_add(d[1][h], d[2][h]);
+                r[2][h] = fs_pk_sub(d[2][h], d[1][h]);
+                r[3][h] = fs_pk_sub(d[1][h], d[3][h]);
             } else if (g <= 5) {                              // (.) B (columns): row i of positions, two outputs per slice
                 const int i = g - 2;
                 if (h == 0) {
-                    dst[(i * 4 + 0) * kNT * kPS] = r[i][0] - r[i][2];
-                    dst[(i * 4 + 1) * kNT * kPS] = r[i][1] + r[i][2];
+                    const f32x2 o = fs_wino_cols01(r[i][0], r[i][1]);
+                    dst[(i * 4 + 0) * kNT * kPS] = o.x;
+                    dst[(i * 4 + 1) * kNT * kPS] = o.y;
                 } else {
-                    dst[(i * 4 + 2) * kNT * kPS] = r[i][2] - r[i][1];
-                    dst[(i * 4 + 3) * kNT * kPS] = r[i][1] - r[i][3];
+                    const f32x2 o = fs_wino_cols23(r[i][0], r[i][1]);
+                    dst[(i * 4 + 2) * kNT * kPS] = o.x;
+                    dst[(i * 4 + 3) * kNT * kPS] = o.y;
                 }
             } else if (g == 6) {                              // the next chunk's filter
                 *reinterpret_cast<float4*>(Un + (tid + (2 * h) * 512) * 4) = uv[2 * h];

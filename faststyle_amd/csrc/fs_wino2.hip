@@ -297,9 +297,13 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
     // each other -- every VALU instruction between two v_mfma_f32_32x32x2_f32 adds ~6.5 cycles, plus ~10 for the first one
     // of a gap; scalar instructions are free (up to ~8 per MFMA), LDS reads nearly so.  Hence: LDS reads and global loads
     // are spread over the gaps, the VALU work of the input transform is bunched into TWO gaps.
-    float td[2][4][4];   // the 4x4 input blocks of the thread's two (tile, channel) pairs
+    // the 4x4 input blocks of the thread's two (tile, channel) pairs, as column PAIRS: the transform arithmetic runs as packed
+    // fp32 (v_pk_add_f32, fs_wino_cols: 16 instead of 32 vector instructions per block)
+    f32x2 td[2][4][2];
     // loop state the slices touch (the load stream runs inside the sweep: nothing but the barrier stands between two sweeps)
-    bool has1 = false, has2 = false, load_live = false;
+    // (ints, not bools: a bool that lives across basic blocks is kept as a 64-bit lane mask -- two scalar registers each, spilled
+    // to vector lanes and read back with v_readlane inside the sweep)
+    int has1 = 0, has2 = 0, load_live = 0;
     Item L = decode(0);          // cursor of the load stream: the step whose loads were issued last
     int l_it = 0, l_chunk = L.cbeg;
     auto advance_load = [&]() {   // returns false when the stream is exhausted
@@ -336,9 +340,9 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
             return;
         }
         if (sl == 4) {
-            has2 = false;
+            has2 = 0;
             if (has1 && load_live) {
-                has2 = advance_load();
+                has2 = advance_load() ? 1 : 0;
                 load_live = has2;
                 if (has2 && !(FS_W2_ABL & 4)) issue_patch(L, l_chunk);
             }
@@ -357,7 +361,10 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
             const int tt = pidx >> 3, tk = pidx & 7;
             const float* src = patch_n + ((2 * (tt >> 3)) * kPT + 2 * (tt & 7)) * kPS + tk;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) td[half][k][j] = src[(k * kPT + j) * kPS];
+            for (int jp = 0; jp < 2; ++jp) {
+                td[half][k][jp].x = src[(k * kPT + 2 * jp) * kPS];
+                td[half][k][jp].y = src[(k * kPT + 2 * jp + 1) * kPS];
+            }
             return;
         }
         if (sl == 28 || sl == 34) {
@@ -365,20 +372,21 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
             const int pidx = tid + half * 256;
             const int tt = pidx >> 3, tk = pidx & 7;
             float* dst = Vn + (tk >> 2) * (kNT * 4) + tt * 4 + (tk & 3);
-            float tr[4][4];
+            f32x2 tr[4][2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {   // B^T d (rows)
-                tr[0][j] = td[half][0][j] - td[half][2][j];
-                tr[1][j] = td[half][1][j] + td[half][2][j];
-                tr[2][j] = td[half][2][j] - td[half][1][j];
-                tr[3][j] = td[half][1][j] - td[half][3][j];
+            for (int jp = 0; jp < 2; ++jp) {   // B^T d (rows), two columns per instruction
+                tr[0][jp] = fs_pk_sub(td[half][0][jp], td[half][2][jp]);
+                tr[1][jp] = fs_pk_add(td[half][1][jp], td[half][2][jp]);
+                tr[2][jp] = fs_pk_sub(td[half][2][jp], td[half][1][jp]);
+                tr[3][jp] = fs_pk_sub(td[half][1][jp], td[half][3][jp]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {   // (.) B (columns)
-                dst[(i * 4 + 0) * kNT * kCC] = tr[i][0] - tr[i][2];
-                dst[(i * 4 + 1) * kNT * kCC] = tr[i][1] + tr[i][2];
-                dst[(i * 4 + 2) * kNT * kCC] = tr[i][2] - tr[i][1];
-                dst[(i * 4 + 3) * kNT * kCC] = tr[i][1] - tr[i][3];
+                const f32x2 o01 = fs_wino_cols01(tr[i][0], tr[i][1]), o23 = fs_wino_cols23(tr[i][0], tr[i][1]);
+                dst[(i * 4 + 0) * kNT * kCC] = o01.x;
+                dst[(i * 4 + 1) * kNT * kCC] = o01.y;
+                dst[(i * 4 + 2) * kNT * kCC] = o23.x;
+                dst[(i * 4 + 3) * kNT * kCC] = o23.y;
             }
         }
     };
@@ -573,7 +581,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
     tr_pro = FS_W2_NOW() - tr_t0;
     long long tr_last = FS_W2_NOW();
 #endif
-    load_live = have1;   // a step beyond the one whose patch is already committed may still exist
+    load_live = have1 ? 1 : 0;   // a step beyond the one whose patch is already committed may still exist
     int q = 0;
     // (nested item / chunk loops rather than one flat loop with a conditional epilogue: a conditional re-zeroing of the 256
     // accumulators makes the register allocator merge two versions of them at the join -- copies and spills)
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
         const Item cur_it = decode(it);
         for (int chunk = cur_it.cbeg; chunk < cur_it.cend; ++chunk, ++q) {
             // does step q+1 exist?  (its patch already sits in the other stage's patch area; L points at it)
-            has1 = (chunk + 1 < cur_it.cend) || (it + 1 < my_items);
+            has1 = ((chunk + 1 < cur_it.cend) || (it + 1 < my_items)) ? 1 : 0;
 #ifdef FS_WINO2_TRACE
             const long long q0 = FS_W2_NOW();
 #endif
