@@ -424,7 +424,8 @@ int fs_conv2d_fwd(fs_ctx* ctx, fs_conv_desc* d) {
     fs::ConvArgs a;
     if (int rc = fill_conv(d, &a)) return rc;
     if (!a.x || !a.w || !a.y) return fail(-1, "fs_conv2d_fwd: null tensor");
-    const int rc = fs::conv_launch(a, ctx->stream);
+    // 3x3 SAME, 64 -> 3 channels (the shape of VGG conv1_1's input gradient): vector-ALU kernel, fs_c3.hip
+    const int rc = fs::conv3x3_to3_eligible(a) ? fs::conv3x3_to3_launch(a, ctx->stream) : fs::conv_launch(a, ctx->stream);
     return rc ? fail(rc, "fs_conv2d_fwd: launch failed (%d)", rc) : 0;
 }
 

@@ -37,6 +37,9 @@ CONV_CASES = [
     ("vgg_first", (2, 16, 20, 3), (3, 3, 3, 64), 1, "SAME"),
     ("one_by_one", (1, 7, 9, 64), (1, 1, 64, 64), 1, "SAME"),
     ("ragged_1px", (1, 3, 1, 16), (3, 3, 16, 16), 1, "SAME"),
+    # 64 -> 3 channels, the shape of VGG conv1_1's input gradient: the vector-ALU kernel (fs_c3.hip); ragged 16x16 blocks
+    ("to3_ragged", (2, 21, 37, 64), (3, 3, 64, 3), 1, "SAME"),
+    ("to3_1px", (1, 1, 1, 64), (3, 3, 64, 3), 1, "SAME"),
 ]
 
 
