@@ -178,7 +178,20 @@ def main():
     torch.cuda.set_device(local)
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL prints a version banner on the process's stdout when the communicator comes up; stdout carries exactly ONE
+        # JSON line here, so file descriptor 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            warm = torch.zeros(1, device="cuda")
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     ddist = dist if launched else None
     eng = engine.Engine(engine.TorchMem("cuda:%d" % local))
     lib = eng.lib
@@ -221,6 +234,19 @@ def main():
         sync()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         res = {"elapsed": elapsed, "graphed": graphed, "loss": float(losses[0].item())}
+        # ---- where the all-reduce + Adam (outside the hipGraph) and the host leave the GPU idle: 20 more steps of the timed
+        # kind with an event before and after each; gap = end of step i -> start of step i+1 on the device time line
+        Gs = 20
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(Gs)]
+        for i in range(Gs):
+            evs[i][0].record()
+            tr.step(pool[i % len(pool)])
+            evs[i][1].record()
+        sync()
+        busy = [evs[i][0].elapsed_time(evs[i][1]) for i in range(Gs)]
+        gaps = [evs[i][1].elapsed_time(evs[i + 1][0]) for i in range(Gs - 1)]
+        res["step_device_ms"] = float(np.median(busy))
+        res["inter_step_gap_us"] = float(np.median(gaps)) * 1e3
         # ---- eager passes of the same step: (1) section wall times by HIP events on the launch stream, no per-kernel events
         e, P = tr.eng, args.profile_steps
         secs = ["tnet_forward", "perceptual_loss", "tnet_backward", "allreduce_adam"]
@@ -356,6 +382,10 @@ def main():
                 "images_per_sec": round(value, 2), "ms_per_step": round(1e3 * step_s, 3), "steps": steps, "batch_per_gpu": batch,
                 "global_batch": batch * world, "hip_graph": leg["graphed"], "final_loss": leg["loss"],
                 "sections_ms_eager": leg["sections_ms"],
+                # the step as the device sees it (events around graph replay + all-reduce + Adam) and the idle time between two
+                # steps: what keeping the all-reduce and the optimiser outside the captured graph costs
+                "step_device_ms": round(leg["step_device_ms"], 3), "inter_step_gap_us": round(leg["inter_step_gap_us"], 1),
+                "host_gap_frac_of_step": round(leg["inter_step_gap_us"] * 1e-3 / (leg["elapsed"] / steps * 1e3), 5),
                 "step_tflops_as_written": round(GF_STEP * value / 1e3, 2),
                 "step_frac_as_written": round(GF_STEP * value / 1e3 / world / PEAK_F32_MFMA_TFLOPS, 4),
                 "step_gflop_executed": round(exec_gflop, 1),
@@ -418,6 +448,8 @@ def main():
             "step_frac_executed": rep["step_frac_executed"], "all_mfma_kernels_tflops": rep["all_mfma_kernels_tflops"],
             "mfma_kernel_ms_per_step": rep["mfma_kernel_ms_per_step"], "sections_ms_eager": rep["sections_ms_eager"],
             "final_loss": rep["final_loss"], "hip_graph": rep["hip_graph"],
+            "step_device_ms": rep["step_device_ms"], "inter_step_gap_us": rep["inter_step_gap_us"],
+            "host_gap_frac_of_step": rep["host_gap_frac_of_step"],
         }
         if b4_leg is not None:
             r4, d4, pk4 = leg_report(b4_leg, 4, args.b4_steps)

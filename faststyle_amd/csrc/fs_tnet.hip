@@ -554,7 +554,9 @@ static int unit_wgrad(const TnetLayout& L, const Unit& u, const float* xin, cons
 int tnet_backward(const TnetLayout& L, const float* params, const float* x, const float* dy, float* grads, float* ws,
                   hipStream_t s, const StreamAux* aux) {
     const int N = L.N;
-    const bool fork = aux && aux->side && aux->nev >= 34;
+    // (no fork while the per-kernel profiler is recording: two streams sharing the chip would charge each kernel with its
+    // neighbour's time -- bench.py's per-kernel table wants every launch alone)
+    const bool fork = aux && aux->side && aux->nev >= 34 && !Profiler::current();
     hipStream_t ws_stream = fork ? aux->side : s;  // stream of the filter-gradient branch
     {  // every input-gradient filter of the step in one launch (the parameters are fixed during a backward)
         WtBatch wb{};
