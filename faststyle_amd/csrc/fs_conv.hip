@@ -598,14 +598,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         // the common stores (every VGG conv, most transform-net convs): bias, ReLU floor, optional consumer mask.
         // Offsets advance by additions: row offset + column offset, no multiply per element.
         const int row_stride = a.Wo * a.Cout;
-        auto run = [&](auto MASKED, auto FULL) {
+        const int Hp = (a.Ho + 1) >> 1, Wp = (a.Wo + 1) >> 1;
+        const float* rsn = a.route_src ? a.route_src + (size_t)n * Hp * Wp * a.Cout : nullptr;
+        auto run = [&](auto MASKED, auto FULL, auto ROUTED) {
             constexpr bool kFull = decltype(FULL)::value;  // every lane has a valid pixel and channel: no per-element predicate
-            constexpr int RB = NACC < 8 ? NACC : 8;  // rows per batch (bounds the registers of the mask batch)
+            constexpr bool kRoute = decltype(ROUTED)::value;  // max-pool gradient routing through the mask tensor (needs MASKED)
+            constexpr int RB = kRoute ? 4 : (NACC < 8 ? NACC : 8);  // rows per batch (bounds the registers of the mask batch)
 #pragma unroll
             for (int m = 0; m < WM; ++m)
 #pragma unroll
                 for (int r0 = 0; r0 < NACC; r0 += RB) {
                     int off[RB];  // element offset of the pixel of row r0+i (channel 0); -1: outside the tile / image
+                    int par[RB];  // kRoute: bit 0 = column parity, bit 1 = row parity, bit 2 / 3 = the horizontal / vertical window partner exists
+                    int pof[RB];  // kRoute: element offset of the pixel's pooling window in route_src
 #pragma unroll
                     for (int rg = 0; rg < RB; rg += 4) {
                         const int t = (wave * WM + m) * MT + F::row(r0 + rg, lane);
@@ -614,6 +619,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             off[rg + j] = (kFull || (t + j < tile_px && py < th_valid && px < tw_valid)) ? roff + coff : -1;
+                            if (kRoute) {
+                                const int oy = ty0 + py, ox = tx0 + px;
+                                par[rg + j] = (ox & 1) | ((oy & 1) << 1) | (((ox ^ 1) < a.Wo) ? 4 : 0) | (((oy ^ 1) < a.Ho) ? 8 : 0);
+                                pof[rg + j] = ((oy >> 1) * Wp + (ox >> 1)) * a.Cout;
+                            }
                             ++px;
                             coff += a.Cout;
                             if (px == p.TW) {
@@ -628,12 +638,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                     // lane has nothing to store), so that their latencies overlap instead of chaining
                     // load -> wait -> store per element
                     float mk[RB][WN];
+                    float nA[kRoute ? RB : 1][WN], nB[kRoute ? RB : 1][WN], nC[kRoute ? RB : 1][WN], da[kRoute ? RB : 1][WN];
                     if (decltype(MASKED)::value) {
 #pragma unroll
                         for (int i = 0; i < RB; ++i)
 #pragma unroll
-                            for (int nn = 0; nn < WN; ++nn)
-                                mk[i][nn] = msn[(kFull || (off[i] >= 0 && cok[nn])) ? off[i] + cof[nn] : 0];
+                            for (int nn = 0; nn < WN; ++nn) {
+                                const bool live = kFull || (off[i] >= 0 && cok[nn]);
+                                const int o = live ? off[i] + cof[nn] : 0;
+                                mk[i][nn] = msn[o];
+                                if (kRoute) {
+                                    // the three other pixels of the 2x2 window (clamped to the pixel itself where the image ends)
+                                    const int dx = (par[i] & 1) ? -a.Cout : a.Cout, dyo = (par[i] & 2) ? -row_stride : row_stride;
+                                    const bool hA = live && (par[i] & 4), hB = live && (par[i] & 8);
+                                    nA[i][nn] = msn[hA ? o + dx : o];
+                                    nB[i][nn] = msn[hB ? o + dyo : o];
+                                    nC[i][nn] = msn[(hA && hB) ? o + dx + dyo : o];
+                                    da[i][nn] = rsn[live ? pof[i] + cof[nn] : 0];
+                                }
+                            }
                     }
 #pragma unroll
                     for (int i = 0; i < RB; ++i) {
@@ -643,6 +666,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                             if (!kFull && !cok[nn]) continue;
                             float v = acc[m][nn][r0 + i] + bs[nn];
                             v = relu_out ? fmaxf(v, 0.f) : v;
+                            if (kRoute) {
+                                // tf.nn.max_pool's gradient goes to the FIRST maximum of the window in row-major order: a partner
+                                // that comes earlier wins ties, one that comes later must be strictly greater
+                                const float me = mk[i][nn];
+                                const bool cx = par[i] & 1, cy = par[i] & 2;
+                                bool win = true;
+                                if (par[i] & 4) win = win && !(cx ? nA[i][nn] >= me : nA[i][nn] > me);
+                                if (par[i] & 8) win = win && !(cy ? nB[i][nn] >= me : nB[i][nn] > me);
+                                if ((par[i] & 12) == 12) win = win && !(cy ? nC[i][nn] >= me : nC[i][nn] > me);
+                                if (win) v += da[i][nn];
+                            }
                             if (decltype(MASKED)::value) v = mk[i][nn] > 0.f ? v : 0.f;
                             yn[off[i] + cof[nn]] = v;
                         }
@@ -650,16 +684,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 }
         };
         const bool full = th_valid == p.TH && tw_valid == p.TW && tile_px == 4 * WM * MT && co0 + BN <= a.Cout;
-        if (msn) {
+        if (msn && rsn) {
             if (full)
-                run(std::true_type{}, std::true_type{});
+                run(std::true_type{}, std::true_type{}, std::true_type{});
             else
-                run(std::true_type{}, std::false_type{});
+                run(std::true_type{}, std::false_type{}, std::true_type{});
+        } else if (msn) {
+            if (full)
+                run(std::true_type{}, std::true_type{}, std::false_type{});
+            else
+                run(std::true_type{}, std::false_type{}, std::false_type{});
         } else {
             if (full)
-                run(std::false_type{}, std::true_type{});
+                run(std::false_type{}, std::true_type{}, std::false_type{});
             else
-                run(std::false_type{}, std::false_type{});
+                run(std::false_type{}, std::false_type{}, std::false_type{});
         }
     } else if (!a.shuffle && !msn) {
         // residual-gradient add (the W1 dgrads of the residual blocks): the cropped addend is loaded for a batch of
@@ -1006,6 +1045,13 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
         if (rc_) return rc_; \
     } while (0)
 
+// route_src (ConvArgs) is served by the store path of the direct kernel that also takes the consumer mask: plain stores, the
+// sum complete in one workgroup (the window partners are read from mask_src in global memory: no tile alignment needed)
+bool conv_route_ok(const ConvArgs& a) {
+    const ConvPlan& p = a.p;
+    return a.mask_src && !a.add_src && !a.shuffle && !a.stats && p.ksplit <= 1 && p.variant < 5;
+}
+
 int conv_launch(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     if (env_int("FS_CONV_DEBUG", 0))  // tuning aid: one line per launch with the chosen plan
@@ -1016,6 +1062,7 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
     const ConvPlan& p = a.p;
     if (p.CC <= 0 || (!p.flat && (a.Cin % 4 || a.Cin % p.CC))) return -1;
     if (p.lds_bytes > 160 * 1024) return -2;
+    if (a.route_src && !conv_route_ok(a)) return -8;
     dim3 grid((unsigned)(a.N * p.tiles_y * p.tiles_x), (unsigned)cdiv(a.Cout, p.BN), (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
     if (p.ksplit > 1) {  // raw partial sums to scratch; the epilogue runs in splitk_epilogue_kernel
         if (!a.split_ws || a.stats || a.shuffle || a.add_pad || p.flat) return -6;

@@ -58,6 +58,9 @@ struct ConvArgs {
     const float* add_src;  // optional residual [N,Ho-2*add_pad,Wo-2*add_pad,Cout] added in the interior
     int add_pad;
     const float* mask_src;  // optional [N,Ho,Wo,Cout]: after the add, v = mask_src > 0 ? v : 0 (ReLU gradient of the consumer)
+    const float* route_src; // optional [N,ceil(Ho/2),ceil(Wo/2),Cout], with mask_src (direct kernel, no add_src / shuffle / split-K): the gradient of a 2x2/2 SAME max-pool over mask_src, routed to the FIRST maximum of every
+                            // window, is added before the mask -- v = mask > 0 ? v + (mask is its window's arg-max ? route_src : 0) : 0
+                            // (the backward of vgg16.py's pool + ReLU behind a tapped layer, fused into the Gram-gradient conv)
     float* pool_out;        // optional [N,Ho/2,Wo/2,Cout] (Winograd kernels, even Ho/Wo, no split-K): max over every 2x2 output tile =
                             // tf.nn.max_pool 2x2/2 of the stored result (vgg16.py:68,104,154) straight from the epilogue's registers
     long long w_nstride;
@@ -266,6 +269,7 @@ struct WinoBatch {  // several filters of one shape in one launch (the 10 residu
 int wt_wino_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s);
 int wt_wino2(const float* w, float* U, int Cin, int Cout, hipStream_t s);                      // fs_wino2.hip
 int wt_wino2_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s);
+bool conv_route_ok(const ConvArgs& a);   // a.p filled: can the launch take a.route_src?
 bool wino2_eligible(const ConvArgs& a);
 void wino2_plan(const ConvArgs& a, ConvPlan* out);
 int wino2_launch(const ConvArgs& a, hipStream_t s);

@@ -290,10 +290,19 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
 
     // ---- backward ----
     // tap gradient of layer l (content term first, the style term accumulates through add_src)
-    auto compute_tap = [&](int l, const float** out) -> int {
+    // tap gradient of layer l (content term first, the style term accumulates through add_src).
+    // fuse_dst != nullptr: the caller wants d_pre[l] = (tap + max-pool gradient of fuse_above routed through act[l]) * (act[l] > 0)
+    // written to fuse_dst.  A layer whose only term is ONE style term gets that from the epilogue of the Gram-gradient conv
+    // itself (ConvArgs::route_src / mask_src) -- the tap tensor is never written and vgg_bwd_route has nothing left to do;
+    // *fused reports it.
+    auto compute_tap = [&](int l, const float** out, const float* fuse_above, float* fuse_dst, bool* fused) -> int {
         const int C = kCout[l], H = L.Hl[l], W = L.Wl[l];
         const size_t act_n = (size_t)N * H * W * C;  // the y half
         const float* tap = nullptr;
+        if (fused) *fused = false;
+        int n_terms = 0;
+        for (int i = 0; i < cfg.n_content; ++i) n_terms += cfg.content_layer[i] == l;
+        for (int i = 0; i < cfg.n_style; ++i) n_terms += cfg.style_layer[i] == l;
         for (int i = 0; i < cfg.n_content; ++i)
             if (cfg.content_layer[i] == l) {
                 const float hwc = (float)H * W * C;
@@ -320,6 +329,21 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
                 float* dst = tap == ws + L.d_tap ? ws + L.d_tap2 : ws + L.d_tap;
                 a.y = dst;
                 a.p = conv_plan(a);
+                // (measured at batch 32: the mask alone -- last layer, no pool behind it -- is free in the conv's epilogue; the pool
+                // routing costs the Gram-gradient conv +0.45 ms for 0.75 ms of vgg_bwd_route saved, one 4-byte load per lane
+                // against that kernel's 16-byte streams: 0.4 % of the step, so it stays a knob, FS_VGG_ROUTE_FUSED=1)
+                if (fuse_dst && n_terms == 1 && (!fuse_above || tune_int("FS_VGG_ROUTE_FUSED", 0))) {
+                    ConvArgs f = a;
+                    f.mask_src = ws + L.act[l];
+                    f.route_src = fuse_above;
+                    f.y = fuse_dst;
+                    if (!fuse_above || conv_route_ok(f)) {
+                        FS_TRY(conv_launch(f, s));
+                        *fused = true;
+                        *out = nullptr;
+                        return 0;
+                    }
+                }
                 FS_TRY(conv_launch(a, s));
                 tap = dst;
             }
@@ -333,8 +357,10 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
     float* pre_nxt = ws + L.d_in[0];
     {
         const float* tap = nullptr;
-        FS_TRY(compute_tap(L.lmax, &tap));
-        FS_TRY(vgg_bwd_route(ws + L.act[L.lmax], nullptr, tap, 0, pre_cur, N, L.Hl[L.lmax], L.Wl[L.lmax], kCout[L.lmax], s));
+        bool fused = false;
+        FS_TRY(compute_tap(L.lmax, &tap, nullptr, pre_cur, &fused));
+        if (!fused)
+            FS_TRY(vgg_bwd_route(ws + L.act[L.lmax], nullptr, tap, 0, pre_cur, N, L.Hl[L.lmax], L.Wl[L.lmax], kCout[L.lmax], s));
     }
     for (int l = L.lmax; l >= 0; --l) {
         const int C = kCout[l], H = L.Hl[l], W = L.Wl[l];
@@ -364,8 +390,8 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
             break;
         }
         const float* tap = nullptr;
-        FS_TRY(compute_tap(l - 1, &tap));
         if (!pool_after(l - 1)) {
+            FS_TRY(compute_tap(l - 1, &tap, nullptr, nullptr, nullptr));
             a.y = pre_nxt;
             a.add_src = tap;
             a.add_pad = 0;
@@ -376,7 +402,10 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
             a.y = ws + L.d_in[1];
             a.p = conv_plan(a);
             FS_TRY(conv_launch(a, s));
-            FS_TRY(vgg_bwd_route(ws + L.act[l - 1], ws + L.d_in[1], tap, 1, pre_nxt, N, L.Hl[l - 1], L.Wl[l - 1], kCout[l - 1], s));
+            bool fused = false;
+            FS_TRY(compute_tap(l - 1, &tap, ws + L.d_in[1], pre_nxt, &fused));
+            if (!fused)
+                FS_TRY(vgg_bwd_route(ws + L.act[l - 1], ws + L.d_in[1], tap, 1, pre_nxt, N, L.Hl[l - 1], L.Wl[l - 1], kCout[l - 1], s));
         }
         float* t = pre_cur;
         pre_cur = pre_nxt;

@@ -236,6 +236,32 @@ def test_perceptual_loss_and_gradient_match_oracle(eng, knob, force_ksplit):
     assert flat_close(eng.mem.to_numpy(dy), dyo)
 
 
+@pytest.mark.parametrize("hw", [(35, 45), (32, 48)])
+def test_pool_gradient_routing_fused_into_the_gram_gradient_conv(eng, knob, hw):
+    """The backward of max-pool + ReLU behind conv1_2 / conv2_2 (first-maximum routing, SAME padding for odd extents) runs
+    in the epilogue of the Gram-gradient conv (ConvArgs::route_src) with FS_VGG_ROUTE_FUSED=1; by default the separate
+    vgg_bwd_route pass does it.  Same arithmetic in the same order: the two must agree bit for bit, and with the oracle."""
+    rng = np.random.default_rng(5)
+    Wv = perceptual.synthetic_vgg_weights(seed=3)
+    eng.vgg_load(Wv)
+    cfg = engine.default_loss_cfg()
+    style = rng.uniform(0, 255, (1, 40, 36, 3)).astype(np.float32)
+    tg = eng.style_targets(eng.mem.from_numpy(style), cfg)
+    y = rng.uniform(0, 255, (2,) + hw + (3,)).astype(np.float32)
+    xc = rng.uniform(0, 255, (2,) + hw + (3,)).astype(np.float32)
+    knob("FS_VGG_ROUTE_FUSED", 1)
+    l1, dy1 = eng.perceptual_loss(eng.mem.from_numpy(y), eng.mem.from_numpy(xc), tg, cfg)
+    l1, dy1 = eng.mem.to_numpy(l1).copy(), eng.mem.to_numpy(dy1).copy()
+    knob("FS_VGG_ROUTE_FUSED", 0)
+    l0, dy0 = eng.perceptual_loss(eng.mem.from_numpy(y), eng.mem.from_numpy(xc), tg, cfg)
+    l0, dy0 = eng.mem.to_numpy(l0), eng.mem.to_numpy(dy0)
+    assert np.array_equal(l0, l1) and np.array_equal(dy0, dy1)
+    tgo = perceptual.target_grams(style.astype(np.float64), f64(Wv), cfg["style_layers"])
+    feats = perceptual.vgg16(xc.astype(np.float64), f64(Wv), upto="conv3_3")
+    _, dyo = perceptual.perceptual_loss(y.astype(np.float64), [feats["conv3_3"]], tgo, f64(Wv), beta=0.0)
+    assert flat_close(dy1, dyo)
+
+
 def test_adam_tf_step_matches_oracle(eng):
     rng = np.random.default_rng(2)
     n = 5000

@@ -26,6 +26,11 @@ CASES = {
     "first9x9_720p": (1, 800, 1360, 3, 16, 9, 1, "VALID"),
     "final9x9_720p": (1, 720, 1280, 16, 3, 9, 1, "SAME"),
     "res_720p": (1, 196, 336, 64, 64, 3, 1, "VALID"),
+    # the narrow layers of the transform net at the metric's batch (32 x 256x256)
+    "t_first_n32": (32, 344, 344, 3, 16, 9, 1, "VALID"),
+    "t_s2a_n32": (32, 336, 336, 16, 32, 3, 2, "SAME"),
+    "t_s2b_n32": (32, 168, 168, 32, 64, 3, 2, "SAME"),
+    "t_final_n32": (32, 256, 256, 16, 3, 9, 1, "SAME"),
 }
 
 
