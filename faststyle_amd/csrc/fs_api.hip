@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 
 #include "fs_bf16.h"
@@ -17,6 +18,7 @@ struct fs_ctx {
     hipStream_t stream;
     // cached layouts (recomputed when the shape changes)
     fs::TnetLayout tnet;
+    unsigned tnet_epoch = 0;   // fs::tune_epoch() the layout was planned under
     bool tnet_valid;
     fs::BTnetLayout* btnet;  // bf16 inference layout (allocated on first use)
     hipStream_t side;      // second stream for the filter-gradient branch of fs_tnet_backward
@@ -58,10 +60,13 @@ int tune_int(const char* name, int unset) {
     }
     return v ? (int)strtol(v, nullptr, 0) : unset;
 }
+static std::atomic<unsigned> g_tune_epoch{1};
 void tune_reload() {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     g_ntune = 0;
+    g_tune_epoch.fetch_add(1);
 }
+unsigned tune_epoch() { return g_tune_epoch.load(); }
 int set_error(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -166,10 +171,12 @@ int fs_tnet_out_shape(int H, int W, int* Ho, int* Wo) {
 
 static const fs::TnetLayout* get_layout(fs_ctx* ctx, int N, int H, int W, int flags) {
     const int deconv = (flags & FS_FLAG_UPSAMPLE_DECONV) ? 1 : 0;
+    // (a layout records plan decisions that depend on the tuning knobs: re-planned after fs_debug_reload_env)
     if (!ctx->tnet_valid || ctx->tnet.N != N || ctx->tnet.H != H || ctx->tnet.W != W || ctx->tnet.deconv != deconv ||
-        ctx->tnet.wino_mode != fs::tnet_wino_mode()) {
+        ctx->tnet.wino_mode != fs::tnet_wino_mode() || ctx->tnet_epoch != fs::tune_epoch()) {
         fs::tnet_layout(N, H, W, deconv, &ctx->tnet);
         ctx->tnet_valid = true;
+        ctx->tnet_epoch = fs::tune_epoch();
     }
     return &ctx->tnet;
 }

@@ -284,6 +284,7 @@ void plan_tile(int Ho, int Wo, int KH, int KW, int stride, int max_px, int* TH, 
 // returned when the variable is absent.  (fs_api.hip)
 int tune_int(const char* name, int unset);
 void tune_reload();
+unsigned tune_epoch();   // bumped by tune_reload: cached plans made under older knob values are stale
 // thread-local message behind fs_last_error(); returns `code` (fs_api.hip)
 int set_error(int code, const char* fmt, ...);
 // tf.image.resize_images(method=2) of TF 1.0 on device u8 [H,W,3] -> f32 [Ho,Wo,3] (fs_io.hip)

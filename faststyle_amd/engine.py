@@ -157,6 +157,13 @@ class Engine(object):
             self._tnet_ws[key] = self._tnet_ws.pop(key)                      # mark as most recently used
         return self._tnet_ws[key]
 
+    def reset_workspaces(self):
+        """Drop every cached workspace (their sizes were planned under the tuning knobs of the time; tests that flip FS_*
+        knobs with fs_debug_reload_env call this, production code never needs to)."""
+        self._sync_stream()
+        self._tnet_ws.clear()
+        self._perc_ws.clear()
+
     @staticmethod
     def _method_flag(upsample_method):
         assert upsample_method in ("resize", "deconv")
