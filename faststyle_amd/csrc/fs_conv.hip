@@ -938,6 +938,10 @@ ConvPlan conv_plan(const ConvArgs& a) {
             return p;
         }
     }
+    if (cstream_eligible(a)) {   // narrow full-resolution layers with enough tiles: persistent streaming kernel (fs_cstream.hip)
+        cstream_plan(a, &p);
+        return p;
+    }
     if (a.Cout <= 16 || a.Cin == 3) {  // narrow outputs, and the flat Cin==3 path, have one variant each
         plan_variant(a, a.Cout <= 16 ? 2 : 0, &p);
         return p;
@@ -1079,8 +1083,9 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
         if (a.src_mode == SRC_DILATE2) fl *= 0.25;
         if (a.shuffle) fl *= 9.0 / 16.0;  // phase-collapsed resize-conv / stride-2 dgrad: 9 of the 16 tap-parity slots are non-zero
         // Winograd F(2x2,3x3): 16 products per 2x2 output tile instead of 36 -- the FLOPs actually executed
-        if (p.variant >= 5) fl = 2.0 * a.N * cdiv(a.Ho, 2) * cdiv(a.Wo, 2) * 16.0 * a.Cin * a.Cout;
-        prof->begin(a.w_nstride ? 8 : (p.variant >= 5 ? 6 : (p.variant < 3 ? p.variant : p.variant + 1)), fl, s);
+        if (p.variant == 5 || p.variant == 6) fl = 2.0 * a.N * cdiv(a.Ho, 2) * cdiv(a.Wo, 2) * 16.0 * a.Cin * a.Cout;
+        // (the streaming kernel, variant 7, is reported with the <32,2,1> direct family it replaces)
+        prof->begin(a.w_nstride ? 8 : (p.variant == 7 ? 1 : (p.variant >= 5 ? 6 : (p.variant < 3 ? p.variant : p.variant + 1))), fl, s);
     }
 #define FS_LAUNCH(MT_, WM_, WN_, FL_)                                                                              \
     do {                                                                                                           \
@@ -1088,7 +1093,10 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
         lds_attr.ensure(reinterpret_cast<const void*>(conv_igemm_kernel<MT_, WM_, WN_, FL_>));                       \
         hipLaunchKernelGGL((conv_igemm_kernel<MT_, WM_, WN_, FL_>), grid, dim3(256), (size_t)p.lds_bytes, s, a);   \
     } while (0)
-    if (p.variant == 6) {
+    if (p.variant == 7) {
+        if (!cstream_eligible(a_in)) return -7;
+        FS_TRY_(cstream_launch(a, s));
+    } else if (p.variant == 6) {
         if (!wino2_eligible(a_in)) return -7;
         FS_TRY_(wino2_launch(a, s));
     } else if (p.variant == 5) {

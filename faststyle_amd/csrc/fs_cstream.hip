@@ -1,0 +1,361 @@
+// Streaming convolution for the narrow, full-resolution layers of the transform net (reference im_transf_net.py:37-70:
+// the 16- and 32-channel stride-2 / resize-conv units next to the image) and their input gradients.
+//
+// These launches hold few FLOPs per byte (K = taps x Cin <= 144, 32..64 output channels): in conv_igemm_kernel a workgroup
+// lives for one tile -- load, wait, multiply, store -- two workgroups per CU in lockstep, and the chip alternates between
+// an HBM burst and an MFMA burst (tools/conv_trace.py: the sweep is 1/3 of a workgroup's life).  Here ONE persistent
+// workgroup per CU (256 threads, one wave per SIMD) walks a strided list of tiles as a software pipeline:
+//     loads of tile t+1 in flight (registers)  |  MFMA sweep of tile t out of LDS  |  barrier  |
+//     commit of tile t+1 over the patch (producer instance norm + ReLU applied)  |  epilogue of tile t (stores drain
+//     during the next sweep; statistics records merged one step later: no barrier of their own)  |  barrier
+// (one patch stage: loads of tile t+1 travel in registers during the sweep of tile t) with the whole filter (K x Cout <= 37 KB)
+// resident in REGISTERS for the workgroup's lifetime.  v_mfma_f32_32x32x2_f32, 16x16-pixel tiles, a wave owns two 32-pixel
+// blocks x NB 32-channel blocks.  Epilogue options are the ones these layers use: per-tile instance-norm
+// partials {mean, M2, count} and the 2x2 pixel-shuffle store of the phase-collapsed resize-conv / stride-2 input gradient.
+#include "fs_kernels.h"
+
+#include <type_traits>
+
+namespace fs {
+
+namespace {
+constexpr unsigned kOOB = 0x80000000u;
+constexpr int kTile = 16;   // output tile side: 256 pixels, two 32-pixel blocks per wave
+}  // namespace
+
+// NB: 32-channel blocks of Cout (= all of it); CIN input channels; KS x KS taps; STRIDE 1 or 2.
+template <int NB, int CIN, int KS, int STRIDE>
+__global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const ConvPlan& p = a.p;
+    constexpr int WM = 2, BN = NB * 32, S = CIN + 1, C4 = CIN / 4, G = KS * KS, KSTEPS = G * CIN / 2;
+    constexpr int C4SH = C4 == 4 ? 2 : 3;
+    constexpr int PH = (kTile - 1) * STRIDE + KS, PW = PH, NPX = PH * PW;
+    constexpr int SX = (NPX * C4 + 255) / 256;            // 16-byte patch loads per thread and tile
+    constexpr int PATCH_F = (NPX * S + 4 + 3) & ~3;       // + four slack floats: the LDS sink of elements a thread does not own
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 31, kq = lane >> 5;
+    float* const red = smem + PATCH_F;   // [2 buffers][4 waves][3: s1, s2, shift][BN]
+    auto fdiv = [](int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); };   // exact for these magnitudes (x < 2^22)
+    auto uniform_ptr = [](const float* ptr) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    };
+
+    // ---- the filter, once, into REGISTERS: lane (lm, kq) multiplies rows k = 2j + kq of [k = tap*Cin + ci][co] against
+    // its columns nn*32 + lm -- KSTEPS x NB values that never change (no filter traffic through LDS at all)
+    float breg[KSTEPS][NB];
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j)
+#pragma unroll
+        for (int nn = 0; nn < NB; ++nn) breg[j][nn] = a.w[(2 * j + kq) * BN + nn * 32 + lm];
+
+    // ---- this lane's pixels: pixel t of the tile = (wave*2 + m)*32 + rr, rr = (r & 3) + 8 (r >> 2) + 4 kq for accumulator
+    // register r; with 16 columns that is row py = 4 wave + 2 m + (r >> 3), column px = 4 kq + (r & 3) + 8 ((r >> 2) & 1)
+    const int pyb = wave * 4, pxb = kq * 4;
+    int laneA[WM];
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+        const int t = (wave * WM + m) * 32 + lm;          // A operand: lane lm feeds pixel t (all 32 rows of the block)
+        laneA[m] = (((t >> 4) * STRIDE) * PW + (t & 15) * STRIDE) * S + kq;
+    }
+
+    // ---- staging descriptors (tile-invariant): element e = tid + i*256 is channel quad c4 of patch pixel e / C4
+    const int c4 = tid & (C4 - 1);   // the same for every element of a thread (256 is a multiple of C4)
+    int pq[SX], pdst[SX];
+#pragma unroll
+    for (int i = 0; i < SX; ++i) {
+        const int e = tid + i * 256;
+        pq[i] = -1;
+        pdst[i] = NPX * S;   // slack
+        if (e < NPX * C4) {
+            const int pix = e >> C4SH;
+            const int py = fdiv(pix, 1.0f / (float)PW), px = pix - py * PW;
+            pq[i] = (py << 8) | px;
+            pdst[i] = pix * S + c4 * 4;
+        }
+    }
+    const unsigned x_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * CIN) * 4u);
+    const bool has_ab = a.in_a != nullptr;
+    const bool in_relu = a.in_relu != 0;
+
+    // ---- items: tile lin = blockIdx.x + it * gridDim.x over (sample, tile row, tile column)
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int total = a.N * tiles;
+    const int GX = (int)gridDim.x;
+    const int my_items = ((int)blockIdx.x < total) ? (total - 1 - (int)blockIdx.x) / GX + 1 : 0;
+    const float inv_tiles = 1.0f / (float)tiles, inv_tx = 1.0f / (float)p.tiles_x;
+    struct Item {
+        int n, ty0, tx0, lin;
+    };
+    auto decode = [&](int it) {
+        Item r;
+        r.lin = (int)blockIdx.x + it * GX;
+        r.n = fdiv(r.lin, inv_tiles);
+        const int tr = r.lin - r.n * tiles;
+        const int tyi = fdiv(tr, inv_tx);
+        r.ty0 = tyi * kTile;
+        r.tx0 = (tr - tyi * p.tiles_x) * kTile;
+        r.lin = __builtin_amdgcn_readfirstlane(r.lin);
+        r.n = __builtin_amdgcn_readfirstlane(r.n);
+        r.ty0 = __builtin_amdgcn_readfirstlane(r.ty0);
+        r.tx0 = __builtin_amdgcn_readfirstlane(r.tx0);
+        return r;
+    };
+    float4 pv[SX];
+    unsigned pok = 0;   // bit i: element i came from inside the image (padding must stay 0 through the on-load affine)
+    float4 va = make_float4(1.f, 1.f, 1.f, 1.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto issue = [&](const Item& I) {   // global loads of the item's patch (zero padding: out-of-range offset -> zeros)
+        const int vy0 = I.ty0 * STRIDE - a.pad_t, vx0 = I.tx0 * STRIDE - a.pad_l;
+        const float* xn = uniform_ptr(a.x + (size_t)I.n * a.H * a.W * CIN);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, x_bytes, 0x00020000);
+        pok = 0;
+#pragma unroll
+        for (int i = 0; i < SX; ++i) {
+            const int sy = vy0 + (pq[i] >> 8), sx = vx0 + (pq[i] & 255);
+            const bool ok = pq[i] >= 0 && (unsigned)sy < (unsigned)a.H && (unsigned)sx < (unsigned)a.W;
+            pok |= ok ? (1u << i) : 0u;
+            pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((sy * a.W + sx) * CIN + c4 * 4) * 4u : kOOB, 0, 0));
+        }
+        if (has_ab) {
+            va = *reinterpret_cast<const float4*>(a.in_a + (size_t)I.n * a.in_nstride + c4 * 4);
+            vb = *reinterpret_cast<const float4*>(a.in_b + (size_t)I.n * a.in_nstride + c4 * 4);
+        }
+    };
+    auto relu1 = [](float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < SX; ++i) {
+            float4 v = pv[i];
+            if (has_ab) {   // producer instance norm folded into the load; padding arrives as 0 and must stay 0
+                const unsigned okm = (pok >> i) & 1u ? 0xFFFFFFFFu : 0u;
+                v.x = fmaf(v.x, va.x, __uint_as_float(__float_as_uint(vb.x) & okm));
+                v.y = fmaf(v.y, va.y, __uint_as_float(__float_as_uint(vb.y) & okm));
+                v.z = fmaf(v.z, va.z, __uint_as_float(__float_as_uint(vb.z) & okm));
+                v.w = fmaf(v.w, va.w, __uint_as_float(__float_as_uint(vb.w) & okm));
+            }
+            if (in_relu) {
+                v.x = relu1(v.x);
+                v.y = relu1(v.y);
+                v.z = relu1(v.z);
+                v.w = relu1(v.w);
+            }
+            float* d = smem + pdst[i];
+            d[0] = v.x;
+            d[1] = v.y;
+            d[2] = v.z;
+            d[3] = v.w;
+        }
+    };
+
+    f32x16 acc[WM][NB];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int nn = 0; nn < NB; ++nn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+    };
+    zero_acc();
+    // the sweep is fully unrolled: every A address is the lane's base + a compile-time offset, B comes from registers
+    auto sweep = [&]() {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int q = 0; q < CIN / 2; ++q) {
+                float av[WM];
+#pragma unroll
+                for (int m = 0; m < WM; ++m) av[m] = smem[laneA[m] + ((g / KS) * PW + (g % KS)) * S + 2 * q];
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < NB; ++nn)
+                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], breg[g * (CIN / 2) + q][nn], acc[m][nn], 0, 0, 0);
+            }
+    };
+
+    // ---- epilogue of one item
+    const int Cr = a.shuffle ? BN >> 2 : BN;
+    const int SH = a.shuf_H > 0 ? a.shuf_H : 2 * a.Ho, SW = a.shuf_W > 0 ? a.shuf_W : 2 * a.Wo;
+    const unsigned y_bytes = __builtin_amdgcn_readfirstlane((unsigned)((a.shuffle ? SH * SW * Cr : a.Ho * a.Wo * BN)) * 4u);
+    const int rowb = a.shuffle ? 2 * SW * Cr * 4 : a.Wo * BN * 4;      // bytes between two tile rows in the output
+    const int colb = a.shuffle ? 2 * Cr * 4 : BN * 4;                  // ... two tile columns
+    int chb[NB], qa[NB], qb[NB];                                       // per channel block: byte offset of the lane's channel
+#pragma unroll
+    for (int nn = 0; nn < NB; ++nn) {
+        const int co = nn * 32 + lm;
+        const int q = a.shuffle ? co / Cr : 0;
+        qa[nn] = q >> 1;
+        qb[nn] = q & 1;
+        chb[nn] = a.shuffle ? ((qa[nn] * SW + qb[nn]) * Cr + (co - q * Cr)) * 4 : co * 4;
+    }
+    auto epilogue = [&](const Item& I, float* rbuf) {
+        const int th_valid = min(kTile, a.Ho - I.ty0), tw_valid = min(kTile, a.Wo - I.tx0);
+        if (a.stats) {
+            // per-WAVE partial sums of (x - c), (x - c)^2 over the wave's four tile rows, c = the wave's own first pixel of the
+            // channel; the four waves' records are merged when the next pipeline step starts (finalize below): no barrier here
+            float cs[NB], s1[NB], s2[NB];
+#pragma unroll
+            for (int nn = 0; nn < NB; ++nn) {
+                const float other = __shfl_xor(acc[0][nn][0], 32);
+                cs[nn] = kq ? other : acc[0][nn][0];
+                s1[nn] = 0.f;
+                s2[nn] = 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = pyb + 2 * m + (r >> 3) < th_valid && pxb + (r & 3) + 8 * ((r >> 2) & 1) < tw_valid;
+#pragma unroll
+                    for (int nn = 0; nn < NB; ++nn) {
+                        const float d = ok ? acc[m][nn][r] - cs[nn] : 0.f;
+                        s1[nn] += d;
+                        s2[nn] = fmaf(d, d, s2[nn]);
+                    }
+                }
+#pragma unroll
+            for (int nn = 0; nn < NB; ++nn) {
+                s1[nn] += __shfl_xor(s1[nn], 32);
+                s2[nn] += __shfl_xor(s2[nn], 32);
+            }
+            if (lane < 32)
+#pragma unroll
+                for (int nn = 0; nn < NB; ++nn) {
+                    rbuf[(wave * 3 + 0) * BN + nn * 32 + lane] = s1[nn];
+                    rbuf[(wave * 3 + 1) * BN + nn * 32 + lane] = s2[nn];
+                    rbuf[(wave * 3 + 2) * BN + nn * 32 + lane] = cs[nn];
+                }
+        }
+        // stores through a buffer resource.  Byte offset = lane part (column, channel: a register, or the out-of-range offset
+        // for a pixel outside the image / the clipped shuffle extent) + scalar part (row) + compile-time part (r)
+        float* yn = a.shuffle ? a.y + (size_t)I.n * SH * SW * Cr : a.y + (size_t)I.n * a.Ho * a.Wo * BN;
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(yn)), 0, y_bytes, 0x00020000);
+#pragma unroll
+        for (int nn = 0; nn < NB; ++nn) {
+            // rows / columns this channel block may store (shuffle: odd extents clip the last phase row / column)
+            const int thv = a.shuffle ? min(th_valid, ((SH - qa[nn] + 1) >> 1) - I.ty0) : th_valid;
+            const int twv = a.shuffle ? min(tw_valid, ((SW - qb[nn] + 1) >> 1) - I.tx0) : tw_valid;
+            const int lane_off = (I.tx0 + pxb) * colb + chb[nn];
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pyl = pyb + 2 * m + (r >> 3), pxc = (r & 3) + 8 * ((r >> 2) & 1);
+                    const bool ok = pyl < thv && pxb + pxc < twv;
+                    const int row_off = (I.ty0 + pyl) * rowb;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][nn][r]), yr, ok ? (unsigned)(lane_off + row_off + pxc * colb) : kOOB, 0, 0);
+                }
+        }
+        zero_acc();
+    };
+    // merge of the four per-wave records of one tile (Chan's update, fixed order) -> {mean, M2, count} of the tile
+    auto finalize = [&](const Item& I, const float* rbuf) {
+        const int th_valid = min(kTile, a.Ho - I.ty0), tw_valid = min(kTile, a.Wo - I.tx0);
+        float cnt = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int rows = min(4, max(0, th_valid - 4 * w));
+            const float cb = (float)(rows * tw_valid);
+            if (cb > 0.f) {
+                const float S1 = rbuf[(w * 3 + 0) * BN + tid], S2 = rbuf[(w * 3 + 1) * BN + tid], sh = rbuf[(w * 3 + 2) * BN + tid];
+                const float mb = sh + S1 / cb, qb2 = fmaxf(S2 - S1 * S1 / cb, 0.f);
+                const float nn_ = cnt + cb, d = mb - mean, rr = cb / nn_;
+                mean += d * rr;
+                m2 += qb2 + d * d * cnt * rr;
+                cnt = nn_;
+            }
+        }
+        float* st = a.stats + ((size_t)I.lin * BN + tid) * 3;
+        st[0] = mean;
+        st[1] = m2;
+        st[2] = cnt;
+    };
+
+    // ---- the pipeline: ONE patch stage.  While tile t is multiplied the loads of tile t+1 are in flight (registers); after
+    // the sweep (barrier A) they are committed over the patch, the epilogue of tile t follows (its stores drain during the
+    // next sweep), barrier B, next tile.
+    if (my_items == 0) return;
+    Item cur = decode(0), prev = cur;
+    issue(cur);
+    commit();
+    __syncthreads();
+    for (int it = 0; it < my_items; ++it) {
+        const bool more = it + 1 < my_items;
+        if (it > 0 && a.stats && tid < BN) finalize(prev, red + ((it - 1) & 1) * 12 * BN);
+        Item nxt = cur;
+        if (more) {
+            nxt = decode(it + 1);
+            issue(nxt);
+        }
+        sweep();
+        __syncthreads();   // A: every wave is done reading the patch
+        if (more) commit();
+        epilogue(cur, red + (it & 1) * 12 * BN);
+        __syncthreads();   // B: next patch and this tile's statistics records visible
+        prev = cur;
+        cur = nxt;
+    }
+    if (a.stats && tid < BN) finalize(prev, red + ((my_items - 1) & 1) * 12 * BN);
+}
+
+// ------------------------------------------------------------------------------------------------------------ host
+static int cstream_instance(const ConvArgs& a) {   // 1: 16 -> 32 channels, 3x3 stride 2;  2: 32 -> 64 channels, 2x2 stride 1
+    if (a.Cin == 16 && a.Cout == 32 && a.KH == 3 && a.KW == 3 && a.stride == 2) return 1;
+    if (a.Cin == 32 && a.Cout == 64 && a.KH == 2 && a.KW == 2 && a.stride == 1) return 2;
+    return 0;
+}
+
+bool cstream_eligible(const ConvArgs& a) {
+    if (!tune_int("FS_CSTREAM", 1) || !cstream_instance(a)) return false;
+    const bool plain = a.src_mode == SRC_PLAIN && a.dil_x <= 1 && !a.bias && !a.out_relu && !a.add_src && !a.mask_src && !a.route_src &&
+                       !a.pool_out && a.w_nstride == 0 && !a.w_wino && !a.w_wino2;
+    if (!plain) return false;
+    if (a.in_a && !a.in_b) return false;
+    if (a.in_relu && !a.in_a) return false;   // (a ReLU on load only comes with its affine here)
+    if (a.pad_t < 0 || a.pad_l < 0 || a.pad_t > 2 || a.pad_l > 2) return false;
+    // persistence pays from about two tiles per workgroup on; smaller launches stay with the one-tile kernel
+    const long tiles = (long)a.N * cdiv(a.Ho, kTile) * cdiv(a.Wo, kTile);
+    return tiles >= tune_int("FS_CSTREAM_MIN_TILES", 512);
+}
+
+void cstream_plan(const ConvArgs& a, ConvPlan* out) {
+    ConvPlan p{};
+    p.variant = 7;
+    p.BN = a.Cout;
+    p.CC = a.Cin;
+    p.TH = p.TW = kTile;
+    p.tiles_y = cdiv(a.Ho, kTile);
+    p.tiles_x = cdiv(a.Wo, kTile);
+    p.PH = p.PW = (kTile - 1) * a.stride + a.KH;
+    p.S = a.Cin + 1;
+    p.ksplit = 1;
+    const int patch_floats = (p.PH * p.PW * p.S + 4 + 3) & ~3;
+    p.lds_bytes = 4 * (patch_floats + 2 * 12 * a.Cout);
+    *out = p;
+}
+
+int cstream_launch(const ConvArgs& a, hipStream_t s) {
+    const ConvPlan& p = a.p;
+    const long total = (long)a.N * p.tiles_y * p.tiles_x;
+    const int wgs = tune_int("FS_CSTREAM_WGS", 256);
+    const unsigned grid = (unsigned)(total < wgs ? total : wgs);
+    const int inst = cstream_instance(a);
+    if (inst == 1) {
+        static BigLds lds_attr;
+        lds_attr.ensure(reinterpret_cast<const void*>(conv_stream_kernel<1, 16, 3, 2>));
+        hipLaunchKernelGGL((conv_stream_kernel<1, 16, 3, 2>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a);
+    } else if (inst == 2) {
+        static BigLds lds_attr;
+        lds_attr.ensure(reinterpret_cast<const void*>(conv_stream_kernel<2, 32, 2, 1>));
+        hipLaunchKernelGGL((conv_stream_kernel<2, 32, 2, 1>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a);
+    } else {
+        return -4;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace fs

@@ -273,6 +273,10 @@ bool conv_route_ok(const ConvArgs& a);   // a.p filled: can the launch take a.ro
 bool wino2_eligible(const ConvArgs& a);
 void wino2_plan(const ConvArgs& a, ConvPlan* out);
 int wino2_launch(const ConvArgs& a, hipStream_t s);
+// streaming conv of the narrow full-resolution layers (fs_cstream.hip): plan variant 7
+bool cstream_eligible(const ConvArgs& a);
+void cstream_plan(const ConvArgs& a, ConvPlan* out);
+int cstream_launch(const ConvArgs& a, hipStream_t s);
 bool conv3x3_to3_eligible(const ConvArgs& a);                                                 // fs_c3.hip
 int conv3x3_to3_launch(const ConvArgs& a, hipStream_t s);
 bool wino_eligible(const ConvArgs& a);

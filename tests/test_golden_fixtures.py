@@ -218,6 +218,8 @@ def knob_hip(monkeypatch):
     def set_knob(name, value):
         monkeypatch.setenv(name, str(value))
         e.lib.fs_debug_reload_env()
+        e.reset_workspaces()
     yield set_knob
     monkeypatch.undo()
     e.lib.fs_debug_reload_env()
+    e.reset_workspaces()

@@ -27,9 +27,11 @@ def knob(monkeypatch, eng):
     def set_knob(name, value):
         monkeypatch.setenv(name, str(value))
         eng.lib.fs_debug_reload_env()
+        eng.reset_workspaces()
     yield set_knob
     monkeypatch.undo()
     eng.lib.fs_debug_reload_env()
+    eng.reset_workspaces()
 
 
 def f64(d):
@@ -144,6 +146,19 @@ def test_tnet_residual_convs_through_the_winograd_kernel(eng, shape, knob):
 def test_tnet_forward_matches_oracle_and_backward_tight_when_kink_free(eng, shape):
     """Smallest legal size (41: REFLECT needs pad < dim), odd sizes (asymmetric SAME padding of
     the stride-2 convs, 45 -> 125 -> 63 -> 32) and a batch of 2."""
+    y, yo, g, want = run_fwd_bwd(eng, kink_free_params(), shape, seed=0)
+    assert np.abs(y - yo).max() / 255.0 < 2e-5
+    assert grads_close(eng, g, want, 2e-4) == []
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 56), (1, 45, 67)])
+def test_tnet_narrow_layers_through_the_streaming_kernel(eng, shape, knob):
+    """fs_cstream.hip takes the 16/32-channel stride-2 and resize-conv units and their input gradients once a launch has a few
+    tiles per workgroup (training batches, 720p frames); FS_CSTREAM_MIN_TILES=1 sends these small shapes through it: odd
+    extents (ragged tiles, clipped pixel-shuffle stores), instance-norm partials per tile, several tiles per workgroup
+    (FS_CSTREAM_WGS=3 makes the persistent loop run).  Same oracle, same tolerances as the one-tile kernel."""
+    knob("FS_CSTREAM_MIN_TILES", 1)
+    knob("FS_CSTREAM_WGS", 3)
     y, yo, g, want = run_fwd_bwd(eng, kink_free_params(), shape, seed=0)
     assert np.abs(y - yo).max() / 255.0 < 2e-5
     assert grads_close(eng, g, want, 2e-4) == []
