@@ -20,23 +20,27 @@ namespace fs {
 
 namespace {
 constexpr unsigned kOOB = 0x80000000u;
-constexpr int kTile = 16;   // output tile side: 256 pixels, two 32-pixel blocks per wave
+constexpr int kTW = 16;     // output tile width; TH (8 or 16) rows: TH/2 32-pixel blocks
 }  // namespace
 
-// NB: 32-channel blocks of Cout (= all of it); CIN input channels; KS x KS taps; STRIDE 1 or 2.
-template <int NB, int CIN, int KS, int STRIDE>
+// TH x 16 output pixels per tile; the four waves tile it as (4/WN waves over the 32-pixel blocks) x (WN waves over the channel
+// blocks), a wave owns WM = (TH/2)/(4/WN) pixel blocks x NB channel blocks (Cout = WN*NB*32); CIN input channels; KS x KS taps;
+// STRIDE 1 or 2.  The register budget of the resident filter decides the split: KS*KS*CIN/2 * NB registers per lane.
+template <int TH, int WN, int NB, int CIN, int KS, int STRIDE>
 __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     HIP_DYNAMIC_SHARED(float, smem)
     const ConvPlan& p = a.p;
-    constexpr int WM = 2, BN = NB * 32, S = CIN + 1, C4 = CIN / 4, G = KS * KS, KSTEPS = G * CIN / 2;
-    constexpr int C4SH = C4 == 4 ? 2 : 3;
-    constexpr int PH = (kTile - 1) * STRIDE + KS, PW = PH, NPX = PH * PW;
+    constexpr int WMW = 4 / WN, WM = (TH / 2) / WMW, BN = WN * NB * 32, S = CIN + 1, C4 = CIN / 4, G = KS * KS, KSTEPS = G * CIN / 2;
+    constexpr int C4SH = C4 == 4 ? 2 : (C4 == 8 ? 3 : 4);
+    constexpr int PH = (TH - 1) * STRIDE + KS, PW = (kTW - 1) * STRIDE + KS, NPX = PH * PW;
+    constexpr int REDF = WMW * 3 * BN;                    // one statistics buffer: [waves over pixels][s1, s2, shift][BN]
     constexpr int SX = (NPX * C4 + 255) / 256;            // 16-byte patch loads per thread and tile
     constexpr int PATCH_F = (NPX * S + 4 + 3) & ~3;       // + four slack floats: the LDS sink of elements a thread does not own
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 31, kq = lane >> 5;
-    float* const red = smem + PATCH_F;   // [2 buffers][4 waves][3: s1, s2, shift][BN]
+    const int mw = wave % WMW, nbw = wave / WMW;          // this wave's place among the pixel blocks / channel blocks
+    float* const red = smem + PATCH_F;   // [2 buffers][REDF]
     auto fdiv = [](int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); };   // exact for these magnitudes (x < 2^22)
     auto uniform_ptr = [](const float* ptr) {
         const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
@@ -50,15 +54,15 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < KSTEPS; ++j)
 #pragma unroll
-        for (int nn = 0; nn < NB; ++nn) breg[j][nn] = a.w[(2 * j + kq) * BN + nn * 32 + lm];
+        for (int nn = 0; nn < NB; ++nn) breg[j][nn] = a.w[(2 * j + kq) * BN + (nbw * NB + nn) * 32 + lm];
 
-    // ---- this lane's pixels: pixel t of the tile = (wave*2 + m)*32 + rr, rr = (r & 3) + 8 (r >> 2) + 4 kq for accumulator
-    // register r; with 16 columns that is row py = 4 wave + 2 m + (r >> 3), column px = 4 kq + (r & 3) + 8 ((r >> 2) & 1)
-    const int pyb = wave * 4, pxb = kq * 4;
+    // ---- this lane's pixels: pixel t of the tile = (mw*WM + m)*32 + rr, rr = (r & 3) + 8 (r >> 2) + 4 kq for accumulator
+    // register r; with 16 columns that is row py = 2 (mw*WM + m) + (r >> 3), column px = 4 kq + (r & 3) + 8 ((r >> 2) & 1)
+    const int pyb = mw * WM * 2, pxb = kq * 4;
     int laneA[WM];
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
-        const int t = (wave * WM + m) * 32 + lm;          // A operand: lane lm feeds pixel t (all 32 rows of the block)
+        const int t = (mw * WM + m) * 32 + lm;            // A operand: lane lm feeds pixel t (all 32 rows of the block)
         laneA[m] = (((t >> 4) * STRIDE) * PW + (t & 15) * STRIDE) * S + kq;
     }
 
@@ -96,8 +100,8 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
         r.n = fdiv(r.lin, inv_tiles);
         const int tr = r.lin - r.n * tiles;
         const int tyi = fdiv(tr, inv_tx);
-        r.ty0 = tyi * kTile;
-        r.tx0 = (tr - tyi * p.tiles_x) * kTile;
+        r.ty0 = tyi * TH;
+        r.tx0 = (tr - tyi * p.tiles_x) * kTW;
         r.lin = __builtin_amdgcn_readfirstlane(r.lin);
         r.n = __builtin_amdgcn_readfirstlane(r.n);
         r.ty0 = __builtin_amdgcn_readfirstlane(r.ty0);
@@ -186,17 +190,18 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     int chb[NB], qa[NB], qb[NB];                                       // per channel block: byte offset of the lane's channel
 #pragma unroll
     for (int nn = 0; nn < NB; ++nn) {
-        const int co = nn * 32 + lm;
+        const int co = (nbw * NB + nn) * 32 + lm;
         const int q = a.shuffle ? co / Cr : 0;
         qa[nn] = q >> 1;
         qb[nn] = q & 1;
         chb[nn] = a.shuffle ? ((qa[nn] * SW + qb[nn]) * Cr + (co - q * Cr)) * 4 : co * 4;
     }
     auto epilogue = [&](const Item& I, float* rbuf) {
-        const int th_valid = min(kTile, a.Ho - I.ty0), tw_valid = min(kTile, a.Wo - I.tx0);
+        const int th_valid = min(TH, a.Ho - I.ty0), tw_valid = min(kTW, a.Wo - I.tx0);
         if (a.stats) {
-            // per-WAVE partial sums of (x - c), (x - c)^2 over the wave's four tile rows, c = the wave's own first pixel of the
-            // channel; the four waves' records are merged when the next pipeline step starts (finalize below): no barrier here
+            // per-WAVE partial sums of (x - c), (x - c)^2 over the wave's 2*WM tile rows, c = the wave's own first pixel of the
+            // channel; the records of the WMW waves that share a channel are merged when the next pipeline step starts
+            // (finalize below): no barrier here
             float cs[NB], s1[NB], s2[NB];
 #pragma unroll
             for (int nn = 0; nn < NB; ++nn) {
@@ -225,9 +230,9 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
             if (lane < 32)
 #pragma unroll
                 for (int nn = 0; nn < NB; ++nn) {
-                    rbuf[(wave * 3 + 0) * BN + nn * 32 + lane] = s1[nn];
-                    rbuf[(wave * 3 + 1) * BN + nn * 32 + lane] = s2[nn];
-                    rbuf[(wave * 3 + 2) * BN + nn * 32 + lane] = cs[nn];
+                    rbuf[(mw * 3 + 0) * BN + (nbw * NB + nn) * 32 + lane] = s1[nn];
+                    rbuf[(mw * 3 + 1) * BN + (nbw * NB + nn) * 32 + lane] = s2[nn];
+                    rbuf[(mw * 3 + 2) * BN + (nbw * NB + nn) * 32 + lane] = cs[nn];
                 }
         }
         // stores through a buffer resource.  Byte offset = lane part (column, channel: a register, or the out-of-range offset
@@ -252,13 +257,13 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
         }
         zero_acc();
     };
-    // merge of the four per-wave records of one tile (Chan's update, fixed order) -> {mean, M2, count} of the tile
+    // merge of the per-wave records of one tile (Chan's update, fixed order) -> {mean, M2, count} of the tile
     auto finalize = [&](const Item& I, const float* rbuf) {
-        const int th_valid = min(kTile, a.Ho - I.ty0), tw_valid = min(kTile, a.Wo - I.tx0);
+        const int th_valid = min(TH, a.Ho - I.ty0), tw_valid = min(kTW, a.Wo - I.tx0);
         float cnt = 0.f, mean = 0.f, m2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int rows = min(4, max(0, th_valid - 4 * w));
+        for (int w = 0; w < WMW; ++w) {
+            const int rows = min(2 * WM, max(0, th_valid - 2 * WM * w));
             const float cb = (float)(rows * tw_valid);
             if (cb > 0.f) {
                 const float S1 = rbuf[(w * 3 + 0) * BN + tid], S2 = rbuf[(w * 3 + 1) * BN + tid], sh = rbuf[(w * 3 + 2) * BN + tid];
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     __syncthreads();
     for (int it = 0; it < my_items; ++it) {
         const bool more = it + 1 < my_items;
-        if (it > 0 && a.stats && tid < BN) finalize(prev, red + ((it - 1) & 1) * 12 * BN);
+        if (it > 0 && a.stats && tid < BN) finalize(prev, red + ((it - 1) & 1) * REDF);
         Item nxt = cur;
         if (more) {
             nxt = decode(it + 1);
@@ -294,23 +299,35 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
         sweep();
         __syncthreads();   // A: every wave is done reading the patch
         if (more) commit();
-        epilogue(cur, red + (it & 1) * 12 * BN);
+        epilogue(cur, red + (it & 1) * REDF);
         __syncthreads();   // B: next patch and this tile's statistics records visible
         prev = cur;
         cur = nxt;
     }
-    if (a.stats && tid < BN) finalize(prev, red + ((my_items - 1) & 1) * 12 * BN);
+    if (a.stats && tid < BN) finalize(prev, red + ((my_items - 1) & 1) * REDF);
 }
 
 // ------------------------------------------------------------------------------------------------------------ host
-static int cstream_instance(const ConvArgs& a) {   // 1: 16 -> 32 channels, 3x3 stride 2;  2: 32 -> 64 channels, 2x2 stride 1
-    if (a.Cin == 16 && a.Cout == 32 && a.KH == 3 && a.KW == 3 && a.stride == 2) return 1;
-    if (a.Cin == 32 && a.Cout == 64 && a.KH == 2 && a.KW == 2 && a.stride == 1) return 2;
+namespace {
+struct CsInst {
+    int Cin, Cout, KS, stride, TH;
+};
+// 1: 16 -> 32, 3x3/2 (initconv_1; gradient of the 32 -> 16 resize-conv)      2: 32 -> 64, 2x2/1 (32 -> 16 resize-conv; gradient of initconv_1)
+// 3: 32 -> 64, 3x3/2 (initconv_2; gradient of the 64 -> 32 resize-conv)      4: 64 -> 128, 2x2/1 (64 -> 32 resize-conv; gradient of initconv_2)
+const CsInst kInst[4] = {{16, 32, 3, 2, 16}, {32, 64, 2, 1, 16}, {32, 64, 3, 2, 8}, {64, 128, 2, 1, 8}};
+}  // namespace
+
+static int cstream_instance(const ConvArgs& a) {
+    for (int i = 0; i < 4; ++i)
+        if (a.Cin == kInst[i].Cin && a.Cout == kInst[i].Cout && a.KH == kInst[i].KS && a.KW == kInst[i].KS && a.stride == kInst[i].stride)
+            return i + 1;
     return 0;
 }
 
 bool cstream_eligible(const ConvArgs& a) {
-    if (!tune_int("FS_CSTREAM", 1) || !cstream_instance(a)) return false;
+    const int inst = cstream_instance(a);
+    if (!tune_int("FS_CSTREAM", 1) || !inst) return false;
+    if (!((tune_int("FS_CSTREAM_MASK", 15) >> (inst - 1)) & 1)) return false;   // tuning aid: bit i enables instance i+1
     const bool plain = a.src_mode == SRC_PLAIN && a.dil_x <= 1 && !a.bias && !a.out_relu && !a.add_src && !a.mask_src && !a.route_src &&
                        !a.pool_out && a.w_nstride == 0 && !a.w_wino && !a.w_wino2;
     if (!plain) return false;
@@ -318,24 +335,35 @@ bool cstream_eligible(const ConvArgs& a) {
     if (a.in_relu && !a.in_a) return false;   // (a ReLU on load only comes with its affine here)
     if (a.pad_t < 0 || a.pad_l < 0 || a.pad_t > 2 || a.pad_l > 2) return false;
     // persistence pays from about two tiles per workgroup on; smaller launches stay with the one-tile kernel
-    const long tiles = (long)a.N * cdiv(a.Ho, kTile) * cdiv(a.Wo, kTile);
+    const long tiles = (long)a.N * cdiv(a.Ho, kInst[inst - 1].TH) * cdiv(a.Wo, kTW);
     return tiles >= tune_int("FS_CSTREAM_MIN_TILES", 512);
 }
 
 void cstream_plan(const ConvArgs& a, ConvPlan* out) {
     ConvPlan p{};
+    const int inst = cstream_instance(a);
+    const int TH = inst ? kInst[inst - 1].TH : 16;
     p.variant = 7;
     p.BN = a.Cout;
     p.CC = a.Cin;
-    p.TH = p.TW = kTile;
-    p.tiles_y = cdiv(a.Ho, kTile);
-    p.tiles_x = cdiv(a.Wo, kTile);
-    p.PH = p.PW = (kTile - 1) * a.stride + a.KH;
+    p.TH = TH;
+    p.TW = kTW;
+    p.tiles_y = cdiv(a.Ho, TH);
+    p.tiles_x = cdiv(a.Wo, kTW);
+    p.PH = (TH - 1) * a.stride + a.KH;
+    p.PW = (kTW - 1) * a.stride + a.KW;
     p.S = a.Cin + 1;
     p.ksplit = 1;
     const int patch_floats = (p.PH * p.PW * p.S + 4 + 3) & ~3;
-    p.lds_bytes = 4 * (patch_floats + 2 * 12 * a.Cout);
+    p.lds_bytes = 4 * (patch_floats + 2 * 12 * a.Cout);   // (statistics buffers: at most 4 wave records x 3 x Cout, twice)
     *out = p;
+}
+
+template <int TH, int WN, int NB, int CIN, int KS, int STRIDE>
+static void cs_launch(const ConvArgs& a, unsigned grid, hipStream_t s) {
+    static BigLds lds_attr;
+    lds_attr.ensure(reinterpret_cast<const void*>(conv_stream_kernel<TH, WN, NB, CIN, KS, STRIDE>));
+    hipLaunchKernelGGL((conv_stream_kernel<TH, WN, NB, CIN, KS, STRIDE>), dim3(grid), dim3(256), (size_t)a.p.lds_bytes, s, a);
 }
 
 int cstream_launch(const ConvArgs& a, hipStream_t s) {
@@ -343,17 +371,12 @@ int cstream_launch(const ConvArgs& a, hipStream_t s) {
     const long total = (long)a.N * p.tiles_y * p.tiles_x;
     const int wgs = tune_int("FS_CSTREAM_WGS", 256);
     const unsigned grid = (unsigned)(total < wgs ? total : wgs);
-    const int inst = cstream_instance(a);
-    if (inst == 1) {
-        static BigLds lds_attr;
-        lds_attr.ensure(reinterpret_cast<const void*>(conv_stream_kernel<1, 16, 3, 2>));
-        hipLaunchKernelGGL((conv_stream_kernel<1, 16, 3, 2>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a);
-    } else if (inst == 2) {
-        static BigLds lds_attr;
-        lds_attr.ensure(reinterpret_cast<const void*>(conv_stream_kernel<2, 32, 2, 1>));
-        hipLaunchKernelGGL((conv_stream_kernel<2, 32, 2, 1>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a);
-    } else {
-        return -4;
+    switch (cstream_instance(a)) {
+        case 1: cs_launch<16, 1, 1, 16, 3, 2>(a, grid, s); break;   // 4 waves over the pixels; 72 filter registers
+        case 2: cs_launch<16, 1, 2, 32, 2, 1>(a, grid, s); break;   // 4 waves over the pixels; 128
+        case 3: cs_launch<8, 2, 1, 32, 3, 2>(a, grid, s); break;    // 2 x 2 waves; 144
+        case 4: cs_launch<8, 4, 1, 64, 2, 1>(a, grid, s); break;    // 4 waves over the channels, 4 pixel blocks each; 128
+        default: return -4;
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
