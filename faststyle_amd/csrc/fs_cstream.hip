@@ -334,9 +334,10 @@ bool cstream_eligible(const ConvArgs& a) {
     if (a.in_a && !a.in_b) return false;
     if (a.in_relu && !a.in_a) return false;   // (a ReLU on load only comes with its affine here)
     if (a.pad_t < 0 || a.pad_l < 0 || a.pad_t > 2 || a.pad_l > 2) return false;
-    // persistence pays from about two tiles per workgroup on; smaller launches stay with the one-tile kernel
+    // measured at batch 4 (256x256: 100-500 tiles, at most two per workgroup): still ahead of the one-tile kernel -- the
+    // resident filter and the cheap addresses count even without a second tile to prefetch; tiny launches stay with it
     const long tiles = (long)a.N * cdiv(a.Ho, kInst[inst - 1].TH) * cdiv(a.Wo, kTW);
-    return tiles >= tune_int("FS_CSTREAM_MIN_TILES", 512);
+    return tiles >= tune_int("FS_CSTREAM_MIN_TILES", 64);
 }
 
 void cstream_plan(const ConvArgs& a, ConvPlan* out) {
