@@ -1,0 +1,306 @@
+// Gram matrices of the style loss, second generation (reference utils.py:66-83:  G[n] = F[n]^T F[n] / (h*w*c) with
+// F[n] = the [h*w, c] feature map of sample n; tapped at conv1_2, conv2_2, conv3_3, conv4_3).
+//
+// Per sample a [C x HW] x [HW x C] product with a tiny result and a long reduction over the pixels.  What the first-generation
+// kernel (fs_wgrad.hip, per_sample) loses is the same thing as everywhere on this path: stage -> wait -> multiply -> store per
+// tile with nothing overlapped.  Here a workgroup owns ONE (sample, 128 x 128-channel output tile, pixel range) item for its
+// whole life and streams the pixels through a single LDS stage, 64 pixels at a time, with the next 64 pixels' loads in
+// flight during the sweep (registers -> one 16-byte LDS write per 16-byte load: the operand needs no transform).
+//   * A and B operands come from the SAME feature map: rows of the output tile are the channels of group I, columns those of
+//     group J; on the diagonal (I == J) one staged tile serves both and only the 10 of 16 32x32 blocks with j >= i are
+//     multiplied -- the result is symmetric, the reduction kernel mirrors it;
+//   * the four waves split the tile's BLOCKS, not its pixels: <= 4 blocks (64 accumulator registers) per wave, no
+//     cross-wave reduction, one partial slab per workgroup; two workgroups fit a CU;
+//   * v_mfma_f32_32x32x2_f32, K = a pair of pixels; partial slabs are summed in a fixed order (deterministic, no atomics).
+#include "fs_kernels.h"
+
+#include <type_traits>
+
+namespace fs {
+
+namespace {
+constexpr unsigned kOOB = 0x80000000u;
+// pixels per staged tile: 64 x 128 channels, or 256 x 64 channels (C = 64 multiplies one block per wave and pixel pair:
+// the longer tile gives the same matrix work between two barriers) -- 16-byte loads per thread, operand and tile: 8 / 16
+
+struct GramArgs {
+    const float* F;   // [N][HW][C]
+    float* slabs;     // [N][pairs][splits][CG*CG]
+    int N, HW, C;
+    int CG;           // channels per group: 64 (C = 64) or 128
+    int groups;       // C / CG
+    int pairs;        // groups*(groups+1)/2: output tiles (I <= J)
+    int splits;       // pixel ranges per (sample, tile)
+};
+}  // namespace
+
+template <int CG>
+__global__ __launch_bounds__(256, 2) void gram_stream_kernel(GramArgs a) {   // two workgroups per CU (<= 256 registers)
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 31, kq = lane >> 5;
+    constexpr int S = CG + 4, c4n = CG >> 2, c4sh = c4n == 16 ? 4 : 5;
+    constexpr int kGP = CG == 64 ? 256 : 64, kGL = kGP * c4n / 256;
+    float* const tA = smem;
+    float* const tB = smem + kGP * S;
+
+    // ---- the item of this workgroup: ((n * pairs + pair) * splits + split); pair -> (I, J), I <= J, row-major upper triangle
+    int lin = (int)blockIdx.x;
+    const int split = lin % a.splits;
+    lin /= a.splits;
+    int pair = lin % a.pairs;
+    const int n = lin / a.pairs;
+    int I = 0;
+    while (pair >= a.groups - I) {
+        pair -= a.groups - I;
+        ++I;
+    }
+    const int J = I + pair;
+    const bool diag = I == J;
+    const int p0 = (int)((long long)a.HW * split / a.splits), p1 = (int)((long long)a.HW * (split + 1) / a.splits);
+
+    // ---- the blocks of this wave: (ib[k], jb[k]), k < nb.  128-channel tile off the diagonal: row block = wave, all four column
+    // blocks; on the diagonal the ten blocks with j >= i are dealt 3, 3, 2, 2; 64-channel tile (C = 64): one block per wave.
+    int ib[4], jb[4], nb;
+    if (CG == 64) {
+        nb = 1;
+        ib[0] = wave >> 1;
+        jb[0] = wave & 1;
+        ib[1] = ib[2] = ib[3] = jb[1] = jb[2] = jb[3] = 0;
+    } else if (!diag) {
+        nb = 4;
+        for (int k = 0; k < 4; ++k) {
+            ib[k] = wave;
+            jb[k] = k;
+        }
+    } else {
+        // the ten (i, j), two bits each, in the order (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
+        constexpr unsigned TI = (1u << 8) | (1u << 10) | (1u << 12) | (2u << 14) | (2u << 16) | (3u << 18);
+        constexpr unsigned TJ = (1u << 2) | (2u << 4) | (3u << 6) | (1u << 8) | (2u << 10) | (3u << 12) | (2u << 14) | (3u << 16) | (3u << 18);
+        const int beg = wave == 0 ? 0 : (wave == 1 ? 3 : (wave == 2 ? 6 : 8));
+        nb = wave < 2 ? 3 : 2;
+        for (int k = 0; k < 4; ++k) {
+            const int kk = k < nb ? k : 0;   // (k >= nb: a redundant copy of the wave's first block, multiplied but never stored)
+            ib[k] = (int)((TI >> (2 * (beg + kk))) & 3u);
+            jb[k] = (int)((TJ >> (2 * (beg + kk))) & 3u);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ib[k] = __builtin_amdgcn_readfirstlane(ib[k]);
+        jb[k] = __builtin_amdgcn_readfirstlane(jb[k]);
+    }
+    nb = __builtin_amdgcn_readfirstlane(nb);
+
+    // ---- staging: element e = tid + i*256 of a 64-pixel x CG-channel tile: pixel e / (CG/4), channel quad e % (CG/4)
+    const unsigned f_bytes = __builtin_amdgcn_readfirstlane((unsigned)((size_t)a.HW * a.C * 4));
+    const float* Fn = a.F + (size_t)n * a.HW * a.C;
+    {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(Fn);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        Fn = reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    }
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Fn), 0, f_bytes, 0x00020000);
+    const int nel = kGP * c4n;                       // elements per operand tile: 1024 (CG = 64) or 2048
+    int epix[kGL], edst[kGL];
+    unsigned ecol[kGL];
+#pragma unroll
+    for (int i = 0; i < kGL; ++i) {
+        const int e = tid + i * 256;
+        const int pix = e >> c4sh, c4 = e & (c4n - 1);
+        epix[i] = e < nel ? pix : 0x40000000;        // (beyond the tile: never inside a pixel range -> no load, no write)
+        edst[i] = pix * S + c4 * 4;
+        ecol[i] = (unsigned)(c4 * 4) * 4u;
+    }
+    float4 va[kGL], vb[kGL];
+    auto issue = [&](int pbase) {   // pixels [pbase, pbase + 64) of the range; beyond p1: zeros (out-of-range offset)
+#pragma unroll
+        for (int i = 0; i < kGL; ++i) {
+            const int px = pbase + epix[i];
+            const bool ok = px < p1;
+            const unsigned rowb = (unsigned)px * (unsigned)a.C * 4u;
+            va[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(fr, ok ? rowb + (unsigned)(I * CG) * 4u + ecol[i] : kOOB, 0, 0));
+            if (!diag)
+                vb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(fr, ok ? rowb + (unsigned)(J * CG) * 4u + ecol[i] : kOOB, 0, 0));
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < kGL; ++i)
+            if (epix[i] < kGP) {
+                *reinterpret_cast<float4*>(tA + edst[i]) = va[i];
+                if (!diag) *reinterpret_cast<float4*>(tB + edst[i]) = vb[i];
+            }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    const int boff = diag ? 0 : kGP * S;   // (an integer offset: selecting between two LDS pointers makes them generic pointers)
+    // operand offsets of the wave's blocks (lane lm = channel inside the block, lane half kq = pixel of the pair)
+    int oa[4], ob[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        oa[k] = kq * S + ib[k] * 32 + lm;
+        ob[k] = boff + kq * S + jb[k] * 32 + lm;
+    }
+    // NBK blocks per wave, compile-time: a sweep without a branch between its matrix instructions (a wave-uniform `if` around
+    // each MFMA keeps the compiler from hoisting the LDS reads of the next pixel pair over it: measured 57 TFLOP/s).  The
+    // diagonal deal is 3, 3, 2, 2: the two waves with two blocks multiply a third, redundant one (block k = 2 repeats their
+    // first) that is never stored.
+    auto sweep = [&](auto NBKT) {
+        constexpr int NBK = decltype(NBKT)::value;
+        // fully unrolled: every operand address is a lane base + a compile-time offset (no address arithmetic in the sweep)
+#pragma unroll
+        for (int j0 = 0; j0 < kGP / 2; j0 += 4) {
+            float av[4][NBK], bv[4][NBK];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < NBK; ++k) {
+                    av[u][k] = smem[oa[k] + 2 * (j0 + u) * S];
+                    bv[u][k] = smem[ob[k] + 2 * (j0 + u) * S];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < NBK; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][k], bv[u][k], acc[k], 0, 0, 0);
+        }
+    };
+
+    // ---- the pipeline over the 64-pixel tiles of the range
+    const int ntiles = (p1 - p0 + kGP - 1) / kGP;
+    if (ntiles > 0) {
+        issue(p0);
+        commit();
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            const bool more = t + 1 < ntiles;
+            if (more) issue(p0 + (t + 1) * kGP);
+            if constexpr (CG == 64) {
+                sweep(std::integral_constant<int, 1>{});
+            } else {
+                if (diag)
+                    sweep(std::integral_constant<int, 3>{});
+                else
+                    sweep(std::integral_constant<int, 4>{});
+            }
+            __syncthreads();   // every wave is done reading the stage
+            if (more) commit();
+            __syncthreads();
+        }
+    }
+    // ---- the partial slab of this workgroup: [CG][CG], row = channel of group I, column = channel of group J
+    float* slab = a.slabs + (size_t)blockIdx.x * CG * CG;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k >= nb) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = ib[k] * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+            slab[row * CG + jb[k] * 32 + lm] = acc[k][r];
+        }
+    }
+}
+
+// G[n][(I*CG + r)*C + J*CG + c] = scale * sum over the pixel ranges, and its mirror image.  grid (CG*CG/1024, pairs, N); a thread
+// owns 4 consecutive columns of one row.  On a diagonal tile the blocks below the diagonal were never multiplied: their
+// elements arrive as the mirror of the blocks above.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(GramArgs a, float scale, float* __restrict__ G) {
+    const int CG = a.CG;
+    const int e4 = (int)blockIdx.x * 256 + (int)threadIdx.x;   // float4 index inside the tile
+    if (e4 * 4 >= CG * CG) return;
+    const int r = (e4 * 4) / CG, c = (e4 * 4) - r * CG;
+    int pair = (int)blockIdx.y, I = 0;
+    while (pair >= a.groups - I) {
+        pair -= a.groups - I;
+        ++I;
+    }
+    const int J = I + pair, n = (int)blockIdx.z;
+    if (I == J && CG == 128 && (r >> 5) > (c >> 5)) return;
+    const float* p = a.slabs + (((size_t)n * a.pairs + blockIdx.y) * a.splits) * CG * CG + (size_t)r * CG + c;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < a.splits; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * CG * CG);
+        s.x += v.x;
+        s.y += v.y;
+        s.z += v.z;
+        s.w += v.w;
+    }
+    s.x *= scale;
+    s.y *= scale;
+    s.z *= scale;
+    s.w *= scale;
+    float* Gn = G + (size_t)n * a.C * a.C;
+    const int gr = I * CG + r, gc = J * CG + c;
+    *reinterpret_cast<float4*>(Gn + (size_t)gr * a.C + gc) = s;
+    const bool mirror = I != J || (CG == 128 && (r >> 5) < (c >> 5));   // (blocks ON the diagonal hold both halves already)
+    if (mirror) {
+        Gn[(size_t)(gc + 0) * a.C + gr] = s.x;
+        Gn[(size_t)(gc + 1) * a.C + gr] = s.y;
+        Gn[(size_t)(gc + 2) * a.C + gr] = s.z;
+        Gn[(size_t)(gc + 3) * a.C + gr] = s.w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ host
+static bool gram2_shape(int N, int HW, int C, GramArgs* out) {
+    if (!(C == 64 || (C % 128 == 0 && C <= 1024)) || N < 1 || HW < 1) return false;
+    if ((size_t)HW * C * 4 >= 0x80000000ull) return false;   // (32-bit byte offsets inside one sample)
+    GramArgs a{};
+    a.N = N;
+    a.HW = HW;
+    a.C = C;
+    a.CG = C == 64 ? 64 : 128;
+    a.groups = C / a.CG;
+    a.pairs = a.groups * (a.groups + 1) / 2;
+    // pixel ranges: enough items for ~3 waves of workgroups over the chip, at least ~4 staged tiles each
+    int splits = 1;
+    const int target = tune_int("FS_GRAM2_ITEMS", 768);
+    while ((long)N * a.pairs * splits < target && HW / (splits * 2) >= 4 * (a.CG == 64 ? 256 : 64)) splits *= 2;
+    a.splits = splits;
+    *out = a;
+    return true;
+}
+
+bool gram2_eligible(int N, int HW, int C) {
+    GramArgs a;
+    return tune_int("FS_GRAM2", 1) != 0 && gram2_shape(N, HW, C, &a);
+}
+
+size_t gram2_slab_floats(int N, int HW, int C) {
+    GramArgs a;
+    if (!gram2_shape(N, HW, C, &a)) return 0;
+    return (size_t)N * a.pairs * a.splits * a.CG * a.CG;
+}
+
+// G[n] = scale * F[n]^T F[n]; slabs: gram2_slab_floats(N, HW, C) floats of scratch
+int gram2_launch(const float* F, float* G, float* slabs, int N, int HW, int C, float scale, hipStream_t s) {
+    GramArgs a;
+    if (!gram2_shape(N, HW, C, &a)) return -1;
+    a.F = F;
+    a.slabs = slabs;
+    const size_t lds = a.CG == 64 ? (size_t)256 * 68 * sizeof(float) : (size_t)2 * 64 * 132 * sizeof(float);
+    Profiler* prof = Profiler::current();
+    // FLOPs EXECUTED: diagonal 128-channel tiles multiply 10 of their 16 blocks
+    const double blocks = a.CG == 64 ? 4.0 * 1 : (16.0 * (a.pairs - a.groups) + 10.0 * a.groups);
+    if (prof) prof->begin(7, 2.0 * N * (double)HW * 32.0 * 32.0 * blocks, s);
+    if (a.CG == 64) {
+        static BigLds lds_attr;
+        lds_attr.ensure(reinterpret_cast<const void*>(gram_stream_kernel<64>));
+        hipLaunchKernelGGL(gram_stream_kernel<64>, dim3((unsigned)(N * a.pairs * a.splits)), dim3(256), lds, s, a);
+    } else {
+        static BigLds lds_attr;
+        lds_attr.ensure(reinterpret_cast<const void*>(gram_stream_kernel<128>));
+        hipLaunchKernelGGL(gram_stream_kernel<128>, dim3((unsigned)(N * a.pairs * a.splits)), dim3(256), lds, s, a);
+    }
+    if (prof) prof->end(s);
+    if (hipGetLastError() != hipSuccess) return -3;
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)cdiv(a.CG * a.CG / 4, 256), (unsigned)a.pairs, (unsigned)N), dim3(256), 0, s, a, scale, G);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace fs

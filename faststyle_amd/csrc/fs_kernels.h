@@ -273,6 +273,10 @@ bool conv_route_ok(const ConvArgs& a);   // a.p filled: can the launch take a.ro
 bool wino2_eligible(const ConvArgs& a);
 void wino2_plan(const ConvArgs& a, ConvPlan* out);
 int wino2_launch(const ConvArgs& a, hipStream_t s);
+// second-generation Gram matrices (fs_gram.hip): G[n] = scale * F[n]^T F[n], F [N][HW][C], C = 64 or a multiple of 128
+bool gram2_eligible(int N, int HW, int C);
+size_t gram2_slab_floats(int N, int HW, int C);
+int gram2_launch(const float* F, float* G, float* slabs, int N, int HW, int C, float scale, hipStream_t s);
 // streaming conv of the narrow full-resolution layers (fs_cstream.hip): plan variant 7
 bool cstream_eligible(const ConvArgs& a);
 void cstream_plan(const ConvArgs& a, ConvPlan* out);

@@ -136,6 +136,8 @@ void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, 
         const WgradPlan p = wgrad_plan(ga);
         const size_t sl = (size_t)N * p.n_slabs * C * C;
         if (sl > max_slab) max_slab = sl;
+        const size_t sl2 = gram2_slab_floats(N, L->Hl[l] * L->Wl[l], C);   // the streaming kernel's partial slabs (fs_gram.hip)
+        if (sl2 > max_slab) max_slab = sl2;
     }
     L->slabs = b.take(max_slab);
     L->d_pre = b.take(max_act);
@@ -229,6 +231,8 @@ static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS],
 
 static int gram_forward(const VggLayout& L, int l, const float* F, float* G, float* ws, hipStream_t s) {
     const int C = kCout[l], H = L.Hl[l], W = L.Wl[l];
+    if (gram2_eligible(L.N, H * W, C))   // streaming kernel (fs_gram.hip)
+        return gram2_launch(F, G, ws + L.slabs, L.N, H * W, C, 1.0f / ((float)H * W * C), s);
     WgradArgs ga = gram_args(L.N, H, W, C);
     ga.x = F;
     ga.dy = F;
