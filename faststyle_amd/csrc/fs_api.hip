@@ -494,9 +494,16 @@ static int fill_wgrad(fs_wgrad_desc* d, fs::WgradArgs* a) {
     return 0;
 }
 
+// the Gram case of fs_conv2d_wgrad (per-sample 1x1 "filter gradient" of a tensor with itself): streaming kernel, fs_gram.hip
+static bool is_gram2(const fs::WgradArgs& a) {
+    return a.per_sample && a.x == a.dy && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.Cin == a.Cout && !a.in_a && !a.dy_a &&
+           a.src_mode == fs::SRC_PLAIN && a.H == a.Ho && a.W == a.Wo && fs::gram2_eligible(a.N, a.H * a.W, a.Cin);
+}
+
 size_t fs_conv2d_wgrad_workspace_bytes(fs_wgrad_desc* d) {
     fs::WgradArgs a;
     if (fill_wgrad(d, &a)) return 0;
+    if (is_gram2(a)) return fs::gram2_slab_floats(a.N, a.H * a.W, a.Cin) * sizeof(float);
     fs::Wg2Args w2;
     if (const size_t f = fs::wgrad2_plan(&a, 1, &w2)) return f * sizeof(float);   // second-generation kernel (fs_wgrad2.hip)
     return (size_t)(a.per_sample ? a.N : 1) * a.p.n_slabs * a.p.K * a.Cout * sizeof(float);
@@ -507,6 +514,11 @@ int fs_conv2d_wgrad(fs_ctx* ctx, fs_wgrad_desc* d, void* ws, size_t ws_bytes) {
     fs::WgradArgs a;
     if (int rc = fill_wgrad(d, &a)) return rc;
     if (!a.x || !a.dy || !d->dw) return fail(-1, "fs_conv2d_wgrad: null tensor");
+    if (is_gram2(a)) {
+        if (ws_bytes < fs::gram2_slab_floats(a.N, a.H * a.W, a.Cin) * sizeof(float)) return fail(-3, "fs_conv2d_wgrad: workspace too small");
+        const int rc2 = fs::gram2_launch(a.x, d->dw, (float*)ws, a.N, a.H * a.W, a.Cin, d->scale, ctx->stream);
+        return rc2 ? fail(rc2, "fs_conv2d_wgrad: launch failed (%d)", rc2) : 0;
+    }
     fs::Wg2Args w2;
     if (const size_t f = fs::wgrad2_plan(&a, 1, &w2)) {
         if (ws_bytes < f * sizeof(float)) return fail(-3, "fs_conv2d_wgrad: workspace too small");

@@ -260,7 +260,8 @@ static bool gram2_shape(int N, int HW, int C, GramArgs* out) {
     // pixel ranges: enough items for ~3 waves of workgroups over the chip, at least ~4 staged tiles each
     int splits = 1;
     const int target = tune_int("FS_GRAM2_ITEMS", 768);
-    while ((long)N * a.pairs * splits < target && HW / (splits * 2) >= 4 * (a.CG == 64 ? 256 : 64)) splits *= 2;
+    const int min_px = tune_int("FS_GRAM2_MIN_TILES", 4) * (a.CG == 64 ? 256 : 64);   // (tests lower it: several ranges on small maps)
+    while ((long)N * a.pairs * splits < target && HW / (splits * 2) >= (min_px > 1 ? min_px : 1)) splits *= 2;
     a.splits = splits;
     *out = a;
     return true;

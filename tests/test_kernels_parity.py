@@ -212,6 +212,26 @@ def test_gram_is_symmetric_psd_and_matches_oracle(eng, hw, c):
     assert ev.min() > -1e-5 * ev.max()
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 37, 256), (1, 30, 31, 64), (3, 17, 9, 128), (1, 12, 11, 384)])
+def test_gram_streaming_kernel_pixel_ranges_and_tile_pairs(eng, shape, monkeypatch):
+    """fs_gram.hip: several pixel ranges per (sample, tile) with ragged ends (range and 64 / 256-pixel tile boundaries inside
+    the map), off-diagonal 128-channel tile pairs and their mirrored halves (C = 256, 384), the symmetric diagonal deal."""
+    monkeypatch.setenv("FS_GRAM2_MIN_TILES", "0")
+    monkeypatch.setenv("FS_GRAM2_ITEMS", "64")
+    eng.lib.fs_debug_reload_env()
+    try:
+        rng = np.random.default_rng(11)
+        f = rng.standard_normal(shape).astype(np.float32)
+        g = down(eng, eng.gram(up(eng, f)))
+        want = perceptual.gram(f.astype(np.float64))
+        assert g.shape == want.shape
+        assert rel(g, want) < TOL
+        assert np.array_equal(g, g.transpose(0, 2, 1))      # mirrored, not recomputed: exactly symmetric off the diagonal blocks
+    finally:
+        monkeypatch.undo()
+        eng.lib.fs_debug_reload_env()
+
+
 # ------------------------------------------------------------------ full-size properties (no CPU oracle at these sizes)
 FULL = [("vgg3_2_b8", (8, 64, 64, 256), 256, 3, 1), ("vgg1_2_b8", (8, 256, 256, 64), 64, 3, 1),
         ("vgg4_2_b4", (4, 32, 32, 512), 512, 3, 1), ("initconv_1_b4", (4, 336, 336, 16), 32, 3, 2),
