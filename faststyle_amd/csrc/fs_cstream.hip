@@ -164,21 +164,30 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
                 for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
     };
     zero_acc();
-    // the sweep is fully unrolled: every A address is the lane's base + a compile-time offset, B comes from registers
+    // the sweep is fully unrolled: every A address is the lane's base + a compile-time offset, B comes from registers.  Explicit
+    // software pipeline pinned with sched_barrier: the A operands of step j + D are read before the matrix instructions of
+    // step j (the compiler's own schedule waits for every read right before its MFMA)
+    auto aoff = [&](int j) { return (((j / (CIN / 2)) / KS) * PW + ((j / (CIN / 2)) % KS)) * S + 2 * (j % (CIN / 2)); };
     auto sweep = [&]() {
+        constexpr int D = WM * NB >= 8 ? 1 : (WM * NB >= 4 ? 2 : 3);
+        float av[D + 1][WM];
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+        for (int d = 0; d < D; ++d)
 #pragma unroll
-            for (int q = 0; q < CIN / 2; ++q) {
-                float av[WM];
+            for (int m = 0; m < WM; ++m) av[d][m] = smem[laneA[m] + aoff(d)];
 #pragma unroll
-                for (int m = 0; m < WM; ++m) av[m] = smem[laneA[m] + ((g / KS) * PW + (g % KS)) * S + 2 * q];
+        for (int j = 0; j < KSTEPS; ++j) {
+            if (j + D < KSTEPS) {
 #pragma unroll
-                for (int m = 0; m < WM; ++m)
-#pragma unroll
-                    for (int nn = 0; nn < NB; ++nn)
-                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], breg[g * (CIN / 2) + q][nn], acc[m][nn], 0, 0, 0);
+                for (int m = 0; m < WM; ++m) av[(j + D) % (D + 1)][m] = smem[laneA[m] + aoff(j + D)];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nn = 0; nn < NB; ++nn)
+#pragma unroll
+                for (int m = 0; m < WM; ++m) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j % (D + 1)][m], breg[j][nn], acc[m][nn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     // ---- epilogue of one item

@@ -153,21 +153,30 @@ __global__ __launch_bounds__(256, 2) void gram_stream_kernel(GramArgs a) {   // 
     // first) that is never stored.
     auto sweep = [&](auto NBKT) {
         constexpr int NBK = decltype(NBKT)::value;
-        // fully unrolled: every operand address is a lane base + a compile-time offset (no address arithmetic in the sweep)
+        // fully unrolled, every operand address a lane base + a compile-time offset; explicit software pipeline pinned with
+        // sched_barrier: the operands of pixel pair j + D are read before the matrix instructions of pair j
+        constexpr int D = NBK >= 3 ? 2 : 3;
+        float av[D + 1][NBK], bv[D + 1][NBK];
 #pragma unroll
-        for (int j0 = 0; j0 < kGP / 2; j0 += 4) {
-            float av[4][NBK], bv[4][NBK];
+        for (int d = 0; d < D; ++d)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int k = 0; k < NBK; ++k) {
+                av[d][k] = smem[oa[k] + 2 * d * S];
+                bv[d][k] = smem[ob[k] + 2 * d * S];
+            }
+#pragma unroll
+        for (int j = 0; j < kGP / 2; ++j) {
+            if (j + D < kGP / 2) {
 #pragma unroll
                 for (int k = 0; k < NBK; ++k) {
-                    av[u][k] = smem[oa[k] + 2 * (j0 + u) * S];
-                    bv[u][k] = smem[ob[k] + 2 * (j0 + u) * S];
+                    av[(j + D) % (D + 1)][k] = smem[oa[k] + 2 * (j + D) * S];
+                    bv[(j + D) % (D + 1)][k] = smem[ob[k] + 2 * (j + D) * S];
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int k = 0; k < NBK; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][k], bv[u][k], acc[k], 0, 0, 0);
+            for (int k = 0; k < NBK; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j % (D + 1)][k], bv[j % (D + 1)][k], acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -246,6 +255,173 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramArgs a, float scal
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Gradient of the style loss through a Gram matrix (the adjoint of utils.py:76-82 behind train.py:203):
+//     dF[n] = F[n] . S[n]   (+ an optional addend: the content-loss gradient of a layer that carries both terms),
+// S[n] = 4 w (G[n] - G_target) / (c^2 h w c), symmetric [C x C] -- a 1x1 convolution with per-sample filters.  Streaming form
+// (cf. fs_cstream.hip): a workgroup owns a contiguous range of pixel tiles of ONE sample (and, for C = 256, one half of the
+// output channels), keeps its slice of S[n] in REGISTERS (K/2 x NB values per lane), and runs tile after tile through one LDS
+// stage with the next tile's loads in flight during the sweep.
+//   C =  64: tile 256 pixels, waves 4 x 1 over (pixel blocks x channel blocks), 2 x 2 blocks per wave,  64 filter registers
+//   C = 128: tile 256 pixels, waves 1 x 4, 8 x 1 blocks per wave,                                        64
+//   C = 256: tile 128 pixels, waves 1 x 4, 4 x 1 blocks per wave, two workgroup groups (128 channels each), 128
+namespace {
+struct GramBwdArgs {
+    const float* F;     // [N][HW][C]
+    const float* S;     // [N][C][C]
+    const float* add;   // optional [N][HW][C]
+    float* dF;          // [N][HW][C]
+    int N, HW, C;
+    int wpg;            // workgroups per (sample, channel half)
+};
+}  // namespace
+
+template <int C, int WN, int TPX>
+__global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    constexpr int NH = C > 128 ? C / 128 : 1;              // channel halves (workgroup groups)
+    constexpr int CW = C / NH;                             // output channels of one workgroup
+    constexpr int WMW = 4 / WN, NB = CW / 32 / WN, WM = TPX / 32 / WMW;
+    constexpr int S = C + 1, C4 = C / 4, KSTEPS = C / 2;
+    constexpr int C4SH = C4 == 16 ? 4 : (C4 == 32 ? 5 : 6);
+    constexpr int SX = TPX * C4 / 256;                     // 16-byte loads per thread and tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 31, kq = lane >> 5;
+    const int mw = wave % WMW, nbw = wave / WMW;
+    // ---- this workgroup: sample n, channel half nh, tiles [t_beg, t_end) of the sample
+    int lin = (int)blockIdx.x;
+    const int wi = lin % a.wpg;
+    lin /= a.wpg;
+    const int nh = lin % NH, n = lin / NH;
+    const int tiles = (a.HW + TPX - 1) / TPX;
+    const int t_beg = (int)((long long)tiles * wi / a.wpg), t_end = (int)((long long)tiles * (wi + 1) / a.wpg);
+    if (t_beg >= t_end) return;
+    const int co0 = nh * CW + nbw * NB * 32;               // first output channel of this wave
+
+    // ---- S[n] rows k = 2j + kq, columns co0 + nn*32 + lm: resident for the workgroup's lifetime
+    const float* Sn = a.S + (size_t)n * C * C;
+    float breg[KSTEPS][NB];
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j)
+#pragma unroll
+        for (int nn = 0; nn < NB; ++nn) breg[j][nn] = Sn[(2 * j + kq) * C + co0 + nn * 32 + lm];
+
+    int laneA[WM];
+#pragma unroll
+    for (int m = 0; m < WM; ++m) laneA[m] = ((mw * WM + m) * 32 + lm) * S + kq;
+
+    const float* Fn = a.F + (size_t)n * a.HW * C;
+    {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(Fn);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        Fn = reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    }
+    const unsigned f_bytes = __builtin_amdgcn_readfirstlane((unsigned)((size_t)a.HW * C * 4));
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Fn), 0, f_bytes, 0x00020000);
+    // staging: element e = tid + i*256 = (pixel e / C4, channel quad e % C4): consecutive threads read consecutive 16 bytes
+    float4 pv[SX];
+    auto issue = [&](int t) {
+        const unsigned base = (unsigned)(t * TPX) * (unsigned)(C * 4);
+#pragma unroll
+        for (int i = 0; i < SX; ++i) {   // (pixels beyond the map: out-of-range offset -> zeros)
+            const unsigned off = base + (unsigned)(tid + i * 256) * 16u;
+            pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(fr, off < f_bytes ? off : kOOB, 0, 0));
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < SX; ++i) {
+            const int e = tid + i * 256;
+            float* d = smem + (e >> C4SH) * S + (e & (C4 - 1)) * 4;
+            d[0] = pv[i].x;
+            d[1] = pv[i].y;
+            d[2] = pv[i].z;
+            d[3] = pv[i].w;
+        }
+    };
+    f32x16 acc[WM][NB];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int nn = 0; nn < NB; ++nn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+    };
+    zero_acc();
+    // explicit software pipeline, pinned with sched_barrier: the A operands of pixel-pair step q + D are read before the matrix
+    // instructions of step q.  (Left to itself the compiler, short of registers, emits read -> wait -> two DEPENDENT MFMAs
+    // per operand: measured 2.3x the matrix time.)
+    auto sweep = [&]() {
+        constexpr int D = WM >= 4 ? 1 : 2;
+        float av[D + 1][WM];
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int m = 0; m < WM; ++m) av[d][m] = smem[laneA[m] + 2 * d];
+#pragma unroll
+        for (int q = 0; q < KSTEPS; ++q) {
+            if (q + D < KSTEPS) {
+#pragma unroll
+                for (int m = 0; m < WM; ++m) av[(q + D) % (D + 1)][m] = smem[laneA[m] + 2 * (q + D)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nn = 0; nn < NB; ++nn)
+#pragma unroll
+                for (int m = 0; m < WM; ++m) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q % (D + 1)][m], breg[q][nn], acc[m][nn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    float* dFn = a.dF + (size_t)n * a.HW * C;
+    {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(dFn);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        dFn = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+    }
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(dFn, 0, f_bytes, 0x00020000);
+    const float* addn = a.add ? a.add + (size_t)n * a.HW * C : nullptr;
+    auto epilogue = [&](int t) {
+        // accumulator register r of lane (lm, kq): pixel (mw*WM + m)*32 + (r & 3) + 8 (r >> 2) + 4 kq of the tile, channel co0 + nn*32 + lm.
+        // Byte offset = lane part + compile-time part; pixels beyond the map get the out-of-range offset and are dropped.
+        const unsigned lane_off = ((unsigned)(t * TPX + mw * WM * 32 + 4 * kq) * (unsigned)C + (unsigned)(co0 + lm)) * 4u;
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int nn = 0; nn < NB; ++nn) {
+                float ad[16];
+                if (addn) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned off = lane_off + (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * C + nn * 32) * 4u;
+                        ad[r] = off < f_bytes ? addn[off >> 2] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned off = lane_off + (unsigned)((m * 32 + (r & 3) + 8 * (r >> 2)) * C + nn * 32) * 4u;
+                    float v = acc[m][nn][r];
+                    if (addn) v += ad[r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, off < f_bytes ? off : kOOB, 0, 0);
+                }
+            }
+        zero_acc();
+    };
+    issue(t_beg);
+    commit();
+    __syncthreads();
+    for (int t = t_beg; t < t_end; ++t) {
+        const bool more = t + 1 < t_end;
+        if (more) issue(t + 1);
+        sweep();
+        __syncthreads();
+        if (more) commit();
+        epilogue(t);
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------ host
 static bool gram2_shape(int N, int HW, int C, GramArgs* out) {
     if (!(C == 64 || (C % 128 == 0 && C <= 1024)) || N < 1 || HW < 1) return false;
@@ -301,6 +477,51 @@ int gram2_launch(const float* F, float* G, float* slabs, int N, int HW, int C, f
     if (prof) prof->end(s);
     if (hipGetLastError() != hipSuccess) return -3;
     hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)cdiv(a.CG * a.CG / 4, 256), (unsigned)a.pairs, (unsigned)N), dim3(256), 0, s, a, scale, G);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+
+bool gram_bwd2_eligible(int N, int HW, int C) {
+    if (!tune_int("FS_GRAM_BWD2", 1) || N < 1 || HW < 1) return false;
+    if (!(C == 64 || C == 128 || C == 256)) return false;
+    return (size_t)HW * C * 4 < 0x7F000000ull;   // 32-bit byte offsets inside one sample, with room for a tile of overshoot
+}
+
+// dF[n] = F[n] S[n] (+ add[n])
+int gram_bwd2_launch(const float* F, const float* S, const float* add, float* dF, int N, int HW, int C, hipStream_t s) {
+    if (!gram_bwd2_eligible(N, HW, C)) return -1;
+    GramBwdArgs a{};
+    a.F = F;
+    a.S = S;
+    a.add = add;
+    a.dF = dF;
+    a.N = N;
+    a.HW = HW;
+    a.C = C;
+    const int NH = C > 128 ? C / 128 : 1, TPX = C == 256 ? 128 : 256;
+    const int tiles = cdiv(HW, TPX);
+    int wpg = tune_int("FS_GRAM_BWD2_WGS", 256) / (N * NH);
+    if (wpg < 1) wpg = 1;
+    if (wpg > tiles) wpg = tiles;
+    a.wpg = wpg;
+    const unsigned grid = (unsigned)(N * NH * wpg);
+    const size_t lds = (size_t)TPX * (C + 1) * sizeof(float);
+    Profiler* prof = Profiler::current();
+    if (prof) prof->begin(8, 2.0 * N * (double)HW * C * C, s);
+    if (C == 64) {
+        static BigLds lds_attr;
+        lds_attr.ensure(reinterpret_cast<const void*>(gram_bwd_kernel<64, 1, 256>));
+        hipLaunchKernelGGL((gram_bwd_kernel<64, 1, 256>), dim3(grid), dim3(256), lds, s, a);
+    } else if (C == 128) {
+        static BigLds lds_attr;
+        lds_attr.ensure(reinterpret_cast<const void*>(gram_bwd_kernel<128, 4, 256>));
+        hipLaunchKernelGGL((gram_bwd_kernel<128, 4, 256>), dim3(grid), dim3(256), lds, s, a);
+    } else {
+        static BigLds lds_attr;
+        lds_attr.ensure(reinterpret_cast<const void*>(gram_bwd_kernel<256, 4, 128>));
+        hipLaunchKernelGGL((gram_bwd_kernel<256, 4, 128>), dim3(grid), dim3(256), lds, s, a);
+    }
+    if (prof) prof->end(s);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -277,6 +277,9 @@ int wino2_launch(const ConvArgs& a, hipStream_t s);
 bool gram2_eligible(int N, int HW, int C);
 size_t gram2_slab_floats(int N, int HW, int C);
 int gram2_launch(const float* F, float* G, float* slabs, int N, int HW, int C, float scale, hipStream_t s);
+// ... and the gradient through them: dF[n] = F[n] S[n] (+ add[n]), S [N][C][C], C = 64, 128 or 256
+bool gram_bwd2_eligible(int N, int HW, int C);
+int gram_bwd2_launch(const float* F, const float* S, const float* add, float* dF, int N, int HW, int C, hipStream_t s);
 // streaming conv of the narrow full-resolution layers (fs_cstream.hip): plan variant 7
 bool cstream_eligible(const ConvArgs& a);
 void cstream_plan(const ConvArgs& a, ConvPlan* out);

@@ -348,7 +348,10 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
                         return 0;
                     }
                 }
-                FS_TRY(conv_launch(a, s));
+                if (gram_bwd2_eligible(N, H * W, C))   // streaming kernel with S[n] in registers (fs_gram.hip)
+                    FS_TRY(gram_bwd2_launch(a.x, a.w, a.add_src, dst, N, H * W, C, s));
+                else
+                    FS_TRY(conv_launch(a, s));
                 tap = dst;
             }
         *out = tap;
