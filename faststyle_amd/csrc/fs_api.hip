@@ -431,6 +431,13 @@ int fs_conv2d_fwd(fs_ctx* ctx, fs_conv_desc* d) {
     fs::ConvArgs a;
     if (int rc = fill_conv(d, &a)) return rc;
     if (!a.x || !a.w || !a.y) return fail(-1, "fs_conv2d_fwd: null tensor");
+    // 1x1 convolution with one C x C filter per sample (+ optional addend): the gradient through a Gram matrix, fs_gram.hip
+    if (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.Cin == a.Cout && a.w_nstride == (long long)a.Cin * a.Cout && a.src_mode == fs::SRC_PLAIN &&
+        !a.in_a && !a.bias && !a.out_relu && !a.shuffle && !a.stats && !a.mask_src && a.add_pad == 0 && a.H == a.Ho && a.W == a.Wo &&
+        fs::gram_bwd2_eligible(a.N, a.H * a.W, a.Cin)) {
+        const int rc0 = fs::gram_bwd2_launch(a.x, a.w, a.add_src, a.y, a.N, a.H * a.W, a.Cin, ctx->stream);
+        return rc0 ? fail(rc0, "fs_conv2d_fwd: launch failed (%d)", rc0) : 0;
+    }
     // 3x3 SAME, 64 -> 3 channels (the shape of VGG conv1_1's input gradient): vector-ALU kernel, fs_c3.hip
     const int rc = fs::conv3x3_to3_eligible(a) ? fs::conv3x3_to3_launch(a, ctx->stream) : fs::conv_launch(a, ctx->stream);
     return rc ? fail(rc, "fs_conv2d_fwd: launch failed (%d)", rc) : 0;

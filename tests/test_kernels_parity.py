@@ -232,6 +232,27 @@ def test_gram_streaming_kernel_pixel_ranges_and_tile_pairs(eng, shape, monkeypat
         eng.lib.fs_debug_reload_env()
 
 
+@pytest.mark.parametrize("shape", [(2, 19, 23, 64), (3, 16, 17, 128), (2, 9, 31, 256), (1, 1, 1, 64)])
+@pytest.mark.parametrize("with_add", [False, True])
+def test_gram_gradient_streaming_kernel(eng, shape, with_add):
+    """dF[n] = F[n] S[n] (+ addend): the 1x1 convolution with one C x C filter per sample behind the style-loss gradient
+    (fs_gram.hip gram_bwd_kernel; C = 64 / 128 / 256, ragged last pixel tile, several workgroups per sample)."""
+    rng = np.random.default_rng(13)
+    n, h, w, c = shape
+    x = rng.standard_normal(shape).astype(np.float32)
+    s = (rng.standard_normal((n, c, c)) * 0.1).astype(np.float32)
+    add = rng.standard_normal(shape).astype(np.float32) if with_add else None
+    kw = {"w_nstride": c * c}
+    if with_add:
+        kw["add_src"] = up(eng, add)
+    y = down(eng, eng.conv2d(up(eng, x), up(eng, s.reshape(n, 1, 1, c, c)), 1, "SAME", **kw))
+    want = np.einsum("nhwc,ncd->nhwd", x.astype(np.float64), s.astype(np.float64))
+    if with_add:
+        want = want + add
+    assert y.shape == want.shape
+    assert rel(y, want) < TOL
+
+
 # ------------------------------------------------------------------ full-size properties (no CPU oracle at these sizes)
 FULL = [("vgg3_2_b8", (8, 64, 64, 256), 256, 3, 1), ("vgg1_2_b8", (8, 256, 256, 64), 64, 3, 1),
         ("vgg4_2_b4", (4, 32, 32, 512), 512, 3, 1), ("initconv_1_b4", (4, 336, 336, 16), 32, 3, 2),
