@@ -398,7 +398,11 @@ def main():
                          "frac_of_f32_mfma_peak": round(gram_fl / (gram_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if gram_ms else None,
                          "forward_tflops": per_kernel.get(names[7], {}).get("tflops"),
                          "backward_tflops": per_kernel.get(names[8], {}).get("tflops"),
-                         "note": "G = F^T F/(hwc) per sample on 4 layers (utils.py:66-83) and dF = F (dG+dG^T); 4.295 GFLOP/img as written"},
+                         "gflop_as_written_per_step": round(4.295 * batch, 2),
+                         "tflops_as_written": round(4.295 * batch / gram_ms, 2) if gram_ms else None,
+                         "note": "G = F^T F/(hwc) per sample on 4 layers (utils.py:66-83) and dF = F (dG+dG^T); 4.295 GFLOP/img as written. "
+                                 "gflop_per_step / tflops / frac count the FLOPs EXECUTED: the forward kernel multiplies 10 of the 16 "
+                                 "32x32 blocks of a diagonal 128x128 tile (the result is symmetric), everything else in full"},
                 "vgg_gram_substep": {"ms": perc_ms, "gflop_executed": round(perc_gflop, 1),
                                      "tflops_executed": round(perc_gflop / perc_ms, 2),
                                      "frac_executed": round(perc_gflop / perc_ms / PEAK_F32_MFMA_TFLOPS, 4),

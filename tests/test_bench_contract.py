@@ -33,7 +33,9 @@ def test_bench_json_contract():
     assert set(r["per_kernel"]) >= {"wino_conv_kernel", "conv_wgrad_kernel", "conv_wgrad_kernel (Gram forward)",
                                     "conv_igemm_kernel (Gram backward)"}
     g = d["gram"]
-    assert 0.0 < g["frac_of_f32_mfma_peak"] < 1.0 and abs(g["gflop_per_step"] - 4.295 * 32) / (4.295 * 32) < 0.02
+    # executed FLOPs: the symmetric diagonal tiles of the forward product are multiplied 10/16 -> between 75 % and 100 % of as-written
+    assert 0.0 < g["frac_of_f32_mfma_peak"] < 1.0 and 0.75 * 4.295 * 32 < g["gflop_per_step"] < 1.02 * 4.295 * 32
+    assert abs(g["gflop_as_written_per_step"] - 4.295 * 32) < 0.1 and g["tflops_as_written"] >= g["tflops"]
     v = d["vgg_gram_substep"]
     assert 0.0 < v["frac_executed"] < 1.0 and v["ms"] < d["ms_per_step"] * 1.2
     assert 0.0 < d["step_frac_executed"] < d["step_frac_of_f32_mfma_peak"]

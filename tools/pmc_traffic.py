@@ -19,7 +19,8 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(conv_igemm_kernel<[^>]*>|conv_wgrad_kernel<[^>]*>|wgrad2_kernel<[^>]*>|conv_bf16_\w+<[^>]*>|[a-z_0-9]+_kernel)", name)
+    m = re.search(r"(conv_igemm_kernel<[^>]*>|conv_wgrad_kernel<[^>]*>|wgrad2_kernel<[^>]*>|conv_stream_kernel<[^>]*>|gram_stream_kernel<[^>]*>|"
+                  r"gram_bwd_kernel<[^>]*>|conv_bf16_\w+<[^>]*>|[a-z_0-9]+_kernel)", name)
     s = m.group(1) if m else name[:60]
     s = s.replace(" ", "")
     return s if s.startswith("wgrad2") else s.replace(",false", "").replace(",true", ",flat")
@@ -45,7 +46,8 @@ def main():
         kernels[k] = {"launches_sampled": len(fe[k]), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
                       "traffic_bytes_per_launch": int((2 * f + w) * 1024)}
     fams = {"wino_conv_kernel": r"^wino2?_conv_kernel$", "conv_wgrad_kernel": r"^(conv_wgrad_kernel<(?!1,4)|wgrad2_kernel<)",
-            "conv_wgrad_kernel (Gram forward)": r"^conv_wgrad_kernel<1,4>"}
+            "conv_wgrad_kernel (Gram forward)": r"^(conv_wgrad_kernel<1,4>|gram_stream_kernel<)",
+            "conv_igemm_kernel (Gram backward)": r"^gram_bwd_kernel<", "conv_igemm_kernel<32,2,1>": r"^conv_stream_kernel<"}
     families = {}
     for fam, pat in fams.items():
         ks = [k for k in kernels if re.search(pat, k)]
