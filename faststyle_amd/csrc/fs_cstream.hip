@@ -254,6 +254,21 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
             const int thv = a.shuffle ? min(th_valid, ((SH - qa[nn] + 1) >> 1) - I.ty0) : th_valid;
             const int twv = a.shuffle ? min(tw_valid, ((SW - qb[nn] + 1) >> 1) - I.tx0) : tw_valid;
             const int lane_off = (I.tx0 + pxb) * colb + chb[nn];
+            float ad[WM][16];
+            if (a.add_src) {
+                // residual-gradient addend [N][Ho - 2 ap][Wo - 2 ap][BN], added in the interior: all loads of the block first
+                const int ap = a.add_pad, aW = a.Wo - 2 * ap, aH = a.Ho - 2 * ap;
+                const float* an = uniform_ptr(a.add_src + (size_t)I.n * aH * aW * BN);
+                const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(an), 0, (unsigned)(aH * aW * BN) * 4u, 0x00020000);
+#pragma unroll
+                for (int m = 0; m < WM; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ay = I.ty0 + pyb + 2 * m + (r >> 3) - ap, ax = I.tx0 + pxb + (r & 3) + 8 * ((r >> 2) & 1) - ap;
+                        const bool in = (unsigned)ay < (unsigned)aH && (unsigned)ax < (unsigned)aW;
+                        ad[m][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ar, in ? (unsigned)((ay * aW + ax) * BN) * 4u + (unsigned)chb[nn] : kOOB, 0, 0));
+                    }
+            }
 #pragma unroll
             for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -261,7 +276,9 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
                     const int pyl = pyb + 2 * m + (r >> 3), pxc = (r & 3) + 8 * ((r >> 2) & 1);
                     const bool ok = pyl < thv && pxb + pxc < twv;
                     const int row_off = (I.ty0 + pyl) * rowb;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][nn][r]), yr, ok ? (unsigned)(lane_off + row_off + pxc * colb) : kOOB, 0, 0);
+                    float v = acc[m][nn][r];
+                    if (a.add_src) v += ad[m][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, ok ? (unsigned)(lane_off + row_off + pxc * colb) : kOOB, 0, 0);
                 }
         }
         zero_acc();
@@ -323,11 +340,12 @@ struct CsInst {
 };
 // 1: 16 -> 32, 3x3/2 (initconv_1; gradient of the 32 -> 16 resize-conv)      2: 32 -> 64, 2x2/1 (32 -> 16 resize-conv; gradient of initconv_1)
 // 3: 32 -> 64, 3x3/2 (initconv_2; gradient of the 64 -> 32 resize-conv)      4: 64 -> 128, 2x2/1 (64 -> 32 resize-conv; gradient of initconv_2)
-const CsInst kInst[4] = {{16, 32, 3, 2, 16}, {32, 64, 2, 1, 16}, {32, 64, 3, 2, 8}, {64, 128, 2, 1, 8}};
+// 5: 64 -> 64, 3x3/1 (the residual convs and their input gradients when the grid is too small for the Winograd kernel: batch 4)
+const CsInst kInst[5] = {{16, 32, 3, 2, 16}, {32, 64, 2, 1, 16}, {32, 64, 3, 2, 8}, {64, 128, 2, 1, 8}, {64, 64, 3, 1, 8}};
 }  // namespace
 
 static int cstream_instance(const ConvArgs& a) {
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 5; ++i)
         if (a.Cin == kInst[i].Cin && a.Cout == kInst[i].Cout && a.KH == kInst[i].KS && a.KW == kInst[i].KS && a.stride == kInst[i].stride)
             return i + 1;
     return 0;
@@ -336,10 +354,14 @@ static int cstream_instance(const ConvArgs& a) {
 bool cstream_eligible(const ConvArgs& a) {
     const int inst = cstream_instance(a);
     if (!tune_int("FS_CSTREAM", 1) || !inst) return false;
-    if (!((tune_int("FS_CSTREAM_MASK", 15) >> (inst - 1)) & 1)) return false;   // tuning aid: bit i enables instance i+1
-    const bool plain = a.src_mode == SRC_PLAIN && a.dil_x <= 1 && !a.bias && !a.out_relu && !a.add_src && !a.mask_src && !a.route_src &&
+    // bit i enables instance i+1.  Instance 5 (residual convs on small grids) is OFF by default: measured +1 % at batch 4
+    // (20 launches 0.68 -> 0.63 ms) for 509 registers, and it would make the kernel choice of the residual convs depend on the
+    // batch size (the data-parallel identity grads(batch) = sum grads(sample) then only holds to rounding-order noise)
+    if (!((tune_int("FS_CSTREAM_MASK", 15) >> (inst - 1)) & 1)) return false;
+    const bool plain = a.src_mode == SRC_PLAIN && a.dil_x <= 1 && !a.bias && !a.out_relu && !a.mask_src && !a.route_src &&
                        !a.pool_out && a.w_nstride == 0 && !a.w_wino && !a.w_wino2;
     if (!plain) return false;
+    if (a.add_src && (a.shuffle || a.stats || a.add_pad < 0)) return false;   // (the residual-gradient addend: plain stores only)
     if (a.in_a && !a.in_b) return false;
     if (a.in_relu && !a.in_a) return false;   // (a ReLU on load only comes with its affine here)
     if (a.pad_t < 0 || a.pad_l < 0 || a.pad_t > 2 || a.pad_l > 2) return false;
@@ -386,6 +408,7 @@ int cstream_launch(const ConvArgs& a, hipStream_t s) {
         case 2: cs_launch<16, 1, 2, 32, 2, 1>(a, grid, s); break;   // 4 waves over the pixels; 128
         case 3: cs_launch<8, 2, 1, 32, 3, 2>(a, grid, s); break;    // 2 x 2 waves; 144
         case 4: cs_launch<8, 4, 1, 64, 2, 1>(a, grid, s); break;    // 4 waves over the channels, 4 pixel blocks each; 128
+        case 5: cs_launch<8, 2, 1, 64, 3, 1>(a, grid, s); break;    // 2 x 2 waves; 288 (what a lone wave's 512 registers allow)
         default: return -4;
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;

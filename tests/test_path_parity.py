@@ -158,6 +158,7 @@ def test_tnet_narrow_layers_through_the_streaming_kernel(eng, shape, knob):
     extents (ragged tiles, clipped pixel-shuffle stores), instance-norm partials per tile, several tiles per workgroup
     (FS_CSTREAM_WGS=3 makes the persistent loop run).  Same oracle, same tolerances as the one-tile kernel."""
     knob("FS_CSTREAM_MIN_TILES", 1)
+    knob("FS_CSTREAM_MASK", 31)     # + the 64 -> 64 3x3 instance (residual convs and both forms of their input gradient), off by default
     knob("FS_CSTREAM_WGS", 3)
     y, yo, g, want = run_fwd_bwd(eng, kink_free_params(), shape, seed=0)
     assert np.abs(y - yo).max() / 255.0 < 2e-5
