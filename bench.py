@@ -445,7 +445,15 @@ def main():
                          "timed_with": "HIP events on the launch stream, eager pass of %d steps right after the timed region" % args.profile_steps,
                          "direct_form_equivalent_tflops": round(dom["tflops"] * 2.25, 2) if di == 6 else None,
                          "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
-                         "per_kernel": per_kernel},
+                         "per_kernel": per_kernel,
+                         # the table's keys are profiler FAMILIES (fs_profile_begin/end); the kernels each one holds today:
+                         "family_members": {
+                             "conv_igemm_kernel<32,2,1>": "conv_stream_kernel<...> (fs_cstream.hip: narrow full-resolution layers) + conv_igemm_kernel<32,2,1>",
+                             "conv_wgrad_kernel": "wgrad2_kernel<...> (fs_wgrad2.hip: the 16 filter gradients) + conv_wgrad_kernel where wgrad2 is not eligible",
+                             "wino_conv_kernel": "wino_conv_kernel (Cin >= 256) + wino2_conv_kernel (Cin <= 128)",
+                             "conv_wgrad_kernel (Gram forward)": "gram_stream_kernel<64|128> (fs_gram.hip); FLOPs executed (symmetric diagonal tiles 10/16)",
+                             "conv_igemm_kernel (Gram backward)": "gram_bwd_kernel<64|128|256> (fs_gram.hip) + conv_igemm_kernel 1x1 with per-sample filters (conv4_3)",
+                             "conv_igemm_kernel<16,4,1>": "conv_igemm_kernel<16,4,1> (9x9 image / output layers) + conv3x3_to3_kernel (fs_c3.hip)"}},
             "gram": rep["gram"], "vgg_gram_substep": rep["vgg_gram_substep"],
             "step_tflops_as_written": rep["step_tflops_as_written"], "step_frac_of_f32_mfma_peak": rep["step_frac_as_written"],
             "step_gflop_executed": rep["step_gflop_executed"], "step_tflops_executed": rep["step_tflops_executed"],
