@@ -1,0 +1,149 @@
+#!/usr/bin/env python
+"""Randomised shapes through the round-2 kernels on the CPU kernel emulator (no GPU needed), against numpy float64:
+
+    python tools/fuzz_emu.py [cases] [seed]
+
+  * conv_stream_kernel (fs_cstream.hip), all five instances: stride-2 3x3 and 2x2-tap convs with the pixel-shuffle store,
+    producer instance norm + ReLU on load, per-tile statistics (merged and compared with the tensor's own mean / variance),
+    the residual-gradient addend; ragged tiles, one to several tiles per workgroup (FS_CSTREAM_WGS);
+  * gram_stream_kernel / gram_reduce_kernel / gram_bwd_kernel (fs_gram.hip): every channel count they take, pixel counts
+    that end inside a tile, several pixel ranges.
+Every case prints one line; a mismatch raises.  tests/ holds fixed-shape versions of the same checks."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import nnops, perceptual  # noqa: E402
+from tests.backends import get_engine  # noqa: E402
+
+TOL = 3e-5
+
+
+def rel(got, want):
+    return float(np.abs(np.asarray(got, np.float64) - want).max() / (np.abs(want).max() + 1e-30))
+
+
+def conv_explicit(x, w, stride, pad_t, pad_l, Ho, Wo):
+    """Cross-correlation with explicit top/left zero padding and a given output extent (bottom/right padding as needed)."""
+    N, H, W, _ = x.shape
+    kh, kw = w.shape[:2]
+    need_h, need_w = (Ho - 1) * stride + kh, (Wo - 1) * stride + kw
+    xp = np.pad(x, ((0, 0), (pad_t, max(0, need_h - H - pad_t)), (pad_l, max(0, need_w - W - pad_l)), (0, 0)))
+    y = np.zeros((N, Ho, Wo, w.shape[3]))
+    for i in range(kh):
+        for j in range(kw):
+            y += np.tensordot(xp[:, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride, :], w[i, j], axes=1)
+    return y
+
+
+def shuffle2(y):
+    """[N,H,W,4*C] (phase q = 2a+b major) -> [N,2H,2W,C]."""
+    N, H, W, C4 = y.shape
+    C = C4 // 4
+    out = np.zeros((N, 2 * H, 2 * W, C))
+    for q in range(4):
+        out[:, (q >> 1)::2, (q & 1)::2, :] = y[..., q * C:(q + 1) * C]
+    return out
+
+
+def merge_stats(st):
+    """[N,T,C,3] {mean, M2, count} per tile -> per (n, c) mean and biased variance."""
+    cnt = st[..., 2].sum(axis=1)
+    mean = (st[..., 0] * st[..., 2]).sum(axis=1) / cnt
+    m2 = (st[..., 1] + st[..., 2] * (st[..., 0] - mean[:, None, :]) ** 2).sum(axis=1)
+    return mean, m2 / cnt
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    os.environ["FS_CSTREAM_MIN_TILES"] = "1"
+    os.environ["FS_CSTREAM_MASK"] = "31"
+    os.environ["FS_GRAM2_MIN_TILES"] = "0"
+    e = get_engine("emu")
+    up, down = e.mem.from_numpy, e.mem.to_numpy
+    inst = [(16, 32, 3, 2), (32, 64, 2, 1), (32, 64, 3, 2), (64, 128, 2, 1), (64, 64, 3, 1)]
+    for it in range(cases):
+        kind = it % 8
+        if kind < 5:
+            cin, cout, ks, st = inst[kind]
+            n = int(rng.integers(1, 4))
+            h, w = int(rng.integers(3, 40)), int(rng.integers(3, 44))
+            os.environ["FS_CSTREAM_WGS"] = str(int(rng.choice([1, 3, 256])))
+            e.lib.fs_debug_reload_env()
+            x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+            wt = (rng.standard_normal((ks, ks, cin, cout)) * 0.1).astype(np.float32)
+            kw = {}
+            xin = x.astype(np.float64)
+            if kind in (0, 2) or (kind == 4 and rng.integers(2)):      # producer instance norm + ReLU on load
+                a = rng.uniform(0.5, 1.5, (n, cin)).astype(np.float32)
+                b = rng.standard_normal((n, cin)).astype(np.float32)
+                kw.update(in_a=up(a), in_b=up(b), in_per_sample=1, in_relu=1)
+                xin = np.maximum(xin * a[:, None, None, :] + b[:, None, None, :], 0.0)
+            if ks == 2:                                               # phase-collapsed form: explicit padding, shuffle store
+                pt, pl = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+                want = shuffle2(conv_explicit(xin, wt.astype(np.float64), 1, pt, pl, h, w))
+                y = down(e.conv2d(up(x), up(wt), 1, (pt, pl, h, w), shuffle=1, **kw))
+            elif kind == 4:                                           # 64 -> 64: VALID forward or "full" input gradient (+ addend)
+                if h < 3 or w < 3:
+                    continue
+                full = bool(rng.integers(2))
+                if full:
+                    ho, wo = h + 2, w + 2
+                    want = conv_explicit(xin, wt.astype(np.float64), 1, 2, 2, ho, wo)
+                    if rng.integers(2) and ho > 4 and wo > 4:
+                        add = rng.standard_normal((n, ho - 4, wo - 4, cout)).astype(np.float32)
+                        want[:, 2:-2, 2:-2, :] += add
+                        kw.update(add_src=up(add), add_pad=2)
+                    y = down(e.conv2d(up(x), up(wt), 1, (2, 2, ho, wo), **kw))
+                else:
+                    want = nnops.conv2d(xin, wt.astype(np.float64), 1, "VALID")
+                    y = down(e.conv2d(up(x), up(wt), 1, "VALID", **kw))
+            else:
+                want = nnops.conv2d(xin, wt.astype(np.float64), st, "SAME")
+                res = e.conv2d(up(x), up(wt), st, "SAME", want_stats=True, **kw)
+                y = down(res[0])
+                mean, var = merge_stats(down(res[1]).astype(np.float64))
+                assert np.abs(mean - want.mean(axis=(1, 2))).max() < 1e-4 * (np.abs(want).max() + 1), "tile statistics: mean"
+                assert np.abs(var - want.var(axis=(1, 2))).max() < 1e-4 * (want.var(axis=(1, 2)).max() + 1e-9), "tile statistics: variance"
+            assert y.shape == want.shape, (y.shape, want.shape)
+            r = rel(y, want)
+            print("case %3d conv_stream %d->%d k%d s%d  %s  wgs %s  rel %.2e" % (it, cin, cout, ks, st, x.shape, os.environ["FS_CSTREAM_WGS"], r), flush=True)
+            assert r < TOL
+        elif kind in (5, 6):
+            c = int(rng.choice([64, 128, 256, 384, 512]))
+            n = int(rng.integers(1, 4))
+            h, w = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+            os.environ["FS_GRAM2_ITEMS"] = str(int(rng.choice([8, 64, 768])))
+            e.lib.fs_debug_reload_env()
+            f = rng.standard_normal((n, h, w, c)).astype(np.float32)
+            g = down(e.gram(up(f)))
+            want = perceptual.gram(f.astype(np.float64))
+            r = rel(g, want)
+            print("case %3d gram_stream %s items %s  rel %.2e" % (it, f.shape, os.environ["FS_GRAM2_ITEMS"], r), flush=True)
+            assert r < TOL and np.array_equal(g, g.transpose(0, 2, 1))
+        else:
+            c = int(rng.choice([64, 128, 256]))
+            n = int(rng.integers(1, 4))
+            h, w = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+            x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+            s = (rng.standard_normal((n, c, c)) * 0.1).astype(np.float32)
+            kw = {"w_nstride": c * c}
+            want = np.einsum("nhwc,ncd->nhwd", x.astype(np.float64), s.astype(np.float64))
+            if rng.integers(2):
+                add = rng.standard_normal(x.shape).astype(np.float32)
+                kw["add_src"] = up(add)
+                want = want + add
+            y = down(e.conv2d(up(x), up(s.reshape(n, 1, 1, c, c)), 1, "SAME", **kw))
+            r = rel(y, want)
+            print("case %3d gram_bwd %s add %s  rel %.2e" % (it, x.shape, "add_src" in kw, r), flush=True)
+            assert r < TOL
+    print("fuzz_emu: %d cases ok" % cases)
+
+
+if __name__ == "__main__":
+    main()
