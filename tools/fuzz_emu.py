@@ -7,7 +7,8 @@
     producer instance norm + ReLU on load, per-tile statistics (merged and compared with the tensor's own mean / variance),
     the residual-gradient addend; ragged tiles, one to several tiles per workgroup (FS_CSTREAM_WGS);
   * gram_stream_kernel / gram_reduce_kernel / gram_bwd_kernel (fs_gram.hip): every channel count they take, pixel counts
-    that end inside a tile, several pixel ranges.
+    that end inside a tile, several pixel ranges;
+  * wino2_conv_kernel with bias / ReLU, wgrad2_kernel, conv3x3_to3_kernel on ragged shapes.
 Every case prints one line; a mismatch raises.  tests/ holds fixed-shape versions of the same checks."""
 import os
 import sys
@@ -68,7 +69,7 @@ def main():
     up, down = e.mem.from_numpy, e.mem.to_numpy
     inst = [(16, 32, 3, 2), (32, 64, 2, 1), (32, 64, 3, 2), (64, 128, 2, 1), (64, 64, 3, 1)]
     for it in range(cases):
-        kind = it % 8
+        kind = it % 11
         if kind < 5:
             cin, cout, ks, st = inst[kind]
             n = int(rng.integers(1, 4))
@@ -126,6 +127,41 @@ def main():
             r = rel(g, want)
             print("case %3d gram_stream %s items %s  rel %.2e" % (it, f.shape, os.environ["FS_GRAM2_ITEMS"], r), flush=True)
             assert r < TOL and np.array_equal(g, g.transpose(0, 2, 1))
+        elif kind == 8:       # second-generation Winograd kernel (fs_wino2.hip): SAME 3x3, bias + ReLU epilogue, ragged 16x16 blocks
+            cin, cout = int(rng.choice([8, 16, 64, 128])), int(rng.choice([64, 128]))
+            n, h, w = int(rng.integers(1, 3)), int(rng.integers(1, 40)), int(rng.integers(1, 40))
+            x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+            wt = (rng.standard_normal((3, 3, cin, cout)) * 0.1).astype(np.float32)
+            bias = rng.standard_normal((cout,)).astype(np.float32)
+            relu = bool(rng.integers(2))
+            y = down(e.conv2d(up(x), up(wt), 1, "SAME", winograd=True, bias=up(bias), out_relu=int(relu)))
+            want = nnops.conv2d(x.astype(np.float64), wt.astype(np.float64), 1, "SAME") + bias
+            if relu:
+                want = np.maximum(want, 0.0)
+            r = rel(y, want)
+            print("case %3d wino2 %s -> %d relu %s  rel %.2e" % (it, x.shape, cout, relu, r), flush=True)
+            assert r < TOL
+        elif kind == 9:       # second-generation filter gradient (fs_wgrad2.hip)
+            cin, cout = int(rng.choice([16, 32, 64])), int(rng.choice([16, 32, 64]))
+            k, st = (3, int(rng.choice([1, 2]))) if rng.integers(2) else (2, 1)
+            n, h, w = int(rng.integers(1, 4)), int(rng.integers(4, 36)), int(rng.integers(4, 36))
+            x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+            pad = "SAME" if k == 3 else "VALID"
+            ho, wo = (-(-h // st), -(-w // st)) if pad == "SAME" else (h - k + 1, w - k + 1)
+            dy = rng.standard_normal((n, ho, wo, cout)).astype(np.float32)
+            dw = down(e.conv2d_wgrad(up(x), up(dy), k, st, pad))
+            want = nnops.conv2d_bwd_filter(x.astype(np.float64), dy.astype(np.float64), k, st, pad)
+            r = rel(dw, want)
+            print("case %3d wgrad2 %s k%d s%d -> %d  rel %.2e" % (it, x.shape, k, st, cout, r), flush=True)
+            assert r < TOL
+        elif kind == 10:      # 64 -> 3 channels on the vector ALU (fs_c3.hip)
+            n, h, w = int(rng.integers(1, 3)), int(rng.integers(1, 45)), int(rng.integers(1, 45))
+            x = rng.standard_normal((n, h, w, 64)).astype(np.float32)
+            wt = (rng.standard_normal((3, 3, 64, 3)) * 0.1).astype(np.float32)
+            y = down(e.conv2d(up(x), up(wt), 1, "SAME"))
+            r = rel(y, nnops.conv2d(x.astype(np.float64), wt.astype(np.float64), 1, "SAME"))
+            print("case %3d conv3x3_to3 %s  rel %.2e" % (it, x.shape, r), flush=True)
+            assert r < TOL
         else:
             c = int(rng.choice([64, 128, 256]))
             n = int(rng.integers(1, 4))
