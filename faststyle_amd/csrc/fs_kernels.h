@@ -199,7 +199,7 @@ __device__ __forceinline__ f32x2 fs_wino_cols23(f32x2 t01, f32x2 t23) {   // {t2
 #endif
 }
 // a + b / a - b on two packed floats as ONE instruction.  (Written as vector arithmetic the backend un-packs v_pk_add_f32
-// next to matrix instructions, betting on co-issue; measured on gfx950 -- exp/mfma_overlap.hip -- every vector instruction
+// next to matrix instructions, betting on co-issue; measured on gfx950 -- tools/mfma_overlap.hip -- every vector instruction
 // beside the fp32 MFMA stream costs its issue time, so fewer instructions is what counts.)
 __device__ __forceinline__ f32x2 fs_pk_add(f32x2 a, f32x2 b) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_PK_ASM)

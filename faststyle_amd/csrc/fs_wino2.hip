@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
     // pairs, filter commit) is threaded through the sweep in small slices -- three slots per position, pinned with
     // sched_barrier: with one wave per SIMD nothing else covers that work, and left to itself the compiler emits each
     // transform as one block of ~60 instructions and LDS round trips during which the matrix pipe idles.
-    // Measured on gfx950 (exp/mfma_overlap.hip, one wave per SIMD): the fp32 matrix instruction and the vector ALU exclude
+    // Measured on gfx950 (tools/mfma_overlap.hip, one wave per SIMD): the fp32 matrix instruction and the vector ALU exclude
     // each other -- every VALU instruction between two v_mfma_f32_32x32x2_f32 adds ~6.5 cycles, plus ~10 for the first one
     // of a gap; scalar instructions are free (up to ~8 per MFMA), LDS reads nearly so.  Hence: LDS reads and global loads
     // are spread over the gaps, the VALU work of the input transform is bunched into TWO gaps.
