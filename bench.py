@@ -2,8 +2,11 @@
 """Headline benchmark of the faststyle hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...;
-   `--nproc-per-node 1` is supported too and runs the RCCL all-reduce at world size 1)
+  N > 1 without a torchrun environment: bench.py starts the N ranks itself -- it re-runs the same command as
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...`
+  (one process per GPU, RCCL); launched that way by the caller it just joins.  `--launch` does the same for --gpus 1
+  (RCCL all-reduce at world size 1); `--rendezvous-only` is a preflight of the launcher alone.  Rank 0 prints the ONE JSON
+  line; `value` is the whole-job rate (max-over-ranks time), `per_rank_images_per_sec` every rank's own.
 
 A "step" is one full train.py loop body (reference train.py:245-275) on a synthetic 256x256 batch: content-target VGG
 pass, transform-net forward, VGG16 + Gram + losses, full backward, ONE RCCL all-reduce (SUM) of the 424,102 gradients
@@ -44,8 +47,15 @@ GF_VGG_GRAM = GF_VGG_CONTENT + GF_VGG_FWD + GF_VGG_DGRAD + GF_GRAM              
 # transform-net forward: executed (phase-collapsed resize-conv) GFLOP and minimum fp32 HBM traffic (MB) per image
 FWD_WORK = {(720, 1280): (70.756, 83.496, 1524.6), (1080, 1920): (155.023, 183.688, 3335.5), (256, 256): (6.163, 7.069, 134.4)}
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: bf16 MFMA, dense (no sparsity)
 PEAK_HBM_TBS = 8.0                    # spec; 6.29 measured (float4 copy)
-TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic_pmc.json")
+
+
+def newest_profile(stem):
+    """profiles/rNN_<stem>: the newest round's file (the rocprofv3 PMC summaries bench.py quotes HBM traffic from)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + stem)))
+    return c[-1] if c else None
 
 
 def parse():
@@ -62,7 +72,63 @@ def parse():
     ap.add_argument("--no-stylize", action="store_true")
     ap.add_argument("--no-b4", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--launch", action="store_true",
+                    help="start the ranks through torch.distributed.run even for --gpus 1 (RCCL all-reduce at world size 1); "
+                         "--gpus N > 1 without a torchrun environment always does")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launcher preflight: every rank joins the process group (RCCL, or gloo when no GPU is visible), SUM-"
+                         "all-reduces its rank, rank 0 prints one JSON line; no engine, no kernels")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_cmd(n, argv, port):
+    """The driver's command form for N ranks on one node (one process per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--launch"]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: re-run this command under torch.distributed.run with N
+    ranks; stdout (rank 0's ONE JSON line) and the return code pass through."""
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = launch_cmd(args.gpus, sys.argv[1:], free_port())
+    print("bench: launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def rendezvous_only(args):
+    import torch
+    import torch.distributed as dist
+    world, rank, local = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    gpu = torch.cuda.is_available()
+    if gpu:
+        torch.cuda.set_device(local)
+    saved_fd = os.dup(1)       # (RCCL's banner must not land on stdout)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("nccl" if gpu else "gloo", **({"device_id": torch.device("cuda", local)} if gpu else {}))
+        t = torch.tensor([float(rank)], device="cuda" if gpu else "cpu")
+        dist.all_reduce(t)
+        if gpu:
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+    assert float(t.item()) == world * (world - 1) / 2, (float(t.item()), world)
+    if rank == 0:
+        print(json.dumps({"rendezvous_ok": True, "n_gpus": world, "backend": "RCCL" if gpu else "gloo", "allreduce_sum_of_ranks": float(t.item())}))
+    dist.destroy_process_group()
 
 
 # ----------------------------------------------------------------------------------------------- CPU baseline
@@ -152,7 +218,7 @@ def fam_table(prof, steps, names):
     tab = {}
     for f, nm in enumerate(names):
         n, fl, ms = prof[3 * f], prof[3 * f + 1], prof[3 * f + 2]
-        if ms > 0:
+        if ms > 0 and nm:
             tf = fl / (ms * 1e-3) / 1e12
             tab[nm] = {"launches_per_step": round(n / steps, 1), "gflop_per_step": round(fl / steps / 1e9, 2),
                        "ms_per_step": round(ms / steps, 3), "avg_launch_us": round(1e3 * ms / n, 1),
@@ -164,6 +230,10 @@ def main():
     global _QUICK
     args = parse()
     _QUICK = args.cpu_quick
+    if "RANK" not in os.environ and (args.gpus > 1 or args.launch):
+        raise SystemExit(self_launch(args))
+    if args.rendezvous_only:
+        return rendezvous_only(args)
     import torch
     import torch.distributed as dist
     from faststyle_amd import _lib, engine, im_transf_net, trainer, utils, vgg16
@@ -172,9 +242,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ       # under torch.distributed.run (any world size)
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                         % (args.gpus, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d inside a %d-rank torch.distributed environment" % (args.gpus, world))
     torch.cuda.set_device(local)
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -196,7 +265,8 @@ def main():
     eng = engine.Engine(engine.TorchMem("cuda:%d" % local))
     lib = eng.lib
     NF = _lib.FS_PROFILE_FAMILIES
-    names = _lib.PROFILE_FAMILY_NAMES
+    names = _lib.profile_family_names(lib)        # one row per kernel symbol
+    F_WINO, F_WINO2_VGG, F_WINO2_TNET, F_GRAM_FWD, F_GRAM_BWD = 5, 6, 7, (12, 13), (14, 15)
 
     B, S = args.batch_per_gpu, args.size
     params = eng.flatten_params(im_transf_net.initial_variables(seed=0), scope="")
@@ -221,19 +291,31 @@ def main():
             return float(t.item())
         return v
 
+    def all_ranks(v):
+        """[v of rank 0, v of rank 1, ...] on every rank"""
+        if world > 1:
+            t = torch.zeros(world, device="cuda", dtype=torch.float64)
+            t[rank] = v
+            dist.all_reduce(t)
+            return [float(x) for x in t.tolist()]
+        return [float(v)]
+
     def train_leg(batch, steps, warmup, tr):
         """Timed region + the eager per-section / per-kernel passes of one batch size."""
         pool = [torch.rand((batch, S, S, 3), device="cuda", generator=g) * 255.0 for _ in range(4)]
-        for i in range(max(warmup, 2 if tr.use_graph else 1)):      # (graph mode: first step captures, second replays)
+        n_warm = max(warmup, 2 if tr.use_graph else 1)             # (graph mode: first step captures, second replays)
+        for i in range(n_warm):
             tr.step(pool[i % len(pool)])
         sync()
         graphed = bool(tr.use_graph and tr.graph is not None)
         t0 = time.perf_counter()
         for i in range(steps):
-            losses = tr.step(pool[(warmup + i) % len(pool)])
+            losses = tr.step(pool[(n_warm + i) % len(pool)])
         sync()
-        elapsed = max_over_ranks(time.perf_counter() - t0)
-        res = {"elapsed": elapsed, "graphed": graphed, "loss": float(losses[0].item())}
+        mine = time.perf_counter() - t0
+        elapsed = max_over_ranks(mine)
+        res = {"elapsed": elapsed, "graphed": graphed, "loss": float(losses[0].item()),
+               "per_rank_images_per_sec": [round(steps * batch / t, 2) for t in all_ranks(mine)]}
         # ---- where the all-reduce + Adam (outside the hipGraph) and the host leave the GPU idle: 20 more steps of the timed
         # kind with an event before and after each; gap = end of step i -> start of step i+1 on the device time line
         Gs = 20
@@ -351,11 +433,26 @@ def main():
             if bf16:
                 mb = mb / 2
             per_gpu = fps / world
-            return {"fps": round(fps, 1), "ms_per_batch": round(1e3 * dt / iters, 3), "batch_per_gpu": n, "iters": iters,
-                    "tflops_executed": round(gf_exec * per_gpu / 1e3, 2), "tflops_as_written": round(gf_written * per_gpu / 1e3, 2),
-                    "frac_f32_mfma_peak_executed": None if bf16 else round(gf_exec * per_gpu / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
-                    "min_traffic_TBps": round(mb * per_gpu / 1e6, 3), "frac_hbm_peak_min_traffic": round(mb * per_gpu / 1e6 / PEAK_HBM_TBS, 4),
-                    "hip_graph": bool(graph and not args.no_graph)}
+            rep = {"fps": round(fps, 1), "ms_per_batch": round(1e3 * dt / iters, 3), "batch_per_gpu": n, "iters": iters,
+                   "tflops_executed": round(gf_exec * per_gpu / 1e3, 2), "tflops_as_written": round(gf_written * per_gpu / 1e3, 2),
+                   "min_traffic_TBps": round(mb * per_gpu / 1e6, 3), "frac_hbm_peak_min_traffic": round(mb * per_gpu / 1e6 / PEAK_HBM_TBS, 4),
+                   "hip_graph": bool(graph and not args.no_graph)}
+            if bf16:     # two roofs: the bf16 matrix cores (2.5 PFLOP/s dense) and HBM -- this leg is built around bytes
+                rep["frac_bf16_mfma_peak_executed"] = round(gf_exec * per_gpu / 1e3 / PEAK_BF16_MFMA_TFLOPS, 4)
+            else:
+                rep["frac_f32_mfma_peak_executed"] = round(gf_exec * per_gpu / 1e3 / PEAK_F32_MFMA_TFLOPS, 4)
+            # HBM bytes actually moved per batch, from the rocprofv3 PMC passes of the same shape (tools/collect_profiles.sh)
+            tp = newest_profile("hbm_traffic_%dp_%s.json" % (shape[1], "b%d_bf16" % n if bf16 else "fp32")) if (n == 1 or bf16) else None
+            if tp:
+                tj = json.load(open(tp))
+                passes = tj.get("forward_passes", 23)
+                if tj.get("kernels"):
+                    tot_b = sum(k["traffic_bytes_per_launch"] * k["launches_sampled"] for k in tj["kernels"].values()) / passes
+                    rep["hbm_counter_bytes_per_batch"] = int(tot_b)
+                    rep["hbm_counter_TBps"] = round(tot_b / (dt / iters) / 1e12, 3)
+                    rep["frac_hbm_peak_counters"] = round(tot_b / (dt / iters) / 1e12 / PEAK_HBM_TBS, 4)
+                    rep["hbm_counter_source"] = os.path.relpath(tp, ROOT)
+            return rep
         fwd["stylize_720p"] = fwd_leg((1, 720, 1280, 3), False, 10, 50, True)
         fwd["stylize_1080p_b8_bf16"] = fwd_leg((8, 1080, 1920, 3), True, 3, 20, False)
         fwd["stylize_1080p_b8_fp32"] = fwd_leg((8, 1080, 1920, 3), False, 2, 8, False)
@@ -376,11 +473,14 @@ def main():
             pl = acc[1]
             perc_gflop = sum(pl[3 * f + 1] for f in range(NF)) / P / 1e9
             perc_ms = leg["sections_ms"]["perceptual_loss"]
-            gram_fl = (pl[3 * 7 + 1] + pl[3 * 8 + 1]) / P
-            gram_ms = (pl[3 * 7 + 2] + pl[3 * 8 + 2]) / P
+            gsum = lambda fams, k: sum(pl[3 * f + k] for f in fams)
+            gram_fl = (gsum(F_GRAM_FWD, 1) + gsum(F_GRAM_BWD, 1)) / P
+            gram_ms = (gsum(F_GRAM_FWD, 2) + gsum(F_GRAM_BWD, 2)) / P
+            tfl = lambda fams: round(gsum(fams, 1) / (gsum(fams, 2) * 1e-3) / 1e12, 2) if gsum(fams, 2) else None
             rep = {
                 "images_per_sec": round(value, 2), "ms_per_step": round(1e3 * step_s, 3), "steps": steps, "batch_per_gpu": batch,
                 "global_batch": batch * world, "hip_graph": leg["graphed"], "final_loss": leg["loss"],
+                "per_rank_images_per_sec": leg["per_rank_images_per_sec"],
                 "sections_ms_eager": leg["sections_ms"],
                 # the step as the device sees it (events around graph replay + all-reduce + Adam) and the idle time between two
                 # steps: what keeping the all-reduce and the optimiser outside the captured graph costs
@@ -396,8 +496,7 @@ def main():
                 "gram": {"gflop_per_step": round(gram_fl / 1e9, 2), "ms_per_step": round(gram_ms, 3),
                          "tflops": round(gram_fl / (gram_ms * 1e-3) / 1e12, 2) if gram_ms else None,
                          "frac_of_f32_mfma_peak": round(gram_fl / (gram_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if gram_ms else None,
-                         "forward_tflops": per_kernel.get(names[7], {}).get("tflops"),
-                         "backward_tflops": per_kernel.get(names[8], {}).get("tflops"),
+                         "forward_tflops": tfl(F_GRAM_FWD), "backward_tflops": tfl(F_GRAM_BWD),
                          "gflop_as_written_per_step": round(4.295 * batch, 2),
                          "tflops_as_written": round(4.295 * batch / gram_ms, 2) if gram_ms else None,
                          "note": "G = F^T F/(hwc) per sample on 4 layers (utils.py:66-83) and dF = F (dG+dG^T); 4.295 GFLOP/img as written. "
@@ -412,21 +511,30 @@ def main():
                                              "time of the section by HIP events in an eager pass (every kernel of it, not only MFMA ones)"},
                 "per_kernel": per_kernel,
             }
+            wf = [F_WINO, F_WINO2_VGG, F_WINO2_TNET]
+            w_fl, w_ms, w_n = (sum(tot[3 * f + k] for f in wf) for k in (1, 2, 0))
+            if w_ms:
+                rep["winograd_family"] = {"kernels": [names[f] for f in wf if tot[3 * f + 2] > 0], "launches_per_step": round(w_n / P, 1),
+                                          "gflop_per_step": round(w_fl / P / 1e9, 1), "ms_per_step": round(w_ms / P, 3),
+                                          "tflops": round(w_fl / (w_ms * 1e-3) / 1e12, 2),
+                                          "frac": round(w_fl / (w_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
             return rep, di, per_kernel
         rep, di, per_kernel = leg_report(main_leg, B, args.steps)
         dom = per_kernel[names[di]]
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, TRAFFIC_FILE)
-        if os.path.exists(tpath):
+        sym = names[di].split(" (")[0]                     # the kernel symbol of the dominant row
+        tpath = newest_profile("hbm_traffic_pmc.json")
+        if tpath:
             tj = json.load(open(tpath))
-            k = tj.get("families", {}).get(names[di]) or tj.get("kernels", {}).get(names[di])
+            k = tj.get("kernels", {}).get(sym)
             if k and tj.get("batch_per_gpu") == B:
-                traffic, traffic_src = k["traffic_bytes_per_launch"], TRAFFIC_FILE
+                traffic, traffic_src = k["traffic_bytes_per_launch"], os.path.relpath(tpath, ROOT)
         out = {
             "metric": "images/sec train-step 256x256 b32 (+ Gram GFLOPs % MFMA peak); 720p stylize fps",
             "value": rep["images_per_sec"], "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": rep["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "per_rank_images_per_sec": rep["per_rank_images_per_sec"],
             "data": "synthetic (uniform[0,255) images; %s VGG16 weights; random-init transform net)"
                     % ("real" if real_vgg else "synthetic He-normal"),
             "config": {"workload": "train.py step: %dx%d, batch %d per GPU (BASELINE metric 'b32' on one GPU; global batch %d), VGG16 "
@@ -437,23 +545,19 @@ def main():
                        "collective": ("one RCCL all-reduce(SUM) of 1,696,408 B per step (world size %d)" % world) if launched else "none (single process)",
                        "style_image": "starry_night_crop.jpg 640x938"},
             "roofline": {"bound": "mfma",
-                         "kernel": names[di] + (" (wino_conv_kernel + wino2_conv_kernel: fp32 MFMA, Winograd F(2x2,3x3) 3x3 conv; achieved = "
-                                                "FLOPs EXECUTED, 16 products per 2x2 outputs instead of 36)" if di == 6 else " (fp32 MFMA)"),
+                         "kernel": names[di] + (": fp32 MFMA, Winograd F(2x2,3x3) 3x3 conv; achieved = FLOPs EXECUTED (16 products per "
+                                                "2x2 outputs instead of 36)" if di in (F_WINO, F_WINO2_VGG, F_WINO2_TNET) else ": fp32 MFMA"),
                          "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE, KiB counters)",
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch of the kernel symbol %s (2*FETCH_SIZE+WRITE_SIZE, KiB "
+                                                             "counters, separate rocprofv3 --pmc passes)" % sym,
                          "traffic_source": traffic_src,
-                         "timed_with": "HIP events on the launch stream, eager pass of %d steps right after the timed region" % args.profile_steps,
-                         "direct_form_equivalent_tflops": round(dom["tflops"] * 2.25, 2) if di == 6 else None,
+                         "timed_with": "HIP events on the launch stream, eager pass of %d steps right after the timed region; every row "
+                                       "of per_kernel is ONE kernel symbol (template instances summed), so row ms = launches x the "
+                                       "average duration of that symbol in profiles/*kernel_stats*" % args.profile_steps,
+                         "direct_form_equivalent_tflops": round(dom["tflops"] * 2.25, 2) if di in (F_WINO, F_WINO2_VGG, F_WINO2_TNET) else None,
                          "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
-                         "per_kernel": per_kernel,
-                         # the table's keys are profiler FAMILIES (fs_profile_begin/end); the kernels each one holds today:
-                         "family_members": {
-                             "conv_igemm_kernel<32,2,1>": "conv_stream_kernel<...> (fs_cstream.hip: narrow full-resolution layers) + conv_igemm_kernel<32,2,1>",
-                             "conv_wgrad_kernel": "wgrad2_kernel<...> (fs_wgrad2.hip: the 16 filter gradients) + conv_wgrad_kernel where wgrad2 is not eligible",
-                             "wino_conv_kernel": "wino_conv_kernel (Cin >= 256) + wino2_conv_kernel (Cin <= 128)",
-                             "conv_wgrad_kernel (Gram forward)": "gram_stream_kernel<64|128> (fs_gram.hip); FLOPs executed (symmetric diagonal tiles 10/16)",
-                             "conv_igemm_kernel (Gram backward)": "gram_bwd_kernel<64|128|256> (fs_gram.hip) + conv_igemm_kernel 1x1 with per-sample filters (conv4_3)",
-                             "conv_igemm_kernel<16,4,1>": "conv_igemm_kernel<16,4,1> (9x9 image / output layers) + conv3x3_to3_kernel (fs_c3.hip)"}},
+                         "winograd_family": rep.get("winograd_family"),
+                         "per_kernel": per_kernel},
             "gram": rep["gram"], "vgg_gram_substep": rep["vgg_gram_substep"],
             "step_tflops_as_written": rep["step_tflops_as_written"], "step_frac_of_f32_mfma_peak": rep["step_frac_as_written"],
             "step_gflop_executed": rep["step_gflop_executed"], "step_tflops_executed": rep["step_tflops_executed"],
@@ -466,6 +570,9 @@ def main():
         if b4_leg is not None:
             r4, d4, pk4 = leg_report(b4_leg, 4, args.b4_steps)
             r4["dominant_kernel"] = names[d4]
+            r4["config"] = ("BASELINE configs[2] (single GPU, batch 4)" if world == 1 else
+                            "BASELINE configs[3] shape: %d ranks x batch 4, global batch %d, one RCCL all-reduce(SUM) of 1,696,408 B "
+                            "per step" % (world, 4 * world))
             out["train_b4_per_gpu"] = r4
         for k, v in fwd.items():
             out[k] = v

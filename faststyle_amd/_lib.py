@@ -18,12 +18,16 @@ FS_VGG_NLAYERS = 10
 FS_FLAG_SAVE_FOR_BWD = 1
 FS_FLAG_UPSAMPLE_DECONV = 2
 FS_FLAG_BF16 = 4
+FS_TNET_WS_Z, FS_TNET_WS_A, FS_TNET_WS_B, FS_TNET_WS_MEAN, FS_TNET_WS_RSTD, FS_TNET_WS_H = 0, 1, 2, 3, 4, 5
 FS_PAD_SAME, FS_PAD_VALID, FS_PAD_EXPLICIT = 0, 1, 2
 FS_SRC_PLAIN, FS_SRC_REFLECT, FS_SRC_DILATE2 = 0, 1, 2
-FS_PROFILE_FAMILIES = 9
-PROFILE_FAMILY_NAMES = ["conv_igemm_kernel<32,2,2>", "conv_igemm_kernel<32,2,1>", "conv_igemm_kernel<16,4,1>", "conv_wgrad_kernel",
-                        "conv_igemm_kernel<32,1,2>", "conv_igemm_kernel<32,1,1>", "wino_conv_kernel",
-                        "conv_wgrad_kernel (Gram forward)", "conv_igemm_kernel (Gram backward)"]
+FS_PROFILE_FAMILIES = 20
+
+
+def profile_family_names(lib):
+    """Row names of fs_profile_end: one per kernel symbol ("" = unused row)."""
+    return [(lib.fs_profile_family_name(f) or b"").decode() for f in range(FS_PROFILE_FAMILIES)]
+
 
 VGG_LAYER_NAMES = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3",
                    "conv4_1", "conv4_2", "conv4_3"]
@@ -71,6 +75,7 @@ PROTOTYPES = {
     "fs_last_error": (c_char_p, []),
     "fs_version": (c_char_p, []),
     "fs_profile_begin": (c_int, [c_void_p]),
+    "fs_profile_family_name": (c_char_p, [c_int]),
     "fs_profile_end": (c_int, [c_void_p, POINTER(ctypes.c_double * (3 * FS_PROFILE_FAMILIES))]),
     "fs_tnet_param_info": (c_int, [c_int, POINTER(c_char_p), POINTER(c_int), POINTER(c_int), POINTER(c_int * 4)]),
     "fs_tnet_out_shape": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
@@ -89,6 +94,11 @@ PROTOTYPES = {
     "fs_vgg_features_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "fs_vgg_features": (c_int, [c_void_p, POINTER(_vp10), POINTER(_vp10), c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int),
                                 POINTER(c_void_p), c_void_p, c_size_t]),
+    "fs_gram_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "fs_gram_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t]),
+    "fs_gram_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t]),
+    "fs_tnet_ws_tensor": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t), POINTER(c_int * 4)]),
+    "fs_perceptual_ws_tensor": (c_int, [c_int, c_int, c_int, POINTER(fs_loss_cfg), c_int, POINTER(c_size_t), POINTER(c_int * 4)]),
     "fs_loss_sqdiff": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_void_p, c_void_p]),
     "fs_loss_tv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fs_adam_tf_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,

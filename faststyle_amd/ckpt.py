@@ -286,13 +286,24 @@ def save_checkpoint(prefix, tensors):
               _put_varint(idx_off) + _put_varint(len(idx_block)))
     footer += b"\x00" * (40 - len(footer)) + _MAGIC
     out += footer
-    # each file goes to "<file>.tmp" and is renamed into place, the data file first and the index -- the file a reader
-    # opens first -- last (as TF's BundleWriter does): a crash mid-save never leaves a truncated bundle behind the
-    # prefix that --resume_from would be pointed at
-    for suffix, payload in ((".data-00000-of-00001", bytes(blob)), (".index", bytes(out))):
-        tmp = prefix + suffix + ".tmp"
-        with open(tmp, "wb") as f:
+    # both files are written to "<file>.tmp" and fsynced FIRST; only then are they renamed into place back to back, the
+    # data file before the index (the file a reader opens first; TF's BundleWriter order), and the directory is fsynced.
+    # Re-saving over an existing prefix (`<model>_final.ckpt`, the same `ckpt-N` after a resume) therefore has no long
+    # window in which new data sits behind the old index (same offsets, stale CRCs); a crash before the renames leaves
+    # the old bundle intact, a crash between them is caught by the per-tensor CRC check of load_checkpoint.
+    files = ((".data-00000-of-00001", bytes(blob)), (".index", bytes(out)))
+    for suffix, payload in files:
+        with open(prefix + suffix + ".tmp", "wb") as f:
             f.write(payload)
             f.flush()
             os.fsync(f.fileno())
-        os.replace(tmp, prefix + suffix)
+    for suffix, _ in files:
+        os.replace(prefix + suffix + ".tmp", prefix + suffix)
+    try:
+        dfd = os.open(os.path.dirname(os.path.abspath(prefix)), os.O_RDONLY)
+        try:
+            os.fsync(dfd)
+        finally:
+            os.close(dfd)
+    except OSError:          # (a file system without directory fsync)
+        pass

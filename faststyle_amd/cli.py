@@ -50,6 +50,8 @@ def train_parser():
         ('--num_steps_break', dict(default=-1, type=int, help='stop after this step (-1: run all epochs)')),
         ('--resume_from', dict(default=None, help='bundle prefix of a training/<model_name>.ckpt-<step> to continue from '
                                              '(weights, Adam slots, global_step); not in the reference')),
+        ('--no_graph', dict(action='store_true', help='launch every kernel of a step eagerly instead of replaying the captured '
+                                                      'hipGraph (the default, and what bench.py times); not in the reference')),
         ('--beta', dict(default=0.0, type=float, help='total-variation weight (about 1e-4 helps deconv models)')),
         ('--style_target_resize', dict(default=1.0, type=float, help='scale factor applied to the style image')),
         ('--upsample_method', dict(UPSAMPLE)),

@@ -139,6 +139,7 @@ int fs_profile_begin(fs_ctx* ctx) {
     fs::Profiler::current() = &g_prof;
     return 0;
 }
+const char* fs_profile_family_name(int family) { return fs::prof_family_name(family); }
 int fs_profile_end(fs_ctx* ctx, double out[3 * FS_PROFILE_FAMILIES]) {
     if (!ctx || !out) return fail(-1, "fs_profile_end: null argument");
     fs::Profiler::current() = nullptr;
@@ -229,6 +230,37 @@ int fs_tnet_backward(fs_ctx* ctx, const float* params, const float* x, const flo
     return rc ? fail(rc, "fs_tnet_backward: launch failed (%d)", rc) : 0;
 }
 
+// inspection: where fs_tnet_forward(FS_FLAG_SAVE_FOR_BWD) leaves its saved tensors inside the caller's workspace
+int fs_tnet_ws_tensor(int N, int H, int W, int flags, int unit, int what, size_t* offset_floats, int dims[4]) {
+    if (N < 1 || H < 41 || W < 41 || (flags & FS_FLAG_BF16)) return fail(-2, "fs_tnet_ws_tensor: fp32 layouts only, H,W >= 41");
+    if (!offset_floats || !dims) return fail(-1, "fs_tnet_ws_tensor: null argument");
+    fs::TnetLayout* L = new fs::TnetLayout();
+    fs::tnet_layout(N, H, W, (flags & FS_FLAG_UPSAMPLE_DECONV) ? 1 : 0, L);
+    int rc = 0;
+    if (what == FS_TNET_WS_H) {
+        if (unit < 0 || unit >= 5) {
+            rc = fail(-2, "fs_tnet_ws_tensor: residual block %d out of range", unit);
+        } else {
+            const fs::Unit& u = L->u[3 + 2 * unit + 1];
+            *offset_floats = L->h[unit];
+            dims[0] = N, dims[1] = u.Hout, dims[2] = u.Wout, dims[3] = 64;
+        }
+    } else if (unit < 0 || unit >= 16 || what < 0 || what > FS_TNET_WS_RSTD) {
+        rc = fail(-2, "fs_tnet_ws_tensor: unit %d / tensor %d out of range", unit, what);
+    } else {
+        const fs::Unit& u = L->u[unit];
+        if (what == FS_TNET_WS_Z) {
+            *offset_floats = u.z;
+            dims[0] = N, dims[1] = u.Hout, dims[2] = u.Wout, dims[3] = u.Cout;
+        } else {
+            *offset_floats = what == FS_TNET_WS_A ? u.a : (what == FS_TNET_WS_B ? u.b : (what == FS_TNET_WS_MEAN ? u.mean : u.rstd));
+            dims[0] = N, dims[1] = u.Cout, dims[2] = dims[3] = 1;
+        }
+    }
+    delete L;
+    return rc;
+}
+
 // ------------------------------------------------------------------------------ VGG / losses
 size_t fs_vgg_prepared_floats(void) { return fs::vgg_prepared_floats(); }
 
@@ -269,6 +301,22 @@ int fs_perceptual_loss(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const 
     if (ws_bytes < L.total_floats * sizeof(float)) return fail(-3, "fs_perceptual_loss: workspace too small");
     const int rc = fs::perceptual_loss(L, w, b, prepared, *cfg, y, content, losses, dy, (float*)ws, ctx->stream);
     return rc ? fail(rc, "fs_perceptual_loss: launch failed (%d)", rc) : 0;
+}
+
+// inspection: where fs_perceptual_loss leaves the post-ReLU activations of a VGG layer inside the caller's workspace
+int fs_perceptual_ws_tensor(int N, int H, int W, const fs_loss_cfg* cfg, int layer, size_t* offset_floats, int dims[4]) {
+    if (int rc = check_cfg(cfg)) return rc;
+    if (N < 1 || H < 1 || W < 1 || !offset_floats || !dims) return fail(-1, "fs_perceptual_ws_tensor: bad argument");
+    fs::VggLayout L;
+    fs::vgg_layout(N, H, W, *cfg, true, &L);
+    if (layer < 0 || layer > L.lmax) return fail(-2, "fs_perceptual_ws_tensor: layer %d is not evaluated (last: %d)", layer, L.lmax);
+    static const int cout[FS_VGG_NLAYERS] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512};
+    *offset_floats = L.act[layer];
+    dims[0] = layer <= L.cmax ? L.NB : L.N;
+    dims[1] = L.Hl[layer];
+    dims[2] = L.Wl[layer];
+    dims[3] = cout[layer];
+    return 0;
 }
 
 size_t fs_style_targets_workspace_bytes(int H, int W) {
@@ -539,6 +587,64 @@ int fs_conv2d_wgrad(fs_ctx* ctx, fs_wgrad_desc* d, void* ws, size_t ws_bytes) {
     int rc = fs::wgrad_launch(a, ctx->stream);
     if (rc) return fail(rc, "fs_conv2d_wgrad: launch failed (%d)", rc);
     return fs::reduce_slabs(a.slabs, a.per_sample ? a.N : 1, a.p.n_slabs, (size_t)a.p.K * a.Cout, d->scale, d->dw, ctx->stream);
+}
+
+// ---- utils.get_grams (utils.py:66-83) and its gradient as named entry points -------------------------------------------
+static int gram_desc(const float* F, int N, int HW, int C, float* G, fs_wgrad_desc* d) {
+    if (N < 1 || HW < 1 || C < 4 || (C % 4) || (C > 128 && (C % 128))) return fail(-2, "fs_gram: C must be a multiple of 4, of 128 beyond 128 (got %d)", C);
+    *d = fs_wgrad_desc{};
+    d->x = d->dy = F;
+    d->dw = G;
+    d->N = N;
+    d->H = d->Ho = 1;
+    d->W = d->Wo = HW;
+    d->Cin = d->Cout = C;
+    d->KH = d->KW = d->stride = 1;
+    d->pad_mode = FS_PAD_EXPLICIT;
+    d->per_sample = 1;
+    d->scale = 1.0f / ((float)HW * (float)C);
+    return 0;
+}
+
+size_t fs_gram_workspace_bytes(int N, int HW, int C) {
+    fs_wgrad_desc d;
+    if (gram_desc(nullptr, N, HW, C, nullptr, &d)) return 0;
+    const size_t fwd = fs_conv2d_wgrad_workspace_bytes(&d);
+    const size_t bwd = (size_t)N * C * C * sizeof(float);   // S = (dG + dG^T) / (HW C)
+    return fwd > bwd ? fwd : bwd;
+}
+
+int fs_gram_fwd(fs_ctx* ctx, const float* F, int N, int HW, int C, float* G, void* ws, size_t ws_bytes) {
+    if (!ctx || !F || !G || !ws) return fail(-1, "fs_gram_fwd: null argument");
+    fs_wgrad_desc d;
+    if (int rc = gram_desc(F, N, HW, C, G, &d)) return rc;
+    return fs_conv2d_wgrad(ctx, &d, ws, ws_bytes);
+}
+
+int fs_gram_bwd(fs_ctx* ctx, const float* F, const float* dG, int N, int HW, int C, float* dF, void* ws, size_t ws_bytes) {
+    if (!ctx || !F || !dG || !dF || !ws) return fail(-1, "fs_gram_bwd: null argument");
+    fs_wgrad_desc d;
+    if (int rc = gram_desc(F, N, HW, C, nullptr, &d)) return rc;
+    if (ws_bytes < (size_t)N * C * C * sizeof(float)) return fail(-3, "fs_gram_bwd: workspace too small");
+    float* S = (float*)ws;
+    if (int rc = fs::gram_symmetrize(dG, S, N, C, d.scale, ctx->stream)) return fail(rc, "fs_gram_bwd: launch failed (%d)", rc);
+    if (fs::gram_bwd2_eligible(N, HW, C)) {
+        const int rc = fs::gram_bwd2_launch(F, S, nullptr, dF, N, HW, C, ctx->stream);
+        return rc ? fail(rc, "fs_gram_bwd: launch failed (%d)", rc) : 0;
+    }
+    fs::ConvArgs a{};   // 1x1 convolution with one C x C filter per sample
+    a.x = F;
+    a.w = S;
+    a.w_nstride = (long long)C * C;
+    a.y = dF;
+    a.N = N;
+    a.H = a.Ho = 1;
+    a.W = a.Wo = HW;
+    a.Cin = a.Cout = C;
+    a.KH = a.KW = a.stride = 1;
+    a.p = fs::conv_plan(a);
+    const int rc = fs::conv_launch(a, ctx->stream);
+    return rc ? fail(rc, "fs_gram_bwd: launch failed (%d)", rc) : 0;
 }
 
 }  // extern "C"

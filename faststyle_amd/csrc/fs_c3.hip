@@ -105,7 +105,7 @@ int conv3x3_to3_launch(const ConvArgs& a, hipStream_t s) {
     static BigLds lds_attr;
     lds_attr.ensure(reinterpret_cast<const void*>(conv3x3_to3_kernel<64>));
     Profiler* prof = Profiler::current();
-    if (prof) prof->begin(2, 2.0 * a.N * a.Ho * a.Wo * 9.0 * a.Cin * a.Cout, s);   // (reported with the narrow-output family)
+    if (prof) prof->begin(PF_C3, 2.0 * a.N * a.Ho * a.Wo * 9.0 * a.Cin * a.Cout, s);   // (reported with the narrow-output family)
     hipLaunchKernelGGL(conv3x3_to3_kernel<64>, dim3((unsigned)(a.N * tx * ty)), dim3(256), (size_t)(kP * kP * (32 + 4) * 4), s, a.x, a.w, a.y, a.H,
                        a.W, tx, ty);
     if (prof) prof->end(s);

@@ -801,6 +801,16 @@ extern "C" int fs_debug_conv_trace(long long* out, int n_wg) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_trace), sizeof(long long) * 8 * (size_t)n_wg, 0, hipMemcpyDeviceToHost);
 }
 #endif
+const char* prof_family_name(int f) {
+    static const char* const names[Profiler::kFamilies] = {
+        "conv_igemm_kernel<32,2,2>", "conv_igemm_kernel<32,2,1>", "conv_igemm_kernel<16,4,1>", "conv_igemm_kernel<32,1,2>",
+        "conv_igemm_kernel<32,1,1>", "wino_conv_kernel", "wino2_conv_kernel (VGG16 convs)", "wino2_conv_kernel (transform-net residual convs)",
+        "conv_stream_kernel", "conv3x3_to3_kernel", "wgrad2_kernel", "conv_wgrad_kernel", "gram_stream_kernel",
+        "conv_wgrad_kernel (Gram forward)", "gram_bwd_kernel", "conv_igemm_kernel (Gram backward, 1x1 per-sample filters)",
+        "wino2h_conv_kernel (transform-net residual convs, half items)", "", "", ""};
+    return f >= 0 && f < Profiler::kFamilies ? names[f] : "";
+}
+
 Profiler*& Profiler::current() {
     static thread_local Profiler* p = nullptr;
     return p;
@@ -1084,8 +1094,11 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
         if (a.shuffle) fl *= 9.0 / 16.0;  // phase-collapsed resize-conv / stride-2 dgrad: 9 of the 16 tap-parity slots are non-zero
         // Winograd F(2x2,3x3): 16 products per 2x2 output tile instead of 36 -- the FLOPs actually executed
         if (p.variant == 5 || p.variant == 6) fl = 2.0 * a.N * cdiv(a.Ho, 2) * cdiv(a.Wo, 2) * 16.0 * a.Cin * a.Cout;
-        // (the streaming kernel, variant 7, is reported with the <32,2,1> direct family it replaces)
-        prof->begin(a.w_nstride ? 8 : (p.variant == 7 ? 1 : (p.variant >= 5 ? 6 : (p.variant < 3 ? p.variant : p.variant + 1))), fl, s);
+        int fam = p.variant;   // conv_igemm_kernel<..> instances 0..4, wino_conv_kernel 5
+        if (a.w_nstride) fam = PF_GRAM_BWD_IGEMM;
+        else if (p.variant == 7) fam = PF_CSTREAM;
+        else if (p.variant == 6) fam = a.prof_tag ? PF_WINO2_TNET : PF_WINO2_VGG;
+        prof->begin(fam, fl, s);
     }
 #define FS_LAUNCH(MT_, WM_, WN_, FL_)                                                                              \
     do {                                                                                                           \

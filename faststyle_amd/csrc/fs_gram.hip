@@ -464,7 +464,7 @@ int gram2_launch(const float* F, float* G, float* slabs, int N, int HW, int C, f
     Profiler* prof = Profiler::current();
     // FLOPs EXECUTED: diagonal 128-channel tiles multiply 10 of their 16 blocks
     const double blocks = a.CG == 64 ? 4.0 * 1 : (16.0 * (a.pairs - a.groups) + 10.0 * a.groups);
-    if (prof) prof->begin(7, 2.0 * N * (double)HW * 32.0 * 32.0 * blocks, s);
+    if (prof) prof->begin(PF_GRAM_STREAM, 2.0 * N * (double)HW * 32.0 * 32.0 * blocks, s);
     if (a.CG == 64) {
         static BigLds lds_attr;
         lds_attr.ensure(reinterpret_cast<const void*>(gram_stream_kernel<64>));
@@ -487,6 +487,22 @@ bool gram_bwd2_eligible(int N, int HW, int C) {
     return (size_t)HW * C * 4 < 0x7F000000ull;   // 32-bit byte offsets inside one sample, with room for a tile of overshoot
 }
 
+// S[n][i][j] = scale * (dG[n][i][j] + dG[n][j][i]): the symmetrised, scaled upstream gradient of a Gram matrix (fs_gram_bwd)
+__global__ __launch_bounds__(256) void gram_symmetrize_kernel(const float* __restrict__ dG, float* __restrict__ S, int C, float scale, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t cc = (size_t)C * C;
+    const size_t n = i / cc, r = i - n * cc;
+    const int row = (int)(r / C), col = (int)(r - (size_t)row * C);
+    S[i] = scale * (dG[i] + dG[n * cc + (size_t)col * C + row]);
+}
+
+int gram_symmetrize(const float* dG, float* S, int N, int C, float scale, hipStream_t s) {
+    const size_t total = (size_t)N * C * C;
+    hipLaunchKernelGGL(gram_symmetrize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dG, S, C, scale, total);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 // dF[n] = F[n] S[n] (+ add[n])
 int gram_bwd2_launch(const float* F, const float* S, const float* add, float* dF, int N, int HW, int C, hipStream_t s) {
     if (!gram_bwd2_eligible(N, HW, C)) return -1;
@@ -507,7 +523,7 @@ int gram_bwd2_launch(const float* F, const float* S, const float* add, float* dF
     const unsigned grid = (unsigned)(N * NH * wpg);
     const size_t lds = (size_t)TPX * (C + 1) * sizeof(float);
     Profiler* prof = Profiler::current();
-    if (prof) prof->begin(8, 2.0 * N * (double)HW * C * C, s);
+    if (prof) prof->begin(PF_GRAM_BWD, 2.0 * N * (double)HW * C * C, s);
     if (C == 64) {
         static BigLds lds_attr;
         lds_attr.ensure(reinterpret_cast<const void*>(gram_bwd_kernel<64, 1, 256>));

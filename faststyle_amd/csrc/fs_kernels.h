@@ -64,6 +64,7 @@ struct ConvArgs {
     float* pool_out;        // optional [N,Ho/2,Wo/2,Cout] (Winograd kernels, even Ho/Wo, no split-K): max over every 2x2 output tile =
                             // tf.nn.max_pool 2x2/2 of the stored result (vgg16.py:68,104,154) straight from the epilogue's registers
     long long w_nstride;
+    int prof_tag;            // 1: launched by the transform net (profiler row; no effect on the computation)
     float* split_ws;         // optional scratch for split-K partials (split_ws_floats capacity); enables ksplit plans
     size_t split_ws_floats;
     ConvPlan p;
@@ -280,6 +281,7 @@ int gram2_launch(const float* F, float* G, float* slabs, int N, int HW, int C, f
 // ... and the gradient through them: dF[n] = F[n] S[n] (+ add[n]), S [N][C][C], C = 64, 128 or 256
 bool gram_bwd2_eligible(int N, int HW, int C);
 int gram_bwd2_launch(const float* F, const float* S, const float* add, float* dF, int N, int HW, int C, hipStream_t s);
+int gram_symmetrize(const float* dG, float* S, int N, int C, float scale, hipStream_t s);   // S[n] = scale * (dG[n] + dG[n]^T)
 // streaming conv of the narrow full-resolution layers (fs_cstream.hip): plan variant 7
 bool cstream_eligible(const ConvArgs& a);
 void cstream_plan(const ConvArgs& a, ConvPlan* out);
@@ -351,11 +353,20 @@ int unfold5(const float* dz, float* dys, int N, int Ho, int Wo, hipStream_t s);
 }  // namespace fs
 
 namespace fs {
-// Optional HIP-event profiler around the MFMA kernels (bench.py's roofline leg): per kernel
-// family it accumulates launches, algorithmic FLOPs and the event-measured duration.
+// Optional HIP-event profiler around the MFMA kernels (bench.py's roofline leg): per kernel SYMBOL (so that a row can be
+// re-derived from a rocprofv3 --kernel-trace --stats summary: average duration x launches) it accumulates launches,
+// FLOPs executed and the event-measured duration.  wino2_conv_kernel is split by caller: the VGG16 convs (bias + ReLU /
+// consumer mask, up to 128 channels) and the transform net's 64-channel residual convs (instance-norm on load, statistics
+// epilogue, 'full' padding + residual add in the input gradients) are different workloads on one symbol.
+enum ProfFam {
+    PF_IGEMM_32_2_2 = 0, PF_IGEMM_32_2_1 = 1, PF_IGEMM_16_4_1 = 2, PF_IGEMM_32_1_2 = 3, PF_IGEMM_32_1_1 = 4,
+    PF_WINO = 5, PF_WINO2_VGG = 6, PF_WINO2_TNET = 7, PF_CSTREAM = 8, PF_C3 = 9, PF_WGRAD2 = 10, PF_WGRAD = 11,
+    PF_GRAM_STREAM = 12, PF_GRAM_WGRAD = 13, PF_GRAM_BWD = 14, PF_GRAM_BWD_IGEMM = 15, PF_WINO2H_TNET = 16, PF_RESERVED17 = 17,
+    PF_RESERVED18 = 18, PF_RESERVED19 = 19
+};
+const char* prof_family_name(int f);
 struct Profiler {
-    static const int kFamilies = 9;  // conv variants 0..2, filter gradients 3, conv variants 3..4 -> 4..5, Winograd conv 6,
-                                     // Gram forward (per-sample F^T F) 7, Gram backward (1x1 conv with per-sample filters) 8
+    static const int kFamilies = 20;   // one per kernel symbol (ProfFam); fs_profile_family_name() names them
     struct Rec { hipEvent_t a, b; int fam; double flops; };
     Rec* recs = nullptr;
     int n = 0, cap = 0;

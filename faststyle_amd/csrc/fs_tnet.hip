@@ -104,6 +104,7 @@ static ConvArgs unit_args(const Unit& u, int N) {
     a.src_mode = u.src_mode;
     a.refl = u.refl;
     a.shuffle = u.kind == 1;
+    a.prof_tag = 1;
     return a;
 }
 
@@ -436,6 +437,7 @@ static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, c
                       const float* add_src, float* ws, hipStream_t s) {
     const int N = L.N;
     ConvArgs a{};
+    a.prof_tag = 1;
     a.N = N;
     a.x = dz;
     a.y = dst;

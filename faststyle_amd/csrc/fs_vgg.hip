@@ -198,7 +198,7 @@ static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, 
     }
     a.p = conv_plan(a);
     if (pooled) *pooled = false;
-    if (pool && a.p.variant >= 5 && a.p.ksplit <= 1 && !(H & 1) && !(W & 1) && tune_int("FS_VGG_POOL_FUSED", 1)) {
+    if (pool && (a.p.variant == 5 || a.p.variant == 6) && a.p.ksplit <= 1 && !(H & 1) && !(W & 1) && tune_int("FS_VGG_POOL_FUSED", 1)) {
         a.pool_out = pool;   // the Winograd epilogues hold whole 2x2 tiles: the pooled tensor comes for one extra store per tile
         if (pooled) *pooled = true;
     }

@@ -639,7 +639,7 @@ int wgrad_launch(const WgradArgs& a_in, hipStream_t s) {
     const int NWV = p.NWV;
     dim3 grid((unsigned)p.n_wg, (unsigned)(cdiv(p.KB, p.waves_k * p.KWV) * cdiv(p.NB, NWV)), (unsigned)(a.per_sample ? a.N : 1));
     Profiler* prof = Profiler::current();
-    if (prof) prof->begin(a.per_sample ? 7 : 3, 2.0 * a.N * a.Ho * a.Wo * (double)p.K * a.Cout, s);
+    if (prof) prof->begin(a.per_sample ? PF_GRAM_WGRAD : PF_WGRAD, 2.0 * a.N * a.Ho * a.Wo * (double)p.K * a.Cout, s);
     if (p.KWV == 1)
         launch_wgrad<1, 4>(a, grid, s);
     else if (p.KWV == 2)

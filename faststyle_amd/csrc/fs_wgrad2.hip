@@ -481,11 +481,32 @@ static void w2_variant(int KB, int NB, int* KM, int* KN, int* waves_k) {
     *waves_k = need >= 3 ? 4 : need;
 }
 
-// Plans `n` problems that share the conv geometry of probs[0] (shapes and pointers may differ): tile, pitches, wave
-// roles, and the deal of workgroups to problems.  Returns the number of slab floats the launch needs (0: not eligible).
+// Plans `n` problems that share the conv geometry of probs[0] (image shapes and pointers may differ): tile, pitches, wave
+// roles, and the deal of workgroups to problems.  The on-load affine of x (in_a/in_b: the producer's instance norm + ReLU)
+// and of dy may be present in some problems and absent in others -- the kernel gates it on the problem's pointer -- but
+// every problem that HAS one must agree on its flags (in_nstride / in_relu, dy_nstride / dy_relu), which are launch-wide.
+// Returns the number of slab floats the launch needs (0: not eligible -- the caller launches per problem).
 size_t wgrad2_plan(const WgradArgs* probs, int n, Wg2Args* out) {
     if (n < 1 || n > kW2MaxProb || !wgrad2_eligible(probs[0])) return 0;
     const WgradArgs& g = probs[0];
+    const WgradArgs* with_in = nullptr;   // first problem with an x affine / a dy affine: the source of the launch-wide flags
+    const WgradArgs* with_dy = nullptr;
+    for (int i = 0; i < n; ++i) {
+        const WgradArgs& q = probs[i];
+        const int gd = g.dil_x > 0 ? g.dil_x : 1, qd = q.dil_x > 0 ? q.dil_x : 1;
+        if (i > 0 && (!wgrad2_eligible(q) || q.Cin != g.Cin || q.Cout != g.Cout || q.KH != g.KH || q.KW != g.KW || q.stride != g.stride ||
+                      q.pad_t != g.pad_t || q.pad_l != g.pad_l || qd != gd || q.src_mode != g.src_mode || q.refl != g.refl ||
+                      q.dy_unshuffle != g.dy_unshuffle || q.per_sample != g.per_sample))
+            return 0;
+        if (q.in_a) {
+            if (!with_in) with_in = &q;
+            if (q.in_nstride != with_in->in_nstride || q.in_relu != with_in->in_relu) return 0;
+        }
+        if (q.dy_a) {
+            if (!with_dy) with_dy = &q;
+            if (q.dy_nstride != with_dy->dy_nstride || q.dy_relu != with_dy->dy_relu) return 0;
+        }
+    }
     Wg2Args A{};
     Wg2Plan& p = A.p;
     A.Cin = g.Cin;
@@ -498,10 +519,10 @@ size_t wgrad2_plan(const WgradArgs* probs, int n, Wg2Args* out) {
     A.dil_x = g.dil_x > 0 ? g.dil_x : 1;
     A.src_mode = g.src_mode;
     A.refl = g.refl;
-    A.in_nstride = g.in_nstride;
-    A.in_relu = g.in_relu;
-    A.dy_nstride = g.dy_nstride;
-    A.dy_relu = g.dy_relu;
+    A.in_nstride = with_in ? with_in->in_nstride : 0;
+    A.in_relu = with_in ? with_in->in_relu : 0;
+    A.dy_nstride = with_dy ? with_dy->dy_nstride : 0;
+    A.dy_relu = with_dy ? with_dy->dy_relu : 0;
     A.dy_unshuffle = g.dy_unshuffle;
     A.debug = tune_int("FS_WGRAD2_DEBUG", 0);   // timing experiments only: 1 skips the sweeps, 2 stages only the first tile
     p.K = g.KH * g.KW * g.Cin;
@@ -630,7 +651,7 @@ int wgrad2_run(const Wg2Args& planned, float* slabs, float* const* dw, float sca
     }
     if (((size_t)a.p.K * a.Cout) % 4) return -1;
     Profiler* prof = Profiler::current();
-    if (prof) prof->begin(3, flops, s);
+    if (prof) prof->begin(PF_WGRAD2, flops, s);
     if (a.Cin == 3)
         w2_launch<18, 1, false>(a, s);
     else if (a.p.KN == 8)

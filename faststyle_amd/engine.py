@@ -6,7 +6,6 @@ injectable (``mem``) so the parity tests can drive the very same code with host 
 the kernel emulator build; the product always uses ``TorchMem`` on a ROCm device.
 """
 import ctypes
-import os
 from collections import OrderedDict
 
 import numpy as np
@@ -16,6 +15,8 @@ from . import _lib as L
 
 class TorchMem(object):
     """Device tensors from PyTorch-ROCm on the current HIP stream."""
+
+    supports_graphs = True     # hipGraph capture of a step (trainer.py); host-array providers of the tests have none
 
     def __init__(self, device="cuda:0"):
         import torch
@@ -75,7 +76,12 @@ def default_loss_cfg():
 
 
 class Engine(object):
-    MAX_CACHED_SHAPES = 8          # workspaces kept per (batch, size, mode) key
+    # Workspaces are cached per shape (a backward must find the workspace its forward filled; a captured hipGraph replays raw
+    # pointers into its own).  The cache is bounded by BYTES, least recently used first: stylizing a directory of mixed
+    # resolutions must not pile up one multi-GB workspace per size.  Entries a live hipGraph replays into are pinned by
+    # their trainer (pin_workspaces) and are never evicted while pinned.
+    MAX_CACHED_BYTES = 24 << 30    # of 288 GB; the largest single shape of the BASELINE configs (1080p batch 8 fp32) needs 17 GB
+    MAX_CACHED_SHAPES = 8
 
     def __init__(self, mem=None, lib=None):
         self.mem = mem if mem is not None else TorchMem()      # initialises the HIP runtime PyTorch ships
@@ -86,6 +92,7 @@ class Engine(object):
         self.ctx = ctx
         self._tnet_ws = {}
         self._perc_ws = {}
+        self._pinned = {}          # id(workspace tensor) -> pin count
         self._keep = []
 
     def close(self):
@@ -142,17 +149,38 @@ class Engine(object):
         L.check(self.lib, self.lib.fs_tnet_out_shape(H, W, ctypes.byref(ho), ctypes.byref(wo)), "fs_tnet_out_shape")
         return ho.value, wo.value
 
+    def _evict(self, cache, incoming_bytes):
+        """Drop least-recently-used, unpinned entries of `cache` until `incoming_bytes` more fit the budget."""
+        def total():
+            return sum(nb for _, nb in self._tnet_ws.values()) + sum(nb for _, nb in self._perc_ws.values())
+        for key in list(cache):
+            if len(cache) < self.MAX_CACHED_SHAPES and total() + incoming_bytes <= self.MAX_CACHED_BYTES:
+                break
+            if self._pinned.get(id(cache[key][0]), 0) == 0:
+                cache.pop(key)
+
+    def pin_workspaces(self, entries, on=True):
+        """entries: workspace tensors a captured hipGraph replays into; pinned entries survive cache eviction."""
+        for t in entries:
+            n = self._pinned.get(id(t), 0) + (1 if on else -1)
+            if n > 0:
+                self._pinned[id(t)] = n
+            else:
+                self._pinned.pop(id(t), None)
+
+    def _tnet_key(self, N, H, W, bf16=False):
+        # the layout (and with it the size) depends on the library's FS_TNET_WINO knob as the LIBRARY sees it (read once and
+        # cached there): ask the library, not os.environ
+        nbytes = self.lib.fs_tnet_workspace_bytes(N, H, W, L.FS_FLAG_BF16 if bf16 else L.FS_FLAG_SAVE_FOR_BWD)
+        if nbytes == 0:
+            raise L.FaststyleError("bad transform-net shape %s" % ((N, H, W, bf16),))
+        return (N, H, W, bf16, nbytes)
+
     def _tnet_workspace(self, N, H, W, bf16=False):
-        key = (N, H, W, bf16, os.environ.get("FS_TNET_WINO", ""))   # (the layout depends on this tuning knob)
+        key = self._tnet_key(N, H, W, bf16)
         if key not in self._tnet_ws:
-            nbytes = self.lib.fs_tnet_workspace_bytes(N, H, W, L.FS_FLAG_BF16 if bf16 else L.FS_FLAG_SAVE_FOR_BWD)
-            if nbytes == 0:
-                raise L.FaststyleError("bad transform-net shape %s" % (key,))
-            # a few shapes stay resident (a captured hipGraph holds raw pointers into its workspace, and a backward
-            # must find the workspace its forward filled); least-recently-used beyond that
-            while len(self._tnet_ws) >= self.MAX_CACHED_SHAPES:
-                self._tnet_ws.pop(next(iter(self._tnet_ws)))
-            self._tnet_ws[key] = (self.mem.empty((nbytes // 4,)), nbytes)
+            self._evict(self._tnet_ws, key[4])
+            self._tnet_ws[key] = (self.mem.empty((key[4] // 4,)), key[4])
         else:
             self._tnet_ws[key] = self._tnet_ws.pop(key)                      # mark as most recently used
         return self._tnet_ws[key]
@@ -163,6 +191,7 @@ class Engine(object):
         self._sync_stream()
         self._tnet_ws.clear()
         self._perc_ws.clear()
+        self._pinned.clear()
 
     @staticmethod
     def _method_flag(upsample_method):
@@ -189,7 +218,7 @@ class Engine(object):
         """Gradient of the 48 tensors given dL/dy; must follow tnet_forward(save_for_bwd=True)."""
         self._sync_stream()
         N, H, W, _ = (int(s) for s in x.shape)
-        if (N, H, W, False, os.environ.get("FS_TNET_WINO", "")) not in self._tnet_ws:
+        if self._tnet_key(N, H, W) not in self._tnet_ws:
             raise L.FaststyleError("tnet_backward(%dx%dx%d) without a tnet_forward(save_for_bwd=True) of that shape" % (N, H, W))
         ws, nbytes = self._tnet_workspace(N, H, W)
         if grads is None:
@@ -266,8 +295,7 @@ class Engine(object):
         nbytes = self.lib.fs_perceptual_workspace_bytes(N, H, W, ctypes.byref(c))
         if key not in self._perc_ws or self._perc_ws[key][1] != nbytes:
             self._perc_ws.pop(key, None)
-            while len(self._perc_ws) >= self.MAX_CACHED_SHAPES:
-                self._perc_ws.pop(next(iter(self._perc_ws)))
+            self._evict(self._perc_ws, nbytes)
             self._perc_ws[key] = (self.mem.empty((nbytes // 4,)), nbytes)
         else:
             self._perc_ws[key] = self._perc_ws.pop(key)
@@ -301,9 +329,50 @@ class Engine(object):
         return outs
 
     def gram(self, feat):
-        """utils.get_grams for one layer (utils.py:76-82): feat [N,h,w,c] -> [N,c,c] = F^T F / (h*w*c)."""
+        """utils.get_grams for one layer (utils.py:76-82): feat [N,h,w,c] -> [N,c,c] = F^T F / (h*w*c)  (fs_gram_fwd)."""
+        self._sync_stream()
         N, h, w, c = (int(s) for s in feat.shape)
-        return self.conv2d_wgrad(feat, feat, 1, 1, "VALID", per_sample=True, scale=1.0 / (h * w * c))
+        G = self.mem.empty((N, c, c))
+        nbytes = self.lib.fs_gram_workspace_bytes(N, h * w, c)
+        ws = self.mem.empty((max(nbytes // 4, 1),))
+        p = self.mem.ptr
+        L.check(self.lib, self.lib.fs_gram_fwd(self.ctx, p(feat), N, h * w, c, p(G), p(ws), nbytes), "fs_gram_fwd")
+        return G
+
+    def gram_bwd(self, feat, dG):
+        """Gradient through utils.get_grams: dF = F (dG + dG^T) / (h*w*c), feat [N,h,w,c], dG [N,c,c]  (fs_gram_bwd)."""
+        self._sync_stream()
+        N, h, w, c = (int(s) for s in feat.shape)
+        dF = self.mem.empty((N, h, w, c))
+        nbytes = self.lib.fs_gram_workspace_bytes(N, h * w, c)
+        ws = self.mem.empty((max(nbytes // 4, 1),))
+        p = self.mem.ptr
+        L.check(self.lib, self.lib.fs_gram_bwd(self.ctx, p(feat), p(dG), N, h * w, c, p(dF), p(ws), nbytes), "fs_gram_bwd")
+        return dF
+
+    # ------------------------------------------------------------------ inspection of the saved tensors (parity tests)
+    def tnet_saved(self, N, H, W, unit, what, upsample_method="resize"):
+        """View of a tensor fs_tnet_forward(save_for_bwd=True) left in the (cached) workspace of this shape."""
+        off, dims = ctypes.c_size_t(), (ctypes.c_int * 4)()
+        L.check(self.lib, self.lib.fs_tnet_ws_tensor(N, H, W, L.FS_FLAG_SAVE_FOR_BWD | self._method_flag(upsample_method), unit, what,
+                                                     ctypes.byref(off), ctypes.byref(dims)), "fs_tnet_ws_tensor")
+        key = self._tnet_key(N, H, W)
+        if key not in self._tnet_ws:
+            raise L.FaststyleError("no transform-net workspace of shape %s" % ((N, H, W),))
+        shape = tuple(dims) if what in (L.FS_TNET_WS_Z, L.FS_TNET_WS_H) else (dims[0], dims[1])
+        return self.mem.view(self._tnet_ws[key][0], off.value, shape)
+
+    def vgg_saved(self, N, H, W, cfg, layer_name):
+        """View of the post-ReLU activations fs_perceptual_loss left in its (cached) workspace: [NB,h,w,c], the first N
+        samples are the net outputs, the next N (up to the last content layer) the content batch."""
+        c = self._cfg(cfg)
+        off, dims = ctypes.c_size_t(), (ctypes.c_int * 4)()
+        L.check(self.lib, self.lib.fs_perceptual_ws_tensor(N, H, W, ctypes.byref(c), L.VGG_LAYER_NAMES.index(layer_name),
+                                                           ctypes.byref(off), ctypes.byref(dims)), "fs_perceptual_ws_tensor")
+        key = (N, H, W, tuple(cfg["content_layers"]), tuple(cfg["style_layers"]))
+        if key not in self._perc_ws:
+            raise L.FaststyleError("no perceptual workspace of shape %s" % ((N, H, W),))
+        return self.mem.view(self._perc_ws[key][0], off.value, tuple(dims))
 
     def loss_sqdiff(self, x, t, scale):
         """scale * sum((x - t)^2) with t broadcast over the leading (batch) axis when smaller; device scalar [1]."""

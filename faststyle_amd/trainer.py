@@ -37,8 +37,9 @@ class Trainer(object):
             eng.vgg_load(vgg_weights)
         # train.py:144-151: target Grams of the style image, computed once
         self.target_grams = eng.style_targets(mem.from_numpy(style_img), self.cfg)
-        self.use_graph = use_graph
+        self.use_graph = bool(use_graph) and getattr(mem, "supports_graphs", False)
         self.graph = None
+        self._graph_keepalive = []
         self._static_in = None
         self._static_losses = None
 
@@ -60,6 +61,7 @@ class Trainer(object):
         """Capture forward+backward for this batch shape into a hipGraph (after eager warm-up so
         every one-time initialisation inside the library has already happened)."""
         import torch
+        self._release_graph()
         self._static_in = batch.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -73,9 +75,23 @@ class Trainer(object):
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._static_losses = self._forward_backward(self._static_in)
         self.graph = g
-        # the graph replays raw pointers into the engine's workspaces: keep them alive for as long as the graph lives,
-        # whatever the engine's per-shape cache does meanwhile
-        self._graph_keepalive = [dict(self.eng._tnet_ws), dict(self.eng._perc_ws)]
+        # the graph replays raw pointers into the two workspaces ITS forward/backward used (the most recently used entry of
+        # each cache): keep exactly those alive and un-evictable for as long as the graph lives
+        e = self.eng
+        self._graph_keepalive = [next(reversed(e._tnet_ws.values()))[0], next(reversed(e._perc_ws.values()))[0]]
+        e.pin_workspaces(self._graph_keepalive, True)
+
+    def _release_graph(self):
+        if self._graph_keepalive:
+            self.eng.pin_workspaces(self._graph_keepalive, False)
+        self._graph_keepalive = []
+        self.graph = None
+
+    def __del__(self):
+        try:
+            self._release_graph()
+        except Exception:
+            pass
 
     def step(self, batch):
         """batch: device tensor [B,H,W,3] float32 RGB 0..255 (train.py:158-160).
@@ -89,7 +105,7 @@ class Trainer(object):
                     import sys
                     print("faststyle: hipGraph capture failed (%s); running eagerly" % ex, file=sys.stderr)
                     self.use_graph = False
-                    self.graph = None
+                    self._release_graph()
         if self.use_graph and self.graph is not None:
             self._static_in.copy_(batch)
             self.graph.replay()
@@ -142,7 +158,7 @@ class Trainer(object):
             self.m = mem.zeros(self.params.shape)
             self.v = mem.zeros(self.params.shape)
             self.global_step = 0
-        self.graph = None                      # a captured graph holds the old buffers
+        self._release_graph()                  # a captured graph holds the old buffers
         if self._world() > 1:
             for t in (self.params, self.m, self.v):
                 self.dist.broadcast(t, src=0)

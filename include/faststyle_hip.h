@@ -32,13 +32,13 @@ const char* fs_last_error(void);
 const char* fs_version(void);
 
 /* ---- measurement hook (bench.py): HIP events around every MFMA-kernel launch on the ctx stream.
- * out[f*3+{0,1,2}] = {launches, algorithmic FLOPs, milliseconds} for kernel family f:
- * 0 conv_igemm<32,2,2>, 1 conv_igemm<32,2,1>, 2 conv_igemm<16,4,1>, 3 conv_wgrad (filter gradients),
- * 4 conv_igemm<32,1,2>, 5 conv_igemm<32,1,1>, 6 wino_conv (Winograd F(2x2,3x3); FLOPs = those executed),
- * 7 Gram forward (conv_wgrad, per-sample F^T F: utils.py:76-82), 8 Gram backward (conv_igemm, 1x1 with per-sample filters). */
-#define FS_PROFILE_FAMILIES 9
+ * out[f*3+{0,1,2}] = {launches, FLOPs executed, milliseconds} of row f; fs_profile_family_name(f) is the kernel symbol the
+ * row belongs to (one row per symbol, so a row can be re-derived from a `rocprofv3 --kernel-trace --stats` summary; the
+ * one symbol shared by two workloads, wino2_conv_kernel, has a row per caller), "" for unused rows. */
+#define FS_PROFILE_FAMILIES 20
 int fs_profile_begin(fs_ctx* ctx);
 int fs_profile_end(fs_ctx* ctx, double out[3 * FS_PROFILE_FAMILIES]);
+const char* fs_profile_family_name(int family);
 
 /* ---- image-transform net: reference im_transf_net.py:14-75 (create_net) ------------------ */
 #define FS_TNET_NPARAMS 424102 /* 48 fp32 tensors, sorted-key (= checkpoint) order */
@@ -104,24 +104,49 @@ int fs_style_targets(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const fl
                      const fs_loss_cfg* cfg, const float* style_img, int H, int W, float* const grams[4], void* ws,
                      size_t ws_bytes);
 
-/* ---- optimiser: tf.train.AdamOptimizer (train.py:203), TF1 epsilon placement ---------------- */
 /* ---- builder-level pieces (the reference's Python helpers, for scripts that compose their own loss) ----
  * fs_vgg_features: libs/vgg16.py:36-220 -- the post-ReLU tensors `vgg/convX_Y:0` of N images (RGB 0..255, the
  *   ImageNet mean is subtracted inside); layers[i] in 0..9 = conv1_1..conv4_3; out[i] device [N,H_l,W_l,C_l].
- *   utils.get_grams (utils.py:66-83) on such a tensor is fs_conv2d_wgrad with per_sample, KH=KW=1, x==dy,
- *   scale 1/(h*w*c).
+ * fs_gram_fwd: utils.get_grams (utils.py:66-83) on one such tensor F[N,HW,C] (the [b,h*w,c] reshape of utils.py:76-77):
+ *   G[n] = F[n]^T F[n] / (HW*C), [N,C,C], exactly symmetric.  C: a multiple of 4, of 128 beyond 128.
+ * fs_gram_bwd: the gradient through it, dF[n] = F[n] (dG[n] + dG[n]^T) / (HW*C) for an upstream dG[N,C,C] (what
+ *   tf.gradients forms behind losses.style_loss, losses.py:61-64).  ws: fs_gram_workspace_bytes(N,HW,C) for both.
+ *   (Inside fs_perceptual_loss the same two kernels run with the symmetric factor folded into the loss kernel.)
  * fs_loss_sqdiff: out[0] = scale * sum_i (x[i] - t[i % t_period])^2 -- losses.content_loss (losses.py:32-37, scale
  *   w/(h*w*c)) and losses.style_loss (losses.py:61-64, scale w/(c*c), t = the [1,c,c] target broadcast over the batch).
  * fs_loss_tv: losses.tv_loss (losses.py:70-97).  scratch: 4096 bytes of device memory; out: device scalar. */
 size_t fs_vgg_features_workspace_bytes(int N, int H, int W, int max_layer);
 int fs_vgg_features(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS], const float* x,
                     int N, int H, int W, int n_layers, const int* layers, float* const* out, void* ws, size_t ws_bytes);
+size_t fs_gram_workspace_bytes(int N, int HW, int C);
+int fs_gram_fwd(fs_ctx* ctx, const float* F, int N, int HW, int C, float* G, void* ws, size_t ws_bytes);
+int fs_gram_bwd(fs_ctx* ctx, const float* F, const float* dG, int N, int HW, int C, float* dF, void* ws, size_t ws_bytes);
 int fs_loss_sqdiff(fs_ctx* ctx, const float* x, const float* t, size_t t_period, size_t n, float scale, float* out,
                    void* scratch);
 int fs_loss_tv(fs_ctx* ctx, const float* x, int N, int H, int W, int C, float* out, void* scratch);
 
+/* ---- optimiser: tf.train.AdamOptimizer (train.py:203), TF1 form -- lr_t = lr*sqrt(1-b2^t)/(1-b1^t), epsilon OUTSIDE the
+ * bias correction: theta -= lr_t * m / (sqrt(v) + eps) ------------------------------------------------------------------ */
 int fs_adam_tf_step(fs_ctx* ctx, float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
                     float beta2, float eps, long long t /* 1-based step */);
+
+/* ---- inspection (parity tests, debugging): where the composite calls leave their saved tensors inside the CALLER's
+ * workspace.  Offsets are in floats from the start of `ws`; the layout is a pure function of the arguments (and of the
+ * library's tuning knobs as cached at the time), so these need no ctx and launch nothing.
+ * fs_tnet_ws_tensor: after fs_tnet_forward(..., FS_FLAG_SAVE_FOR_BWD).  unit 0..15 = initconv_0..2, resblock_k conv 1 / 2
+ *   (3+2k, 4+2k), upsample_0..2.  what: FS_TNET_WS_Z the raw conv output z [N,Ho,Wo,C] (before the instance norm);
+ *   _A / _B / _MEAN / _RSTD the per-sample constants [N,C] (the unit's activation is relu(a*z + b), a = gamma*rstd,
+ *   b = beta - mean*a; im_transf_net.py:238-245); FS_TNET_WS_H (unit = k in 0..4) the output of residual block k.
+ * fs_perceptual_ws_tensor: after fs_perceptual_loss.  The post-ReLU activations `vgg/convX_Y:0` of layer 0..9, [NB,h,w,c]:
+ *   the first N samples belong to y, the next N (layers up to the last content layer only) to the content batch. */
+#define FS_TNET_WS_Z 0
+#define FS_TNET_WS_A 1
+#define FS_TNET_WS_B 2
+#define FS_TNET_WS_MEAN 3
+#define FS_TNET_WS_RSTD 4
+#define FS_TNET_WS_H 5
+int fs_tnet_ws_tensor(int N, int H, int W, int flags, int unit, int what, size_t* offset_floats, int dims[4]);
+int fs_perceptual_ws_tensor(int N, int H, int W, const fs_loss_cfg* cfg, int layer, size_t* offset_floats, int dims[4]);
 
 /* ---- single ops (used by the parity tests; same kernels the composite calls launch) --------- */
 #define FS_PAD_SAME 0
@@ -149,9 +174,12 @@ typedef struct {
     int add_pad;
     long long w_nstride; /* per-sample filter stride in floats (0: shared) */
     const float* w_wino; /* optional: the same filter as transformed by fs_wino_transform_filter (16*Cin*Cout floats, layout
-                          * private to the library); an eligible conv (3x3, stride 1, SAME / VALID / 'full' padding, Cin % 8 == 0,
-                          * Cout % 64 == 0) then runs on a Winograd F(2x2,3x3) kernel -- the path the VGG16 convs of
-                          * fs_perceptual_loss and the residual convs of the transform net take */
+                          * private to the library); an eligible conv -- 3x3, stride 1, SAME / VALID / 'full' padding,
+                          * Cin % 8 == 0, Cin <= 128, Cout % 64 == 0 -- then runs on the second-generation Winograd
+                          * F(2x2,3x3) kernel, the one the 64/128-channel VGG16 convs of fs_perceptual_loss and the residual
+                          * convs of the transform net take.  Any other shape (Cin > 128 included: the composite calls run
+                          * those layers on the first-generation kernel, whose filter order this descriptor does not carry)
+                          * silently takes the direct kernel -- same result within the parity tolerance. */
 } fs_conv_desc;
 /* U = G g G^T for every (ci, co) filter g = w[:, :, ci, co] of a 3x3 HWIO filter (Lavin & Gray F(2x2,3x3)), 16 values per
  * filter, in the order the Winograd kernels stage them; the caller owns U (16*Cin*Cout floats; Cin % 8 == 0).

@@ -52,19 +52,26 @@ def vgg16(imgs, weights, upto="conv4_3", keep=False):
     return (feats, cache) if keep else feats
 
 
-def vgg16_bwd(dfeats, feats, weights, cache, upto="conv4_3"):
+def vgg16_bwd(dfeats, feats, weights, cache, upto="conv4_3", masks=None):
     """dL/d(imgs) given dL/d(feature) for any subset of layers (dgrad only: VGG is frozen,
-    train.py:198-199)."""
+    train.py:198-199).
+
+    ``masks`` (tests only): the NON-DIFFERENTIABLE decisions of the backward pass taken from another evaluation of the same
+    forward -- ``masks["conv3_2"]`` a boolean ReLU mask, ``masks["pool1/idx"]`` the arg-max (0..3) of every pooling window --
+    instead of this evaluation's own.  A pre-activation within float32 noise of zero (or two window entries within noise
+    of each other) is decided differently by a float32 and a float64 forward; with the float32 path's decisions injected,
+    everything that remains is smooth and the two gradients agree to rounding."""
     names = [l[0] for l in VGG_LAYERS]
     names = names[:names.index(upto) + 1]
+    masks = masks or {}
     dh = None
     for name in reversed(names):
         if name.startswith("pool"):
-            dh = F.max_pool_2x2_bwd(dh, cache[name + "/idx"], cache[name + "/in_hw"])
+            dh = F.max_pool_2x2_bwd(dh, masks.get(name + "/idx", cache[name + "/idx"]), cache[name + "/in_hw"])
             continue
         if name in dfeats:
             dh = dfeats[name] if dh is None else dh + dfeats[name]
-        dz = dh * (feats[name] > 0)
+        dz = dh * masks.get(name, feats[name] > 0)
         dh = F.conv2d_bwd_input(dz, weights[name + "_W"], cache[name + "/in"].shape[1:3], 1, "SAME")
     return dh
 
@@ -126,7 +133,7 @@ def target_grams(style_img, vgg_w, style_layers):
 
 def perceptual_loss(y, content_targets, tgt_grams, vgg_w, content_layers=("conv3_3",),
                     style_layers=("conv1_2", "conv2_2", "conv3_3", "conv4_3"),
-                    content_weights=(1.0,), style_weights=(5.0, 5.0, 5.0, 5.0), beta=0.0):
+                    content_weights=(1.0,), style_weights=(5.0, 5.0, 5.0, 5.0), beta=0.0, masks=None):
     """train.py:164-184: loss = content + style + beta*tv on y (the net output, fed to
     VGG directly).  Returns (dict of loss scalars, dL/dy)."""
     upto = max(list(content_layers) + list(style_layers))
@@ -139,7 +146,7 @@ def perceptual_loss(y, content_targets, tgt_grams, vgg_w, content_layers=("conv3
         dfeats[n] = dfeats.get(n, 0) + g
     for n, g in zip(style_layers, sgrads):
         dfeats[n] = dfeats.get(n, 0) + gram_bwd(g, feats[n])
-    dy = vgg16_bwd(dfeats, feats, vgg_w, cache, upto=upto)
+    dy = vgg16_bwd(dfeats, feats, vgg_w, cache, upto=upto, masks=masks)
     tv, dtv = tv_loss(y)
     t = y.dtype.type
     loss = closs + sloss + t(beta) * tv
@@ -165,9 +172,10 @@ def train_step(params, batch, tgt_grams, vgg_w, beta=0.0, **kw):
     content targets from the RAW batch (train.py:250-251 overrides Y with the batch),
     then forward/backward through create_net + VGG.  Returns (losses, grads dict)."""
     content_layers = kw.get("content_layers", ("conv3_3",))
+    masks = kw.pop("masks", None) or {}           # {"vgg": ..., "tnet": ...}: see vgg16_bwd / tnet.create_net_bwd
     feats = vgg16(batch, vgg_w, upto=max(content_layers))
     content_targets = [feats[n] for n in content_layers]
     y, cache = tnet.create_net(batch, params, "resize", keep=True)
-    losses, dy = perceptual_loss(y, content_targets, tgt_grams, vgg_w, beta=beta, **kw)
-    grads = tnet.create_net_bwd(dy, params, cache)
+    losses, dy = perceptual_loss(y, content_targets, tgt_grams, vgg_w, beta=beta, masks=masks.get("vgg"), **kw)
+    grads = tnet.create_net_bwd(dy, params, cache, masks=masks.get("tnet"))
     return losses, grads, y

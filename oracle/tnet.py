@@ -125,10 +125,15 @@ def create_net(x, params, upsample_method="resize", keep=False):
     return (y, c) if keep else y
 
 
-def create_net_bwd(dy, params, cache):
+def create_net_bwd(dy, params, cache, masks=None):
     """Gradients of create_net wrt its 48 parameters, given dL/dy.  Returns a dict with
-    the same keys as ``params`` (the input image gets no gradient in train.py)."""
+    the same keys as ``params`` (the input image gets no gradient in train.py).
+
+    ``masks`` (tests only): boolean ReLU masks of the ten rectified units taken from another evaluation of the same forward
+    (keys ``initconv_0..2``, ``resblock_k`` for the ReLU between a block's two convs, ``upsample_0..1``) instead of this
+    evaluation's own sign pattern -- see perceptual.vgg16_bwd."""
     P, c = params, cache
+    masks = masks or {}
     deconv = c["method"] == "deconv"
     g = {}
     name = "upsample_2"
@@ -143,7 +148,7 @@ def create_net_bwd(dy, params, cache):
         g[name + "/W"] = F.conv2d_bwd_filter(c[name + "/in"], dz, 9, 1, "SAME")
         dh = F.conv2d_bwd_input(dz, P[name + "/W"], c[name + "/in"].shape[1:3], 1, "SAME")
     for name in ("upsample_1", "upsample_0"):
-        dn = dh * (c[name + "/n"] > 0)
+        dn = dh * masks.get(name, c[name + "/n"] > 0)
         dz, g[name + "/INscale"], g[name + "/INshift"] = F.inst_norm_bwd(dn, c[name + "/in_cache"])
         if deconv:
             g[name + "/W"] = F.conv2d_bwd_filter(dz, c[name + "/in"], 3, 2, "SAME")
@@ -158,7 +163,7 @@ def create_net_bwd(dy, params, cache):
         dz2, g[name + "/INscale2"], g[name + "/INshift2"] = F.inst_norm_bwd(dh, c[name + "/in_cache2"])
         g[name + "/W2"] = F.conv2d_bwd_filter(c[name + "/a1"], dz2, 3, 1, "VALID")
         da1 = F.conv2d_bwd_input(dz2, P[name + "/W2"], c[name + "/a1"].shape[1:3], 1, "VALID")
-        dn1 = da1 * (c[name + "/n1"] > 0)
+        dn1 = da1 * masks.get(name, c[name + "/n1"] > 0)
         dz1, g[name + "/INscale1"], g[name + "/INshift1"] = F.inst_norm_bwd(dn1, c[name + "/in_cache1"])
         g[name + "/W1"] = F.conv2d_bwd_filter(c[name + "/in"], dz1, 3, 1, "VALID")
         dskip = np.pad(dh, ((0, 0), (2, 2), (2, 2), (0, 0)))
@@ -166,7 +171,7 @@ def create_net_bwd(dy, params, cache):
     strides = {"initconv_0": 1, "initconv_1": 2, "initconv_2": 2}
     for name in ("initconv_2", "initconv_1", "initconv_0"):
         k = 9 if name == "initconv_0" else 3
-        dn = dh * (c[name + "/n"] > 0)
+        dn = dh * masks.get(name, c[name + "/n"] > 0)
         dz, g[name + "/INscale"], g[name + "/INshift"] = F.inst_norm_bwd(dn, c[name + "/in_cache"])
         g[name + "/W"] = F.conv2d_bwd_filter(c[name + "/in"], dz, k, strides[name], "SAME")
         if name != "initconv_0":

@@ -30,8 +30,12 @@ def test_bench_json_contract():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 1.0
     assert r["traffic"] is None or r["traffic"] > 1e6
-    assert set(r["per_kernel"]) >= {"wino_conv_kernel", "conv_wgrad_kernel", "conv_wgrad_kernel (Gram forward)",
-                                    "conv_igemm_kernel (Gram backward)"}
+    # one row per kernel SYMBOL (wino2 split by caller), each with its own frac
+    assert set(r["per_kernel"]) >= {"wino_conv_kernel", "wino2_conv_kernel (VGG16 convs)", "wino2_conv_kernel (transform-net residual convs)",
+                                    "wgrad2_kernel", "gram_stream_kernel", "gram_bwd_kernel", "conv_stream_kernel"}
+    for row in r["per_kernel"].values():
+        assert abs(row["frac"] - row["tflops"] / 157.3) < 1e-3 and abs(row["ms_per_step"] * 1e3 - row["launches_per_step"] * row["avg_launch_us"]) < 2.0
+    assert r["kernel"].split(":")[0] in r["per_kernel"] and 0.05 < r["winograd_family"]["frac"] < 1.0
     g = d["gram"]
     # executed FLOPs: the symmetric diagonal tiles of the forward product are multiplied 10/16 -> between 75 % and 100 % of as-written
     assert 0.0 < g["frac_of_f32_mfma_peak"] < 1.0 and 0.75 * 4.295 * 32 < g["gflop_per_step"] < 1.02 * 4.295 * 32
@@ -42,6 +46,46 @@ def test_bench_json_contract():
     b4 = d["train_b4_per_gpu"]
     assert b4["batch_per_gpu"] == 4 and b4["hip_graph"] is True and b4["images_per_sec"] > 0
     assert d["stylize_720p"]["fps"] > 0 and d["stylize_1080p_b8_bf16"]["fps"] > 0
+    assert 0 < d["stylize_1080p_b8_bf16"]["frac_bf16_mfma_peak_executed"] < 1 and 0 < d["stylize_720p"]["frac_f32_mfma_peak_executed"] < 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert c["torch_cpu"]["value"] > 0 and c["one_core"]["cores"] == 1 and c["stylize_720p"]["torch_cpu_fps"] > 0
+
+
+def test_launch_command_is_the_drivers_form():
+    import bench
+    cmd = bench.launch_cmd(8, ["--gpus", "8", "--steps", "5", "--launch"], 29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "5"] and cmd[-5].endswith("bench.py")     # --launch is consumed by the launcher
+
+
+def test_bench_starts_its_own_ranks_cpu_gloo():
+    """`python bench.py --gpus 2` with no torchrun environment re-runs itself under torch.distributed.run: two ranks
+    rendezvous on 127.0.0.1 (gloo here: no GPU), all-reduce, and rank 0 alone prints ONE JSON line."""
+    env = dict((k, v) for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["rendezvous_ok"] is True and d["n_gpus"] == 2 and d["allreduce_sum_of_ranks"] == 1.0
+    assert "launching 2 ranks" in out.stderr and "torch.distributed.run" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_world1_rccl():
+    """The self-launch path on the one GPU a test box has: `bench.py --gpus 1 --launch` -> torch.distributed.run with one
+    rank -> RCCL process group, the all-reduce inside the step, per-rank values in the line."""
+    env = dict((k, v) for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--launch", "--steps", "3", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-stylize", "--b4-steps", "4", "--profile-steps", "1"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), lines[:5]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "RCCL all-reduce" in d["config"]["collective"] and len(d["per_rank_images_per_sec"]) == 1
+    assert abs(d["per_rank_images_per_sec"][0] - d["value"]) / d["value"] < 0.02
+    assert "configs[2]" in d["train_b4_per_gpu"]["config"]

@@ -170,45 +170,55 @@ def test_tnet_and_train_step_with_inputs_outside_0_255(eng):
     assert cos > 0.9999 and abs(np.linalg.norm(g) / np.linalg.norm(want) - 1.0) < 5e-3, cos
 
 
-# ------------------------------------------------------------------ BASELINE configs[2] at its real shape, several seeds
+# ------------------------------------------------------------------ BASELINE configs[2] at its real shape
+def _grads_close(e, g, want, tol):
+    """per-tensor max error relative to the tensor's magnitude (floored at 5 % of the largest gradient: tensors that are
+    zero by symmetry hold summation noise only) -- the measure of tests/test_path_parity.py"""
+    floor = 5e-2 * max(np.abs(w).max() for w in want.values())
+    bad = []
+    for name, off, shape in e.param_table():
+        n = int(np.prod(shape))
+        err = np.abs(g[off:off + n].reshape(shape) - want[name]).max() / max(np.abs(want[name]).max(), floor)
+        if not err < tol:
+            bad.append((name, float(err)))
+    return bad
+
+
 @pytest.mark.gpu
-def test_hip_train_step_256_b4_real_style_image_eight_seeds(knob_hip):
-    """256x256, batch 4, style_images/starry_night_crop.jpg (640x938): the step the bench times.  For 8 seeded batches the
-    losses and the 424,102 gradients of the HIP path against the float32 numpy oracle, once through the Winograd kernels and
-    once through the direct kernels (FS_CONV_WINO=0); reports the worst gradient cosine / relative L2 of each."""
+@pytest.mark.parametrize("seed,mode", [(100, "winograd"), (101, "winograd"), (100, "direct")])
+def test_hip_train_step_256_b4_real_style_image_all_48_gradients_tight(knob_hip, mode, seed):
+    """256x256, batch 4, style_images/starry_night_crop.jpg (640x938), the reference initialisation: the step of BASELINE
+    configs[2] (reference train.py:158-204).  The float64 oracle runs with the HIP path's own ReLU masks and pooling arg-max
+    injected (tests/maskinject.py), so nothing non-smooth separates the two: losses 2e-5, EVERY one of the 48 gradient
+    tensors 2e-4 of its magnitude, whole-vector relative L2 2e-4 -- once through the Winograd kernels, once through the
+    direct kernels (FS_CONV_WINO=0).  (Round 2 held this shape only to cos > 0.9999 / relative L2 < 1.5e-2 and attributed
+    the slack to flipped ReLU / max-pool ties; the injected comparison shows that attribution was right -- and leaves a
+    real gradient bug nowhere to hide.)"""
     from faststyle_amd import utils
+    from tests import maskinject
     e = get_engine("hip")
+    knob_hip("FS_CONV_WINO", 1 if mode == "winograd" else 0)
     style = utils.imread(os.path.join(ROOT, "style_images", "starry_night_crop.jpg")).astype(np.float32)[None]
     Wv = perceptual.synthetic_vgg_weights(seed=3)
     cfg = engine.default_loss_cfg()
     P = tnet.init_params(seed=0)
-    tgo = perceptual.target_grams(style, Wv, cfg["style_layers"])
-    names = [n for n, _, _ in e.param_table()]
-    oracle = []
-    for seed in range(8):
-        x = np.random.default_rng(100 + seed).uniform(0, 255, (4, 256, 256, 3)).astype(np.float32)
-        lo, go, _ = perceptual.train_step(P, x, tgo, Wv)
-        oracle.append((x, lo, np.concatenate([go[n].ravel() for n in names]).astype(np.float64)))
-    report = {}
-    for mode in ("winograd", "direct"):
-        knob_hip("FS_CONV_WINO", 1 if mode == "winograd" else 0)
-        e.vgg_load(Wv)
-        flat = e.mem.from_numpy(e.flatten_params(P, scope=""))
-        tg = e.style_targets(e.mem.from_numpy(style), cfg)
-        worst_cos, worst_l2, worst_loss = 1.0, 0.0, 0.0
-        for x, lo, want in oracle:
-            xd = e.mem.from_numpy(x)
-            y = e.tnet_forward(flat, xd, save_for_bwd=True)
-            losses, dy = e.perceptual_loss(y, xd, tg, cfg)
-            g = e.mem.to_numpy(e.tnet_backward(flat, xd, dy)).astype(np.float64)
-            lh = e.mem.to_numpy(losses)
-            worst_loss = max(worst_loss, abs(lh[0] - lo["loss"]) / abs(lo["loss"]))
-            worst_cos = min(worst_cos, float(np.dot(g, want) / (np.linalg.norm(g) * np.linalg.norm(want))))
-            worst_l2 = max(worst_l2, float(np.linalg.norm(g - want) / np.linalg.norm(want)))
-        report[mode] = (worst_loss, worst_cos, worst_l2)
-    print("256x256 b4, 8 seeds, worst (loss rel. error, gradient cosine, gradient rel. L2): %s" % report)
-    for mode, (wl, wc, w2) in report.items():
-        assert wl < 1e-3 and wc > 0.9999 and w2 < 1.5e-2, (mode, wl, wc, w2)
+    x = np.random.default_rng(seed).uniform(0, 255, (4, 256, 256, 3)).astype(np.float32)
+    lh, lo, g, go, masks = maskinject.step_with_injected_masks(e, P, x, style, Wv, cfg)
+    np.testing.assert_allclose(lh[:3], [lo["loss"], lo["content_loss"], lo["style_loss"]], rtol=2e-5)
+    bad = _grads_close(e, g, go, 2e-4)
+    want = np.concatenate([go[n].ravel() for n, _, _ in e.param_table()])
+    cos = float(np.dot(g, want) / (np.linalg.norm(g) * np.linalg.norm(want)))
+    l2 = float(np.linalg.norm(g - want) / np.linalg.norm(want))
+    l2_own = float("nan")
+    if seed == 100 and mode == "winograd":   # what the un-injected comparison is made of: the same oracle with its OWN decisions
+        lo_own, go_own, _ = perceptual.train_step(mg.f64(P), x.astype(np.float64),
+                                                  perceptual.target_grams(style.astype(np.float64), mg.f64(Wv), cfg["style_layers"]), mg.f64(Wv))
+        own = np.concatenate([go_own[n].ravel() for n, _, _ in e.param_table()])
+        l2_own = float(np.linalg.norm(g - own) / np.linalg.norm(own))
+        assert l2_own < 1.5e-2
+    print("256x256 b4 seed %d %s: masks injected cos %.9f relL2 %.2e | oracle's own masks relL2 %.2e" % (seed, mode, cos, l2, l2_own))
+    assert bad == [], bad
+    assert l2 < 2e-4
 
 
 @pytest.fixture

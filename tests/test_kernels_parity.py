@@ -210,6 +210,31 @@ def test_gram_is_symmetric_psd_and_matches_oracle(eng, hw, c):
     assert np.abs(g - g.transpose(0, 2, 1)).max() <= 1e-6 * np.abs(g).max()
     ev = np.linalg.eigvalsh(g[0].astype(np.float64))
     assert ev.min() > -1e-5 * ev.max()
+    # the named entry point (fs_gram_fwd) is the same computation
+    g2 = down(eng, eng.gram(ft))
+    assert rel(g2, want) < TOL and g2.shape == (2, c, c)
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 23, 64), (3, 16, 17, 128), (2, 9, 11, 256), (1, 6, 5, 512), (2, 7, 3, 32)])
+def test_gram_named_exports_forward_and_gradient(eng, shape):
+    """fs_gram_fwd / fs_gram_bwd (utils.py:66-83 and the gradient tf.gradients forms behind losses.style_loss): checked
+    against the oracle's gram / gram_bwd with an arbitrary (NON-symmetric) upstream dG, and through the adjoint identity
+    <gram_bwd(F, dG), X> = d/dt <gram(F + tX), dG> at t = 0."""
+    rng = np.random.default_rng(17)
+    n, h, w, c = shape
+    f = rng.standard_normal(shape).astype(np.float32)
+    dG = rng.standard_normal((n, c, c)).astype(np.float32)
+    g = down(eng, eng.gram(up(eng, f)))
+    assert rel(g, perceptual.gram(f.astype(np.float64))) < TOL
+    dF = down(eng, eng.gram_bwd(up(eng, f), up(eng, dG)))
+    want = perceptual.gram_bwd(dG.astype(np.float64), f.astype(np.float64))
+    assert dF.shape == want.shape and rel(dF, want) < TOL
+    X = rng.standard_normal(shape)
+    F64 = f.astype(np.float64).reshape(n, h * w, c)
+    Xm = X.reshape(n, h * w, c)
+    dgram = (np.matmul(Xm.transpose(0, 2, 1), F64) + np.matmul(F64.transpose(0, 2, 1), Xm)) / (h * w * c)
+    lhs, rhs = float((dF.astype(np.float64) * X).sum()), float((dgram * dG).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1e-6) + 1e-6 * np.abs(dF).sum() / dF.size
 
 
 @pytest.mark.parametrize("shape", [(2, 40, 37, 256), (1, 30, 31, 64), (3, 17, 9, 128), (1, 12, 11, 384)])

@@ -34,6 +34,21 @@ def knob(monkeypatch, eng):
     eng.reset_workspaces()
 
 
+@pytest.fixture
+def knob_hip(monkeypatch):
+    """The same for the product library only (GPU-only tests that are not parametrised over the engines)."""
+    e = get_engine("hip")
+
+    def set_knob(name, value):
+        monkeypatch.setenv(name, str(value))
+        e.lib.fs_debug_reload_env()
+        e.reset_workspaces()
+    yield set_knob
+    monkeypatch.undo()
+    e.lib.fs_debug_reload_env()
+    e.reset_workspaces()
+
+
 def f64(d):
     return {k: np.asarray(v, np.float64) for k, v in d.items()}
 
@@ -417,3 +432,106 @@ def test_hip_1080p_batch_consistency_and_bf16_agreement():
         if not bf16:
             ref = y1
     assert psnr(y1, ref) > 40 and np.abs(y1 - ref).mean() / 255.0 < 1e-2
+
+
+@pytest.mark.gpu
+def test_hip_1080p_batch8_bf16_is_the_configured_batch():
+    """BASELINE config 5 AS CONFIGURED: bf16, 1080p, batch 8 per GPU -- the shape bench.py times (persistent workgroups
+    walk 8 images; item lists 8x the batch-1 case).  Eight different frames; every output must equal the batch-1 result
+    of its own frame within the bf16 tiling-walk envelope, and the batch must stay inside the bf16-vs-fp32 accuracy
+    envelope measured at batch 1."""
+    import torch
+    from PIL import Image
+    e = get_engine("hip")
+    flat = e.mem.from_numpy(e.flatten_params(starry()))
+    img = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "ref_assets", "chicago.jpg")).convert("RGB")
+                     .resize((1920, 1080), Image.BICUBIC), dtype=np.float32)
+    frames = np.stack([np.roll(img, (37 * k, 101 * k), axis=(0, 1)) if k % 2 == 0 else np.ascontiguousarray(np.roll(img, 53 * k, axis=1)[::-1])
+                       for k in range(8)])
+    x8 = e.mem.from_numpy(frames)
+    y8 = e.tnet_forward(flat, x8, bf16=True)
+    assert tuple(y8.shape) == (8, 1080, 1920, 3) and bool(torch.isfinite(y8).all())
+    for k in (0, 3, 7):
+        y1 = e.tnet_forward(flat, x8[k:k + 1].contiguous(), bf16=True)
+        d = (y8[k] - y1[0]).abs()
+        assert float(d.max()) < 3.0 and float(d.mean()) < 0.2, (k, float(d.max()), float(d.mean()))
+    yf = e.tnet_forward(flat, x8[5:6].contiguous())                       # fp32 path, one frame
+    err = (y8[5] - yf[0]).abs()
+    mse = float((err.double() ** 2).mean())
+    assert 10 * np.log10(255.0 ** 2 / mse) > 40 and float(err.mean()) / 255.0 < 1e-2
+
+
+# ------------------------------------------------------------------ the metric's own workload: 256x256, batch 32
+@pytest.mark.gpu
+def test_hip_train_step_b32_256_kernel_paths_and_data_parallel_identity(knob_hip):
+    """BASELINE.json's metric shape, 32 x 256 x 256 (reference train.py:158-160 with --batch_size 32), the step bench.py
+    times.  At this size the persistent item lists run several rounds, the transform net's residual convs switch to the
+    Winograd kernel (>= 200 items), the filter-gradient slabs and the Gram pixel ranges split differently than at batch 4
+    -- paths no smaller test takes.  No CPU oracle at this size, so:
+      (a) the default kernels against the direct-convolution kernels (FS_CONV_WINO=0, FS_TNET_WINO=0) on the same inputs:
+          forward pixels 2e-5 of the range, the four losses 2e-5, gradient direction;
+      (b) the data-parallel identity the RCCL SUM all-reduce relies on: the gradient of the batch equals the sum of
+          the gradients of its eight batch-4 shards (= the 8 x b4 shape of BASELINE configs[3]), losses likewise."""
+    import torch
+    from faststyle_amd import utils
+    e = get_engine("hip")
+    style = utils.imread(os.path.join(ROOT, "style_images", "starry_night_crop.jpg")).astype(np.float32)[None]
+    Wv = perceptual.synthetic_vgg_weights(seed=3)
+    cfg = engine.default_loss_cfg()
+    P = tnet.init_params(seed=0)
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.rand((32, 256, 256, 3), device="cuda", generator=gen) * 255.0
+
+    def run(xb):
+        e.vgg_load(Wv)
+        flat = e.mem.from_numpy(e.flatten_params(P, scope=""))
+        tg = e.style_targets(e.mem.from_numpy(style), cfg)
+        y = e.tnet_forward(flat, xb, save_for_bwd=True)
+        losses, dy = e.perceptual_loss(y, xb, tg, cfg)
+        g = e.tnet_backward(flat, xb, dy)
+        return y.double(), losses.double().clone(), g.double().clone()
+
+    y_new, l_new, g_new = run(x)
+    shard_l, shard_g = torch.zeros(4, device="cuda", dtype=torch.float64), torch.zeros_like(g_new)
+    for r in range(8):
+        _, l_r, g_r = run(x[4 * r:4 * r + 4].contiguous())
+        shard_l += l_r
+        shard_g += g_r
+    knob_hip("FS_CONV_WINO", 0)
+    knob_hip("FS_TNET_WINO", 0)
+    y_dir, l_dir, g_dir = run(x)
+
+    def cos_l2(a, b):
+        return float(torch.dot(a, b) / (a.norm() * b.norm())), float((a - b).norm() / b.norm())
+    assert bool(torch.isfinite(g_new).all()) and float(g_new.norm()) > 0
+    assert float((y_new - y_dir).abs().max()) < 2e-5 * 255
+    assert float(((l_new - l_dir).abs() / l_dir.abs().clamp_min(1e-30))[:3].max()) < 2e-5, (l_new, l_dir)
+    c1, e1 = cos_l2(g_new, g_dir)
+    # (b): losses are batch sums (losses.py:32,63), instance norm / Grams are per sample
+    assert float(((shard_l - l_new).abs() / l_new.abs().clamp_min(1e-30))[:3].max()) < 2e-5, (shard_l, l_new)
+    c2, e2 = cos_l2(shard_g, g_new)
+    print("b32 256x256: default vs direct kernels cos %.8f relL2 %.2e; sum of 8 b4 shards vs b32 cos %.8f relL2 %.2e" % (c1, e1, c2, e2))
+    assert c1 > 0.99999 and c2 > 0.99999, (c1, e1, c2, e2)
+
+
+# ------------------------------------------------------------------ gradients to rounding: the oracle with the HIP path's masks
+def maskinject_units():
+    from tests import maskinject
+    return maskinject.RELU_UNITS.values()
+
+
+def test_train_step_gradients_to_rounding_with_injected_masks(eng):
+    """Shipped weights (real ReLU sign patterns, not the kink-free construction), synthetic VGG: with the HIP path's own
+    ReLU masks and pooling arg-max fed to the float64 oracle's backward, ALL 48 gradients are held to the per-tensor 2e-4
+    that test_tnet_..._kink_free needs special parameters for."""
+    rng = np.random.default_rng(21)
+    P = tnet.strip_scope(starry())
+    x = rng.uniform(0, 255, (2, 48, 56, 3)).astype(np.float32)
+    style = rng.uniform(0, 255, (1, 40, 52, 3)).astype(np.float32)
+    cfg = engine.default_loss_cfg()
+    cfg["beta"] = 1e-4
+    from tests import maskinject
+    lh, lo, g, go, masks = maskinject.step_with_injected_masks(eng, P, x, style, perceptual.synthetic_vgg_weights(3), cfg)
+    np.testing.assert_allclose(lh[:3], [lo["loss"], lo["content_loss"], lo["style_loss"]], rtol=2e-5)
+    assert grads_close(eng, g, go, 2e-4) == []
+    assert set(masks["tnet"]) == set(maskinject_units()) and "pool3/idx" in masks["vgg"]

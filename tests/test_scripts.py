@@ -26,7 +26,7 @@ def test_cli_flags_match_reference():
                  "learn_rate": 1e-3, "batch_size": 4, "n_epochs": 2, "preprocess_size": [256, 256], "run_name": None,
                  "loss_content_layers": ["conv3_3"], "loss_style_layers": ["conv1_2", "conv2_2", "conv3_3", "conv4_3"],
                  "content_weights": [1.0], "style_weights": [5.0, 5.0, 5.0, 5.0], "num_steps_ckpt": 1000,
-                 "num_pipe_buffer": 4000, "num_steps_break": -1, "resume_from": None, "beta": 0.0, "style_target_resize": 1.0,
+                 "num_pipe_buffer": 4000, "num_steps_break": -1, "resume_from": None, "no_graph": False, "beta": 0.0, "style_target_resize": 1.0,
                  "upsample_method": "resize"}
 
 
@@ -58,12 +58,14 @@ def test_train_cli_runs_reference_loop(tmp_path, monkeypatch, capsys, method):
     (work / "libs").mkdir()
     np.savez(str(work / "libs" / "vgg16_weights.npz"), **vgg16.synthetic_weights(3))     # train.py:148 reads it from CWD
     monkeypatch.chdir(work)
-    train.main(train.setup_parser().parse_args(
+    tr = train.main(train.setup_parser().parse_args(
         ["--train_dir", "synthetic", "--model_name", "t",
          "--style_img_path", os.path.join(ROOT, "style_images", "starry_night_crop.jpg"),
          "--style_target_resize", "0.25", "--preprocess_size", "128", "128", "--batch_size", "2",
          "--num_steps_break", "11", "--num_steps_ckpt", "10", "--upsample_method", method] +
         (["--beta", "1e-4"] if method == "deconv" else [])))
+    # the script runs what bench.py times: forward + backward replay ONE captured hipGraph (opt-out: --no_graph)
+    assert tr.use_graph and tr.graph is not None and tr.global_step == 12
     out = [l for l in capsys.readouterr().out.splitlines() if l and "amdgpu" not in l]
     assert out[0] == "Precomputing target style layers." and "Starting training..." in out and out[-1] == "Done training."
     steps = [int(l.split()[0]) for l in out if l.split()[0].isdigit()]

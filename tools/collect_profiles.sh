@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence under profiles/ (run on the GPU box from the repo root; everything is written to
-# gpurun_out/prof/ -- copy what should be judged into profiles/r02_*).  Counters are collected in their own passes
+# gpurun_out/prof/ -- copy what should be judged into profiles/rNN_*).  Counters are collected in their own passes
 # (--kernel-trace + --pmc only).  Every python command runs under its own timeout.
 export TMPDIR=/tmp
 R=$PWD
@@ -41,7 +41,7 @@ done
 cd $R
 PROV="rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on MI355X, per-launch average over all launches of the kernel. Counters are KiB; gfx950 correction (MI355X_MICROARCH.md HBM section): FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled. traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024."
 python tools/pmc_traffic.py $O/pmc_b32_FETCH_SIZE $O/pmc_b32_WRITE_SIZE $O/hbm_traffic_pmc.json "$PROV Command: python bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-stylize --no-b4 --no-graph (train step, batch 32)." 32 > $O/traffic_b32.txt
-python tools/pmc_traffic.py $O/pmc_720p_b1_fp32_FETCH_SIZE $O/pmc_720p_b1_fp32_WRITE_SIZE $O/hbm_traffic_720p_fp32.json "$PROV Command: python tools/fwd720.py 720 1280 1 fp32 (23 forward passes)." > $O/traffic_720p.txt
-python tools/pmc_traffic.py $O/pmc_1080p_b8_bf16_FETCH_SIZE $O/pmc_1080p_b8_bf16_WRITE_SIZE $O/hbm_traffic_1080p_b8_bf16.json "$PROV Command: python tools/fwd720.py 1080 1920 8 bf16 (23 forward passes)." > $O/traffic_1080p.txt
+python tools/pmc_traffic.py $O/pmc_720p_b1_fp32_FETCH_SIZE $O/pmc_720p_b1_fp32_WRITE_SIZE $O/hbm_traffic_720p_fp32.json "$PROV Command: python tools/fwd720.py 720 1280 1 fp32 (23 forward passes)." - 23 > $O/traffic_720p.txt
+python tools/pmc_traffic.py $O/pmc_1080p_b8_bf16_FETCH_SIZE $O/pmc_1080p_b8_bf16_WRITE_SIZE $O/hbm_traffic_1080p_b8_bf16.json "$PROV Command: python tools/fwd720.py 1080 1920 8 bf16 (23 forward passes)." - 23 > $O/traffic_1080p.txt
 find $O -type d \( -name 'stats_*' -o -name 'pmc_*' \) -prune -exec rm -rf {} +
 head -14 $O/kernel_stats_b32.txt; head -8 $O/traffic_b32.txt; tail -1 $O/bench_b32_under_rocprofv3.json | cut -c1-200; cat $O/fwd_*.log | grep forward

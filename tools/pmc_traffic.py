@@ -6,7 +6,7 @@ Units / corrections (MI355X_MICROARCH.md, HBM section): the counters are in KiB;
 reports half of the bytes of wide coalesced reads -> doubled.  The doubling is calibrated in the same run
 on maxpool_kernel, whose algorithmic bytes are known (reads its whole input once, writes a quarter).
 
-usage: pmc_traffic.py <dir_fetch> <dir_write> <out.json> [provenance text] [batch_per_gpu]
+usage: pmc_traffic.py <dir_fetch> <dir_write> <out.json> [provenance text] [batch_per_gpu | -] [forward_passes]
 
 Besides the per-kernel table the output has "families": the kernel families of bench.py's roofline table (both Winograd
 generations under "wino_conv_kernel", both filter-gradient generations under "conv_wgrad_kernel"), launch-weighted."""
@@ -56,8 +56,10 @@ def main():
             families[fam] = {"kernels": ks, "launches_sampled": n,
                              "traffic_bytes_per_launch": int(sum(kernels[k]["traffic_bytes_per_launch"] * kernels[k]["launches_sampled"] for k in ks) / n)}
     doc = {"_provenance": prov, "kernels": kernels, "families": families}
-    if len(sys.argv) > 5:
+    if len(sys.argv) > 5 and sys.argv[5] != "-":
         doc["batch_per_gpu"] = int(sys.argv[5])
+    if len(sys.argv) > 6:
+        doc["forward_passes"] = int(sys.argv[6])     # launches_sampled / forward_passes = launches per batch
     json.dump(doc, open(out, "w"), indent=1)
     for k, v in list(kernels.items())[:12]:
         print("%-40s %4d launches  %10.1f MB/launch" % (k, v["launches_sampled"], v["traffic_bytes_per_launch"] / 1e6))

@@ -2,8 +2,10 @@
 """Drop-in for the reference's train.py (same flags, checkpoint names, logging cadence):
 trains the image-transform net against the VGG16 perceptual loss -- every FLOP in
 libfaststyle_hip.so on MI355X, optionally data-parallel (one process per GPU, launched with
-``python -m torch.distributed.run --nproc-per-node N train.py ...``; ``--batch_size`` is then the
-per-GPU batch and gradients are SUM-all-reduced once per step over RCCL).
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P train.py ...``
+-- the launcher ``bench.py --gpus N`` uses for itself; ``--batch_size`` is then the per-GPU batch and gradients are
+SUM-all-reduced once per step over RCCL).  The forward + backward of a step replay ONE captured hipGraph, exactly
+what bench.py times (``--no_graph`` launches the ~170 kernels eagerly instead).
 
 Differences from the reference that are forced by the environment and stated, not hidden:
   * ``--train_dir`` is, as in the reference, a directory of ``train-*`` TFRecord shards written by
@@ -105,7 +107,7 @@ def main(args):
     params = eng.flatten_params(im_transf_net.initial_variables(seed=0, upsample_method=method), scope="",
                                 upsample_method=method)
     tr = trainer.Trainer(eng, params, vgg_w, style_img, cfg, learn_rate=args.learn_rate,
-                         dist=dist if world > 1 else None, upsample_method=method)
+                         dist=dist if world > 1 else None, upsample_method=method, use_graph=not args.no_graph)
 
     # Log directory of this run (behaviour of train.py:207-217): --run_name when given, otherwise the first
     # "<model_name><k>", k = 0, 1, 2, ..., that is not yet a directory under summaries/train/.
@@ -163,6 +165,7 @@ def main(args):
         batches = (eng.mem.from_numpy(b) for b in gen)
     if rank == 0:
         print('Starting training...')
+    clean_exit = False        # the loop ended the same way on every rank (epochs exhausted / num_steps_break)
     try:
         for batch in batches:
             current_step = tr.global_step
@@ -187,6 +190,7 @@ def main(args):
         else:
             if rank == 0:
                 print('Done training.')
+        clean_exit = True
     finally:
         # Save the model (the image transformation network) for later usage (train.py:283-286)
         try:
@@ -195,13 +199,22 @@ def main(args):
                 train_writer.close()
         finally:
             if world > 1:
-                # leave together: a rank that tears the process group down while a peer still sits in a collective
-                # turns that peer's exit into a watchdog abort (and rank 0's final save above must not depend on it)
-                try:
+                if clean_exit:
+                    # every rank ran the same number of steps: leave together, so that a rank tearing the process group down
+                    # does not turn a peer's last collective into a watchdog abort
                     dist.barrier()
-                except Exception as ex:      # a peer died: nothing left to wait for
-                    print('train.py: barrier before shutdown failed (%s)' % ex, file=sys.stderr)
-                dist.destroy_process_group()
+                    dist.destroy_process_group()
+                else:
+                    # THIS rank is leaving through an exception while its peers sit in the gradient all-reduce of a step it
+                    # never reached.  A barrier here would pair with that all-reduce (mismatched collectives: undefined
+                    # behaviour, at best a watchdog timeout).  Rank 0's final model is on disk; exit at once and non-zero
+                    # so that torch.distributed.run tears the peers down.
+                    import traceback
+                    traceback.print_exc()
+                    sys.stdout.flush()
+                    sys.stderr.flush()
+                    os._exit(1)
+    return tr          # (the reference's main returns nothing; tests look at the trainer: hipGraph captured, step count)
 
 
 if __name__ == "__main__":
