@@ -15,6 +15,7 @@ struct ConvBPlan {
     int TH, TW, tiles_y, tiles_x, PH, PW;
     int lds_bytes;
     int wst_off;   // byte offset of the per-tile statistics scratch [4][BN][4] in LDS
+    int bs;        // > 0: instance of the streaming kernel (fs_bstream.hip) that takes this launch; 0: the kernels of fs_bf16.hip
 };
 
 struct ConvBArgs {
@@ -34,6 +35,9 @@ struct ConvBArgs {
     ConvBPlan p;
 };
 
+int bstream_instance(const ConvBArgs& a);            // fs_bstream.hip: 0 = not eligible
+void bstream_plan(const ConvBArgs& a, ConvBPlan* out);
+int bstream_launch(const ConvBArgs& a, hipStream_t s);
 ConvBPlan conv_bf16_plan(const ConvBArgs& a);
 int conv_bf16_launch(const ConvBArgs& a, hipStream_t s);
 

@@ -689,6 +689,10 @@ static inline int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
 ConvBPlan conv_bf16_plan(const ConvBArgs& a) {
     ConvBPlan p{};
+    if (bstream_instance(a)) {   // every layer behind the image layer: persistent streaming kernel, filter in registers
+        bstream_plan(a, &p);
+        return p;
+    }
     p.c4 = a.Cin == 3;
     p.BN = a.Cout > 32 ? 64 : 32;
     p.cout_pad = roundup(a.Cout, p.BN);
@@ -737,6 +741,7 @@ ConvBPlan conv_bf16_plan(const ConvBArgs& a) {
 }
 
 int conv_bf16_launch(const ConvBArgs& a_in, hipStream_t s) {
+    if (a_in.p.bs) return bstream_launch(a_in, s);
     ConvBArgs a = a_in;
     if (a.dil_x < 1) a.dil_x = 1;
     const ConvBPlan& p = a.p;

@@ -301,9 +301,15 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
             }
         }
         float* st = a.stats + ((size_t)I.lin * BN + tid) * 3;
-        st[0] = mean;
-        st[1] = m2;
-        st[2] = cnt;
+        if (a.fin.counter) {   // read by the launch's last workgroup (fused finalize): coherent stores
+            FS_COHERENT_STORE(st, mean);
+            FS_COHERENT_STORE(st + 1, m2);
+            FS_COHERENT_STORE(st + 2, cnt);
+        } else {
+            st[0] = mean;
+            st[1] = m2;
+            st[2] = cnt;
+        }
     };
 
     // ---- the pipeline: ONE patch stage.  While tile t is multiplied the loads of tile t+1 are in flight (registers); after
@@ -323,14 +329,17 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
             issue(nxt);
         }
         sweep();
-        __syncthreads();   // A: every wave is done reading the patch
+        FS_LDS_BARRIER();   // A: every wave is done reading the patch
         if (more) commit();
         epilogue(cur, red + (it & 1) * REDF);
-        __syncthreads();   // B: next patch and this tile's statistics records visible
+        FS_LDS_BARRIER();   // B: next patch and this tile's statistics records (LDS) visible.  LDS-only on purpose: __syncthreads()
+                            // waits for vmcnt(0), i.e. for every store of the epilogue to be acknowledged, before the next sweep
+                            // may start -- the stores are meant to drain DURING it
         prev = cur;
         cur = nxt;
     }
     if (a.stats && tid < BN) finalize(prev, red + ((my_items - 1) & 1) * REDF);
+    fs_fused_in_finalize(a.fin, a.stats, a.N, smem);   // (every workgroup has at least one tile: grid <= tiles)
 }
 
 // ------------------------------------------------------------------------------------------------------------ host

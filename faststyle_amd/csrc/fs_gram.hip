@@ -415,10 +415,10 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
         const bool more = t + 1 < t_end;
         if (more) issue(t + 1);
         sweep();
-        __syncthreads();
+        FS_LDS_BARRIER();
         if (more) commit();
         epilogue(t);
-        __syncthreads();
+        FS_LDS_BARRIER();   // (LDS only: the tile's stores drain during the next sweep instead of being waited for here)
     }
 }
 

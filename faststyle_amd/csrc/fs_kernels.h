@@ -21,7 +21,8 @@ enum SrcMode {
 };
 
 struct ConvPlan {
-    int variant;  // conv_igemm_kernel<MT,WM,WN>: 0 <32,2,2>  1 <32,2,1>  2 <16,4,1>  3 <32,1,2>  4 <32,1,1>;  5 wino_conv_kernel;  6 wino2_conv_kernel
+    int variant;  // conv_igemm_kernel<MT,WM,WN>: 0 <32,2,2>  1 <32,2,1>  2 <16,4,1>  3 <32,1,2>  4 <32,1,1>;  5 wino_conv_kernel;  6 wino2_conv_kernel;
+                  // 7 conv_stream_kernel;  8 wino2h_conv_kernel
     int BN;       // output channels per workgroup
     int flat;     // Cin==3: K runs over (kw,ci) contiguously per kernel row
     int CC;       // input channels staged per chunk
@@ -33,6 +34,40 @@ struct ConvPlan {
     int ksplit;   // > 1: blockIdx.z splits the input-channel chunks; raw partials go to ConvArgs::split_ws
     int xcd_swizzle;  // workgroup -> (tile, channel block) map that keeps sharers of an input patch on one XCD
     int skew;  // > 0: first-round workgroups in odd wave slots start late by skew x 2048 cycles (see conv_igemm_kernel)
+};
+
+// Device-coherent accesses for the few values workgroups of ONE launch hand to each other (the statistics records of the
+// fused instance-norm finalize): agent-scope relaxed atomics compile to loads / stores that bypass the non-coherent per-XCD
+// L2 (sc1), so no cache-wide release/acquire (buffer_wbl2 / buffer_inv: measured ~35 us per launch with __threadfence()) is
+// needed -- the producer waits for its own stores (s_waitcnt vmcnt(0)) before it bumps the counter.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FS_COHERENT_STORE(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define FS_COHERENT_LOAD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define FS_COUNTER_BUMP(ptr) __hip_atomic_fetch_add((ptr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define FS_DRAIN_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define FS_COHERENT_STORE(ptr, v) (*(ptr) = (v))
+#define FS_COHERENT_LOAD(ptr) (*(ptr))
+#define FS_COUNTER_BUMP(ptr) atomicAdd((ptr), 1u)
+#define FS_DRAIN_STORES() __threadfence()
+#endif
+
+// Instance-norm finalize fused into the kernel that produces the statistics records (fs_wino2 / fs_wino2h / fs_cstream): the
+// LAST workgroup of the launch to finish merges the per-tile {mean, M2, count} records of every (sample, channel) and
+// writes mean, rstd, a = gamma*rstd, b = beta - mean*a (im_transf_net.py:238-245) -- what in_finalize_kernel does in a
+// launch of its own (~4.5 us + two launch gaps; 16 of them are ~10 % of a 720p frame).  counter == nullptr: off.
+struct FinArgs {
+    unsigned* counter;   // zero before the launch; the kernel leaves it zero
+    const float* gamma;  // [C]
+    const float* beta;
+    float* mean;         // [N][C] each
+    float* rstd;
+    float* a;
+    float* b;
+    int T;               // records per sample (tiles of the launch)
+    int C;               // real channels
+    int groups;          // virtual channel groups per real channel (4 for the phase-collapsed resize-conv), Cv = C * groups
+    float eps;
 };
 
 struct ConvArgs {
@@ -65,6 +100,8 @@ struct ConvArgs {
                             // tf.nn.max_pool 2x2/2 of the stored result (vgg16.py:68,104,154) straight from the epilogue's registers
     long long w_nstride;
     int prof_tag;            // 1: launched by the transform net (profiler row; no effect on the computation)
+    FinArgs fin;             // fused instance-norm finalize (with stats; persistent kernels only)
+    int half_items;          // 1: with w_wino2, prefer the half-item Winograd kernel (fs_wino2h.hip: grids too small for 64-tile items)
     float* split_ws;         // optional scratch for split-K partials (split_ws_floats capacity); enables ksplit plans
     size_t split_ws_floats;
     ConvPlan p;
@@ -237,6 +274,101 @@ __device__ __forceinline__ f32x2 fs_pk_sub(f32x2 a, f32x2 b) {
 #define FS_KERNARG_PTR(T, param) (&(param))
 #endif
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a workgroup-scope release/acquire over every address
+// space: the compiler puts `s_waitcnt vmcnt(0) lgkmcnt(0)` in front of s_barrier, i.e. every global load still in flight is
+// waited for -- fatal for a software pipeline that keeps the next step's global loads travelling ACROSS the barrier.  Where
+// the threads of a workgroup exchange data through LDS only, this waits for the LDS operations alone.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_LDS_BARRIER_OFF)   /* -DFS_LDS_BARRIER_OFF: A/B build with plain __syncthreads() */
+#define FS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define FS_LDS_BARRIER() __syncthreads()
+#endif
+
+// Wait for every vector-memory operation of this wave (s_waitcnt vmcnt(0); gfx9 encoding, the other counters left at their
+// maxima).  Placed at the END of a pipeline prologue: the compiler inserts waits statically, so a load that is still pending
+// on ONE path into a loop header (the prologue's) costs a vmcnt(0) in EVERY iteration if its destination register is
+// recycled inside the loop -- draining once before the loop removes that path's pending set.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FS_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
+#else
+#define FS_WAIT_VMEM() ((void)0)
+#endif
+
+// The tail of a persistent kernel with ConvArgs::fin set, called by EVERY thread of EVERY workgroup after its last
+// statistics record is written.  `scratch`: >= 2 KB of LDS nobody else uses any more.  One workgroup -- the last to arrive at
+// the counter -- does the merge: thread = (pair = (sample, channel), lane of LP) with LP = 256 / pairs lanes per pair
+// (1, 2, 4, ... 64), two passes over the records in float64 (count and mean first, then M2 around that mean: the same value
+// as Chan's pairwise update, without its division per record), fixed order -> deterministic.  The counter only decides WHO
+// merges; it is reset for the next launch.
+__device__ inline void fs_fused_in_finalize(const FinArgs& f, const float* stats, int N, float* scratch) {
+    if (!f.counter) return;
+    const int tid = threadIdx.x;
+    unsigned* flag = reinterpret_cast<unsigned*>(scratch);
+    FS_DRAIN_STORES();   // this thread's records (FS_COHERENT_STORE: written through to the coherence point) have landed ...
+    __syncthreads();     // ... and so have those of the whole workgroup, before it is counted
+    if (tid == 0) *flag = FS_COUNTER_BUMP(f.counter) == gridDim.x * gridDim.y * gridDim.z - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!*flag) return;
+    double* red = reinterpret_cast<double*>(scratch + 16);   // [256] doubles, 16-byte aligned
+    const int C = f.C, G = f.groups, Cv = C * G, R = f.T * G;
+    const int pairs = N * C;
+    int LP = 1;
+    while (LP < 64 && LP * 2 * pairs <= 256) LP *= 2;
+    const int PPB = 256 / LP;   // pairs per pass
+    for (int p0 = 0; p0 < pairs; p0 += PPB) {
+        const int pl = tid / LP, ln = tid - pl * LP;
+        const int pr = p0 + pl;
+        const bool live = pr < pairs;
+        const int n = live ? pr / C : 0, c = live ? pr - n * C : 0;
+        const float* base = stats + ((size_t)n * f.T * Cv + c) * 3;
+        auto rec = [&](int i) {   // record i of the pair: tile i / G, group i % G
+            const int t = i / G, q = i - t * G;
+            return base + ((size_t)t * Cv + q * C) * 3;
+        };
+        double cnt = 0, sm = 0;
+        if (live)
+            for (int i = ln; i < R; i += LP) {
+                const float* st = rec(i);
+                const double cb = FS_COHERENT_LOAD(st + 2);
+                cnt += cb;
+                sm += cb * (double)FS_COHERENT_LOAD(st);
+            }
+        __syncthreads();
+        red[tid] = cnt;
+        __syncthreads();
+        double tc = 0;
+        for (int k = 0; k < LP; ++k) tc += red[pl * LP + k];
+        __syncthreads();
+        red[tid] = sm;
+        __syncthreads();
+        double ts = 0;
+        for (int k = 0; k < LP; ++k) ts += red[pl * LP + k];
+        const double mu = tc > 0 ? ts / tc : 0.0;
+        double m2 = 0;
+        if (live)
+            for (int i = ln; i < R; i += LP) {
+                const float* st = rec(i);
+                const double cb = FS_COHERENT_LOAD(st + 2), d = (double)FS_COHERENT_LOAD(st) - mu;
+                m2 += (double)FS_COHERENT_LOAD(st + 1) + cb * d * d;
+            }
+        __syncthreads();
+        red[tid] = m2;
+        __syncthreads();
+        if (live && ln == 0) {
+            double tm = 0;
+            for (int k = 0; k < LP; ++k) tm += red[pl * LP + k];
+            const float var = (float)(tm / tc);
+            const float r = 1.0f / sqrtf(var + f.eps);
+            const float fm = (float)mu;
+            const float av = f.gamma[c] * r;
+            f.mean[pr] = fm;
+            f.rstd[pr] = r;
+            f.a[pr] = av;
+            f.b[pr] = f.beta[c] - fm * av;
+        }
+    }
+    if (tid == 0) FS_COHERENT_STORE(f.counter, 0u);
+}
 // More than 64 KiB of dynamic LDS (gfx950: 160 KiB per CU) needs hipFuncAttributeMaxDynamicSharedMemorySize, once per
 // kernel AND device (one static BigLds per kernel instantiation; thread-safe).
 struct BigLds {
@@ -274,6 +406,10 @@ bool conv_route_ok(const ConvArgs& a);   // a.p filled: can the launch take a.ro
 bool wino2_eligible(const ConvArgs& a);
 void wino2_plan(const ConvArgs& a, ConvPlan* out);
 int wino2_launch(const ConvArgs& a, hipStream_t s);
+bool wino2h_eligible(const ConvArgs& a);                                                       // fs_wino2h.hip: plan variant 8
+long wino2h_items(const ConvArgs& a);
+void wino2h_plan(const ConvArgs& a, ConvPlan* out);
+int wino2h_launch(const ConvArgs& a, hipStream_t s);
 // second-generation Gram matrices (fs_gram.hip): G[n] = scale * F[n]^T F[n], F [N][HW][C], C = 64 or a multiple of 128
 bool gram2_eligible(int N, int HW, int C);
 size_t gram2_slab_floats(int N, int HW, int C);
@@ -298,6 +434,17 @@ void plan_tile(int Ho, int Wo, int KH, int KW, int stride, int max_px, int* TH, 
 int tune_int(const char* name, int unset);
 void tune_reload();
 unsigned tune_epoch();   // bumped by tune_reload: cached plans made under older knob values are stale
+// does a launch of this size qualify?  (one workgroup reads N*C*T*groups records: beyond a few 10^4 a launch of its own,
+// spread over the chip, is faster)
+inline bool fused_finalize_ok(int N, int C, int T, int groups) {
+    // OFF by default -- measured on MI355X (round 3): correct, but SLOWER than the launch it replaces.  The merge runs on ONE
+    // compute unit while the other 255 idle: with device-scope fences +36 us per unit, with coherent (sc1) record stores /
+    // loads and no fence still +27 us (batch 4: transform-net forward 0.60 -> 0.98 ms; 720p 908 -> 708 fps) against the
+    // 4.5 us in_finalize launch.  Kept behind the knob as a recorded experiment (tests/test_path_parity.py runs it on the
+    // emulator so that it does not rot).
+    return tune_int("FS_FUSED_FINALIZE", 0) && (long)N * C * T * groups <= (long)tune_int("FS_FUSED_FINALIZE_MAX", 24576);
+}
+
 // thread-local message behind fs_last_error(); returns `code` (fs_api.hip)
 int set_error(int code, const char* fmt, ...);
 // tf.image.resize_images(method=2) of TF 1.0 on device u8 [H,W,3] -> f32 [Ho,Wo,3] (fs_io.hip)

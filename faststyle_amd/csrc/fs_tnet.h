@@ -30,7 +30,8 @@ struct Unit {
     int w_off, g_off, b_off;  // offsets into the flat parameter buffer
     size_t z, stats, mean, rstd, a, b;  // workspace offsets (floats)
     int tiles;
-    int wino;        // forward through wino_conv_kernel (3x3 VALID residual convs on grids that fill the chip)
+    int wino;        // forward through a Winograd kernel: 1 wino(2)_conv_kernel (3x3 VALID residual convs on grids that fill the
+                     // chip with 64-tile items), 2 wino2h_conv_kernel (half items: smaller grids, batch 4 per GPU)
     size_t wino_u;   // its transformed filter [16][Cin][Cout] in the workspace
     ConvPlan plan;
     WgradPlan wplan;
@@ -44,10 +45,12 @@ struct TnetLayout {
     size_t h[5];      // residual block outputs
     size_t weff[2];   // collapsed resize-conv filters
     size_t zfold, wfold, dwfold;  // kw-folded output layer: Z / unfolded dY [N,Ho,Wo+4,16], filters, filter grads
+    size_t fin_counter; // 16 unsigned: the "last workgroup" counters of the fused instance-norm finalize (fs_kernels.h FinArgs)
     size_t fwd_floats;
     size_t wTu[16];   // per-unit input-gradient filters (flip+transpose / collapsed), all built by one wt_batch launch
     size_t g[3], dz[2], wT, dweff, inbwd, slabs;  // backward scratch (dz double-buffered: filter gradients run on a side stream)
     size_t wino_d[10]; // Winograd-transformed input-gradient filters of the residual convs (0: direct kernel)
+    int wino_dh[10];   // ... through the half-item kernel
     size_t dzres[10]; // dz of the ten residual convs, kept until their filter gradients run as ONE launch (fs_wgrad2.hip)
     int res_batch;    // 1: that batched launch is planned (shapes eligible)
     size_t total_floats;

@@ -250,9 +250,17 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
             a.stats = reinterpret_cast<float*>(16);
             const long blocks = (long)N * cdiv(u.Hc, 16) * cdiv(u.Wc, 16) * (u.Cc / 64 > 0 ? u.Cc / 64 : 1);
             if (mode && u.kind == 0 && i >= 3 && i <= 12 && (wino_eligible(a) || wino2_eligible(a)) && (mode == 2 || blocks >= 200)) u.wino = 1;
+            // ... and through the half-item kernel (<= 32 tiles per item: twice the items) when 64-tile items leave most of
+            // the chip idle -- batch 4 per GPU: 100..144 items of 16x16 pixels, 180..252 half items
+            if (!u.wino && mode && mode != 2 && u.kind == 0 && i >= 3 && i <= 12 && tune_int("FS_WINO_V", 2) >= 2 && tune_int("FS_TNET_WINO_HALF", 1)) {
+                ConvArgs h = a;
+                h.half_items = 1;
+                if (wino2h_eligible(h) && wino2h_items(h) >= tune_int("FS_WINO2H_MIN_ITEMS", 96)) u.wino = 2;
+            }
             if (!u.wino) a.w_wino = a.w_wino2 = nullptr;
             a.stats = nullptr;
         }
+        a.half_items = u.wino == 2;
         u.plan = conv_plan(a);
         u.wino_u = u.wino ? b.take((size_t)16 * u.Cin * u.Cc) : 0;
         u.tiles = u.kind == 2 ? cdiv(u.Hout * u.Wout, 256) : u.plan.tiles_y * u.plan.tiles_x;
@@ -277,6 +285,7 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
     L->zfold = b.take((size_t)N * L->u[15].Hc * L->u[15].Wc * 16);
     L->wfold = b.take(18 * 16 * 16);
     L->dwfold = b.take(18 * 16 * 16);
+    L->fin_counter = b.take(64);
     L->fwd_floats = b.off;
     // ---- backward scratch ----
     for (int k = 0; k < 3; ++k) L->g[k] = b.take(max_act);
@@ -291,7 +300,23 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
     for (int i = 3; i <= 12; ++i) {   // residual input gradients (3x3 'full' convs of dz) through the Winograd kernel when its blocks fill the chip
         const Unit& u = L->u[i];
         const long blocks = (long)N * cdiv(u.Hin, 16) * cdiv(u.Win, 16);
-        const bool on = L->wino_mode && tune_int("FS_WINO_V", 2) >= 2 && (L->wino_mode == 2 || blocks >= 200);
+        bool on = L->wino_mode && tune_int("FS_WINO_V", 2) >= 2 && (L->wino_mode == 2 || blocks >= 200);
+        L->wino_dh[i - 3] = 0;
+        if (!on && L->wino_mode && L->wino_mode != 2 && tune_int("FS_WINO_V", 2) >= 2 && tune_int("FS_TNET_WINO_HALF", 1)) {
+            ConvArgs h{};   // the 3x3 'full' conv of dz that unit_dgrad launches
+            h.N = N;
+            h.H = u.Hout;
+            h.W = u.Wout;
+            h.Cin = h.Cout = 64;
+            h.Ho = u.Hin;
+            h.Wo = u.Win;
+            h.KH = h.KW = 3;
+            h.stride = 1;
+            h.pad_t = h.pad_l = 2;
+            h.w_wino2 = reinterpret_cast<const float*>(16);
+            h.half_items = 1;
+            if (wino2h_eligible(h) && wino2h_items(h) >= tune_int("FS_WINO2H_MIN_ITEMS", 96)) on = L->wino_dh[i - 3] = 1;
+        }
         L->wino_d[i - 3] = on ? b.take((size_t)16 * 64 * 64) : 0;
     }
     L->inbwd = b.take(max_inbwd);
@@ -384,6 +409,17 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
             }
         FS_TRY(tune_int("FS_WINO_V", 2) >= 2 ? wt_wino2_batch(nb, 64, 64, s) : wt_wino_batch(nb, 64, 64, s));
     }
+    // units whose conv kernel is persistent (fs_wino2 / fs_wino2h / fs_cstream) and whose record count is small merge their
+    // own instance-norm statistics (the last workgroup to finish; FinArgs in fs_kernels.h): no in_finalize launch
+    bool fused[16];
+    bool any_fused = false;
+    for (int i = 0; i < 16; ++i) {
+        const Unit& u = L.u[i];
+        fused[i] = u.kind != 2 && (u.plan.variant == 6 || u.plan.variant == 7 || u.plan.variant == 8) &&
+                   fused_finalize_ok(N, u.Cout, u.tiles, u.kind == 1 ? 4 : 1);
+        any_fused = any_fused || fused[i];
+    }
+    if (any_fused && hipMemsetAsync(ws + L.fin_counter, 0, 64, s) != hipSuccess) return -10;
     const float* src = x;
     const float* src_a = nullptr;
     const float* src_b = nullptr;
@@ -399,11 +435,26 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
         a.w = (u.kind == 1 || (u.kind == 3 && i < 15)) ? ws + L.weff[i - 13] : ((u.kind == 2 || u.kind == 3) ? ws + L.wfold : params + u.w_off);
         a.w_wino = (u.wino && tune_int("FS_WINO_V", 2) < 2) ? ws + u.wino_u : nullptr;
         a.w_wino2 = (u.wino && tune_int("FS_WINO_V", 2) >= 2) ? ws + u.wino_u : nullptr;
+        a.half_items = u.wino == 2;
         a.y = u.kind == 2 ? ws + L.zfold : ws + u.z;
         a.stats = u.kind == 2 ? nullptr : ws + u.stats;
+        if (fused[i]) {
+            a.fin.counter = reinterpret_cast<unsigned*>(ws + L.fin_counter) + i;
+            a.fin.gamma = params + u.g_off;
+            a.fin.beta = params + u.b_off;
+            a.fin.mean = ws + u.mean;
+            a.fin.rstd = ws + u.rstd;
+            a.fin.a = ws + u.a;
+            a.fin.b = ws + u.b;
+            a.fin.T = u.tiles;
+            a.fin.C = u.Cout;
+            a.fin.groups = u.kind == 1 ? 4 : 1;
+            a.fin.eps = 1e-3f;
+        }
         FS_TRY(conv_launch(a, s));
         if (u.kind == 2)  // shifted 5-term sum of the virtual channels -> z + statistics partials
             FS_TRY(fold5_fwd(ws + L.zfold, ws + u.z, ws + u.stats, N, u.Hout, u.Wout, s));
+        if (!fused[i])
         FS_TRY(in_finalize(ws + u.stats, N, u.tiles, u.Cout, u.kind == 1 ? 4 : 1, params + u.g_off, params + u.b_off, 1e-3f,
                            ws + u.mean, ws + u.rstd, ws + u.a, ws + u.b, s,
                            ws + u.stats + (size_t)N * u.tiles * (u.kind == 2 ? u.Cout : u.Cc) * 3));
@@ -444,7 +495,10 @@ static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, c
     a.w = ws + L.wTu[&u - L.u];  // built at the start of tnet_backward
     {
         const int ui = (int)(&u - L.u);
-        if (ui >= 3 && ui <= 12 && L.wino_d[ui - 3]) a.w_wino2 = ws + L.wino_d[ui - 3];
+        if (ui >= 3 && ui <= 12 && L.wino_d[ui - 3]) {
+            a.w_wino2 = ws + L.wino_d[ui - 3];
+            a.half_items = L.wino_dh[ui - 3];
+        }
     }
     a.add_src = add_src;
     a.add_pad = add_src ? 2 : 0;

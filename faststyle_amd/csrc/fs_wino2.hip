@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
                             m02 = acc[8][0] + acc[9][0] + acc[10][0];
                 red[512 + nb * 32 + lm] = m00 + m01 + m02;
             }
-            __syncthreads();
+            FS_LDS_BARRIER();   // (LDS exchange only; __syncthreads() would also wait for every global load / store in flight)
             cs = red[512 + nb * 32 + lm];
         }
 #pragma unroll
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
             // contributors of a channel (2 lane halves x 2 tile blocks) meet in LDS
             red[(((mb * 2 + kq) * 64) + nb * 32 + lm) * 2] = s1;
             red[(((mb * 2 + kq) * 64) + nb * 32 + lm) * 2 + 1] = s2;
-            __syncthreads();
+            FS_LDS_BARRIER();   // (the item's 64 stores per lane keep draining behind it)
             if (tid < 64) {
                 float S1 = 0.f, S2 = 0.f;
 #pragma unroll
@@ -544,11 +544,17 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
                 const float cnt = (float)(th_valid * tw_valid);
                 float* st = a.stats + ((size_t)I.tile_lin * a.Cout + I.co0 + tid) * 3;
                 const float shift = red[512 + tid];
-                st[0] = shift + S1 / cnt;
-                st[1] = fmaxf(S2 - S1 * S1 / cnt, 0.f);
-                st[2] = cnt;
+                if (a.fin.counter) {   // read by the launch's last workgroup (fused finalize): coherent stores
+                    FS_COHERENT_STORE(st, shift + S1 / cnt);
+                    FS_COHERENT_STORE(st + 1, fmaxf(S2 - S1 * S1 / cnt, 0.f));
+                    FS_COHERENT_STORE(st + 2, cnt);
+                } else {
+                    st[0] = shift + S1 / cnt;
+                    st[1] = fmaxf(S2 - S1 * S1 / cnt, 0.f);
+                    st[2] = cnt;
+                }
             }
-            __syncthreads();   // `red` is reused by the next item
+            FS_LDS_BARRIER();   // `red` is reused by the next item
         }
     };
     auto epilogue = [&](const Item& I) {
@@ -582,6 +588,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
     long long tr_last = FS_W2_NOW();
 #endif
     load_live = have1 ? 1 : 0;   // a step beyond the one whose patch is already committed may still exist
+    FS_WAIT_VMEM();   // (fs_kernels.h: no prologue load may still be pending at the loop header, or every iteration waits vmcnt(0))
     int q = 0;
     // (nested item / chunk loops rather than one flat loop with a conditional epilogue: a conditional re-zeroing of the 256
     // accumulators makes the register allocator merge two versions of them at the join -- copies and spills)
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
             const long long q1 = FS_W2_NOW();
             const long long q2 = q1;
 #endif
-            __syncthreads();
+            FS_LDS_BARRIER();   // stages are exchanged through LDS only; the global loads of steps q+1 / q+2 stay in flight
 #ifdef FS_WINO2_TRACE
             const long long q3 = FS_W2_NOW();
             tr_sweep += q1 - q0;
@@ -622,6 +629,7 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
         tr_epi += tr_last - e0;
 #endif
     }
+    fs_fused_in_finalize(a.fin, a.stats, a.N, smem);   // (every workgroup has at least one item: grid <= items)
 #ifdef FS_WINO2_TRACE
     if (tid == 0 && blockIdx.x < 4096) {
         long long* t = g_wino2_trace + (size_t)blockIdx.x * 8;

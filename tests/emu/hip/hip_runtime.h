@@ -358,6 +358,8 @@ static inline float atomicAdd(float* p, float v) {
     lk.clear(std::memory_order_release);
     return o;
 }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }   /* blocks run on several host threads */
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 // individually rounded float ops (the emulator build uses -ffp-contract=off semantics for these)
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }

@@ -157,6 +157,32 @@ def test_tnet_residual_convs_through_the_winograd_kernel(eng, shape, knob):
     assert grads_close(eng, g, want, 2e-4) == []
 
 
+@pytest.mark.parametrize("shape,block", [((2, 48, 56), 0), ((1, 45, 67), 1), ((3, 52, 44), 2), ((1, 64, 48), 3), ((2, 56, 72), -1)])
+def test_tnet_residual_convs_through_the_half_item_winograd_kernel(eng, shape, block, knob):
+    """fs_wino2h.hip: what a batch of 4 at 256x256 selects by itself (100..252 items on 256 CUs) -- the ten residual convs and
+    their ten input gradients through the half-item Winograd kernel (<= 32 tiles x 64 channels, waves split by channel block
+    x position-row pair, output-row shares exchanged through LDS).  FS_WINO2H_MIN_ITEMS=1 selects it at test sizes;
+    FS_WINO2H_SHAPE pins each block shape (4x8, 5x6, 6x5, 8x4 tiles; -1: the planner's pick) so that ragged edge blocks, blocks
+    with 30 of 32 tiles and several items per workgroup (FS_WINO2_WGS=3: the cross-item pipeline) are all visited.  Same
+    oracle, same tolerances as every other path."""
+    knob("FS_WINO2H_MIN_ITEMS", 1)
+    knob("FS_WINO2_WGS", 3)
+    if block >= 0:
+        knob("FS_WINO2H_SHAPE", block)
+    if block in (1, 2):      # ... and the (off-by-default) fused instance-norm finalize: the launch's last workgroup merges the records
+        knob("FS_FUSED_FINALIZE", 1)
+    rng = np.random.default_rng(9)
+    P = tnet.strip_scope(starry())
+    flat = eng.mem.from_numpy(eng.flatten_params(P, scope=""))
+    x = rng.uniform(0, 255, shape + (3,)).astype(np.float32)
+    y = eng.mem.to_numpy(eng.tnet_forward(flat, eng.mem.from_numpy(x)))
+    yo = tnet.create_net(x.astype(np.float64), f64(P))
+    assert np.abs(y - yo).max() / 255.0 < 2e-5
+    yk, yok, g, want = run_fwd_bwd(eng, kink_free_params(), shape, seed=0)
+    assert np.abs(yk - yok).max() / 255.0 < 2e-5
+    assert grads_close(eng, g, want, 2e-4) == []
+
+
 @pytest.mark.parametrize("shape", [(2, 48, 56), (1, 41, 41), (1, 45, 67)])
 def test_tnet_forward_matches_oracle_and_backward_tight_when_kink_free(eng, shape):
     """Smallest legal size (41: REFLECT needs pad < dim), odd sizes (asymmetric SAME padding of
@@ -342,12 +368,15 @@ def test_hip_720p_forward_matches_oracle():
 
 
 @pytest.mark.gpu
-def test_hip_train_step_256_matches_oracle_and_batch_sum_property():
+def test_hip_train_step_256_matches_oracle_and_batch_sum_property(knob_hip):
     """BASELINE config 3 shape (256x256): losses + all 48 gradients vs the float32 oracle on a
     batch of 2, and the data-parallel identity grads(batch) == sum of per-sample grads (losses are
     batch-summed, losses.py:32,63; instance norm is per sample) that the 8-GPU SUM all-reduce
-    relies on."""
+    relies on.  (The identity is held to 1e-4 of the largest gradient, which needs the SAME kernels on
+    both sides -- a different summation order flips ReLU ties: the half-item Winograd kernel a batch of 2 selects for the
+    residual convs is therefore also selected for the single samples.)"""
     e = get_engine("hip")
+    knob_hip("FS_WINO2H_MIN_ITEMS", 32)
     rng = np.random.default_rng(1)
     Wv = perceptual.synthetic_vgg_weights(seed=3)
     e.vgg_load(Wv)
@@ -389,8 +418,9 @@ def test_tnet_bf16_forward_against_bf16_restatement_and_fp32_oracle(eng, shape, 
     """FS_FLAG_BF16 against (a) the numpy restatement with the same rounding points -- differences are
     accumulation-order noise flipping an occasional bf16 rounding -- and (b) the fp32/fp64 oracle, where
     the error is the precision of bfloat16 itself (~1e-2 of the range; reported, not held to 1e-3)."""
-    if grid_cap:      # persistent workgroups: 3 workgroups walk all the tiles of the single-chunk layers (crossing images)
-        knob("FS_BF16_GRID", grid_cap)
+    if grid_cap:      # persistent workgroups: 3 workgroups walk all the tiles of a layer (crossing images): the pipeline of
+        knob("FS_BF16_GRID", grid_cap)          # fs_bstream.hip (every layer behind the image layer) and of the image layer's kernel
+        knob("FS_BSTREAM_WGS", grid_cap)
     rng = np.random.default_rng(4)
     P = tnet.strip_scope(starry())
     flat = eng.mem.from_numpy(eng.flatten_params(P, scope=""))
