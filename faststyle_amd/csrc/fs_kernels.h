@@ -257,6 +257,18 @@ __device__ __forceinline__ f32x2 fs_pk_sub(f32x2 a, f32x2 b) {
     return a - b;
 #endif
 }
+__device__ __forceinline__ f32x2 fs_pk_fma(f32x2 a, f32x2 b, f32x2 c) {   // a * b + c on two packed floats, one instruction
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_PK_ASM)
+    f32x2 o;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+#else
+    f32x2 o;
+    o.x = fmaf(a.x, b.x, c.x);
+    o.y = fmaf(a.y, b.y, c.y);
+    return o;
+#endif
+}
 // 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4): `gsrc` is the lane's own source, `lds_wave`
 // the wave-uniform destination -- lane l lands at lds_wave + 16*l bytes.  Completion is covered by vmcnt / the next barrier.
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -320,6 +320,14 @@ static inline unsigned raw_buffer_load_b32(buffer_rsrc r, unsigned voff, unsigne
     else if (voff < 0x80000000u) { fprintf(stderr, "emu: buffer load out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
     return v;
 }
+struct uint3_emu { unsigned x, y, z; };
+static inline uint3_emu raw_buffer_load_b96(buffer_rsrc r, unsigned voff, unsigned soff) {
+    uint3_emu v{0u, 0u, 0u};
+    const unsigned long long end = (unsigned long long)voff + soff + 12ull;
+    if (voff < 0x80000000u && end <= r.nbytes) memcpy(&v, r.base + voff + soff, 12);
+    else if (voff < 0x80000000u) { fprintf(stderr, "emu: buffer load out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
+    return v;
+}
 static inline void raw_buffer_store_b32(unsigned v, buffer_rsrc r, unsigned voff, unsigned soff) {
     const unsigned long long end = (unsigned long long)voff + soff + 4ull;
     if (voff < 0x80000000u && end <= r.nbytes) memcpy(const_cast<unsigned char*>(r.base) + voff + soff, &v, 4);
@@ -334,6 +342,7 @@ static inline float fmed3f(float a, float b, float c) {
 #define __builtin_amdgcn_make_buffer_rsrc(ptr, stride, nbytes, flags) \
     fsemu::buffer_rsrc{reinterpret_cast<const unsigned char*>(ptr), (unsigned)(nbytes)}
 #define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) fsemu::raw_buffer_load_b128((r), (unsigned)(voff), (unsigned)(soff))
+#define __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, aux) fsemu::raw_buffer_load_b96((r), (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, aux) fsemu::raw_buffer_load_b32((r), (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_raw_buffer_store_b32(v, r, voff, soff, aux) fsemu::raw_buffer_store_b32((v), (r), (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_fmed3f(a, b, c) fsemu::fmed3f((a), (b), (c))
