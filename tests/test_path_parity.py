@@ -157,12 +157,12 @@ def test_tnet_residual_convs_through_the_winograd_kernel(eng, shape, knob):
     assert grads_close(eng, g, want, 2e-4) == []
 
 
-@pytest.mark.parametrize("shape,block", [((2, 48, 56), 0), ((1, 45, 67), 1), ((3, 52, 44), 2), ((1, 64, 48), 3), ((2, 56, 72), -1)])
+@pytest.mark.parametrize("shape,block", [((2, 48, 56), 0), ((1, 45, 67), 1), ((3, 52, 44), 2), ((2, 56, 72), -1)])
 def test_tnet_residual_convs_through_the_half_item_winograd_kernel(eng, shape, block, knob):
     """fs_wino2h.hip: what a batch of 4 at 256x256 selects by itself (100..252 items on 256 CUs) -- the ten residual convs and
     their ten input gradients through the half-item Winograd kernel (<= 32 tiles x 64 channels, waves split by channel block
     x position-row pair, output-row shares exchanged through LDS).  FS_WINO2H_MIN_ITEMS=1 selects it at test sizes;
-    FS_WINO2H_SHAPE pins each block shape (4x8, 5x6, 6x5, 8x4 tiles; -1: the planner's pick) so that ragged edge blocks, blocks
+    FS_WINO2H_SHAPE pins a block shape (4x8, 5x6, 6x5 tiles; -1: the planner's pick among those and 8x4) so that ragged edge blocks, blocks
     with 30 of 32 tiles and several items per workgroup (FS_WINO2_WGS=3: the cross-item pipeline) are all visited.  Same
     oracle, same tolerances as every other path."""
     knob("FS_WINO2H_MIN_ITEMS", 1)
