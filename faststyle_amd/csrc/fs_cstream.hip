@@ -41,8 +41,8 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     const int lm = lane & 31, kq = lane >> 5;
     const int mw = wave % WMW, nbw = wave / WMW;          // this wave's place among the pixel blocks / channel blocks
     float* const red = smem + PATCH_F;   // [2 buffers][REDF]
-    auto fdiv = [](int x, float inv_d) { return (int)(((float)x + 0.5f) * inv_d); };   // exact for these magnitudes (x < 2^22)
-    auto uniform_ptr = [](const float* ptr) {
+    auto fdiv = [](int x, float inv_d) __attribute__((always_inline)) { return (int)(((float)x + 0.5f) * inv_d); };   // exact for these magnitudes (x < 2^22)
+    auto uniform_ptr = [](const float* ptr) __attribute__((always_inline)) {
         const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
         return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
@@ -69,16 +69,19 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     // ---- staging descriptors (tile-invariant): element e = tid + i*256 is channel quad c4 of patch pixel e / C4
     const int c4 = tid & (C4 - 1);   // the same for every element of a thread (256 is a multiple of C4)
     int pq[SX], pdst[SX];
+    unsigned poffb[SX];   // byte offset of the element from the patch's first pixel (interior tiles: no per-element arithmetic)
 #pragma unroll
     for (int i = 0; i < SX; ++i) {
         const int e = tid + i * 256;
         pq[i] = -1;
         pdst[i] = NPX * S;   // slack
+        poffb[i] = kOOB;
         if (e < NPX * C4) {
             const int pix = e >> C4SH;
             const int py = fdiv(pix, 1.0f / (float)PW), px = pix - py * PW;
             pq[i] = (py << 8) | px;
             pdst[i] = pix * S + c4 * 4;
+            poffb[i] = (unsigned)((py * a.W + px) * CIN + c4 * 4) * 4u;
         }
     }
     const unsigned x_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * CIN) * 4u);
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     struct Item {
         int n, ty0, tx0, lin;
     };
-    auto decode = [&](int it) {
+    auto decode = [&](int it) __attribute__((always_inline)) {
         Item r;
         r.lin = (int)blockIdx.x + it * GX;
         r.n = fdiv(r.lin, inv_tiles);
@@ -109,32 +112,52 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
         return r;
     };
     float4 pv[SX];
-    unsigned pok = 0;   // bit i: element i came from inside the image (padding must stay 0 through the on-load affine)
+    unsigned pok = 0;   // bit i: element i came from inside the image (padding must stay 0 through the on-load affine);
+                        // bit 31: the WHOLE patch did (interior tile: predicate-free loads and commit)
     float4 va = make_float4(1.f, 1.f, 1.f, 1.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto issue = [&](const Item& I) {   // global loads of the item's patch (zero padding: out-of-range offset -> zeros)
+    auto issue = [&](const Item& I) __attribute__((always_inline)) {   // global loads of the item's patch (zero padding: out-of-range offset -> zeros)
         const int vy0 = I.ty0 * STRIDE - a.pad_t, vx0 = I.tx0 * STRIDE - a.pad_l;
         const float* xn = uniform_ptr(a.x + (size_t)I.n * a.H * a.W * CIN);
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, x_bytes, 0x00020000);
-        pok = 0;
+        if (vy0 >= 0 && vx0 >= 0 && vy0 + PH <= a.H && vx0 + PW <= a.W) {
+            // interior tile (the vast majority): per-thread offsets are tile-invariant, the tile's origin rides in the scalar
+            // offset operand -- no address arithmetic, no bounds checks (measured on the bf16 twin of this kernel,
+            // tools/bstream_trace.py: the per-element form cost as much as the matrix instructions of a tile)
+            pok = 0xFFFFFFFFu;
+            const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)((vy0 * a.W + vx0) * CIN) * 4u);
 #pragma unroll
-        for (int i = 0; i < SX; ++i) {
-            const int sy = vy0 + (pq[i] >> 8), sx = vx0 + (pq[i] & 255);
-            const bool ok = pq[i] >= 0 && (unsigned)sy < (unsigned)a.H && (unsigned)sx < (unsigned)a.W;
-            pok |= ok ? (1u << i) : 0u;
-            pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((sy * a.W + sx) * CIN + c4 * 4) * 4u : kOOB, 0, 0));
+            for (int i = 0; i < SX; ++i) pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, poffb[i], base, 0));
+        } else {
+            pok = 0;
+#pragma unroll
+            for (int i = 0; i < SX; ++i) {
+                const int sy = vy0 + (pq[i] >> 8), sx = vx0 + (pq[i] & 255);
+                const bool ok = pq[i] >= 0 && (unsigned)sy < (unsigned)a.H && (unsigned)sx < (unsigned)a.W;
+                pok |= ok ? (1u << i) : 0u;
+                pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((sy * a.W + sx) * CIN + c4 * 4) * 4u : kOOB, 0, 0));
+            }
         }
         if (has_ab) {
             va = *reinterpret_cast<const float4*>(a.in_a + (size_t)I.n * a.in_nstride + c4 * 4);
             vb = *reinterpret_cast<const float4*>(a.in_b + (size_t)I.n * a.in_nstride + c4 * 4);
         }
     };
-    auto relu1 = [](float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); };
-    auto commit = [&]() {
+    auto relu1 = [](float x) __attribute__((always_inline)) {   // ONE v_max_f32 (fmaxf / fmed3 come with a canonicalising second instruction)
+#if defined(__HIP_DEVICE_COMPILE__)
+        float r;
+        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+        return r;
+#else
+        return x > 0.f ? x : 0.f;
+#endif
+    };
+    auto commit_as = [&](auto MASKED) __attribute__((always_inline)) {
+        constexpr bool masked = decltype(MASKED)::value;
 #pragma unroll
         for (int i = 0; i < SX; ++i) {
             float4 v = pv[i];
             if (has_ab) {   // producer instance norm folded into the load; padding arrives as 0 and must stay 0
-                const unsigned okm = (pok >> i) & 1u ? 0xFFFFFFFFu : 0u;
+                const unsigned okm = (!masked || ((pok >> i) & 1u)) ? 0xFFFFFFFFu : 0u;
                 v.x = fmaf(v.x, va.x, __uint_as_float(__float_as_uint(vb.x) & okm));
                 v.y = fmaf(v.y, va.y, __uint_as_float(__float_as_uint(vb.y) & okm));
                 v.z = fmaf(v.z, va.z, __uint_as_float(__float_as_uint(vb.z) & okm));
@@ -153,9 +176,15 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
             d[3] = v.w;
         }
     };
+    auto commit = [&]() __attribute__((always_inline)) {
+        if (pok >> 31)   // (wave-uniform) interior tile: no masking
+            commit_as(std::false_type{});
+        else
+            commit_as(std::true_type{});
+    };
 
     f32x16 acc[WM][NB];
-    auto zero_acc = [&]() {
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -167,8 +196,8 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     // the sweep is fully unrolled: every A address is the lane's base + a compile-time offset, B comes from registers.  Explicit
     // software pipeline pinned with sched_barrier: the A operands of step j + D are read before the matrix instructions of
     // step j (the compiler's own schedule waits for every read right before its MFMA)
-    auto aoff = [&](int j) { return (((j / (CIN / 2)) / KS) * PW + ((j / (CIN / 2)) % KS)) * S + 2 * (j % (CIN / 2)); };
-    auto sweep = [&]() {
+    auto aoff = [&](int j) __attribute__((always_inline)) { return (((j / (CIN / 2)) / KS) * PW + ((j / (CIN / 2)) % KS)) * S + 2 * (j % (CIN / 2)); };
+    auto sweep = [&]() __attribute__((always_inline)) {
         constexpr int D = WM * NB >= 8 ? 1 : (WM * NB >= 4 ? 2 : 3);
         float av[D + 1][WM];
 #pragma unroll
@@ -205,7 +234,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
         qb[nn] = q & 1;
         chb[nn] = a.shuffle ? ((qa[nn] * SW + qb[nn]) * Cr + (co - q * Cr)) * 4 : co * 4;
     }
-    auto epilogue = [&](const Item& I, float* rbuf) {
+    auto epilogue = [&](const Item& I, float* rbuf) __attribute__((always_inline)) {
         const int th_valid = min(TH, a.Ho - I.ty0), tw_valid = min(kTW, a.Wo - I.tx0);
         if (a.stats) {
             // per-WAVE partial sums of (x - c), (x - c)^2 over the wave's 2*WM tile rows, c = the wave's own first pixel of the
@@ -284,7 +313,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
         zero_acc();
     };
     // merge of the per-wave records of one tile (Chan's update, fixed order) -> {mean, M2, count} of the tile
-    auto finalize = [&](const Item& I, const float* rbuf) {
+    auto finalize = [&](const Item& I, const float* rbuf) __attribute__((always_inline)) {
         const int th_valid = min(TH, a.Ho - I.ty0), tw_valid = min(kTW, a.Wo - I.tx0);
         float cnt = 0.f, mean = 0.f, m2 = 0.f;
 #pragma unroll
