@@ -24,6 +24,8 @@ stats_table $O/stats_b32 $O/kernel_stats_b32.txt
 #    ... and at batch 4 per GPU (BASELINE configs[2])
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_b4 --output-format csv -- python $R/bench.py --no-cpu-baseline --no-stylize --no-b4 --batch-per-gpu 4 --steps 100 > $O/bench_b4_under_rocprofv3.json 2> $O/bench_b4_stderr.txt
 stats_table $O/stats_b4 $O/kernel_stats_b4.txt
+#    ... and the launcher path on the one GPU: bench.py starts its own rank through torch.distributed.run (RCCL, world size 1)
+timeout 300 python $R/bench.py --gpus 1 --launch --no-cpu-baseline --no-stylize --steps 30 > $O/bench_b32_selflaunch_world1.json 2> $O/bench_selflaunch_stderr.txt
 # 2. HBM traffic counters of the b32 step, one pass each, eager launches so every launch is a separate dispatch record
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C -d $O/pmc_b32_$C --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-stylize --no-b4 --no-graph > /dev/null 2>&1

@@ -20,7 +20,7 @@ from collections import defaultdict
 
 def short(name):
     m = re.search(r"(conv_igemm_kernel<[^>]*>|conv_wgrad_kernel<[^>]*>|wgrad2_kernel<[^>]*>|conv_stream_kernel<[^>]*>|gram_stream_kernel<[^>]*>|"
-                  r"gram_bwd_kernel<[^>]*>|conv_bf16_\w+<[^>]*>|[a-z_0-9]+_kernel)", name)
+                  r"gram_bwd_kernel<[^>]*>|conv_bf16_\w+<[^>]*>|conv_bstream_kernel<[^>]*>|[a-z_0-9]+_kernel)", name)
     s = m.group(1) if m else name[:60]
     s = s.replace(" ", "")
     return s if s.startswith("wgrad2") else s.replace(",false", "").replace(",true", ",flat")
