@@ -1073,9 +1073,9 @@ bool conv_route_ok(const ConvArgs& a) {
 int conv_launch(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     if (env_int("FS_CONV_DEBUG", 0))  // tuning aid: one line per launch with the chosen plan
-        fprintf(stderr, "conv N%d %dx%dx%d -> %dx%dx%d k%dx%d s%d src%d: variant %d tile %dx%d (patch %dx%d) CC %d ksplit %d lds %d wgs %d\n",
+        fprintf(stderr, "conv N%d %dx%dx%d -> %dx%dx%d k%dx%d s%d src%d: variant %d tile %dx%d (patch %dx%d) CC %d ksplit %d rem %d/%d lds %d wgs %d\n",
                 a.N, a.H, a.W, a.Cin, a.Ho, a.Wo, a.Cout, a.KH, a.KW, a.stride, a.src_mode, a.p.variant, a.p.TH, a.p.TW, a.p.PH,
-                a.p.PW, a.p.CC, a.p.ksplit, a.p.lds_bytes, a.N * a.p.tiles_y * a.p.tiles_x * cdiv(a.Cout, a.p.BN));
+                a.p.PW, a.p.CC, a.p.ksplit, a.p.rem_full, a.p.rem_ks, a.p.lds_bytes, a.N * a.p.tiles_y * a.p.tiles_x * cdiv(a.Cout, a.p.BN));
     if (a.dil_x < 1) a.dil_x = 1;
     const ConvPlan& p = a.p;
     if (p.CC <= 0 || (!p.flat && (a.Cin % 4 || a.Cin % p.CC))) return -1;

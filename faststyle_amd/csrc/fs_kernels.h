@@ -32,6 +32,8 @@ struct ConvPlan {
     int PH, PW;   // staged patch extent
     int lds_bytes;
     int ksplit;   // > 1: blockIdx.z splits the input-channel chunks; raw partials go to ConvArgs::split_ws
+    int rem_full;     // wino2, remainder split: items [0, rem_full) are whole items (rem_full = a multiple of the persistent grid) ...
+    int rem_ks;       // ... and each item behind them is split into rem_ks units over its input-channel chunks (0: no split)
     int xcd_swizzle;  // workgroup -> (tile, channel block) map that keeps sharers of an input patch on one XCD
     int skew;  // > 0: first-round workgroups in odd wave slots start late by skew x 2048 cycles (see conv_igemm_kernel)
 };
@@ -101,6 +103,8 @@ struct ConvArgs {
     long long w_nstride;
     int prof_tag;            // 1: launched by the transform net (profiler row; no effect on the computation)
     FinArgs fin;             // fused instance-norm finalize (with stats; persistent kernels only)
+    float* rem_ws;           // optional scratch for the remainder split of fs_wino2 (rem_ws_floats capacity): the items of the last,
+    size_t rem_ws_floats;    // partial round of a persistent launch are split over the reduction dimension across ALL workgroups
     int half_items;          // 1: with w_wino2, prefer the half-item Winograd kernel (fs_wino2h.hip: grids too small for 64-tile items)
     float* split_ws;         // optional scratch for split-K partials (split_ws_floats capacity); enables ksplit plans
     size_t split_ws_floats;

@@ -45,6 +45,7 @@ struct TnetLayout {
     size_t h[5];      // residual block outputs
     size_t weff[2];   // collapsed resize-conv filters
     size_t zfold, wfold, dwfold;  // kw-folded output layer: Z / unfolded dY [N,Ho,Wo+4,16], filters, filter grads
+    size_t rem_ws;      // scratch of the remainder split of fs_wino2 (256 units x 16x16 pixels x 64 channels)
     size_t fin_counter; // 16 unsigned: the "last workgroup" counters of the fused instance-norm finalize (fs_kernels.h FinArgs)
     size_t fwd_floats;
     size_t wTu[16];   // per-unit input-gradient filters (flip+transpose / collapsed), all built by one wt_batch launch

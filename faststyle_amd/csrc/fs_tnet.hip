@@ -108,6 +108,8 @@ static ConvArgs unit_args(const Unit& u, int N) {
     return a;
 }
 
+constexpr int kRemUnits = 256;   // at most one persistent grid of split units
+
 int tnet_wino_mode() {
     return tune_int("FS_TNET_WINO", 1);
 }
@@ -261,6 +263,8 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
             a.stats = nullptr;
         }
         a.half_items = u.wino == 2;
+        a.rem_ws = reinterpret_cast<float*>(16);   // (planning looks at the capacity only)
+        a.rem_ws_floats = (size_t)kRemUnits * 16384;
         u.plan = conv_plan(a);
         u.wino_u = u.wino ? b.take((size_t)16 * u.Cin * u.Cc) : 0;
         u.tiles = u.kind == 2 ? cdiv(u.Hout * u.Wout, 256) : u.plan.tiles_y * u.plan.tiles_x;
@@ -286,6 +290,7 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
     L->wfold = b.take(18 * 16 * 16);
     L->dwfold = b.take(18 * 16 * 16);
     L->fin_counter = b.take(64);
+    L->rem_ws = b.take((size_t)kRemUnits * 16384);
     L->fwd_floats = b.off;
     // ---- backward scratch ----
     for (int k = 0; k < 3; ++k) L->g[k] = b.take(max_act);
@@ -415,7 +420,7 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
     bool any_fused = false;
     for (int i = 0; i < 16; ++i) {
         const Unit& u = L.u[i];
-        fused[i] = u.kind != 2 && (u.plan.variant == 6 || u.plan.variant == 7 || u.plan.variant == 8) &&
+        fused[i] = u.kind != 2 && (u.plan.variant == 6 || u.plan.variant == 7 || u.plan.variant == 8) && u.plan.rem_ks == 0 &&
                    fused_finalize_ok(N, u.Cout, u.tiles, u.kind == 1 ? 4 : 1);
         any_fused = any_fused || fused[i];
     }
@@ -438,6 +443,8 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
         a.half_items = u.wino == 2;
         a.y = u.kind == 2 ? ws + L.zfold : ws + u.z;
         a.stats = u.kind == 2 ? nullptr : ws + u.stats;
+        a.rem_ws = ws + L.rem_ws;
+        a.rem_ws_floats = (size_t)kRemUnits * 16384;
         if (fused[i]) {
             a.fin.counter = reinterpret_cast<unsigned*>(ws + L.fin_counter) + i;
             a.fin.gamma = params + u.g_off;
@@ -557,6 +564,8 @@ static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, c
         a.pad_l = u.K - 1 - u.pad_l;
         a.src_mode = u.stride == 2 ? SRC_DILATE2 : SRC_PLAIN;
     }
+    a.rem_ws = ws + L.rem_ws;
+    a.rem_ws_floats = (size_t)kRemUnits * 16384;
     a.p = conv_plan(a);
     return conv_launch(a, s);
 }

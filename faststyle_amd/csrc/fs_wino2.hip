@@ -98,6 +98,14 @@ extern "C" int fs_debug_conv_trace_reset() {
 #define FS_W2_NOW() ((long long)__builtin_readcyclecounter())
 #endif
 
+// REM = true (transform-net launches with a.p.rem_ks > 0): REMAINDER SPLIT.  A persistent launch of `items` items on G
+// workgroups takes ceil(items / G) rounds, and the last one is mostly empty (batch 32, 74-pixel maps: 800 items = 3.1 rounds
+// -> 4; a 720p frame: 273 items = 1.07 rounds -> 2).  Here the items of that last partial round are split over their
+// input-channel chunks into rem_ks units each (rem * rem_ks <= G): every workgroup multiplies ONE unit after its whole items
+// and leaves the output-transformed partial tile in scratch; wino2_rem_epilogue_kernel sums the rem_ks partials of an item
+// and does what the item's epilogue would have done (statistics record / residual add, store).  The VGG16 launches
+// (thousands of items) instantiate REM = false: the code of round 2, unchanged.
+template <bool REM>
 __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
     HIP_DYNAMIC_SHARED(float, smem)
 #ifdef FS_WINO2_TRACE
@@ -123,16 +131,28 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
     const int ncob = a.Cout / kBN;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
     const int nchunks_all = a.Cin / kCC;
-    const int total_items = a.N * blocks * ncob * ks;
+    const int whole_items = a.N * blocks * ncob * ks;
+    const int rem_full = REM ? p.rem_full : whole_items, rem_ks = REM ? p.rem_ks : 1;
+    const int total_items = REM ? rem_full + (whole_items - rem_full) * rem_ks : whole_items;   // whole items + units
+    const float inv_rks = 1.0f / (float)rem_ks;
     const int G = (int)gridDim.x;
     const int my_items = ((int)blockIdx.x < total_items) ? (total_items - 1 - (int)blockIdx.x) / G + 1 : 0;
     const float inv_ks = 1.0f / (float)ks, inv_ncob = 1.0f / (float)ncob, inv_blocks = 1.0f / (float)blocks, inv_tx = 1.0f / (float)p.tiles_x;
     struct Item {
-        int n, oy0, ox0, co0, cbeg, cend, z, tile_lin;
+        int n, oy0, ox0, co0, cbeg, cend, z, tile_lin, slot;   // slot >= 0: a UNIT of the remainder split (its partial tile's place in scratch)
     };
     auto decode = [&](int it) {
         Item r;
-        const int lin = (int)blockIdx.x + it * G;
+        int lin = (int)blockIdx.x + it * G;
+        int rz = 0;
+        r.slot = -1;
+        if (REM && lin >= rem_full) {   // unit u of the remainder split: item rem_full + u / rem_ks, chunk range u % rem_ks
+            const int u = lin - rem_full;
+            const int ri = fdiv(u, inv_rks);
+            rz = u - ri * rem_ks;
+            r.slot = u;
+            lin = rem_full + ri;
+        }
         const int t1 = fdiv(lin, inv_ks);
         r.z = lin - t1 * ks;
         const int t2 = fdiv(t1, inv_ncob);
@@ -146,6 +166,11 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
         r.co0 = cob * kBN;
         r.cbeg = ks > 1 ? r.z * nchunks_all / ks : 0;
         r.cend = ks > 1 ? (r.z + 1) * nchunks_all / ks : nchunks_all;
+        if (REM && r.slot >= 0) {
+            r.cbeg = rz * nchunks_all / rem_ks;
+            r.cend = (rz + 1) * nchunks_all / rem_ks;
+        }
+        r.slot = __builtin_amdgcn_readfirstlane(r.slot);
         r.n = __builtin_amdgcn_readfirstlane(r.n);
         r.oy0 = __builtin_amdgcn_readfirstlane(r.oy0);
         r.ox0 = __builtin_amdgcn_readfirstlane(r.ox0);
@@ -557,8 +582,33 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
             FS_LDS_BARRIER();   // `red` is reused by the next item
         }
     };
+    // a unit of the remainder split: output transform in registers as usual, the partial 16x16-pixel x 64-channel tile goes
+    // to scratch as [slot][pixel][channel] (no bias / statistics / add: wino2_rem_epilogue_kernel does those on the sum)
+    auto epilogue_partial = [&](const Item& I) {
+        float* dst = a.rem_ws + (size_t)I.slot * (4 * kNT * kBN) + ((8 * mb) * (2 * kTT) + 8 * kq) * kBN + nb * 32 + lm;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float m[16];
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) m[pos] = FS_ACC_READ(acc[pos][r]);
+            float s4[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s4[0][j] = m[0 + j] + m[4 + j] + m[8 + j];
+                s4[1][j] = m[4 + j] - m[8 + j] - m[12 + j];
+            }
+#pragma unroll
+            for (int ai = 0; ai < 2; ++ai) {
+                const int py = 2 * (r >> 2) + ai, px = 2 * (r & 3);
+                dst[(py * (2 * kTT) + px) * kBN] = s4[ai][0] + s4[ai][1] + s4[ai][2];
+                dst[(py * (2 * kTT) + px + 1) * kBN] = s4[ai][1] - s4[ai][2] - s4[ai][3];
+            }
+        }
+    };
     auto epilogue = [&](const Item& I) {
-        if (I.oy0 + 2 * kTT <= a.Ho && I.ox0 + 2 * kTT <= a.Wo)
+        if (REM && I.slot >= 0)
+            epilogue_partial(I);
+        else if (I.oy0 + 2 * kTT <= a.Ho && I.ox0 + 2 * kTT <= a.Wo)
             epilogue_body(std::true_type{}, I);
         else
             epilogue_body(std::false_type{}, I);
@@ -645,6 +695,81 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
 #endif
 }
 
+// Second half of the remainder split: one workgroup per split item sums the rem_ks partial tiles of its units and finishes
+// the item -- the per-block instance-norm record of the raw conv output (same {mean, M2, count} form and shift rule as the
+// kernel's own epilogue) or the residual-gradient addend, and the store.  thread = (channel, one row of the 16x16 block):
+// all of a thread's loads are issued before its first store (a serial pixel loop here costs one memory latency per pixel).
+__global__ __launch_bounds__(1024) void wino2_rem_epilogue_kernel(ConvArgs a) {
+    __shared__ float red[16 * 64 * 2];
+    const ConvPlan& p = a.p;
+    const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
+    const int ncob = a.Cout / kBN, blocks = p.tiles_y * p.tiles_x;
+    const int item = p.rem_full + (int)blockIdx.x;
+    const int t2 = item / ncob, cob = item - t2 * ncob;
+    const int n = t2 / blocks, br = t2 - n * blocks;
+    const int byi = br / p.tiles_x;
+    const int oy0 = byi * 2 * kTT, ox0 = (br - byi * p.tiles_x) * 2 * kTT, co = cob * kBN + c;
+    const int ks = p.rem_ks;
+    const float* __restrict__ part = a.rem_ws + (size_t)blockIdx.x * ks * (4 * kNT * kBN) + c;
+    const int oy = oy0 + g;
+    float v[16], cs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = 0.f;
+    for (int z = 0; z < ks; ++z) {
+        const float* pz = part + (size_t)z * (4 * kNT) * kBN;
+        cs += pz[0];   // shift of the one-pass statistics: the block's first pixel of the channel
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] += pz[(g * 16 + i) * kBN];
+    }
+    const int Ha = a.Ho - 2 * a.add_pad, Wa = a.Wo - 2 * a.add_pad;
+    if (a.stats) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float d = (oy < a.Ho && ox0 + i < a.Wo) ? v[i] - cs : 0.f;
+            s1 += d;
+            s2 = fmaf(d, d, s2);
+        }
+        red[(g * 64 + c) * 2] = s1;
+        red[(g * 64 + c) * 2 + 1] = s2;
+    }
+    if (a.add_src) {
+        const float* __restrict__ adn = a.add_src + (size_t)n * Ha * Wa * a.Cout;
+        const int ay = oy - a.add_pad;
+        float ad[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ax = ox0 + i - a.add_pad;
+            ad[i] = (ay >= 0 && ay < Ha && ax >= 0 && ax < Wa) ? adn[((size_t)ay * Wa + ax) * a.Cout + co] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] += ad[i];
+    }
+    if (oy < a.Ho) {
+        float* yr = a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox0) * a.Cout + co;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (ox0 + i < a.Wo) yr[(size_t)i * a.Cout] = v[i];
+    }
+    if (a.stats) {
+        __syncthreads();
+        if (tid < 64) {
+            float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                S1 += red[(q * 64 + tid) * 2];
+                S2 += red[(q * 64 + tid) * 2 + 1];
+            }
+            const int th_valid = min(2 * kTT, a.Ho - oy0), tw_valid = min(2 * kTT, a.Wo - ox0);
+            const float cnt = (float)(th_valid * tw_valid);
+            float* st = a.stats + ((size_t)t2 * a.Cout + co) * 3;
+            st[0] = cs + S1 / cnt;
+            st[1] = fmaxf(S2 - S1 * S1 / cnt, 0.f);
+            st[2] = cnt;
+        }
+    }
+}
+
 bool wino2_eligible(const ConvArgs& a) {
     // SAME (pad 1: the VGG convs), VALID (pad 0: residual convs of the transform net) or FULL (pad 2: their input
     // gradients); the on-load affine needs pad 0
@@ -676,17 +801,40 @@ void wino2_plan(const ConvArgs& a, ConvPlan* out) {
             ks *= 2;
         p.ksplit = ks;
     }
+    // remainder split (transform-net launches; see wino2_conv_kernel<true>): whole rounds of whole items, the last partial
+    // round split over the input-channel chunks so that it occupies the whole chip for a fraction of a round
+    if (a.rem_ws && a.prof_tag && p.ksplit == 1 && !a.bias && !a.out_relu && !a.mask_src && !a.pool_out && !a.fin.counter && tune_int("FS_WINO2_REM", 1)) {
+        const long G = tune_int("FS_WINO2_WGS", 256);
+        if (items > G) {
+            const long full = items / G * G, rem = items - full;
+            int rks = 1;
+            while (rks * 2 <= nchunks && rem * rks * 2 <= G) rks *= 2;
+            if (rem > 0 && rks > 1 && (size_t)rem * rks * (4 * kNT * kBN) <= a.rem_ws_floats) {
+                p.rem_full = (int)full;
+                p.rem_ks = rks;
+            }
+        }
+    }
     *out = p;
 }
 
 int wino2_launch(const ConvArgs& a, hipStream_t s) {
     const ConvPlan& p = a.p;
-    static BigLds lds_attr;
-    lds_attr.ensure(reinterpret_cast<const void*>(wino2_conv_kernel));
     const long items = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / kBN) * (p.ksplit > 1 ? p.ksplit : 1);
     const int wgs = tune_int("FS_WINO2_WGS", 256);
+    if (p.rem_ks > 0) {   // whole items of the full rounds + units of the split remainder, then the remainder's epilogue
+        static BigLds lds_attr_rem;
+        lds_attr_rem.ensure(reinterpret_cast<const void*>(wino2_conv_kernel<true>));
+        if (!a.rem_ws || p.rem_full <= 0 || p.rem_full % wgs) return -9;
+        const long rem = items - p.rem_full;
+        hipLaunchKernelGGL(wino2_conv_kernel<true>, dim3((unsigned)wgs), dim3(256), (size_t)p.lds_bytes, s, a);
+        hipLaunchKernelGGL(wino2_rem_epilogue_kernel, dim3((unsigned)rem), dim3(1024), 0, s, a);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
+    static BigLds lds_attr;
+    lds_attr.ensure(reinterpret_cast<const void*>(wino2_conv_kernel<false>));
     const long grid = items < wgs ? items : wgs;
-    hipLaunchKernelGGL(wino2_conv_kernel, dim3((unsigned)grid), dim3(256), (size_t)p.lds_bytes, s, a);
+    hipLaunchKernelGGL(wino2_conv_kernel<false>, dim3((unsigned)grid), dim3(256), (size_t)p.lds_bytes, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

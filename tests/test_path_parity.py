@@ -139,12 +139,17 @@ def test_tnet_forward_with_two_level_statistics_merge(eng, knob):
     assert np.abs(y - yo).max() / 255.0 < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(2, 48, 56), (1, 45, 67)])
-def test_tnet_residual_convs_through_the_winograd_kernel(eng, shape, knob):
+@pytest.mark.parametrize("shape,wgs", [((2, 48, 56), 0), ((1, 45, 67), 0), ((2, 48, 56), 6), ((1, 45, 67), 4), ((3, 52, 44), 10)])
+def test_tnet_residual_convs_through_the_winograd_kernel(eng, shape, wgs, knob):
     """FS_TNET_WINO=2 forces what 720p / 1080p frames (and large training batches) select by themselves: the ten 3x3
     VALID residual convs through wino_conv_kernel -- producer instance norm + ReLU on load, per-block statistics --
-    forward against the oracle with the shipped weights, and the backward pass on top of that forward."""
+    forward against the oracle with the shipped weights, and the backward pass on top of that forward.
+    wgs > 0: a persistent grid of that many workgroups, chosen so that the launches end in a PARTIAL round -- the remainder
+    split of fs_wino2.hip (leftover items split over their input-channel chunks across all workgroups, partial tiles summed
+    by wino2_rem_epilogue_kernel: statistics records in the forward, the residual-gradient addend in the backward)."""
     knob("FS_TNET_WINO", 2)
+    if wgs:
+        knob("FS_WINO2_WGS", wgs)
     rng = np.random.default_rng(9)
     P = tnet.strip_scope(starry())
     flat = eng.mem.from_numpy(eng.flatten_params(P, scope=""))
@@ -454,7 +459,9 @@ def test_hip_1080p_batch_consistency_and_bf16_agreement():
         y1 = e.mem.to_numpy(e.tnet_forward(flat, x1, bf16=bf16))
         y2 = e.mem.to_numpy(e.tnet_forward(flat, x2, bf16=bf16))
         assert y1.shape == (1, 1080, 1920, 3) and np.isfinite(y2).all()
-        assert np.array_equal(y2[0], y2[1])
+        # (the two copies are the same to summation order, not to the bit: the remainder split of the residual Winograd
+        # launches sums the input channels of the launch's LAST items in rem_ks partial sums -- fs_wino2.hip)
+        assert np.abs(y2[0] - y2[1]).max() < (1e-3 * 255 if not bf16 else 3.0)
         # same arithmetic, different tiling walk: fp32 summation-order noise (measured 1.2e-4); in the bf16 path that
         # noise flips an occasional bfloat16 rounding, so there the bound is a few bf16 steps of the 0..255 range
         d = np.abs(y2[0] - y1[0])
