@@ -48,21 +48,80 @@ __global__ __launch_bounds__(256) void wt_fold5_back_kernel(const float* dwf, fl
 // the instance norm (same format as the conv epilogue's: [N][T][3][3], T = ceil(Ho*Wo/256)).
 __device__ __forceinline__ float fold_ld(float v) { return v; }
 __device__ __forceinline__ float fold_ld(unsigned short v) { return __builtin_bit_cast(float, (unsigned)v << 16); }  // bf16
+// The block's 256 pixels read Z columns ox .. ox+4 of their rows: a contiguous range of at most 260 + 4 x (rows crossed) Z
+// pixels.  Each is fetched ONCE as whole 16-channel rows (two / four 16-byte loads per thread) and laid out channel-major in
+// LDS, so the 15 reads of a pixel are conflict-free LDS reads instead of 15 two-byte global loads (the kernel was bound by
+// the number of global-load instructions: 1080p batch 8, 0.30 ms for 0.73 GB).  Blocks whose range exceeds the LDS array
+// (maps narrower than ~9 pixels) read global memory directly, as before; the sums run in the same order either way.
+constexpr int kFoldCap = 384;
+template <typename TZ>
+__device__ __forceinline__ void fold_ld16(const TZ* src, float* o);
+template <>
+__device__ __forceinline__ void fold_ld16<float>(const float* src, float* o) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 t = s4[k];
+        o[4 * k] = t.x;
+        o[4 * k + 1] = t.y;
+        o[4 * k + 2] = t.z;
+        o[4 * k + 3] = t.w;
+    }
+}
+template <>
+__device__ __forceinline__ void fold_ld16<unsigned short>(const unsigned short* src, float* o) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint4 t = s4[k];
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[8 * k + 2 * e] = __builtin_bit_cast(float, w[e] << 16);
+            o[8 * k + 2 * e + 1] = __builtin_bit_cast(float, w[e] & 0xFFFF0000u);
+        }
+    }
+}
 template <typename TZ>
 __global__ __launch_bounds__(256) void fold5_fwd_kernel(const TZ* Z, float* z, float* stats, int HW, int Wo) {
     __shared__ float sh[4];
+    __shared__ float zl[15 * kFoldCap];
     const int n = blockIdx.y, T = gridDim.x;
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int p0 = blockIdx.x * 256, p = p0 + threadIdx.x;
     const bool ok = p < HW;
+    const int Wz = Wo + 4;
+    const int oy0 = p0 / Wo, p1 = min(p0 + 255, HW - 1), oy1 = p1 / Wo;
+    const int zq0 = oy0 * Wz + (p0 - oy0 * Wo), count = oy1 * Wz + (p1 - oy1 * Wo) + 4 - zq0 + 1;   // (block-uniform)
+    const TZ* Zn = Z + (size_t)n * (HW / Wo) * Wz * 16;
+    const bool staged = count <= kFoldCap;
+    if (staged) {
+        for (int zi = threadIdx.x; zi < count; zi += 256) {
+            float o[16];
+            fold_ld16<TZ>(Zn + (size_t)(zq0 + zi) * 16, o);
+#pragma unroll
+            for (int j = 0; j < 15; ++j) zl[j * kFoldCap + zi] = o[j];
+        }
+        __syncthreads();
+    }
     float y[3] = {0.f, 0.f, 0.f};
     if (ok) {
         const int oy = p / Wo, ox = p - oy * Wo;
-        const TZ* src = Z + (((size_t)n * (HW / Wo) + oy) * (Wo + 4) + ox) * 16;
+        if (staged) {
+            const int zi = oy * Wz + ox - zq0;
 #pragma unroll
-        for (int v = 0; v < 5; ++v) {
-            y[0] += fold_ld(src[v * 16 + v * 3 + 0]);
-            y[1] += fold_ld(src[v * 16 + v * 3 + 1]);
-            y[2] += fold_ld(src[v * 16 + v * 3 + 2]);
+            for (int v = 0; v < 5; ++v) {
+                y[0] += zl[(v * 3 + 0) * kFoldCap + zi + v];
+                y[1] += zl[(v * 3 + 1) * kFoldCap + zi + v];
+                y[2] += zl[(v * 3 + 2) * kFoldCap + zi + v];
+            }
+        } else {
+            const TZ* src = Zn + ((size_t)oy * Wz + ox) * 16;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                y[0] += fold_ld(src[v * 16 + v * 3 + 0]);
+                y[1] += fold_ld(src[v * 16 + v * 3 + 1]);
+                y[2] += fold_ld(src[v * 16 + v * 3 + 2]);
+            }
         }
         float* dst = z + ((size_t)n * HW + p) * 3;
         dst[0] = y[0];

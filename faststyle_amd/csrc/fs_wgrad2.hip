@@ -289,55 +289,65 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wg2Args a) {
     const bool active = kb0 < p.KB;
     // (k-blocks beyond K read the zero slack and are multiplied like the others: a per-instruction guard would put every
     // matrix instruction behind its own branch)
-    auto sweep = [&](const float* stage) {
-        const float* patch = stage;
-        const float* dyl = stage + p.patch_floats + m16;
+    // Every operand read of step s+1 is PINNED into a matrix-instruction slot of step s (one address add + one ds_read_b32 per
+    // slot, sched_barrier after every slot), two register sets.  Round 2 left the placement to sched_group_barrier hints: the
+    // backend then sank most reads of a step to just before their own matrix instruction (ds_read, s_waitcnt lgkmcnt(0),
+    // v_mfma -- the LDS latency exposed on every instruction: 107 cycles per matrix instruction in the 9x9 instances against
+    // 32 of issue time; ablation FS_WGRAD2_DEBUG=2).  The lane's share of every operand address is folded into fixed byte
+    // offsets (ab[], bb), so a step's offset is two scalars.
+    int ab[KM];
+#pragma unroll
+    for (int q = 0; q < KM; ++q) ab[q] = (abase[q] + k4 * a.stride * S) * 4;
+    const int bb = (p.patch_floats + m16 + k4 * DP) * 4;
+    const char* const lds0 = reinterpret_cast<const char*>(smem);
+    auto sweep = [&](const float* stage) __attribute__((always_inline)) {
+        const int st = (int)(stage - smem) * 4;               // byte offset of the stage (wave-uniform)
         int cy = wp, cx = 0;                                  // load cursor
-        auto ld = [&](float (&av)[KM], float (&bv)[KN]) {
-            const int px = cx * 4 + k4;
-            const int poff = (cy * a.stride * PW + px * a.stride) * S;
-            const float* pb = dyl + (cy * TW + px) * DP;   // (B first: the first matrix instruction of the next step needs it)
-#pragma unroll
-            for (int j = 0; j < KN; ++j) bv[j] = pb[j * 16];
-#pragma unroll
-            for (int q = 0; q < KM; ++q) av[q] = patch[abase[q] + poff];
+        int sa = 0, sb = 0;
+        auto cursor = [&]() __attribute__((always_inline)) {  // byte offsets of the cursor's step, then advance it
+            sa = st + (cy * a.stride * PW + cx * 4 * a.stride) * S * 4;
+            sb = st + (cy * TW + cx * 4) * DP * 4;
             if (++cx == spr) {
                 cx = 0;
                 cy += waves_p;
                 if (cy >= TH) cy = wp;   // past the last step: wrap (the prefetch of a step that does not exist re-reads step 0)
             }
         };
-        auto mm = [&](const float (&av)[KM], const float (&bv)[KN]) {
-#pragma unroll
-            for (int q = 0; q < KM; ++q)
-#pragma unroll
-                for (int j = 0; j < KN; ++j)
-                    acc[q][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[j], acc[q][j], 0, 0, 0);
-        };
-        // nsteps is even (the planner picks tile widths that are multiples of 8), so the body is branch-free: the loads of
-        // step s+1 are in flight while the matrix instructions of step s issue
+        constexpr int NM = KM * KN, NL = KM + KN;
         float a0[KM], b0[KN], a1[KM], b1[KN];
-        // issue order inside a half iteration: a few matrix instructions, then one operand address + LDS read of the next
-        // step, and so on -- left to itself the compiler clusters all reads in front of the MFMA block and the matrix pipe
-        // idles while they issue (one wave per SIMD: nothing else covers them)
-        constexpr int NM = KM * KN, NL = KM + (KN + 1) / 2, PER = NM / NL > 0 ? NM / NL : 1;
-        auto interleave = [&]() {
+        cursor();
 #pragma unroll
-            for (int g = 0; g < NL; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);     // VALU (the read's address)
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+        for (int j = 0; j < KN; ++j) b0[j] = *reinterpret_cast<const float*>(lds0 + (bb + sb) + j * 64);
+#pragma unroll
+        for (int q = 0; q < KM; ++q) a0[q] = *reinterpret_cast<const float*>(lds0 + (ab[q] + sa));
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (waits are placed statically: anything still pending on the way INTO the loop -- these reads, a scalar load --
+        // becomes an lgkmcnt(0) in front of the first matrix instruction of EVERY iteration; drain once here instead)
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+        // one step: the matrix instructions of (ca, cb); read r of the next step rides in slot r * NM / NL (B operands first:
+        // the first matrix instruction of the next step needs them)
+        auto step = [&](const float (&ca)[KM], const float (&cb)[KN], float (&na)[KM], float (&nb)[KN]) __attribute__((always_inline)) {
+            cursor();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+#pragma unroll
+                for (int r = 0; r < NL; ++r) {
+                    if (r * NM / NL != i) continue;
+                    if (r < KN)
+                        nb[r] = *reinterpret_cast<const float*>(lds0 + (bb + sb) + r * 64);
+                    else
+                        na[r - KN] = *reinterpret_cast<const float*>(lds0 + (ab[r - KN] + sa));
+                }
+                acc[i / KN][i % KN] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[i / KN], cb[i % KN], acc[i / KN][i % KN], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (NM > NL * PER) __builtin_amdgcn_sched_group_barrier(0x008, NM - NL * PER, 0);
         };
-        ld(a0, b0);
+        // nsteps is even (the planner picks tile widths that are multiples of 8), so the body is branch-free
         for (int s = 0; s < nsteps; s += 2) {
-            ld(a1, b1);
-            mm(a0, b0);
-            interleave();
-            ld(a0, b0);
-            mm(a1, b1);
-            interleave();
+            step(a0, b0, a1, b1);
+            step(a1, b1, a0, b0);
         }
     };
 
