@@ -24,10 +24,24 @@
 // wide filters (K x Cout beyond one workgroup's registers) and ragged channel counts.
 #include "fs_kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
 namespace fs {
+
+// an opaque identity on a vector register: the value is materialised there (no rematerialisation from its parts at the uses)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FS_PIN_VGPR(x) asm volatile("" : "+v"(x))
+// LDS byte address of a pointer into shared memory / a float at LDS byte address `addr` (an integer, so that base registers
+// hold COMPLETE addresses: with pointer arithmetic on the shared array the backend adds the array's base in front of the reads)
+#define FS_LDS_ADDR(p) ((int)(size_t)(const __attribute__((address_space(3))) char*)(p))
+#define FS_LDS_F32(base, addr) (*(const __attribute__((address_space(3))) float*)(size_t)(unsigned)(addr))
+#else
+#define FS_PIN_VGPR(x) ((void)0)
+#define FS_LDS_ADDR(p) 0
+#define FS_LDS_F32(base, addr) (*reinterpret_cast<const float*>((base) + (addr)))
+#endif
 
 namespace {
 constexpr int kXN = 12;   // float4 (for 3-channel inputs: pixels) of patch per thread and tile
@@ -58,7 +72,13 @@ __device__ __forceinline__ bool w2_coord(int mode, int refl, int v, int n_src, i
 
 // XVEC: Cin is a multiple of 4 and the input is read as it lies in memory (SRC_PLAIN) -- 16-byte loads, every transform-net
 // layer but the first; !XVEC: 3-channel inputs through any virtual-input mode (reflect padding of the image), scalar loads.
-template <int KM, int KN, bool XVEC>
+// SA > 0: STATIC TILE GEOMETRY -- SA = stride * patch pixel pitch S and SD = dY pixel pitch DP (floats), SPR = tile width / 4,
+// THc = tile rows, PWc = patch width, WPc = waves over the pixel rows, all known at compile time: the sweep of a tile is one
+// straight line in which every operand read is a lane-constant base register + an IMMEDIATE offset -- no vector-ALU
+// instruction in the matrix-instruction slots (tools/mfma16_slots.hip: beside v_mfma_f32_16x16x4_f32 a ds_read_b32 with an
+// immediate offset is free, 32.6 cycles per slot; the address add in front of it makes the slot 58.9).  Instantiated for
+// the tiles the planner picks for the 9x9 layers and the residual 3x3 batch; SA = 0: any geometry, one add per read.
+template <int KM, int KN, bool XVEC, int SA = 0, int SD = 0, int SPR = 0, int THc = 0, int PWc = 0, int WPc = 0>
 __global__ __launch_bounds__(256) void wgrad2_kernel(Wg2Args a) {
     HIP_DYNAMIC_SHARED(float, smem)
     const Wg2Plan& p = a.p;
@@ -302,6 +322,71 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wg2Args a) {
     const char* const lds0 = reinterpret_cast<const char*>(smem);
     auto sweep = [&](const float* stage) __attribute__((always_inline)) {
         const int st = (int)(stage - smem) * 4;               // byte offset of the stage (wave-uniform)
+        constexpr int NM = KM * KN, NL = KM + KN;
+        float a0[KM], b0[KN], a1[KM], b1[KN];
+        if constexpr (SA > 0) {
+            constexpr int STEP_A = 16 * SA, STEP_B = 16 * SD;                              // bytes per step (4 pixels)
+            constexpr int ROW_A = PWc * SA * 4 * WPc, ROW_B = 4 * SPR * SD * 4 * WPc;      // bytes between two rows of a wave
+            constexpr int RW = THc / WPc;                                                  // rows per tile and wave
+            const int l0 = FS_LDS_ADDR(lds0);   // (0 on the CPU emulator, where FS_LDS_F32 adds the array's address instead)
+            int rb[KM];
+#pragma unroll
+            for (int q = 0; q < KM; ++q) {
+                rb[q] = ab[q] + (l0 + st + wp * (ROW_A / WPc));
+                FS_PIN_VGPR(rb[q]);   // (or the backend keeps "lane part + scalar row offset" apart and re-adds them in front of every read)
+            }
+            int rbB = bb + (l0 + st + wp * (ROW_B / WPc));
+            FS_PIN_VGPR(rbB);
+#pragma unroll
+            for (int j = 0; j < KN; ++j) b0[j] = FS_LDS_F32(lds0, rbB + j * 64);
+#pragma unroll
+            for (int q = 0; q < KM; ++q) a0[q] = FS_LDS_F32(lds0, rb[q]);
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // (nothing may be pending on the way into the row loop: see the generic path)
+#endif
+            // one step: the matrix instructions of (ca, cb); read r of the NEXT step (bases + off_a / off_b) rides in slot
+            // r * NM / NL
+            auto step = [&](int off_a, int off_b, const float (&ca)[KM], const float (&cb)[KN], float (&na)[KM], float (&nb)[KN]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < NL; ++r) {
+                        if (r * NM / NL != i) continue;
+                        if (r < KN)
+                            nb[r] = FS_LDS_F32(lds0, rbB + (off_b + r * 64));
+                        else
+                            na[r - KN] = FS_LDS_F32(lds0, rb[r - KN] + off_a);
+                    }
+                    acc[i / KN][i % KN] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[i / KN], cb[i % KN], acc[i / KN][i % KN], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            // a ROLLED loop over the wave's rows (the accumulators stay in place across its back edge; a fully unrolled tile
+            // made the register allocator alternate between two accumulator sets), the SPR steps of a row unrolled.  The bases
+            // move to the next row in front of the row's last step, which prefetches that row's first (past the last row: the
+            // first row again -- a prefetch nobody uses).  SPR is even: a row starts on register set 0.
+#pragma unroll 1
+            for (int r = 0; r < RW; ++r) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cx = 0; cx + 2 < SPR; cx += 2) {
+                    step((cx + 1) * STEP_A, (cx + 1) * STEP_B, a0, b0, a1, b1);
+                    step((cx + 2) * STEP_A, (cx + 2) * STEP_B, a1, b1, a0, b0);
+                }
+                step((SPR - 1) * STEP_A, (SPR - 1) * STEP_B, a0, b0, a1, b1);
+                const int d_a = r + 1 == RW ? -(RW - 1) * ROW_A : ROW_A, d_b = r + 1 == RW ? -(RW - 1) * ROW_B : ROW_B;
+#pragma unroll
+                for (int q = 0; q < KM; ++q) {
+                    rb[q] += d_a;
+                    FS_PIN_VGPR(rb[q]);
+                }
+                rbB += d_b;
+                FS_PIN_VGPR(rbB);
+                __builtin_amdgcn_sched_barrier(0);
+                step(0, 0, a1, b1, a0, b0);
+            }
+            return;
+        }
         int cy = wp, cx = 0;                                  // load cursor
         int sa = 0, sb = 0;
         auto cursor = [&]() __attribute__((always_inline)) {  // byte offsets of the cursor's step, then advance it
@@ -313,8 +398,6 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wg2Args a) {
                 if (cy >= TH) cy = wp;   // past the last step: wrap (the prefetch of a step that does not exist re-reads step 0)
             }
         };
-        constexpr int NM = KM * KN, NL = KM + KN;
-        float a0[KM], b0[KN], a1[KM], b1[KN];
         cursor();
 #pragma unroll
         for (int j = 0; j < KN; ++j) b0[j] = *reinterpret_cast<const float*>(lds0 + (bb + sb) + j * 64);
@@ -634,11 +717,11 @@ size_t wgrad2_plan(const WgradArgs* probs, int n, Wg2Args* out) {
     return slab_floats;
 }
 
-template <int KM, int KN, bool XVEC>
+template <int KM, int KN, bool XVEC, int SA = 0, int SD = 0, int SPR = 0, int THc = 0, int PWc = 0, int WPc = 0>
 static void w2_launch(const Wg2Args& a, hipStream_t s) {
     static BigLds lds_attr;
-    lds_attr.ensure(reinterpret_cast<const void*>(wgrad2_kernel<KM, KN, XVEC>));
-    hipLaunchKernelGGL((wgrad2_kernel<KM, KN, XVEC>), dim3((unsigned)a.n_wg), dim3(256), (size_t)a.p.lds_bytes, s, a);
+    lds_attr.ensure(reinterpret_cast<const void*>(wgrad2_kernel<KM, KN, XVEC, SA, SD, SPR, THc, PWc, WPc>));
+    hipLaunchKernelGGL((wgrad2_kernel<KM, KN, XVEC, SA, SD, SPR, THc, PWc, WPc>), dim3((unsigned)a.n_wg), dim3(256), (size_t)a.p.lds_bytes, s, a);
 }
 
 // Launches a planned batch (slab pointers are bound here) and the reduction into dw[i] (scale applied).
@@ -662,16 +745,41 @@ int wgrad2_run(const Wg2Args& planned, float* slabs, float* const* dw, float sca
     if (((size_t)a.p.K * a.Cout) % 4) return -1;
     Profiler* prof = Profiler::current();
     if (prof) prof->begin(PF_WGRAD2, flops, s);
-    if (a.Cin == 3)
-        w2_launch<18, 1, false>(a, s);
-    else if (a.p.KN == 8)
+    // instances with static tile geometry (immediate-offset operand reads) for the tiles the planner picks on the transform
+    // net's 9x9 layers (256x256 at batch 32 / batch 4 per GPU) and residual batch; anything else -- and everything under
+    // FS_WGRAD2_STATIC=0 -- takes the any-geometry instance of its (KM, KN)
+    const Wg2Plan& p = a.p;
+    const int wvp = 4 / p.waves_k;
+    auto geo = [&](int sa, int sd, int spr, int th, int pw, int wp) {
+        return tune_int("FS_WGRAD2_STATIC", 1) != 0 && a.stride * p.S == sa && p.DP == sd && p.TW == 4 * spr && p.TH == th && p.PW == pw && wvp == wp;
+    };
+    if (tune_int("FS_CONV_DEBUG", 0))
+        fprintf(stderr, "wgrad2: KM %d KN %d Cin %d Cout %d K %d stride %d S %d DP %d tile %dx%d PW %d waves_p %d wgs %d nprob %d\n", p.KM, p.KN, a.Cin,
+                a.Cout, p.K, a.stride, p.S, p.DP, p.TH, p.TW, p.PW, wvp, a.n_wg, a.nprob);
+    if (a.Cin == 3) {
+        if (geo(3, 16, 8, 16, 40, 4))
+            w2_launch<18, 1, false, 3, 16, 8, 16, 40, 4>(a, s);
+        else if (geo(3, 16, 4, 16, 24, 4))
+            w2_launch<18, 1, false, 3, 16, 4, 16, 24, 4>(a, s);
+        else
+            w2_launch<18, 1, false>(a, s);
+    } else if (p.KN == 8) {
         w2_launch<4, 8, true>(a, s);
-    else if (a.p.KN == 4)
-        w2_launch<9, 4, true>(a, s);
-    else if (a.p.KN == 2)
+    } else if (p.KN == 4) {
+        if (geo(80, 80, 2, 8, 10, 1))
+            w2_launch<9, 4, true, 80, 80, 2, 8, 10, 1>(a, s);
+        else
+            w2_launch<9, 4, true>(a, s);
+    } else if (p.KN == 2) {
         w2_launch<9, 2, true>(a, s);
-    else
-        w2_launch<18, 1, true>(a, s);
+    } else {
+        if (geo(16, 16, 6, 16, 29, 4))
+            w2_launch<18, 1, true, 16, 16, 6, 16, 29, 4>(a, s);
+        else if (geo(16, 16, 4, 16, 21, 4))
+            w2_launch<18, 1, true, 16, 16, 4, 16, 21, 4>(a, s);
+        else
+            w2_launch<18, 1, true>(a, s);
+    }
     if (prof) prof->end(s);
     hipLaunchKernelGGL(reduce_slabs_batch_kernel, dim3((unsigned)((max4 + 7) / 8), (unsigned)a.nprob), dim3(256), 0, s, r);
     return hipGetLastError() == hipSuccess ? 0 : -3;

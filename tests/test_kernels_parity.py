@@ -181,7 +181,9 @@ def test_dgrad_through_forward_kernel(eng, stride, h, w_):
     assert rel(dx, want) < TOL
 
 
-WGRAD_CASES = [("res", (2, 12, 14, 64), 64, 3, 1, "VALID", 0), ("s2", (2, 13, 11, 16), 32, 3, 2, "SAME", 0),
+# ("res_8x8_tile": 16 x 16 outputs make the planner pick the 8 x 8-pixel tile of the training shapes -> the residual instance
+# of wgrad2_kernel with static tile geometry, immediate-offset operand reads)
+WGRAD_CASES = [("res", (2, 12, 14, 64), 64, 3, 1, "VALID", 0), ("res_8x8_tile", (1, 18, 18, 64), 64, 3, 1, "VALID", 0), ("s2", (2, 13, 11, 16), 32, 3, 2, "SAME", 0),
                ("first_reflect", (1, 45, 43, 3), 16, 9, 1, "SAME", 1), ("final", (1, 14, 18, 16), 3, 9, 1, "SAME", 0)]
 
 

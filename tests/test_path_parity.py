@@ -211,6 +211,18 @@ def test_tnet_narrow_layers_through_the_streaming_kernel(eng, shape, knob):
     assert grads_close(eng, g, want, 2e-4) == []
 
 
+@pytest.mark.parametrize("wgs,shape", [(2, (1, 48, 56)), (12, (1, 48, 48))])
+def test_tnet_backward_filter_gradients_on_the_batch4_tiles(eng, knob, wgs, shape):
+    """The filter gradients of the two 9x9 layers run wgrad2_kernel instances with STATIC tile geometry (operand reads by
+    immediate offsets): 16 x 32 / 16 x 24-pixel tiles at batch 32 -- which the small shapes above happen to pick too -- and
+    16 x 16 tiles at batch 4 per GPU.  The workgroup budget steers the planner to the 16 x 16 tiles at these sizes: 2 for the
+    output layer (patch 21 wide), 12 for the image layer (patch 24 wide)."""
+    knob("FS_WGRAD2_WGS", wgs)
+    y, yo, g, want = run_fwd_bwd(eng, kink_free_params(), shape, seed=3)
+    assert np.abs(y - yo).max() / 255.0 < 2e-5
+    assert grads_close(eng, g, want, 2e-4) == []
+
+
 @pytest.mark.parametrize("shape", [(2, 48, 56), (1, 45, 67)])
 def test_tnet_deconv_method_forward_and_backward(eng, shape):
     """--upsample_method deconv (im_transf_net.py:57-63): conv2d_transpose 3x3 s2 x2 and 9x9 s1 with
