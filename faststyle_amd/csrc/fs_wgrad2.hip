@@ -756,30 +756,34 @@ int wgrad2_run(const Wg2Args& planned, float* slabs, float* const* dw, float sca
     if (tune_int("FS_CONV_DEBUG", 0))
         fprintf(stderr, "wgrad2: KM %d KN %d Cin %d Cout %d K %d stride %d S %d DP %d tile %dx%d PW %d waves_p %d wgs %d nprob %d\n", p.KM, p.KN, a.Cin,
                 a.Cout, p.K, a.stride, p.S, p.DP, p.TH, p.TW, p.PW, wvp, a.n_wg, a.nprob);
+    // (geometry: stride * S, DP, tile width / 4, tile rows, patch width, waves over the pixel rows)
+#define FS_W2_GEO(KM, KN, XV, SA, SD, SPR, TH, PW, WP) \
+    if (geo(SA, SD, SPR, TH, PW, WP)) {                                                        \
+        if (tune_int("FS_CONV_DEBUG", 0)) fprintf(stderr, "wgrad2: static instance %d %d | %d %d %d %d %d %d\n", KM, KN, SA, SD, SPR, TH, PW, WP); \
+        w2_launch<KM, KN, XV, SA, SD, SPR, TH, PW, WP>(a, s);                                  \
+    } else
     if (a.Cin == 3) {
-        if (geo(3, 16, 8, 16, 40, 4))
-            w2_launch<18, 1, false, 3, 16, 8, 16, 40, 4>(a, s);
-        else if (geo(3, 16, 4, 16, 24, 4))
-            w2_launch<18, 1, false, 3, 16, 4, 16, 24, 4>(a, s);
-        else
-            w2_launch<18, 1, false>(a, s);
+        FS_W2_GEO(18, 1, false, 3, 16, 6, 16, 32, 4)      // image layer 9x9, 256 + 80 = 336-pixel maps: 16 x 24 tiles
+        FS_W2_GEO(18, 1, false, 3, 16, 4, 16, 24, 4)      // ... 16 x 16 tiles (maps that are multiples of 16 only)
+        w2_launch<18, 1, false>(a, s);
     } else if (p.KN == 8) {
+        FS_W2_GEO(4, 8, true, 80, 144, 2, 8, 9, 1)        // first resize-conv (2x2 phase-collapsed, 64 -> 4 x 32)
         w2_launch<4, 8, true>(a, s);
     } else if (p.KN == 4) {
-        if (geo(80, 80, 2, 8, 10, 1))
-            w2_launch<9, 4, true, 80, 80, 2, 8, 10, 1>(a, s);
-        else
-            w2_launch<9, 4, true>(a, s);
+        FS_W2_GEO(9, 4, true, 80, 80, 2, 8, 10, 1)        // the ten residual 3x3 filters (one launch)
+        FS_W2_GEO(9, 4, true, 80, 80, 2, 6, 17, 2)        // second stride-2 conv (32 -> 64)
+        FS_W2_GEO(9, 4, true, 48, 80, 2, 16, 9, 4)        // second resize-conv (32 -> 4 x 16), batch 32
+        FS_W2_GEO(9, 4, true, 48, 80, 2, 8, 9, 4)         // ... batch 4 per GPU
+        w2_launch<9, 4, true>(a, s);
     } else if (p.KN == 2) {
+        FS_W2_GEO(9, 2, true, 48, 48, 2, 12, 17, 4)       // first stride-2 conv (16 -> 32)
         w2_launch<9, 2, true>(a, s);
     } else {
-        if (geo(16, 16, 6, 16, 29, 4))
-            w2_launch<18, 1, true, 16, 16, 6, 16, 29, 4>(a, s);
-        else if (geo(16, 16, 4, 16, 21, 4))
-            w2_launch<18, 1, true, 16, 16, 4, 16, 21, 4>(a, s);
-        else
-            w2_launch<18, 1, true>(a, s);
+        FS_W2_GEO(18, 1, true, 16, 16, 6, 16, 29, 4)      // kw-folded output layer (9x2 taps, 16 -> 15), batch 32: 16 x 24 tiles
+        FS_W2_GEO(18, 1, true, 16, 16, 4, 16, 21, 4)      // ... batch 4 per GPU: 16 x 16 tiles
+        w2_launch<18, 1, true>(a, s);
     }
+#undef FS_W2_GEO
     if (prof) prof->end(s);
     hipLaunchKernelGGL(reduce_slabs_batch_kernel, dim3((unsigned)((max4 + 7) / 8), (unsigned)a.nprob), dim3(256), 0, s, r);
     return hipGetLastError() == hipSuccess ? 0 : -3;

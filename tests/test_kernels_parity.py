@@ -19,6 +19,20 @@ def eng(request):
     return get_engine(request.param)
 
 
+@pytest.fixture
+def knob(monkeypatch, eng):
+    """Set an FS_* tuning knob for one test (the library caches the environment: it is told to re-read it now and again
+    once monkeypatch has restored the environment)."""
+    def set_knob(name, value):
+        monkeypatch.setenv(name, str(value))
+        eng.lib.fs_debug_reload_env()
+        eng.reset_workspaces()
+    yield set_knob
+    monkeypatch.undo()
+    eng.lib.fs_debug_reload_env()
+    eng.reset_workspaces()
+
+
 def up(e, a):
     return e.mem.from_numpy(a)
 
@@ -183,13 +197,20 @@ def test_dgrad_through_forward_kernel(eng, stride, h, w_):
 
 # ("res_8x8_tile": 16 x 16 outputs make the planner pick the 8 x 8-pixel tile of the training shapes -> the residual instance
 # of wgrad2_kernel with static tile geometry, immediate-offset operand reads)
-WGRAD_CASES = [("res", (2, 12, 14, 64), 64, 3, 1, "VALID", 0), ("res_8x8_tile", (1, 18, 18, 64), 64, 3, 1, "VALID", 0), ("s2", (2, 13, 11, 16), 32, 3, 2, "SAME", 0),
-               ("first_reflect", (1, 45, 43, 3), 16, 9, 1, "SAME", 1), ("final", (1, 14, 18, 16), 3, 9, 1, "SAME", 0)]
+WGRAD_CASES = [("res", (2, 12, 14, 64), 64, 3, 1, "VALID", 0, 0), ("res_8x8_tile", (1, 18, 18, 64), 64, 3, 1, "VALID", 0, 0),
+               ("s2", (2, 13, 11, 16), 32, 3, 2, "SAME", 0, 0), ("first_reflect", (1, 45, 43, 3), 16, 9, 1, "SAME", 1, 0),
+               ("final", (1, 14, 18, 16), 3, 9, 1, "SAME", 0, 0),
+               # static-geometry instances of the other transform-net layers (last field: FS_WGRAD2_WGS, which steers the
+               # planner to the tile the training shapes get): first stride-2 conv 12 x 8, resize-convs 8 x 8 and 16 x 8
+               ("s2_12x8_tile", (1, 72, 32, 16), 32, 3, 2, "SAME", 0, 1), ("up0_8x8_tile", (1, 17, 17, 64), 128, 2, 1, "VALID", 0, 0),
+               ("up1_16x8_tile", (1, 33, 17, 32), 64, 2, 1, "VALID", 0, 1)]
 
 
 @pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
-def test_wgrad_matches_oracle(eng, case):
-    _, xs, co, k, stride, padding, reflect = case
+def test_wgrad_matches_oracle(eng, case, knob):
+    _, xs, co, k, stride, padding, reflect, wgs = case
+    if wgs:
+        knob("FS_WGRAD2_WGS", wgs)
     rng = np.random.default_rng(6)
     x = rng.standard_normal(xs).astype(np.float32)
     xv = nnops.reflect_pad(x, 40) if reflect else x
