@@ -201,7 +201,7 @@ WGRAD_CASES = [("res", (2, 12, 14, 64), 64, 3, 1, "VALID", 0, 0), ("res_8x8_tile
                ("s2", (2, 13, 11, 16), 32, 3, 2, "SAME", 0, 0), ("first_reflect", (1, 45, 43, 3), 16, 9, 1, "SAME", 1, 0),
                ("final", (1, 14, 18, 16), 3, 9, 1, "SAME", 0, 0),
                # static-geometry instances of the other transform-net layers (last field: FS_WGRAD2_WGS, which steers the
-               # planner to the tile the training shapes get): first stride-2 conv 12 x 8, resize-convs 8 x 8 and 16 x 8
+               # planner to the tile the training shapes get): first stride-2 conv 12 x 8, second resize-conv 16 x 8; the first resize-conv keeps the any-geometry instance
                ("s2_12x8_tile", (1, 72, 32, 16), 32, 3, 2, "SAME", 0, 1), ("up0_8x8_tile", (1, 17, 17, 64), 128, 2, 1, "VALID", 0, 0),
                ("up1_16x8_tile", (1, 33, 17, 32), 64, 2, 1, "VALID", 0, 1)]
 
