@@ -807,7 +807,7 @@ const char* prof_family_name(int f) {
         "conv_igemm_kernel<32,1,1>", "wino_conv_kernel", "wino2_conv_kernel (VGG16 convs)", "wino2_conv_kernel (transform-net residual convs)",
         "conv_stream_kernel", "conv3x3_to3_kernel", "wgrad2_kernel", "conv_wgrad_kernel", "gram_stream_kernel",
         "conv_wgrad_kernel (Gram forward)", "gram_bwd_kernel", "conv_igemm_kernel (Gram backward, 1x1 per-sample filters)",
-        "wino2h_conv_kernel (transform-net residual convs, half items)", "", "", ""};
+        "wino2h_conv_kernel (transform-net residual convs, half items)", "conv_s16_kernel", "", ""};
     return f >= 0 && f < Profiler::kFamilies ? names[f] : "";
 }
 
@@ -956,6 +956,10 @@ ConvPlan conv_plan(const ConvArgs& a) {
         cstream_plan(a, &p);
         return p;
     }
+    if (s16_eligible(a)) {   // 16 output channels (9x9 image layer, input gradient of the output layer, kw-folded output layer): fs_s16.hip
+        s16_plan(a, &p);
+        return p;
+    }
     if (a.Cout <= 16 || a.Cin == 3) {  // narrow outputs, and the flat Cin==3 path, have one variant each
         plan_variant(a, a.Cout <= 16 ? 2 : 0, &p);
         return p;
@@ -1101,6 +1105,7 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
         int fam = p.variant;   // conv_igemm_kernel<..> instances 0..4, wino_conv_kernel 5
         if (a.w_nstride) fam = PF_GRAM_BWD_IGEMM;
         else if (p.variant == 7) fam = PF_CSTREAM;
+        else if (p.variant == 9) fam = PF_S16;
         else if (p.variant == 8) fam = PF_WINO2H_TNET;
         else if (p.variant == 6) fam = a.prof_tag ? PF_WINO2_TNET : PF_WINO2_VGG;
         prof->begin(fam, fl, s);
@@ -1117,6 +1122,9 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
     } else if (p.variant == 7) {
         if (!cstream_eligible(a_in)) return -7;
         FS_TRY_(cstream_launch(a, s));
+    } else if (p.variant == 9) {
+        if (!s16_eligible(a_in)) return -7;
+        FS_TRY_(s16_launch(a, s));
     } else if (p.variant == 6) {
         if (!wino2_eligible(a_in)) return -7;
         FS_TRY_(wino2_launch(a, s));

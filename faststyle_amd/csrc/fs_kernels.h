@@ -22,7 +22,7 @@ enum SrcMode {
 
 struct ConvPlan {
     int variant;  // conv_igemm_kernel<MT,WM,WN>: 0 <32,2,2>  1 <32,2,1>  2 <16,4,1>  3 <32,1,2>  4 <32,1,1>;  5 wino_conv_kernel;  6 wino2_conv_kernel;
-                  // 7 conv_stream_kernel;  8 wino2h_conv_kernel
+                  // 7 conv_stream_kernel;  8 wino2h_conv_kernel;  9 conv_s16_kernel
     int BN;       // output channels per workgroup
     int flat;     // Cin==3: K runs over (kw,ci) contiguously per kernel row
     int CC;       // input channels staged per chunk
@@ -438,6 +438,9 @@ int gram_symmetrize(const float* dG, float* S, int N, int C, float scale, hipStr
 bool cstream_eligible(const ConvArgs& a);
 void cstream_plan(const ConvArgs& a, ConvPlan* out);
 int cstream_launch(const ConvArgs& a, hipStream_t s);
+bool s16_eligible(const ConvArgs& a);                                                          // fs_s16.hip: plan variant 9 (16 output channels: 9x9 image layer, kw-folded output layer)
+void s16_plan(const ConvArgs& a, ConvPlan* out);
+int s16_launch(const ConvArgs& a, hipStream_t s);
 bool conv3x3_to3_eligible(const ConvArgs& a);                                                 // fs_c3.hip
 int conv3x3_to3_launch(const ConvArgs& a, hipStream_t s);
 bool wino_eligible(const ConvArgs& a);
@@ -524,7 +527,7 @@ namespace fs {
 enum ProfFam {
     PF_IGEMM_32_2_2 = 0, PF_IGEMM_32_2_1 = 1, PF_IGEMM_16_4_1 = 2, PF_IGEMM_32_1_2 = 3, PF_IGEMM_32_1_1 = 4,
     PF_WINO = 5, PF_WINO2_VGG = 6, PF_WINO2_TNET = 7, PF_CSTREAM = 8, PF_C3 = 9, PF_WGRAD2 = 10, PF_WGRAD = 11,
-    PF_GRAM_STREAM = 12, PF_GRAM_WGRAD = 13, PF_GRAM_BWD = 14, PF_GRAM_BWD_IGEMM = 15, PF_WINO2H_TNET = 16, PF_RESERVED17 = 17,
+    PF_GRAM_STREAM = 12, PF_GRAM_WGRAD = 13, PF_GRAM_BWD = 14, PF_GRAM_BWD_IGEMM = 15, PF_WINO2H_TNET = 16, PF_S16 = 17,
     PF_RESERVED18 = 18, PF_RESERVED19 = 19
 };
 const char* prof_family_name(int f);

@@ -1,0 +1,386 @@
+// Streaming convolution with SIXTEEN output channels: the layers next to the image (reference im_transf_net.py:37, 69-70) --
+//   * the 9x9 image layer 3 -> 16 (REFLECT-40 fused) and the input gradient of the 9x9 output layer (3 -> 16, zero padding);
+//   * the kw-folded output layer 16 -> 16 "virtual" channels (9x2 taps, horizontal spacing 5; fs_fold.hip).
+//
+// Round 1-2 ran them through conv_igemm_kernel<16,4,1>: one tile per workgroup (load, wait, multiply, store), the whole filter
+// re-staged through LDS for every tile, and an inner loop in which the backend shuffles the accumulators through
+// v_accvgpr_read / mov / write every iteration (two register sets behind a conditional prefetch).  This is the streaming
+// recipe of fs_cstream.hip for v_mfma_f32_16x16x4_f32 (16 pixels x 16 channels x 4 k):
+//   * persistent workgroups (two per CU: ~150 registers per lane) walk a strided list of 16x16-pixel tiles; ONE patch stage:
+//     the loads of tile t+1 travel in registers during the sweep of tile t;
+//   * the whole filter lives in REGISTERS as B fragments (63 / 72 registers), no filter traffic through LDS;
+//   * the sweep is one straight line of 252 / 288 matrix instructions per wave; every A operand is ONE lane-constant base
+//     register + an immediate offset, read one step ahead and pinned into the slot of the previous step's matrix instruction
+//     (tools/mfma16_slots.hip: beside a 32-cycle 16x16x4 instruction an immediate-offset ds_read_b32 is free, every vector-ALU
+//     instruction costs 13+ cycles);
+//   * K runs over (kw, ci) contiguously per kernel row for the 3-channel inputs (27 -> 28: 7 k-steps per row, the 28th
+//     multiplies a zero of the filter), over the 16 channels of a tap for the folded layer (LDS pixel pitch 17: the 16 pixels
+//     of an A fragment fall into distinct banks);
+//   * epilogue options these layers use: per-tile instance-norm records {mean, M2, count}, plain stores.
+#include "fs_kernels.h"
+
+#include <type_traits>
+
+namespace fs {
+
+namespace {
+constexpr unsigned kOOB = 0x80000000u;
+constexpr int kT = 16;   // tile side
+}  // namespace
+
+template <int CIN, int KH, int KW, int DILX>
+__global__ __launch_bounds__(256, 2) void conv_s16_kernel(ConvArgs a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const ConvPlan& p = a.p;
+    constexpr bool C3 = CIN == 3;
+    constexpr int S = C3 ? 3 : CIN + 1;                                   // LDS floats per patch pixel
+    constexpr int PH = kT - 1 + KH, PW = kT - 1 + (KW - 1) * DILX + 1, NPX = PH * PW;
+    constexpr int SPR = C3 ? (KW * 3 + 3) / 4 : CIN / 4;                  // k-steps per kernel row (C3) / per tap
+    constexpr int KSTEPS = (C3 ? KH : KH * KW) * SPR;
+    constexpr int C4 = C3 ? 1 : CIN / 4;                                  // staged elements per pixel (a pixel's 3 floats / float4s)
+    constexpr int NE = NPX * C4, SX = (NE + 255) / 256;
+    constexpr int PATCH_F = (NPX * S + 8 + 3) & ~3;                       // + slack: the sink of unowned elements, the k = 27 overrun
+    constexpr int REDF = 4 * 3 * 16;                                      // one statistics buffer: [wave][s1, s2, shift][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m16 = lane & 15, k4 = lane >> 4;
+    float* const red = smem + PATCH_F;   // [2][REDF]
+    auto fdiv = [](int x, float inv_d) __attribute__((always_inline)) { return (int)(((float)x + 0.5f) * inv_d); };   // exact for x < 2^22
+    auto uniform_ptr = [](const float* ptr) __attribute__((always_inline)) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    };
+
+    // ---- the filter, once, into registers: lane (channel m16, k4) holds row 4 j + k4 of k-step j
+    float breg[KSTEPS];
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) {
+        if (C3) {
+            const int kh = j / SPR, k = 4 * (j % SPR) + k4;   // k = kw * 3 + ci
+            breg[j] = k < KW * 3 ? a.w[(kh * KW * 3 + k) * 16 + m16] : 0.f;
+        } else {
+            const int tap = j / SPR, ci = 4 * (j % SPR) + k4;
+            breg[j] = a.w[(tap * CIN + ci) * 16 + m16];
+        }
+    }
+    // ---- A operands: block m of this wave is tile row 4 wave + m, lane (m16, k4) feeds pixel column m16, row k4 of the k-step
+    const int laneA = ((4 * wave) * PW + m16) * S + k4;
+    auto aoff = [](int j, int m) __attribute__((always_inline)) {   // compile-time float offset of k-step j, block m
+        if (C3) return ((j / SPR) * PW + m * PW) * S + 4 * (j % SPR);
+        const int tap = j / SPR;
+        return ((tap / KW + m) * PW + (tap % KW) * DILX) * S + 4 * (j % SPR);
+    };
+
+    // ---- staging descriptors (tile-invariant): element e = tid + i*256 is float4 c4 of patch pixel e / C4 (C3: the pixel's 3 floats)
+    const int c4 = C3 ? 0 : (tid & (C4 - 1));
+    int pq[SX], pdst[SX];
+    unsigned poffb[SX];
+#pragma unroll
+    for (int i = 0; i < SX; ++i) {
+        const int e = tid + i * 256;
+        pq[i] = -1;
+        pdst[i] = NPX * S;   // slack
+        poffb[i] = kOOB;
+        if (e < NE) {
+            const int pix = C3 ? e : e / C4;
+            const int py = fdiv(pix, 1.0f / (float)PW), px = pix - py * PW;
+            pq[i] = (py << 8) | px;
+            pdst[i] = pix * S + c4 * 4;
+            poffb[i] = (unsigned)((py * a.W + px) * CIN + c4 * 4) * 4u;
+        }
+    }
+    const unsigned x_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * CIN) * 4u);
+    const bool has_ab = !C3 && a.in_a != nullptr;
+    const bool in_relu = !C3 && a.in_relu != 0;
+    const int refl = a.src_mode == SRC_REFLECT ? a.refl : 0;
+
+    // ---- items: tile lin = blockIdx.x + it * gridDim.x over (sample, tile row, tile column)
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int total = a.N * tiles;
+    const int GX = (int)gridDim.x;
+    const int my_items = ((int)blockIdx.x < total) ? (total - 1 - (int)blockIdx.x) / GX + 1 : 0;
+    const float inv_tiles = 1.0f / (float)tiles, inv_tx = 1.0f / (float)p.tiles_x;
+    struct Item {
+        int n, ty0, tx0, lin;
+    };
+    auto decode = [&](int it) __attribute__((always_inline)) {
+        Item r;
+        r.lin = (int)blockIdx.x + it * GX;
+        r.n = fdiv(r.lin, inv_tiles);
+        const int tr = r.lin - r.n * tiles;
+        const int tyi = fdiv(tr, inv_tx);
+        r.ty0 = tyi * kT;
+        r.tx0 = (tr - tyi * p.tiles_x) * kT;
+        r.lin = __builtin_amdgcn_readfirstlane(r.lin);
+        r.n = __builtin_amdgcn_readfirstlane(r.n);
+        r.ty0 = __builtin_amdgcn_readfirstlane(r.ty0);
+        r.tx0 = __builtin_amdgcn_readfirstlane(r.tx0);
+        return r;
+    };
+    float pv[SX][4];
+    unsigned pok = 0;   // bit i: element i came from inside the image; bit 31: the whole patch did (interior tile)
+    float4 va = make_float4(1.f, 1.f, 1.f, 1.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto issue = [&](const Item& I) __attribute__((always_inline)) {
+        // (vy0, vx0): the patch's first pixel in the coordinates of the (mirror-padded) source
+        const int vy0 = I.ty0 - a.pad_t, vx0 = I.tx0 - a.pad_l;
+        const float* xn = uniform_ptr(a.x + (size_t)I.n * a.H * a.W * CIN);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, x_bytes, 0x00020000);
+        const int iy0 = vy0 - refl, ix0 = vx0 - refl;   // ... in the coordinates of the stored image
+        if (iy0 >= 0 && ix0 >= 0 && iy0 + PH <= a.H && ix0 + PW <= a.W) {
+            // interior tile (the vast majority): tile-invariant per-thread offsets, the origin rides in the scalar offset operand
+            pok = 0xFFFFFFFFu;
+            const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)((iy0 * a.W + ix0) * CIN) * 4u);
+#pragma unroll
+            for (int i = 0; i < SX; ++i) {
+                if (C3) {
+                    const auto t = __builtin_amdgcn_raw_buffer_load_b96(xr, poffb[i], base, 0);
+                    __builtin_memcpy(pv[i], &t, 12);
+                } else {
+                    const auto t = __builtin_amdgcn_raw_buffer_load_b128(xr, poffb[i], base, 0);
+                    __builtin_memcpy(pv[i], &t, 16);
+                }
+            }
+        } else {
+            pok = 0;
+#pragma unroll
+            for (int i = 0; i < SX; ++i) {
+                const int vy = vy0 + (pq[i] >> 8), vx = vx0 + (pq[i] & 255);
+                // zero padding outside the (mirror-padded) source; inside it, mirror padding by `refl` pixels (tf.pad REFLECT)
+                const bool ok = pq[i] >= 0 && (unsigned)vy < (unsigned)(a.H + 2 * refl) && (unsigned)vx < (unsigned)(a.W + 2 * refl);
+                int sy = vy - refl, sx = vx - refl;
+                sy = sy < 0 ? -sy : sy;
+                sx = sx < 0 ? -sx : sx;
+                sy = sy >= a.H ? 2 * (a.H - 1) - sy : sy;
+                sx = sx >= a.W ? 2 * (a.W - 1) - sx : sx;
+                pok |= ok ? (1u << i) : 0u;
+                const unsigned vo = ok ? (unsigned)((sy * a.W + sx) * CIN + c4 * 4) * 4u : kOOB;
+                if (C3) {
+                    const auto t = __builtin_amdgcn_raw_buffer_load_b96(xr, vo, 0, 0);
+                    __builtin_memcpy(pv[i], &t, 12);
+                } else {
+                    const auto t = __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0, 0);
+                    __builtin_memcpy(pv[i], &t, 16);
+                }
+            }
+        }
+        if (has_ab) {
+            va = *reinterpret_cast<const float4*>(a.in_a + (size_t)I.n * a.in_nstride + c4 * 4);
+            vb = *reinterpret_cast<const float4*>(a.in_b + (size_t)I.n * a.in_nstride + c4 * 4);
+        }
+    };
+    auto relu1 = [](float x) __attribute__((always_inline)) {   // ONE v_max_f32
+#if defined(__HIP_DEVICE_COMPILE__)
+        float r;
+        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+        return r;
+#else
+        return x > 0.f ? x : 0.f;
+#endif
+    };
+    auto commit_as = [&](auto MASKED) __attribute__((always_inline)) {
+        constexpr bool masked = decltype(MASKED)::value;
+#pragma unroll
+        for (int i = 0; i < SX; ++i) {
+            float* d = smem + pdst[i];
+            if (C3) {
+                d[0] = pv[i][0];
+                d[1] = pv[i][1];
+                d[2] = pv[i][2];
+            } else {
+                float v[4] = {pv[i][0], pv[i][1], pv[i][2], pv[i][3]};
+                if (has_ab) {   // producer instance norm folded into the load; padding arrives as 0 and must stay 0
+                    const unsigned okm = (!masked || ((pok >> i) & 1u)) ? 0xFFFFFFFFu : 0u;
+                    v[0] = fmaf(v[0], va.x, __uint_as_float(__float_as_uint(vb.x) & okm));
+                    v[1] = fmaf(v[1], va.y, __uint_as_float(__float_as_uint(vb.y) & okm));
+                    v[2] = fmaf(v[2], va.z, __uint_as_float(__float_as_uint(vb.z) & okm));
+                    v[3] = fmaf(v[3], va.w, __uint_as_float(__float_as_uint(vb.w) & okm));
+                }
+                if (in_relu) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = relu1(v[c]);
+                }
+                d[0] = v[0];
+                d[1] = v[1];
+                d[2] = v[2];
+                d[3] = v[3];
+            }
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+        if (pok >> 31)   // (wave-uniform) interior tile: no masking
+            commit_as(std::false_type{});
+        else
+            commit_as(std::true_type{});
+    };
+
+    f32x4 acc[4];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+    // one straight line: matrix instruction (j, m) with the read of (j + 1, m) in its slot
+    auto sweep = [&]() __attribute__((always_inline)) {
+        float av[2][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) av[0][m] = smem[laneA + aoff(0, m)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < KSTEPS; ++j) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (j + 1 < KSTEPS) av[(j + 1) & 1][m] = smem[laneA + aoff(j + 1, m)];
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j & 1][m], breg[j], acc[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // ---- epilogue of one item: accumulator register r of block m, lane (m16, k4) = pixel (row 4 wave + m, column 4 k4 + r), channel m16
+    const unsigned y_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.Ho * a.Wo * 16) * 4u);
+    auto epilogue = [&](const Item& I, float* rbuf) __attribute__((always_inline)) {
+        const int th_valid = min(kT, a.Ho - I.ty0), tw_valid = min(kT, a.Wo - I.tx0);
+        if (a.stats) {
+            // per-WAVE partial sums of (x - c), (x - c)^2 over the wave's four tile rows, c = the wave's own first pixel of the
+            // channel; the four records of a tile are merged when the next pipeline step starts (finalize below): no barrier here
+            const float cs = __shfl(acc[0][0], m16);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = 4 * wave + m < th_valid && 4 * k4 + r < tw_valid;
+                    const float d = ok ? acc[m][r] - cs : 0.f;
+                    s1 += d;
+                    s2 = fmaf(d, d, s2);
+                }
+            s1 += __shfl_xor(s1, 16);
+            s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lane < 16) {
+                rbuf[(wave * 3 + 0) * 16 + lane] = s1;
+                rbuf[(wave * 3 + 1) * 16 + lane] = s2;
+                rbuf[(wave * 3 + 2) * 16 + lane] = cs;
+            }
+        }
+        float* yn = a.y + (size_t)I.n * a.Ho * a.Wo * 16;
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(yn)), 0, y_bytes, 0x00020000);
+        const int lane_off = ((I.tx0 + 4 * k4) * 16 + m16) * 4;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = 4 * wave + m;
+            const int row_off = (I.ty0 + row) * a.Wo * 64;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = row < th_valid && 4 * k4 + r < tw_valid;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][r]), yr, ok ? (unsigned)(lane_off + row_off + r * 64) : kOOB, 0, 0);
+            }
+        }
+        zero_acc();
+    };
+    // merge of the four per-wave records of one tile (Chan's update, fixed order) -> {mean, M2, count} of the tile
+    auto finalize = [&](const Item& I, const float* rbuf) __attribute__((always_inline)) {
+        const int th_valid = min(kT, a.Ho - I.ty0), tw_valid = min(kT, a.Wo - I.tx0);
+        float cnt = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int rows = min(4, max(0, th_valid - 4 * w));
+            const float cb = (float)(rows * tw_valid);
+            if (cb > 0.f) {
+                const float S1 = rbuf[(w * 3 + 0) * 16 + tid], S2 = rbuf[(w * 3 + 1) * 16 + tid], sh = rbuf[(w * 3 + 2) * 16 + tid];
+                const float mb = sh + S1 / cb, qb2 = fmaxf(S2 - S1 * S1 / cb, 0.f);
+                const float nn_ = cnt + cb, d = mb - mean, rr = cb / nn_;
+                mean += d * rr;
+                m2 += qb2 + d * d * cnt * rr;
+                cnt = nn_;
+            }
+        }
+        float* st = a.stats + ((size_t)I.lin * 16 + tid) * 3;
+        st[0] = mean;
+        st[1] = m2;
+        st[2] = cnt;
+    };
+
+    // ---- the pipeline (fs_cstream.hip): ONE patch stage.  While tile t is multiplied the loads of tile t+1 are in flight
+    // (registers); after the sweep (barrier A) they are committed over the patch, the epilogue of tile t follows (its stores
+    // drain during the next sweep), barrier B, next tile.
+    if (my_items == 0) return;
+    if (tid < 8) smem[NPX * S + tid] = 0.f;   // the slack is read by the k = 27 overrun of the last patch pixel (times a zero weight)
+    Item cur = decode(0), prev = cur;
+    issue(cur);
+    commit();
+    __syncthreads();
+    for (int it = 0; it < my_items; ++it) {
+        const bool more = it + 1 < my_items;
+        if (it > 0 && a.stats && tid < 16) finalize(prev, red + ((it - 1) & 1) * REDF);
+        Item nxt = cur;
+        if (more) {
+            nxt = decode(it + 1);
+            issue(nxt);
+        }
+        sweep();
+        FS_LDS_BARRIER();   // A: every wave is done reading the patch
+        if (more) commit();
+        epilogue(cur, red + (it & 1) * REDF);
+        FS_LDS_BARRIER();   // B: next patch and this tile's statistics records (LDS) visible; the stores drain during the next sweep
+        prev = cur;
+        cur = nxt;
+    }
+    if (a.stats && tid < 16) finalize(prev, red + ((my_items - 1) & 1) * REDF);
+}
+
+// ------------------------------------------------------------------------------------------------------------ host
+static int s16_instance(const ConvArgs& a) {
+    if (a.Cout != 16 || a.stride != 1) return 0;
+    if (a.Cin == 3 && a.KH == 9 && a.KW == 9 && a.dil_x <= 1 && (a.src_mode == SRC_PLAIN || a.src_mode == SRC_REFLECT) && !a.in_a && !a.in_relu) return 1;
+    if (a.Cin == 16 && a.KH == 9 && a.KW == 2 && a.dil_x == 5 && a.src_mode == SRC_PLAIN) return 2;
+    return 0;
+}
+
+bool s16_eligible(const ConvArgs& a) {
+    const int inst = s16_instance(a);
+    if (!tune_int("FS_S16", 1) || !inst) return false;
+    if (a.bias || a.out_relu || a.mask_src || a.route_src || a.pool_out || a.w_nstride || a.w_wino || a.w_wino2 || a.shuffle || a.add_src || a.fin.counter)
+        return false;
+    if (a.in_a && !a.in_b) return false;
+    if (a.in_relu && !a.in_a) return false;
+    if (a.pad_t < 0 || a.pad_l < 0) return false;
+    const long tiles = (long)a.N * cdiv(a.Ho, kT) * cdiv(a.Wo, kT);
+    return tiles >= tune_int("FS_S16_MIN_TILES", 64);
+}
+
+void s16_plan(const ConvArgs& a, ConvPlan* out) {
+    ConvPlan p{};
+    const int inst = s16_instance(a);
+    p.variant = 9;
+    p.BN = 16;
+    p.CC = a.Cin;
+    p.flat = a.Cin == 3;   // (K runs over (kw, ci) contiguously per kernel row)
+    p.TH = p.TW = kT;
+    p.tiles_y = cdiv(a.Ho, kT);
+    p.tiles_x = cdiv(a.Wo, kT);
+    p.PH = kT - 1 + a.KH;
+    p.PW = inst == 1 ? kT - 1 + 9 : kT - 1 + 5 + 1;
+    p.S = inst == 1 ? 3 : 17;
+    const int patch_f = (p.PH * p.PW * p.S + 8 + 3) & ~3;
+    p.lds_bytes = 4 * (patch_f + 2 * 4 * 3 * 16);
+    p.ksplit = 1;
+    *out = p;
+}
+
+int s16_launch(const ConvArgs& a, hipStream_t s) {
+    const ConvPlan& p = a.p;
+    const long total = (long)a.N * p.tiles_y * p.tiles_x;
+    const int wgs = tune_int("FS_S16_WGS", 512);
+    const unsigned grid = (unsigned)(total < wgs ? total : wgs);
+    switch (s16_instance(a)) {
+        case 1: hipLaunchKernelGGL((conv_s16_kernel<3, 9, 9, 1>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a); break;
+        case 2: hipLaunchKernelGGL((conv_s16_kernel<16, 9, 2, 5>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a); break;
+        default: return -4;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace fs
