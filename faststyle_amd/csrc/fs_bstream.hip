@@ -83,7 +83,7 @@ extern "C" int fs_debug_conv_trace_reset() {
 #endif
 
 template <int BN, int CIN, int KH, int KW, int STRIDE, int DILX>
-__global__ __launch_bounds__(256) void conv_bstream_kernel(ConvBArgs a) {
+__global__ __launch_bounds__(256, (BN == 32 ? 2 : 1)) void conv_bstream_kernel(ConvBArgs a) {
     HIP_DYNAMIC_SHARED(float, smem_f)
 #ifdef FS_BSTREAM_TRACE
     const long long tr_t0 = FS_BS_NOW();
@@ -550,6 +550,11 @@ struct BsInst {
 // 4: 64 -> 32 resize-conv (2x2 taps, 128 virtual channels: two channel halves per tile)   5: 32 -> 16 resize-conv (2x2, 64 virtual)
 // 6: the kw-folded output layer (9 x 2 taps, spacing 5, 16 virtual channels of a 32-wide block)
 // 7: the image layer (3 -> 16, 9x9, fp32 RGB in, REFLECT-40 fused; 12-tap kernel rows of 4-channel bf16 pixels)
+// The three 32-wide instances (1, 6, 7) fit 256 registers (__launch_bounds__(256, 2)): with the default persistent grid of 512
+// TWO of their workgroups share a CU, and one's commit / epilogue issues beside the other's matrix instructions (bf16 MFMA and
+// vector ALU co-issue across waves, unlike fp32 MFMA): 1080p batch 8 1861 -> 2154 fps.  The 64-wide instances keep the filter of
+// a 32-channel block (144 registers for the residual convs) beside 64 accumulator registers: one workgroup per CU (32-channel
+// blocks for them were tried: 343-358 registers, 91-108 spilled when forced under 256).
 const BsInst kBs[7] = {{32, 16, 3, 3, 2, 1}, {64, 32, 3, 3, 2, 1}, {64, 64, 3, 3, 1, 1}, {64, 64, 2, 2, 1, 1}, {64, 32, 2, 2, 1, 1}, {32, 16, 9, 2, 1, 5},
                        {32, 3, 9, 9, 1, 1}};
 }  // namespace
@@ -607,9 +612,9 @@ int bstream_launch(const ConvBArgs& a_in, hipStream_t s) {
     const ConvBPlan& p = a.p;
     if (p.lds_bytes > 160 * 1024) return -2;
     const long total = (long)a.N * p.tiles_y * p.tiles_x;
-    const int wgs = tune_int("FS_BSTREAM_WGS", 256);
+    const int wgs = p.BN == 32 ? tune_int("FS_BSTREAM_WGS", 512) : tune_int("FS_BSTREAM_WGS64", 256);
     const int ny = p.cout_pad / p.BN;
-    long gx = wgs / ny;   // one persistent workgroup per CU over both grid dimensions
+    long gx = wgs / ny;   // persistent workgroups over both grid dimensions: two per CU where 256 registers allow it, else two rounds of one
     if (gx < 1) gx = 1;
     if (gx > total) gx = total;
     const dim3 grid((unsigned)gx, (unsigned)ny);

@@ -455,6 +455,7 @@ def test_tnet_bf16_forward_against_bf16_restatement_and_fp32_oracle(eng, shape, 
     if grid_cap:      # persistent workgroups: 3 workgroups walk all the tiles of a layer (crossing images): the pipeline of
         knob("FS_BF16_GRID", grid_cap)          # fs_bstream.hip (every layer behind the image layer) and of the image layer's kernel
         knob("FS_BSTREAM_WGS", grid_cap)
+        knob("FS_BSTREAM_WGS64", grid_cap)
     rng = np.random.default_rng(4)
     P = tnet.strip_scope(starry())
     flat = eng.mem.from_numpy(eng.flatten_params(P, scope=""))
