@@ -149,7 +149,6 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
         uvo[i] = (unsigned)((pos * a.Cin + k) * a.Cout + co0 + c4 * 4) * 4u;
     }
     float4 pv[2], uv[4];
-    const int cbeg_k = __builtin_amdgcn_readfirstlane(p.ksplit > 1 ? (int)blockIdx.z * (a.Cin / kCC) / p.ksplit : 0);   // first chunk of this workgroup
     // producer instance norm + ReLU folded into the load (transform-net convs; VALID padding only, so every patch pixel
     // that reaches a stored output is a real pixel and padding needs no masking).  Both elements of a thread belong
     // to the same channel quad (tid & 1), so one float4 of scales and of shifts per chunk.
@@ -157,31 +156,20 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
     const float* ian = has_ab ? uniform_ptr(a.in_a + (size_t)n * a.in_nstride) : nullptr;
     const float* ibn = has_ab ? uniform_ptr(a.in_b + (size_t)n * a.in_nstride) : nullptr;
     float4 va = make_float4(1.f, 1.f, 1.f, 1.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
-    const unsigned ab_bytes = __builtin_amdgcn_readfirstlane(has_ab ? (unsigned)a.Cin * 4u : 0u);
-    const __amdgpu_buffer_rsrc_t ar_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_ab ? ian : xn), 0, ab_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t br_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_ab ? ibn : xn), 0, ab_bytes, 0x00020000);
-    // (`live` = the chunk exists.  The loads are issued UNCONDITIONALLY -- a chunk that does not exist reads through the
-    // out-of-range offset, answered with zeros without a memory access -- so that the compiler can count the loads in flight:
-    // behind an `if` it has to assume none were issued and waits vmcnt(0) for the next older load it needs)
-    auto issue_patch = [&](int chunk, bool live = true) {
+    auto issue_patch = [&](int chunk) {
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(xn)), 0, x_bytes, 0x00020000);
-        const int cl = live ? chunk : cbeg_k;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, live ? gvo[i] : kOOB, cl * kCC * 4, 0));
-        // (through buffer resources, not pointers: a pointer that went through uniform_ptr has lost its address space and
-        // becomes a FLAT load, which may complete out of order with the buffer loads -- the compiler then waits vmcnt(0)
-        // wherever any older load is needed; without a producer affine the resources have size 0 and return zeros)
-        if (has_ab) {   // (kernel-uniform; the VGG launches skip the two loads)
-            const unsigned abo = (unsigned)(cl * kCC + (tid & 1) * 4) * 4u;
-            va = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ar_k, abo, 0, 0));
-            vb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(br_k, abo, 0, 0));
+        for (int i = 0; i < 2; ++i) pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, gvo[i], chunk * kCC * 4, 0));
+        if (has_ab) {
+            va = *reinterpret_cast<const float4*>(ian + chunk * kCC + (tid & 1) * 4);
+            vb = *reinterpret_cast<const float4*>(ibn + chunk * kCC + (tid & 1) * 4);
         }
     };
-    auto issue_filter = [&](int chunk, bool live = true) {
+    auto issue_filter = [&](int chunk) {
         const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(ub)), 0, u_bytes, 0x00020000);
-        const int uso = (live ? chunk : cbeg_k) * kCC * a.Cout * 4;
+        const int uso = chunk * kCC * a.Cout * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) uv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, live ? uvo[i] : kOOB, uso, 0));
+        for (int i = 0; i < 4; ++i) uv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, uvo[i], uso, 0));
     };
     auto commit_patch = [&](float* patch) {
 #pragma unroll
@@ -345,7 +333,6 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
     transform(patch0, Vl0);
     if (nloc > 1) commit_patch(patch0 + kPatchFloats);
     __syncthreads();
-    FS_WAIT_VMEM();   // (fs_kernels.h: no prologue load may still be pending at the loop header, or every iteration waits vmcnt(0))
 #ifdef FS_CONV_TRACE
     const long long tr_pro = FS_WINO_NOW();
 #endif
@@ -359,22 +346,21 @@ __global__ __launch_bounds__(512) void wino_conv_kernel(ConvArgs a) {
 #ifdef FS_CONV_TRACE
         const long long q0 = FS_WINO_NOW();
 #endif
-        issue_patch(cbeg + j + 2, has2);
+        if (has2) issue_patch(cbeg + j + 2);
         // (also on the last chunk, where the prepared stage is never read: a second, transform-free instantiation
         // makes the register allocator copy the 128 accumulators at the join and spill)
         sweep_fused(std::true_type{}, Vc, Uc, patch0 + nxt * kPatchFloats, Vn, Un);
 #ifdef FS_CONV_TRACE
         tr_sweep += FS_WINO_NOW() - q0;
 #endif
-        issue_filter(cbeg + j + 2, has2);
-        if (has2) commit_patch(patch0 + cur * kPatchFloats);
+        if (has2) {
+            issue_filter(cbeg + j + 2);
+            commit_patch(patch0 + cur * kPatchFloats);
+        }
 #ifdef FS_CONV_TRACE
         const long long q4 = FS_WINO_NOW();
 #endif
-        // LDS-only barrier (fs_kernels.h): the filter loads of chunk j+2 were issued a few instructions ago and are only
-        // needed by the NEXT sweep's commit slices -- __syncthreads() would wait for them here (s_waitcnt vmcnt(0)), a
-        // global-memory round trip per chunk
-        FS_LDS_BARRIER();
+        __syncthreads();
 #ifdef FS_CONV_TRACE
         const long long q5 = FS_WINO_NOW();
         tr_commit += q4 - q0;
