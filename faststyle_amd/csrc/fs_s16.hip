@@ -28,11 +28,14 @@ constexpr unsigned kOOB = 0x80000000u;
 constexpr int kT = 16;   // tile side
 }  // namespace
 
-template <int CIN, int KH, int KW, int DILX>
+// NB: 16-channel output blocks (Cout = 16 NB).  NB = 4 is VGG16's conv1_1 (3 -> 64, 3x3, image mean folded into the load,
+// bias + ReLU): every A fragment feeds four matrix instructions.
+template <int CIN, int KH, int KW, int DILX, int NB = 1>
 __global__ __launch_bounds__(256, 2) void conv_s16_kernel(ConvArgs a) {
     HIP_DYNAMIC_SHARED(float, smem)
     const ConvPlan& p = a.p;
     constexpr bool C3 = CIN == 3;
+    constexpr int COUT = 16 * NB;
     constexpr int S = C3 ? 3 : CIN + 1;                                   // LDS floats per patch pixel
     constexpr int PH = kT - 1 + KH, PW = kT - 1 + (KW - 1) * DILX + 1, NPX = PH * PW;
     constexpr int SPR = C3 ? (KW * 3 + 3) / 4 : CIN / 4;                  // k-steps per kernel row (C3) / per tap
@@ -53,17 +56,19 @@ __global__ __launch_bounds__(256, 2) void conv_s16_kernel(ConvArgs a) {
     };
 
     // ---- the filter, once, into registers: lane (channel m16, k4) holds row 4 j + k4 of k-step j
-    float breg[KSTEPS];
+    float breg[KSTEPS][NB];
 #pragma unroll
-    for (int j = 0; j < KSTEPS; ++j) {
-        if (C3) {
-            const int kh = j / SPR, k = 4 * (j % SPR) + k4;   // k = kw * 3 + ci
-            breg[j] = k < KW * 3 ? a.w[(kh * KW * 3 + k) * 16 + m16] : 0.f;
-        } else {
-            const int tap = j / SPR, ci = 4 * (j % SPR) + k4;
-            breg[j] = a.w[(tap * CIN + ci) * 16 + m16];
+    for (int j = 0; j < KSTEPS; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (C3) {
+                const int kh = j / SPR, k = 4 * (j % SPR) + k4;   // k = kw * 3 + ci
+                breg[j][nb] = k < KW * 3 ? a.w[(kh * KW * 3 + k) * COUT + nb * 16 + m16] : 0.f;
+            } else {
+                const int tap = j / SPR, ci = 4 * (j % SPR) + k4;
+                breg[j][nb] = a.w[(tap * CIN + ci) * COUT + nb * 16 + m16];
+            }
         }
-    }
     // ---- A operands: block m of this wave is tile row 4 wave + m, lane (m16, k4) feeds pixel column m16, row k4 of the k-step
     const int laneA = ((4 * wave) * PW + m16) * S + k4;
     auto aoff = [](int j, int m) __attribute__((always_inline)) {   // compile-time float offset of k-step j, block m
@@ -92,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv_s16_kernel(ConvArgs a) {
     }
     const unsigned x_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * CIN) * 4u);
     const bool has_ab = !C3 && a.in_a != nullptr;
+    const bool has_ab3 = C3 && a.in_a != nullptr;   // per-channel affine of a 3-channel input (VGG: image - mean)
     const bool in_relu = !C3 && a.in_relu != 0;
     const int refl = a.src_mode == SRC_REFLECT ? a.refl : 0;
 
@@ -168,6 +174,12 @@ __global__ __launch_bounds__(256, 2) void conv_s16_kernel(ConvArgs a) {
             va = *reinterpret_cast<const float4*>(a.in_a + (size_t)I.n * a.in_nstride + c4 * 4);
             vb = *reinterpret_cast<const float4*>(a.in_b + (size_t)I.n * a.in_nstride + c4 * 4);
         }
+        if (has_ab3) {
+            const float* pa = a.in_a + (size_t)I.n * a.in_nstride;
+            const float* pb = a.in_b + (size_t)I.n * a.in_nstride;
+            va = make_float4(pa[0], pa[1], pa[2], 0.f);
+            vb = make_float4(pb[0], pb[1], pb[2], 0.f);
+        }
     };
     auto relu1 = [](float x) __attribute__((always_inline)) {   // ONE v_max_f32
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -184,9 +196,16 @@ __global__ __launch_bounds__(256, 2) void conv_s16_kernel(ConvArgs a) {
         for (int i = 0; i < SX; ++i) {
             float* d = smem + pdst[i];
             if (C3) {
-                d[0] = pv[i][0];
-                d[1] = pv[i][1];
-                d[2] = pv[i][2];
+                float v0 = pv[i][0], v1 = pv[i][1], v2 = pv[i][2];
+                if (has_ab3) {   // padding arrives as 0 and must stay 0 (tf.nn.conv2d pads the mean-subtracted image with zeros)
+                    const unsigned okm = (!masked || ((pok >> i) & 1u)) ? 0xFFFFFFFFu : 0u;
+                    v0 = fmaf(v0, va.x, __uint_as_float(__float_as_uint(vb.x) & okm));
+                    v1 = fmaf(v1, va.y, __uint_as_float(__float_as_uint(vb.y) & okm));
+                    v2 = fmaf(v2, va.z, __uint_as_float(__float_as_uint(vb.z) & okm));
+                }
+                d[0] = v0;
+                d[1] = v1;
+                d[2] = v2;
             } else {
                 float v[4] = {pv[i][0], pv[i][1], pv[i][2], pv[i][3]};
                 if (has_ab) {   // producer instance norm folded into the load; padding arrives as 0 and must stay 0
@@ -214,10 +233,12 @@ __global__ __launch_bounds__(256, 2) void conv_s16_kernel(ConvArgs a) {
             commit_as(std::true_type{});
     };
 
-    f32x4 acc[4];
+    f32x4 acc[4][NB];
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     zero_acc();
     // one straight line: matrix instruction (j, m) with the read of (j + 1, m) in its slot
@@ -231,27 +252,34 @@ __global__ __launch_bounds__(256, 2) void conv_s16_kernel(ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 if (j + 1 < KSTEPS) av[(j + 1) & 1][m] = smem[laneA + aoff(j + 1, m)];
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j & 1][m], breg[j], acc[m], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j & 1][m], breg[j][nb], acc[m][nb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     };
 
     // ---- epilogue of one item: accumulator register r of block m, lane (m16, k4) = pixel (row 4 wave + m, column 4 k4 + r), channel m16
-    const unsigned y_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.Ho * a.Wo * 16) * 4u);
+    const unsigned y_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.Ho * a.Wo * COUT) * 4u);
+    float bias[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bias[nb] = a.bias ? a.bias[nb * 16 + m16] : 0.f;
+    const bool out_relu = a.out_relu != 0;
     auto epilogue = [&](const Item& I, float* rbuf) __attribute__((always_inline)) {
         const int th_valid = min(kT, a.Ho - I.ty0), tw_valid = min(kT, a.Wo - I.tx0);
-        if (a.stats) {
+        if (NB == 1 && a.stats) {
             // per-WAVE partial sums of (x - c), (x - c)^2 over the wave's four tile rows, c = the wave's own first pixel of the
             // channel; the four records of a tile are merged when the next pipeline step starts (finalize below): no barrier here
-            const float cs = __shfl(acc[0][0], m16);
+            const float cs = __shfl(acc[0][0][0], m16);
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool ok = 4 * wave + m < th_valid && 4 * k4 + r < tw_valid;
-                    const float d = ok ? acc[m][r] - cs : 0.f;
+                    const float d = ok ? acc[m][0][r] - cs : 0.f;
                     s1 += d;
                     s2 = fmaf(d, d, s2);
                 }
@@ -265,17 +293,22 @@ __global__ __launch_bounds__(256, 2) void conv_s16_kernel(ConvArgs a) {
                 rbuf[(wave * 3 + 2) * 16 + lane] = cs;
             }
         }
-        float* yn = a.y + (size_t)I.n * a.Ho * a.Wo * 16;
+        float* yn = a.y + (size_t)I.n * a.Ho * a.Wo * COUT;
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(yn)), 0, y_bytes, 0x00020000);
-        const int lane_off = ((I.tx0 + 4 * k4) * 16 + m16) * 4;
+        const int lane_off = ((I.tx0 + 4 * k4) * COUT + m16) * 4;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int row = 4 * wave + m;
-            const int row_off = (I.ty0 + row) * a.Wo * 64;
+            const int row_off = (I.ty0 + row) * a.Wo * COUT * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = row < th_valid && 4 * k4 + r < tw_valid;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][r]), yr, ok ? (unsigned)(lane_off + row_off + r * 64) : kOOB, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    float v = acc[m][nb][r] + bias[nb];
+                    if (out_relu) v = relu1(v);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, ok ? (unsigned)(lane_off + row_off + r * COUT * 4 + nb * 64) : kOOB, 0, 0);
+                }
             }
         }
         zero_acc();
@@ -314,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv_s16_kernel(ConvArgs a) {
     __syncthreads();
     for (int it = 0; it < my_items; ++it) {
         const bool more = it + 1 < my_items;
-        if (it > 0 && a.stats && tid < 16) finalize(prev, red + ((it - 1) & 1) * REDF);
+        if (NB == 1 && it > 0 && a.stats && tid < 16) finalize(prev, red + ((it - 1) & 1) * REDF);
         Item nxt = cur;
         if (more) {
             nxt = decode(it + 1);
@@ -328,13 +361,17 @@ __global__ __launch_bounds__(256, 2) void conv_s16_kernel(ConvArgs a) {
         prev = cur;
         cur = nxt;
     }
-    if (a.stats && tid < 16) finalize(prev, red + ((my_items - 1) & 1) * REDF);
+    if (NB == 1 && a.stats && tid < 16) finalize(prev, red + ((my_items - 1) & 1) * REDF);
 }
 
 // ------------------------------------------------------------------------------------------------------------ host
 static int s16_instance(const ConvArgs& a) {
-    if (a.Cout != 16 || a.stride != 1) return 0;
-    if (a.Cin == 3 && a.KH == 9 && a.KW == 9 && a.dil_x <= 1 && (a.src_mode == SRC_PLAIN || a.src_mode == SRC_REFLECT) && !a.in_a && !a.in_relu) return 1;
+    if (a.stride != 1) return 0;
+    if (a.Cout == 64) {   // VGG16 conv1_1: 3 -> 64, 3x3 (mean on load, bias + ReLU)
+        return (a.Cin == 3 && a.KH == 3 && a.KW == 3 && a.dil_x <= 1 && a.src_mode == SRC_PLAIN && !a.in_relu && !a.stats && tune_int("FS_S16_VGG", 1)) ? 3 : 0;
+    }
+    if (a.Cout != 16 || a.bias || a.out_relu) return 0;
+    if (a.Cin == 3 && a.KH == 9 && a.KW == 9 && a.dil_x <= 1 && (a.src_mode == SRC_PLAIN || a.src_mode == SRC_REFLECT) && !a.in_relu) return 1;
     if (a.Cin == 16 && a.KH == 9 && a.KW == 2 && a.dil_x == 5 && a.src_mode == SRC_PLAIN) return 2;
     return 0;
 }
@@ -342,8 +379,7 @@ static int s16_instance(const ConvArgs& a) {
 bool s16_eligible(const ConvArgs& a) {
     const int inst = s16_instance(a);
     if (!tune_int("FS_S16", 1) || !inst) return false;
-    if (a.bias || a.out_relu || a.mask_src || a.route_src || a.pool_out || a.w_nstride || a.w_wino || a.w_wino2 || a.shuffle || a.add_src || a.fin.counter)
-        return false;
+    if (a.mask_src || a.route_src || a.pool_out || a.w_nstride || a.w_wino || a.w_wino2 || a.shuffle || a.add_src || a.fin.counter) return false;
     if (a.in_a && !a.in_b) return false;
     if (a.in_relu && !a.in_a) return false;
     if (a.pad_t < 0 || a.pad_l < 0) return false;
@@ -355,15 +391,15 @@ void s16_plan(const ConvArgs& a, ConvPlan* out) {
     ConvPlan p{};
     const int inst = s16_instance(a);
     p.variant = 9;
-    p.BN = 16;
+    p.BN = a.Cout;
     p.CC = a.Cin;
     p.flat = a.Cin == 3;   // (K runs over (kw, ci) contiguously per kernel row)
     p.TH = p.TW = kT;
     p.tiles_y = cdiv(a.Ho, kT);
     p.tiles_x = cdiv(a.Wo, kT);
     p.PH = kT - 1 + a.KH;
-    p.PW = inst == 1 ? kT - 1 + 9 : kT - 1 + 5 + 1;
-    p.S = inst == 1 ? 3 : 17;
+    p.PW = inst == 2 ? kT - 1 + 5 + 1 : kT - 1 + a.KW;
+    p.S = inst == 2 ? 17 : 3;
     const int patch_f = (p.PH * p.PW * p.S + 8 + 3) & ~3;
     p.lds_bytes = 4 * (patch_f + 2 * 4 * 3 * 16);
     p.ksplit = 1;
@@ -378,6 +414,7 @@ int s16_launch(const ConvArgs& a, hipStream_t s) {
     switch (s16_instance(a)) {
         case 1: hipLaunchKernelGGL((conv_s16_kernel<3, 9, 9, 1>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a); break;
         case 2: hipLaunchKernelGGL((conv_s16_kernel<16, 9, 2, 5>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a); break;
+        case 3: hipLaunchKernelGGL((conv_s16_kernel<3, 3, 3, 1, 4>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a); break;
         default: return -4;
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;

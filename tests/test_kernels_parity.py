@@ -195,6 +195,23 @@ def test_dgrad_through_forward_kernel(eng, stride, h, w_):
     assert rel(dx, want) < TOL
 
 
+@pytest.mark.parametrize("shape", [(2, 35, 45), (1, 32, 48)])
+def test_conv1_1_through_the_sixteen_channel_streaming_kernel(eng, knob, shape):
+    """VGG16 conv1_1 (3 -> 64, 3x3 SAME; libs/vgg16.py:36-48) as conv_s16_kernel<3,3,3,1,4> runs it in the training step: image
+    mean folded into the load as a per-channel affine (the zero padding must stay zero), bias, ReLU -- against the float64
+    restatement, ragged sizes (partial edge tiles)."""
+    knob("FS_S16_MIN_TILES", 1)
+    rng = np.random.default_rng(21)
+    x = rng.uniform(0, 255, shape + (3,)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 64)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    ia = np.ones(3, np.float32)
+    ib = -np.array([123.68, 116.779, 103.939], np.float32)
+    y = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME", in_a=up(eng, ia), in_b=up(eng, ib), bias=up(eng, b), out_relu=1))
+    want = np.maximum(nnops.conv2d(x.astype(np.float64) + ib.astype(np.float64), w.astype(np.float64), 1, "SAME") + b, 0.0)
+    assert y.shape == want.shape and rel(y, want) < TOL
+
+
 # ("res_8x8_tile": 16 x 16 outputs make the planner pick the 8 x 8-pixel tile of the training shapes -> the residual instance
 # of wgrad2_kernel with static tile geometry, immediate-offset operand reads)
 WGRAD_CASES = [("res", (2, 12, 14, 64), 64, 3, 1, "VALID", 0, 0), ("res_8x8_tile", (1, 18, 18, 64), 64, 3, 1, "VALID", 0, 0),
