@@ -8,7 +8,9 @@
     the residual-gradient addend; ragged tiles, one to several tiles per workgroup (FS_CSTREAM_WGS);
   * gram_stream_kernel / gram_reduce_kernel / gram_bwd_kernel (fs_gram.hip): every channel count they take, pixel counts
     that end inside a tile, several pixel ranges;
-  * wino2_conv_kernel with bias / ReLU, wgrad2_kernel, conv3x3_to3_kernel on ragged shapes.
+  * wino2_conv_kernel with bias / ReLU, wgrad2_kernel, conv3x3_to3_kernel on ragged shapes;
+  * conv_s16_kernel (fs_s16.hip): the 9x9 3 -> 16 layer with mirror or zero padding and per-tile statistics, VGG conv1_1's
+    form (3 -> 64, per-channel affine on load over zero padding, bias + ReLU); ragged tiles, several persistent grid sizes.
 Every case prints one line; a mismatch raises.  tests/ holds fixed-shape versions of the same checks."""
 import os
 import sys
@@ -65,12 +67,39 @@ def main():
     os.environ["FS_CSTREAM_MIN_TILES"] = "1"
     os.environ["FS_CSTREAM_MASK"] = "31"
     os.environ["FS_GRAM2_MIN_TILES"] = "0"
+    os.environ["FS_S16_MIN_TILES"] = "1"
     e = get_engine("emu")
     up, down = e.mem.from_numpy, e.mem.to_numpy
     inst = [(16, 32, 3, 2), (32, 64, 2, 1), (32, 64, 3, 2), (64, 128, 2, 1), (64, 64, 3, 1)]
     for it in range(cases):
-        kind = it % 11
-        if kind < 5:
+        kind = it % 12
+        if kind == 11:        # 16-channel-block streaming kernel (fs_s16.hip)
+            n, h, w = int(rng.integers(1, 3)), int(rng.integers(9, 50)), int(rng.integers(9, 50))
+            os.environ["FS_S16_WGS"] = str(int(rng.choice([1, 3, 512])))
+            e.lib.fs_debug_reload_env()
+            x = rng.uniform(0, 255, (n, h, w, 3)).astype(np.float32)
+            if rng.integers(2):   # the image layer: 9x9, 3 -> 16, mirror padding by r < min(h, w) or zero padding, statistics
+                refl = int(rng.integers(0, min(h, w, 41)))
+                wt = (rng.standard_normal((9, 9, 3, 16)) * 0.05).astype(np.float32)
+                xv = nnops.reflect_pad(x.astype(np.float64), refl) if refl else x.astype(np.float64)
+                want = nnops.conv2d(xv, wt.astype(np.float64), 1, "SAME")
+                res = e.conv2d(up(x), up(wt), 1, "SAME", want_stats=True, src_mode=1 if refl else 0, refl=refl)
+                y = down(res[0])
+                mean, var = merge_stats(down(res[1]).astype(np.float64))
+                assert np.abs(mean - want.mean(axis=(1, 2))).max() < 1e-4 * (np.abs(want).max() + 1), "tile statistics: mean"
+                assert np.abs(var - want.var(axis=(1, 2))).max() < 1e-4 * (want.var(axis=(1, 2)).max() + 1e-9), "tile statistics: variance"
+                what = "9x9 3->16 refl %d" % refl
+            else:                 # VGG conv1_1: 3x3, 3 -> 64, image - mean on load (zero padding stays zero), bias + ReLU
+                wt = (rng.standard_normal((3, 3, 3, 64)) * 0.1).astype(np.float32)
+                b = rng.standard_normal(64).astype(np.float32)
+                ia, ib = rng.uniform(0.5, 1.5, 3).astype(np.float32), -rng.uniform(90, 130, 3).astype(np.float32)
+                want = np.maximum(nnops.conv2d(x.astype(np.float64) * ia + ib, wt.astype(np.float64), 1, "SAME") + b, 0.0)
+                y = down(e.conv2d(up(x), up(wt), 1, "SAME", in_a=up(ia), in_b=up(ib), bias=up(b), out_relu=1))
+                what = "3x3 3->64 affine+bias+relu"
+            r = rel(y, want)
+            print("case %3d conv_s16 %s %s wgs %s  rel %.2e" % (it, what, x.shape, os.environ["FS_S16_WGS"], r), flush=True)
+            assert y.shape == want.shape and r < TOL
+        elif kind < 5:
             cin, cout, ks, st = inst[kind]
             n = int(rng.integers(1, 4))
             h, w = int(rng.integers(3, 40)), int(rng.integers(3, 44))
