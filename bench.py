@@ -244,6 +244,12 @@ def main():
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ       # under torch.distributed.run (any world size)
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d inside a %d-rank torch.distributed environment" % (args.gpus, world))
+    # FS_DIST_BACKEND=gloo + FS_DIST_SHARE_GPU=1 (tests only): N ranks time-share the ONE GPU of a test box -- RCCL refuses two
+    # ranks on one device, gloo stages the 1.7 MB gradient through the host.  The line then says so in config.collective.
+    backend = os.environ.get("FS_DIST_BACKEND", "nccl")
+    share_gpu = os.environ.get("FS_DIST_SHARE_GPU") == "1"
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -253,7 +259,7 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group(backend, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
             warm = torch.zeros(1, device="cuda")
             dist.all_reduce(warm)
             torch.cuda.synchronize()
@@ -401,6 +407,7 @@ def main():
         def fwd_leg(shape, bf16, warm, iters, graph):
             x = torch.rand(shape, device="cuda", generator=g) * 255.0
             run = lambda: eng.tnet_forward(flat, x, bf16=bf16)
+            held = []
             for _ in range(warm):
                 run()
             sync()
@@ -417,6 +424,7 @@ def main():
                     fg = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(fg, capture_error_mode="thread_local"):
                         run()
+                    held = eng.pin_last_used(tnet=True)       # the graph replays into this workspace: no eviction under it
                     run = fg.replay
                     run()
                     sync()
@@ -427,6 +435,7 @@ def main():
                 run()
             sync()
             dt = max_over_ranks(time.perf_counter() - t0)
+            eng.release_pins(held)
             n = shape[0]
             fps = world * iters * n / dt
             gf_exec, gf_written, mb = FWD_WORK[(shape[1], shape[2])]
@@ -542,7 +551,9 @@ def main():
                                    "hipGraph-replayed; secondary line train_b4_per_gpu = the same step at batch 4 per GPU "
                                    "(BASELINE configs[2]; configs[3] at N=8)" % (S, S, B, B * world),
                        "global_batch": B * world, "batch_per_gpu": B, "image_size": [S, S], "parallelism": "dp%d" % world,
-                       "collective": ("one RCCL all-reduce(SUM) of 1,696,408 B per step (world size %d)" % world) if launched else "none (single process)",
+                       "collective": ("one %s all-reduce(SUM) of 1,696,408 B per step (world size %d)%s" % (
+                           "RCCL" if backend == "nccl" else backend, world,
+                           "; TEST MODE: the ranks time-share one GPU" if share_gpu else "")) if launched else "none (single process)",
                        "style_image": "starry_night_crop.jpg 640x938"},
             "roofline": {"bound": "mfma",
                          "kernel": names[di] + (": fp32 MFMA, Winograd F(2x2,3x3) 3x3 conv; achieved = FLOPs EXECUTED (16 products per "

@@ -93,6 +93,7 @@ class Engine(object):
         self._tnet_ws = {}
         self._perc_ws = {}
         self._pinned = {}          # id(workspace tensor) -> pin count
+        self._tnet_nbytes = {}     # (N, H, W, bf16) -> fs_tnet_workspace_bytes, see _tnet_key
         self._keep = []
 
     def close(self):
@@ -168,12 +169,34 @@ class Engine(object):
             else:
                 self._pinned.pop(id(t), None)
 
+    def pin_last_used(self, tnet=True, perceptual=False):
+        """The capture contract: whoever captures engine calls into a hipGraph calls this right after the capture and keeps the
+        returned list (the workspace tensors the captured calls used = the most recently used entry of each cache, now
+        pinned against eviction AND kept alive by the list) for as long as the graph lives; release_pins() afterwards."""
+        held = []
+        if tnet and self._tnet_ws:
+            held.append(next(reversed(self._tnet_ws.values()))[0])
+        if perceptual and self._perc_ws:
+            held.append(next(reversed(self._perc_ws.values()))[0])
+        self.pin_workspaces(held, True)
+        return held
+
+    def release_pins(self, held):
+        if held:
+            self.pin_workspaces(held, False)
+            del held[:]
+
     def _tnet_key(self, N, H, W, bf16=False):
         # the layout (and with it the size) depends on the library's FS_TNET_WINO knob as the LIBRARY sees it (read once and
         # cached there): ask the library, not os.environ
-        nbytes = self.lib.fs_tnet_workspace_bytes(N, H, W, L.FS_FLAG_BF16 if bf16 else L.FS_FLAG_SAVE_FOR_BWD)
-        if nbytes == 0:
-            raise L.FaststyleError("bad transform-net shape %s" % ((N, H, W, bf16),))
+        # (memoised: the C entry point rebuilds the whole layout, 40-65 us of host time -- per frame in an eager loop;
+        # reset_workspaces(), which every knob flip is followed by, drops the memo)
+        nbytes = self._tnet_nbytes.get((N, H, W, bf16))
+        if nbytes is None:
+            nbytes = self.lib.fs_tnet_workspace_bytes(N, H, W, L.FS_FLAG_BF16 if bf16 else L.FS_FLAG_SAVE_FOR_BWD)
+            if nbytes == 0:
+                raise L.FaststyleError("bad transform-net shape %s" % ((N, H, W, bf16),))
+            self._tnet_nbytes[(N, H, W, bf16)] = nbytes
         return (N, H, W, bf16, nbytes)
 
     def _tnet_workspace(self, N, H, W, bf16=False):
@@ -192,6 +215,7 @@ class Engine(object):
         self._tnet_ws.clear()
         self._perc_ws.clear()
         self._pinned.clear()
+        self._tnet_nbytes.clear()
 
     @staticmethod
     def _method_flag(upsample_method):

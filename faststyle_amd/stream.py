@@ -29,6 +29,7 @@ class FrameStylizer(object):
         self._in_f32 = mem.empty(self.shape)
         self._out_u8 = mem.upload_u8(np.zeros(self.out_shape, np.uint8))
         self._graph = None
+        self._graph_keepalive = []       # the engine workspace the captured graph replays into (pinned, see _capture)
         self._use_graph = use_graph and hasattr(mem, "torch")
         self._y = None
 
@@ -52,6 +53,20 @@ class FrameStylizer(object):
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._device_pass()
         self._graph = g
+        # the graph replays raw pointers into the engine's transform-net workspace of this shape: pin it against the
+        # engine's byte-bounded LRU eviction and keep it alive for as long as the graph lives
+        self._graph_keepalive = self.eng.pin_last_used(tnet=True)
+
+    def release(self):
+        """Drop the captured graph and un-pin its workspace."""
+        self._graph = None
+        self.eng.release_pins(self._graph_keepalive)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
     def __call__(self, frames_u8):
         """frames_u8: host uint8 [H,W,3] (or [B,H,W,3]) -> host uint8 stylized frame(s) of the net's output size."""

@@ -77,13 +77,10 @@ class Trainer(object):
         self.graph = g
         # the graph replays raw pointers into the two workspaces ITS forward/backward used (the most recently used entry of
         # each cache): keep exactly those alive and un-evictable for as long as the graph lives
-        e = self.eng
-        self._graph_keepalive = [next(reversed(e._tnet_ws.values()))[0], next(reversed(e._perc_ws.values()))[0]]
-        e.pin_workspaces(self._graph_keepalive, True)
+        self._graph_keepalive = self.eng.pin_last_used(tnet=True, perceptual=True)
 
     def _release_graph(self):
-        if self._graph_keepalive:
-            self.eng.pin_workspaces(self._graph_keepalive, False)
+        self.eng.release_pins(self._graph_keepalive)
         self._graph_keepalive = []
         self.graph = None
 

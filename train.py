@@ -87,10 +87,15 @@ def main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # FS_DIST_BACKEND=gloo + FS_DIST_SHARE_GPU=1: test switches -- N ranks on the ONE GPU of a test box (RCCL refuses two ranks
+    # on one device; gloo stages the 1.7 MB gradient through the host).  Production: RCCL, one GPU per rank.
+    backend = os.environ.get("FS_DIST_BACKEND", "nccl")
+    if os.environ.get("FS_DIST_SHARE_GPU") == "1":
+        local = local_rank = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group(backend, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
     eng = engine.Engine(engine.TorchMem("cuda:%d" % local))
 
     # Load in style image that will define the model (train.py:135-137).
@@ -185,7 +190,8 @@ def main(args):
                                                             ("summaries/content_loss", lv[1]), ("summaries/tv_loss", lv[3])])
                     print(current_step, lv[0])
             if current_step == args.num_steps_break:
-                print('Done training.')
+                if rank == 0:
+                    print('Done training.')
                 break
         else:
             if rank == 0:
@@ -207,10 +213,17 @@ def main(args):
                 else:
                     # THIS rank is leaving through an exception while its peers sit in the gradient all-reduce of a step it
                     # never reached.  A barrier here would pair with that all-reduce (mismatched collectives: undefined
-                    # behaviour, at best a watchdog timeout).  Rank 0's final model is on disk; exit at once and non-zero
-                    # so that torch.distributed.run tears the peers down.
+                    # behaviour, at best a watchdog timeout).  Exit at once and non-zero so that torch.distributed.run tears the
+                    # peers down.  If THIS rank is rank 0 its final model is on disk (the save above); if a peer failed, rank 0
+                    # is killed inside its all-reduce and the newest training/<name>.ckpt-<step> (+ --resume_from) is what
+                    # survives.  os._exit skips atexit handlers: close what this rank holds open first.
                     import traceback
                     traceback.print_exc()
+                    if rank == 0:
+                        try:
+                            log.close()
+                        except Exception:
+                            pass
                     sys.stdout.flush()
                     sys.stderr.flush()
                     os._exit(1)
