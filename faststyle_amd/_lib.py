@@ -51,7 +51,8 @@ class fs_conv_desc(Structure):
                 ("src_mode", c_int), ("refl", c_int),
                 ("in_a", c_void_p), ("in_b", c_void_p), ("in_per_sample", c_int), ("in_relu", c_int),
                 ("bias", c_void_p), ("out_relu", c_int), ("shuffle", c_int), ("stats", c_void_p),
-                ("add_src", c_void_p), ("add_pad", c_int), ("w_nstride", c_longlong), ("w_wino", c_void_p)]
+                ("add_src", c_void_p), ("add_pad", c_int), ("w_nstride", c_longlong), ("w_wino", c_void_p),
+                ("w_wino4", c_void_p), ("mask_src", c_void_p), ("pool_out", c_void_p)]
 
 
 class fs_wgrad_desc(Structure):
@@ -106,6 +107,7 @@ PROTOTYPES = {
     "fs_conv2d_fwd": (c_int, [c_void_p, POINTER(fs_conv_desc)]),
     "fs_conv2d_plan": (c_int, [POINTER(fs_conv_desc), POINTER(c_int)]),
     "fs_wino_transform_filter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "fs_wino4_transform_filter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fs_instnorm_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "fs_instnorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

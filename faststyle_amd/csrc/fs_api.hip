@@ -456,6 +456,9 @@ static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
     a->add_src = d->add_src;
     a->add_pad = d->add_pad;
     a->w_nstride = d->w_nstride;
+    a->mask_src = d->mask_src;
+    a->w_wino4 = d->w_wino4;
+    if (a->w_wino4 && !fs::wino4_eligible(*a)) a->w_wino4 = nullptr;   // (not a 3x3 stride-1 SAME conv of the supported shapes)
     if (fs::tune_int("FS_WINO_V", 2) >= 2) {   // the filter layout fs_wino_transform_filter produced (see there)
         a->w_wino2 = d->w_wino;
         if (a->w_wino2 && !fs::wino2_eligible(*a)) a->w_wino2 = nullptr;   // (not a 3x3 stride-1 conv of the supported shapes: direct kernel)
@@ -464,6 +467,11 @@ static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
         if (a->w_wino && !fs::wino_eligible(*a)) a->w_wino = nullptr;
     }
     a->p = fs::conv_plan(*a);
+    if (d->pool_out) {   // only the Winograd epilogues hold whole pooling windows
+        if (!(a->p.variant == 5 || a->p.variant == 6 || a->p.variant == 10) || a->p.ksplit > 1 || (a->Ho & 1) || (a->Wo & 1))
+            return fail(-2, "fs_conv2d: pool_out needs a Winograd-eligible conv with even Ho, Wo");
+        a->pool_out = d->pool_out;
+    }
     return 0;
 }
 
@@ -497,6 +505,13 @@ int fs_wino_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, flo
     if (Cin % 8) return fail(-2, "fs_wino_transform_filter: Cin must be a multiple of 8 (got %d)", Cin);
     const int rc = fs::tune_int("FS_WINO_V", 2) >= 2 ? fs::wt_wino2(w, U, Cin, Cout, ctx->stream) : fs::wt_wino(w, U, Cin, Cout, ctx->stream);
     return rc ? fail(rc, "fs_wino_transform_filter: launch failed (%d)", rc) : 0;
+}
+
+int fs_wino4_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, float* U) {
+    if (!ctx || !w || !U) return fail(-1, "fs_wino4_transform_filter: null argument");
+    if (Cin < 4 || Cout < 64 || (Cin % 4) || (Cout % 64)) return fail(-2, "fs_wino4_transform_filter: Cin %% 4 == 0 and Cout %% 64 == 0 (got %dx%d)", Cin, Cout);
+    const int rc = fs::wt_wino4(w, U, Cin, Cout, ctx->stream);
+    return rc ? fail(rc, "fs_wino4_transform_filter: launch failed (%d)", rc) : 0;
 }
 
 int fs_instnorm_finalize(fs_ctx* ctx, const float* stats, int N, int tiles, int C, int groups, const float* gamma,

@@ -6,9 +6,11 @@
 #include <cstddef>
 #include <cstdint>
 #include <mutex>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int fs_u32x4 __attribute__((ext_vector_type(4)));   // payload type of raw_buffer_store_b128
 
 namespace fs {
 
@@ -22,7 +24,7 @@ enum SrcMode {
 
 struct ConvPlan {
     int variant;  // conv_igemm_kernel<MT,WM,WN>: 0 <32,2,2>  1 <32,2,1>  2 <16,4,1>  3 <32,1,2>  4 <32,1,1>;  5 wino_conv_kernel;  6 wino2_conv_kernel;
-                  // 7 conv_stream_kernel;  8 wino2h_conv_kernel;  9 conv_s16_kernel
+                  // 7 conv_stream_kernel;  8 wino2h_conv_kernel;  9 conv_s16_kernel;  10 wino4_conv_kernel (F(4x4,3x3))
     int BN;       // output channels per workgroup
     int flat;     // Cin==3: K runs over (kw,ci) contiguously per kernel row
     int CC;       // input channels staged per chunk
@@ -77,6 +79,7 @@ struct ConvArgs {
     const float* w;  // [KH*KW, Cin, Cout] (HWIO); + n*w_nstride for per-sample weights
     const float* w_wino;  // optional: the same filter Winograd-transformed, [16][Cin][Cout] (fs::wt_wino); enables variant 5
     const float* w_wino2; // optional: ... in the K-contiguous order [16][Cin/8][Cout][8] (fs::wt_wino2); enables variant 6
+    const float* w_wino4; // optional: the filter transformed for F(4x4,3x3), [36][Cin/4][Cout/64][2][4][16][2] (fs::wt_wino4); enables variant 10
     float* y;        // [N,Ho,Wo,Cout], or [N,2Ho,2Wo,Cout/4] when shuffle
     int N, H, W, Cin;
     int Ho, Wo, Cout;
@@ -194,6 +197,17 @@ WgradPlan wgrad_plan(const WgradArgs& a);
 int wgrad_launch(const WgradArgs& a, hipStream_t s);
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// f(integral_constant<int, I0>) ... f(integral_constant<int, I1 - 1>) as straight-line code.  (#pragma unroll is a request the
+// loop unroller declines beyond its size budget -- a 36-step sweep with its staging slices inlined is -- and a rolled loop
+// over an accumulator array puts the accumulators in scratch memory.)
+template <int I0, int I1, class F>
+__device__ __forceinline__ void fs_static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        fs_static_for<I0 + 1, I1>(f);
+    }
+}
 
 // Address of a kernel's (single, by-value) argument struct in the kernel-argument segment, for kernels that index a
 // table inside it at run time.  (Host passes -- the launch stub, the CPU emulator of tests/ -- take the parameter's own
@@ -443,6 +457,10 @@ void s16_plan(const ConvArgs& a, ConvPlan* out);
 int s16_launch(const ConvArgs& a, hipStream_t s);
 bool conv3x3_to3_eligible(const ConvArgs& a);                                                 // fs_c3.hip
 int conv3x3_to3_launch(const ConvArgs& a, hipStream_t s);
+int wt_wino4(const float* w, float* U, int Cin, int Cout, hipStream_t s);                      // fs_wino4.hip: Winograd F(4x4,3x3), plan variant 10
+bool wino4_eligible(const ConvArgs& a);
+void wino4_plan(const ConvArgs& a, ConvPlan* out);
+int wino4_launch(const ConvArgs& a, hipStream_t s);
 bool wino_eligible(const ConvArgs& a);
 void wino_plan(const ConvArgs& a, ConvPlan* out);
 int wino_launch(const ConvArgs& a, hipStream_t s);
@@ -528,7 +546,7 @@ enum ProfFam {
     PF_IGEMM_32_2_2 = 0, PF_IGEMM_32_2_1 = 1, PF_IGEMM_16_4_1 = 2, PF_IGEMM_32_1_2 = 3, PF_IGEMM_32_1_1 = 4,
     PF_WINO = 5, PF_WINO2_VGG = 6, PF_WINO2_TNET = 7, PF_CSTREAM = 8, PF_C3 = 9, PF_WGRAD2 = 10, PF_WGRAD = 11,
     PF_GRAM_STREAM = 12, PF_GRAM_WGRAD = 13, PF_GRAM_BWD = 14, PF_GRAM_BWD_IGEMM = 15, PF_WINO2H_TNET = 16, PF_S16 = 17,
-    PF_RESERVED18 = 18, PF_RESERVED19 = 19
+    PF_WINO4 = 18, PF_RESERVED19 = 19
 };
 const char* prof_family_name(int f);
 struct Profiler {

@@ -49,7 +49,19 @@ static size_t wino_offset(int l, bool dgrad) {  // l >= 1
 static size_t wino_region_floats() { return wino_offset(FS_VGG_NLAYERS, false) - flipt_floats(); }
 // (the same transformed filters once more in the K-contiguous order of the second-generation kernel, fs_wino2.hip)
 static size_t wino2_offset(int l, bool dgrad) { return wino_offset(l, dgrad) + wino_region_floats(); }
-size_t vgg_prepared_floats() { return wino_offset(FS_VGG_NLAYERS, false) + wino_region_floats(); }
+// (... and the F(4x4,3x3) filters of fs_wino4.hip, 36 positions each, both orientations)
+static size_t wino4_offset(int l, bool dgrad) {  // l >= 1
+    size_t n = wino_offset(FS_VGG_NLAYERS, false) + wino_region_floats();
+    for (int i = 1; i < FS_VGG_NLAYERS; ++i) {
+        const size_t sz = ((size_t)36 * kCin[i] * kCout[i] + 63) & ~(size_t)63;
+        if (i == l && !dgrad) return n;
+        n += sz;
+        if (i == l && dgrad) return n;
+        n += sz;
+    }
+    return n;
+}
+size_t vgg_prepared_floats() { return wino4_offset(FS_VGG_NLAYERS, false); }
 // debugging aid: FS_VGG_WINO_MASK selects the layers that may take the Winograd kernel (bit l: forward of layer l,
 // bit 16+l: its input gradient); default all
 static bool wino_layer_on(int bit) {
@@ -69,6 +81,8 @@ int vgg_prepare(const float* const w[FS_VGG_NLAYERS], float* prepared, hipStream
         FS_TRY(wt_wino(prepared + prepared_offset(l), prepared + wino_offset(l, true), kCout[l], kCin[l], s));  // [3][3][Cout][Cin]
         FS_TRY(wt_wino2(w[l], prepared + wino2_offset(l, false), kCin[l], kCout[l], s));
         FS_TRY(wt_wino2(prepared + prepared_offset(l), prepared + wino2_offset(l, true), kCout[l], kCin[l], s));
+        FS_TRY(wt_wino4(w[l], prepared + wino4_offset(l, false), kCin[l], kCout[l], s));
+        FS_TRY(wt_wino4(prepared + prepared_offset(l), prepared + wino4_offset(l, true), kCout[l], kCin[l], s));
     }
     return 0;
 }
@@ -172,13 +186,14 @@ void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, 
 }
 
 // pool: optional destination of the 2x2/2 max-pool of the result; *pooled tells whether the conv launch produced it
-static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, const float* w_wino, const float* w_wino2, const float* bias, const float* ab,
+static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, const float* w_wino, const float* w_wino2, const float* w_wino4, const float* bias, const float* ab,
                     float* y, float* split_ws, size_t split_ws_floats, hipStream_t s, float* pool = nullptr, bool* pooled = nullptr) {
     ConvArgs a{};
     a.x = x;
     a.w = w;
     a.w_wino = w_wino;
     a.w_wino2 = w_wino2;
+    a.w_wino4 = w_wino4;
     a.y = y;
     a.N = N;
     a.H = a.Ho = H;
@@ -198,7 +213,7 @@ static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, 
     }
     a.p = conv_plan(a);
     if (pooled) *pooled = false;
-    if (pool && (a.p.variant == 5 || a.p.variant == 6) && a.p.ksplit <= 1 && !(H & 1) && !(W & 1) && tune_int("FS_VGG_POOL_FUSED", 1)) {
+    if (pool && (a.p.variant == 5 || a.p.variant == 6 || a.p.variant == 10) && a.p.ksplit <= 1 && !(H & 1) && !(W & 1) && tune_int("FS_VGG_POOL_FUSED", 1)) {
         a.pool_out = pool;   // the Winograd epilogues hold whole 2x2 tiles: the pooled tensor comes for one extra store per tile
         if (pooled) *pooled = true;
     }
@@ -216,7 +231,7 @@ static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS],
         const int nb = l <= L.cmax ? L.NB : L.N;
         const bool wl = prepared && l >= 1 && wino_layer_on(l);
         FS_TRY(vgg_conv(src, nb, L.Hl[l], L.Wl[l], l, w[l], wl ? prepared + wino_offset(l, false) : nullptr,
-                        wl ? prepared + wino2_offset(l, false) : nullptr, b[l],
+                        wl ? prepared + wino2_offset(l, false) : nullptr, wl ? prepared + wino4_offset(l, false) : nullptr, b[l],
                         ws + L.ab, ws + L.act[l], ws + L.splitws, L.splitws_floats, s,
                         (pool_after(l) && l < L.lmax) ? ws + L.pool[pool_index(l)] : nullptr, &pooled));
         src = ws + L.act[l];
@@ -376,6 +391,7 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         a.w = prepared + prepared_offset(l);
         a.w_wino = (l >= 1 && wino_layer_on(16 + l)) ? prepared + wino_offset(l, true) : nullptr;
         a.w_wino2 = (l >= 1 && wino_layer_on(16 + l)) ? prepared + wino2_offset(l, true) : nullptr;
+        a.w_wino4 = (l >= 1 && wino_layer_on(16 + l)) ? prepared + wino4_offset(l, true) : nullptr;
         a.N = N;
         a.H = a.Ho = H;
         a.W = a.Wo = W;

@@ -474,7 +474,13 @@ class Engine(object):
         d.shuffle = int(kw.get("shuffle", 0))
         d.add_pad = int(kw.get("add_pad", 0))
         d.w_nstride = int(kw.get("w_nstride", 0))
-        if kw.get("winograd"):     # F(2x2,3x3): transform the filter into a caller-owned buffer, hand it over with the conv
+        d.mask_src = p(kw.get("mask_src"))
+        if kw.get("winograd") == 4:     # F(4x4,3x3) (fs_wino4.hip)
+            U = self.mem.empty((36, Cin, Cout))
+            L.check(self.lib, self.lib.fs_wino4_transform_filter(self.ctx, p(w), Cin, Cout, p(U)), "fs_wino4_transform_filter")
+            d.w_wino4 = p(U)
+            self._keep = [U]
+        elif kw.get("winograd"):     # F(2x2,3x3): transform the filter into a caller-owned buffer, hand it over with the conv
             U = self.mem.empty((16, Cin, Cout))
             L.check(self.lib, self.lib.fs_wino_transform_filter(self.ctx, p(w), Cin, Cout, p(U)), "fs_wino_transform_filter")
             d.w_wino = p(U)
@@ -486,11 +492,17 @@ class Engine(object):
         else:
             y = self.mem.empty((N, d.Ho, d.Wo, Cout))
         d.y = p(y)
+        pool = None
+        if kw.get("want_pool"):
+            pool = self.mem.empty((N, d.Ho // 2, d.Wo // 2, Cout))
+            d.pool_out = p(pool)
         stats = None
         if kw.get("want_stats"):
             stats = self.mem.empty((N, tiles.value, Cout, 3))
             d.stats = p(stats)
         L.check(self.lib, self.lib.fs_conv2d_fwd(self.ctx, ctypes.byref(d)), "fs_conv2d_fwd")
+        if pool is not None:
+            return y, pool
         return (y, stats, tiles.value) if kw.get("want_stats") else y
 
     def instnorm_finalize(self, stats, tiles, C, groups, gamma, beta, eps=1e-3):

@@ -180,11 +180,22 @@ typedef struct {
                           * convs of the transform net take.  Any other shape (Cin > 128 included: the composite calls run
                           * those layers on the first-generation kernel, whose filter order this descriptor does not carry)
                           * silently takes the direct kernel -- same result within the parity tolerance. */
+    const float* w_wino4; /* optional: the filter as transformed by fs_wino4_transform_filter (36*Cin*Cout floats): a 3x3
+                           * stride-1 SAME conv with Cin % 4 == 0 and Cout % 64 == 0 then runs on the Winograd F(4x4,3x3) kernel
+                           * (fs_wino4.hip), the one fs_perceptual_loss runs conv1_2 ... conv4_3 and their input gradients on
+                           * (reference libs/vgg16.py:45-173).  Takes precedence over w_wino; other shapes fall through. */
+    const float* mask_src; /* optional [N,Ho,Wo,Cout]: y = mask_src > 0 ? y : 0 -- the consumer-ReLU mask of the VGG input-gradient
+                            * convs (the gradient of vgg16.py:48's tf.nn.relu folded into the conv in front of it) */
+    float* pool_out;       /* optional [N,Ho/2,Wo/2,Cout] (Winograd kernels only, even Ho and Wo): tf.nn.max_pool 2x2/2 of the
+                            * stored result (vgg16.py:68,104,154) written by the same launch */
 } fs_conv_desc;
 /* U = G g G^T for every (ci, co) filter g = w[:, :, ci, co] of a 3x3 HWIO filter (Lavin & Gray F(2x2,3x3)), 16 values per
  * filter, in the order the Winograd kernels stage them; the caller owns U (16*Cin*Cout floats; Cin % 8 == 0).
  * fs_vgg_prepare does this once for the frozen VGG16 filters. */
 int fs_wino_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, float* U);
+/* The same for F(4x4,3x3) (interpolation points 0, +-1, +-2, infinity; computed in float64, rounded once): 36 values per
+ * filter, U holds 36*Cin*Cout floats; Cin % 4 == 0, Cout % 64 == 0. */
+int fs_wino4_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, float* U);
 /* tf.nn.conv2d (im_transf_net.py:115, vgg16.py:47) on the matrix cores. */
 int fs_conv2d_fwd(fs_ctx* ctx, fs_conv_desc* d);
 /* resolves Ho/Wo/pads and returns the per-image tile count the launch will use */

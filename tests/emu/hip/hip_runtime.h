@@ -333,6 +333,12 @@ static inline void raw_buffer_store_b32(unsigned v, buffer_rsrc r, unsigned voff
     if (voff < 0x80000000u && end <= r.nbytes) memcpy(const_cast<unsigned char*>(r.base) + voff + soff, &v, 4);
     else if (voff < 0x80000000u) { fprintf(stderr, "emu: buffer store out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
 }
+typedef unsigned int u32x4_emu __attribute__((ext_vector_type(4)));
+static inline void raw_buffer_store_b128(u32x4_emu v, buffer_rsrc r, unsigned voff, unsigned soff) {
+    const unsigned long long end = (unsigned long long)voff + soff + 16ull;
+    if (voff < 0x80000000u && end <= r.nbytes) memcpy(const_cast<unsigned char*>(r.base) + voff + soff, &v, 16);
+    else if (voff < 0x80000000u) { fprintf(stderr, "emu: buffer store out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
+}
 static inline float fmed3f(float a, float b, float c) {
     const float lo = a < b ? a : b, hi = a < b ? b : a;
     return c < lo ? lo : (c > hi ? hi : c);
@@ -345,6 +351,7 @@ static inline float fmed3f(float a, float b, float c) {
 #define __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, aux) fsemu::raw_buffer_load_b96((r), (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, aux) fsemu::raw_buffer_load_b32((r), (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_raw_buffer_store_b32(v, r, voff, soff, aux) fsemu::raw_buffer_store_b32((v), (r), (unsigned)(voff), (unsigned)(soff))
+#define __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, aux) fsemu::raw_buffer_store_b128((v), (r), (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_fmed3f(a, b, c) fsemu::fmed3f((a), (b), (c))
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
@@ -353,6 +360,9 @@ static inline void fs_emu_global_load_lds_b128(const void* gsrc, void* lds_wave)
     memcpy(static_cast<char*>(lds_wave) + 16 * fsemu::blk().cur->lane, gsrc, 16);
 }
 #define __builtin_amdgcn_s_sleep(imm) ((void)0)
+/* a wave executes in lockstep on the GPU; the emulator's fibers do not -- where lanes of ONE wave exchange data through LDS
+ * without a workgroup barrier (fs_wino4.hip's transform), the kernel marks the hand-off with a wave barrier */
+#define __builtin_amdgcn_wave_barrier() fsemu::wave_sync()
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)   /* only ever applied to wave-uniform values */

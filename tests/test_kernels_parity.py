@@ -98,6 +98,67 @@ def test_winograd_conv_matches_oracle(eng, case):
     assert rel(y, direct) < TOL and not np.array_equal(y, direct)      # really the other algorithm
 
 
+WINO4_CASES = [
+    # name, x shape, Cout, epilogue: None | "bias_relu" | "pool" (bias + ReLU + the fused 2x2 max-pool) | "mask" (consumer-ReLU mask: the input-gradient form)
+    ("one_block", (1, 16, 32, 8), 64, None),
+    ("ragged_2img", (2, 21, 37, 8), 64, "bias_relu"),     # partial 16x32 blocks, a last tile row / column of 1 pixel
+    ("two_coblocks_pool", (1, 24, 40, 12), 128, "pool"),   # even extents that are not multiples of the 4x4 tile
+    ("mask_multi_item", (3, 20, 36, 16), 128, "mask"),     # 12 items walked by a persistent grid of 5 (FS_WINO4_WGS): several items per workgroup
+    ("tiny", (1, 3, 1, 4), 64, None),
+]
+
+
+@pytest.mark.parametrize("case", WINO4_CASES, ids=[c[0] for c in WINO4_CASES])
+def test_winograd_f4x4_conv_matches_oracle(eng, knob, case):
+    """wino4_conv_kernel (fs_wino4.hip, Winograd F(4x4,3x3): the VGG16 3x3 convs of fs_perceptual_loss, reference
+    libs/vgg16.py:45-173, and their input gradients) through fs_conv2d_fwd with a caller-transformed filter
+    (fs_wino4_transform_filter).  Same float64 oracle as every other conv; the tolerance is 5e-5 of the output's magnitude
+    instead of 2e-5: the F(4x4) transforms multiply by 2, 4, 5, 8 and 1/6, 1/12, 1/24 (measured ~1e-5 at 512 input channels;
+    the north-star budget is 1e-3).  Checked against the direct kernel too."""
+    name, xs, cout, epi = case
+    if name == "mask_multi_item":
+        knob("FS_WINO4_WGS", 5)
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal(xs).astype(np.float32)
+    w = (rng.standard_normal((3, 3, xs[3], cout)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32) if epi in ("bias_relu", "pool") else None
+    kw = dict(bias=up(eng, bias), out_relu=1) if bias is not None else {}
+    mask = None
+    if epi == "mask":
+        mask = rng.standard_normal((xs[0], xs[1], xs[2], cout)).astype(np.float32)
+        kw["mask_src"] = up(eng, mask)
+    direct = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME", **kw))
+    out = eng.conv2d(up(eng, x), up(eng, w), 1, "SAME", winograd=4, want_pool=(epi == "pool"), **kw)
+    y = down(eng, out[0] if epi == "pool" else out)
+    want = nnops.conv2d(x.astype(np.float64), w.astype(np.float64), 1, "SAME")
+    if bias is not None:
+        want = np.maximum(want + bias, 0.0)
+    if mask is not None:
+        want = np.where(mask > 0, want, 0.0)
+    assert y.shape == want.shape
+    assert rel(y, want) < 5e-5
+    assert rel(y, direct) < 5e-5 and not np.array_equal(y, direct)      # really the other algorithm
+    if epi == "pool":
+        pooled = down(eng, out[1])
+        # the pooled tensor is the max over the STORED values, bit for bit
+        assert np.array_equal(pooled, nnops.max_pool_2x2(y)[0])
+
+
+def test_winograd_f4x4_accuracy_on_a_deep_reduction(eng):
+    """The error of F(4x4,3x3) where it is largest -- post-ReLU-like data, 512 input channels (conv4_2's reduction): held to 5e-5 of
+    the output's magnitude (the direct fp32 kernel: ~3e-7, F(2x2,3x3): ~7e-7; float32 numpy restatement of F(4x4): 1.2e-5)."""
+    rng = np.random.default_rng(17)
+    x = (np.maximum(rng.standard_normal((1, 16, 32, 512)), 0) * 50).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 512, 64)) * 0.02).astype(np.float32)
+    want = nnops.conv2d(x.astype(np.float64), w.astype(np.float64), 1, "SAME")
+    direct = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME"))
+    wino = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME", winograd=4))
+    e_d, e_w = rel(direct, want), rel(wino, want)
+    rms = float(np.sqrt(((wino - want) ** 2).mean()) / np.sqrt((want ** 2).mean()))
+    print("F(4x4,3x3) at 512 input channels: max error %.2e of the magnitude (direct %.2e), relative rms %.2e" % (e_w, e_d, rms))
+    assert e_w < 5e-5 and rms < 1e-5, (e_d, e_w, rms)
+
+
 def test_winograd_accuracy_is_that_of_the_direct_kernel(eng):
     """F(2x2,3x3) only adds / subtracts / halves in its transforms: on post-ReLU-like data with a deep reduction
     (256 input channels) its error against the fp64 oracle stays within 2x of the direct fp32 kernel's."""

@@ -408,9 +408,11 @@ def test_hip_train_step_256_matches_oracle_and_batch_sum_property(knob_hip):
     batch-summed, losses.py:32,63; instance norm is per sample) that the 8-GPU SUM all-reduce
     relies on.  (The identity is held to 1e-4 of the largest gradient, which needs the SAME kernels on
     both sides -- a different summation order flips ReLU ties: the half-item Winograd kernel a batch of 2 selects for the
-    residual convs is therefore also selected for the single samples.)"""
+    residual convs is therefore also selected for the single samples, and the VGG Winograd convs run without split-K,
+    which a batch of 1 and a batch of 2 would otherwise take with different factors on conv3_x / conv4_x.)"""
     e = get_engine("hip")
     knob_hip("FS_WINO2H_MIN_ITEMS", 32)
+    knob_hip("FS_WINO_KSPLIT", 1)
     rng = np.random.default_rng(1)
     Wv = perceptual.synthetic_vgg_weights(seed=3)
     e.vgg_load(Wv)
