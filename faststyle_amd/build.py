@@ -13,6 +13,11 @@ SOURCES = ["fs_conv.hip", "fs_wino.hip", "fs_wino2.hip", "fs_wino2h.hip", "fs_wi
 OUT = os.path.join(HERE, "libfaststyle_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed"]
+# Per-source flags.  fs_wino4.hip: no SLP vectorisation -- with it (ROCm 7.2 clang) the packed-fp32 code of the output transform
+# produced WRONG values on gfx950 in two of the three epilogue instantiations (high halves of v_pk_* results, lanes 12-15 of every
+# row of 16; the CPU emulator build of the same source is right, tools/_dbg_w4.py shows it on the GPU), and packed fp32 beside
+# fp32 matrix instructions is slower anyway (MI355X_MICROARCH.md, price of one filler beside MFMAs).
+FILE_FLAGS = {"fs_wino4.hip": ["-fno-slp-vectorize"]}
 
 
 def _newest(paths):
@@ -34,7 +39,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None, objdir=None):
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
-            jobs.append([hipcc] + FLAGS + list(extra_flags) + ["-I", CSRC, "-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(s), []) + list(extra_flags) + ["-I", CSRC, "-c", s, "-o", o])
     if not jobs and os.path.exists(out) and os.path.getmtime(out) >= _newest(objs):
         return out
 

@@ -49,6 +49,10 @@ constexpr int kVF = 36 * kNT * kCC;              // 4608
 constexpr int kPatchF = 4 * kPlane + 4;          // 2568
 constexpr int kStageF = kUF + kVF + kPatchF;     // 16392 floats = 65,568 bytes per stage
 constexpr unsigned kOOB = 0x80000000u;
+#ifndef FS_W4_NA
+#define FS_W4_NA 32
+#endif
+constexpr int kNA = FS_W4_NA;                    // positions whose accumulators live in the accumulator file (the other 36 - kNA: vector registers)
 }  // namespace
 
 // U4[pos][ci/4][co/64][half = (co/32)%2][k = ci%4][m = co%16][mb = (co/16)%2] = (G g G^T)[pos], g = w[:, :, ci, co]  (w HWIO)
@@ -118,6 +122,38 @@ extern "C" int fs_debug_wino4_trace(long long* out, int n_wg) {
 #else
 #define FS_W4_MFMA_V(accq, av, bv) (accq) = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), (accq), 0, 0, 0)
 #endif
+// v_permlane32_swap_b32 (gfx950): lanes 32..63 of the first register trade places with lanes 0..31 of the second -- the two halves of a wave exchange a
+// register pair in ONE instruction, no LDS round trip
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FS_W4_SWAP(va_, vb_)                                                                                               \
+    do {                                                                                                                   \
+        const auto r_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(va_), __float_as_uint(vb_), false, false);        \
+        (va_) = __uint_as_float(r_[0]);                                                                                    \
+        (vb_) = __uint_as_float(r_[1]);                                                                                    \
+    } while (0)
+#elif defined(FS_EMULATOR)
+#define FS_W4_SWAP(va_, vb_)                                                     \
+    do {                                                                         \
+        const float as_ = __shfl_xor((va_), 32), bs_ = __shfl_xor((vb_), 32);    \
+        if ((threadIdx.x & 63) < 32) (vb_) = as_;                                \
+        else (va_) = bs_;                                                        \
+    } while (0)
+#else
+#define FS_W4_SWAP(va_, vb_) ((void)0)
+#endif
+// LDS accesses through COMPLETE byte addresses held in pinned vector registers (the lesson of fs_wgrad2.hip): with pointer
+// arithmetic on the shared array the backend re-derives "array base + stage + lane part + row" in front of the accesses -- six
+// vector adds per sweep for the patch rows alone, each ~12 cycles beside the matrix instructions.  One base register per
+// stream (computed before the sweep's first matrix instruction), everything else an immediate offset.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FS_W4_ADDR(p) ((int)(size_t)(const __attribute__((address_space(3))) char*)(p))
+#define FS_W4_LDS(T, addr) (*(__attribute__((address_space(3))) T*)(size_t)(unsigned)(addr))
+#define FS_W4_PIN(x) asm volatile("" : "+v"(x))
+#else   /* emulator / host pass: addresses are byte offsets from the workgroup's LDS array */
+#define FS_W4_ADDR(p) ((int)(reinterpret_cast<const char*>(p) - reinterpret_cast<const char*>(smem)))
+#define FS_W4_LDS(T, addr) (*reinterpret_cast<T*>(reinterpret_cast<char*>(smem) + (addr)))
+#define FS_W4_PIN(x) ((void)0)
+#endif
 // B^T x for one 6-vector (input transform, one dimension): 12 instructions
 #define FS_W4_BT(d0, d1, d2, d3, d4, d5, t0, t1, t2, t3, t4, t5) \
     do {                                                         \
@@ -143,6 +179,10 @@ extern "C" int fs_debug_wino4_trace(long long* out, int n_wg) {
         y3 = fmaf(8.f, s_, q_) + m5;                     \
     } while (0)
 
+// EPI: the epilogue form, a compile-time constant (a run-time choice costs a select per stored element): 0 raw (split-K partials,
+// the input gradient in front of a max-pool), 1 bias + ReLU (+ the fused 2x2 max-pool) -- the forward convs, 2 the consumer's
+// ReLU mask -- the input gradients
+template <int EPI>
 __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
     HIP_DYNAMIC_SHARED(float, smem)
 #ifdef FS_WINO4_TRACE
@@ -232,13 +272,11 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
     float4 uv[9];
     // patch: pixel e = tid + 256 i of the 18 x 34 patch, one float4 = the chunk's 4 channels (e >= 612: plane padding)
     float4 pv[3];
-    int ppy[3], ppx[3], pdst[3];
+    int pdst[3];
     unsigned gvo[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int e = tid + 256 * i;
-        ppy[i] = e < kPP ? e / kPW : -4096;
-        ppx[i] = e < kPP ? e - (e / kPW) * kPW : 0;
         pdst[i] = e < kPP ? e : kPP + (e - kPP) % (kPlane - kPP);
         gvo[i] = kOOB;
     }
@@ -248,11 +286,15 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
     const float* ub = uniform_ptr(a.w_wino4);
     const unsigned uvo = (unsigned)(((tid >> 6) * a.Cin * a.Cout + (tid & 63) * 4) * 4);
     unsigned uvo_eff = uvo;   // kOOB while the step the filter loads are for does not exist
-    auto patch_offsets = [&](const Item& I, int live) __attribute__((always_inline)) {
+    auto patch_offsets = [&](const Item& I, int live) __attribute__((always_inline)) {   // (once per item: the pixel coordinates are recomputed, not kept)
+        int t_ = tid;
+        FS_W4_PIN(t_);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int sy = I.oy0 - 1 + ppy[i], sx = I.ox0 - 1 + ppx[i];
-            const bool ok = live && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W;
+            const int e = t_ + 256 * i;
+            const int py = (int)(((float)e + 0.5f) * (1.0f / (float)kPW)), px = e - py * kPW;
+            const int sy = I.oy0 - 1 + py, sx = I.ox0 - 1 + px;
+            const bool ok = live && e < kPP && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W;
             gvo[i] = ok ? (unsigned)((sy * a.W + sx) * a.Cin) * 4u : kOOB;
         }
     };
@@ -261,44 +303,45 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, x_bytes, 0x00020000);
         pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, gvo[i], chunk * kCC * 4, 0));
     };
-    auto commit_patch_one = [&](float* patch, int i) __attribute__((always_inline)) {
-        float* d = patch + pdst[i];
-        d[0] = pv[i].x;
-        d[kPlane] = pv[i].y;
-        d[2 * kPlane] = pv[i].z;
-        d[3 * kPlane] = pv[i].w;
+    auto commit_patch_one = [&](int a_pc, int i) __attribute__((always_inline)) {   // a_pc: address of pixel pdst[i] in plane 0
+        FS_W4_LDS(float, a_pc) = pv[i].x;
+        FS_W4_LDS(float, a_pc + kPlane * 4) = pv[i].y;
+        FS_W4_LDS(float, a_pc + 2 * kPlane * 4) = pv[i].z;
+        FS_W4_LDS(float, a_pc + 3 * kPlane * 4) = pv[i].w;
     };
     auto issue_filter_one = [&](const Item& I, int chunk, int i) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ub), 0, u_bytes, 0x00020000);
         const unsigned so = (unsigned)((chunk * ncob + I.cob) * 1024) + (unsigned)i * u_pos4;
         uv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, uvo_eff, so, 0));
     };
-    auto commit_filter_one = [&](float* Ul, int i) __attribute__((always_inline)) { *reinterpret_cast<float4*>(Ul + (tid + 256 * i) * 4) = uv[i]; };
+    auto commit_filter_one = [&](int a_un, int i) __attribute__((always_inline)) { FS_W4_LDS(float4, a_un + i * 4096) = uv[i]; };   // a_un: address of float4 `tid`
     // input transform V = B^T d B of the 32 tiles x 4 channels of a chunk, split over PAIRS of lanes: wave w owns tile row w
     // (8 tiles x 4 channels); lane = (half h, channel c, tile column tx).  Half h does B^T d for columns 3h .. 3h+2 (18 reads of
-    // the patch, 36 instructions), the halves exchange through the wave's own scratch T[36][32] in LDS (same wave: program
-    // order, no barrier), half h does (.) B for rows 3h .. 3h+2 (18 reads of T, 36 instructions, 18 writes of V).
+    // the patch, 36 instructions); the halves trade nine registers each (v_permlane32_swap: rows 0..2 of the upper half's
+    // columns against rows 3..5 of the lower half's) and half h does (.) B for rows 3h .. 3h+2 (36 instructions, 18 writes of V).
     const int h_t = lane >> 5, c_t = (lane >> 3) & 3, tx_t = lane & 7;
     const int tsrc = c_t * kPlane + (4 * wave) * kPW + 4 * tx_t + 3 * h_t;            // patch offset of the lane's three columns
-    const int tT = 2 * kStageF + wave * (36 * 32) + (lane & 31);                      // the lane's slot in its wave's scratch (floats from smem)
     const int tdst = (wave >> 1) * 64 + c_t * 16 + (wave & 1) * 8 + tx_t;             // V offset of (tile 8 wave + tx, channel c)
     float td[18], tt[18];
-    auto transform_read = [&](const float* patch, int k0, int k1) __attribute__((always_inline)) {   // k = i * 3 + jj: d[i][3h + jj]
+    auto transform_read = [&](int a_pn, int k0, int k1) __attribute__((always_inline)) {   // k = i * 3 + jj: d[i][3h + jj]; a_pn: address of d[0][3h]
 #pragma unroll
-        for (int k = k0; k < k1; ++k) td[k] = patch[tsrc + (k / 3) * kPW + (k % 3)];
+        for (int k = k0; k < k1; ++k) td[k] = FS_W4_LDS(float, a_pn + ((k / 3) * kPW + (k % 3)) * 4);
     };
     auto transform_rows = [&]() __attribute__((always_inline)) {   // t[:, j] = B^T d[:, j] for the lane's three columns: tt[i * 3 + jj]
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj)
             FS_W4_BT(td[jj], td[3 + jj], td[6 + jj], td[9 + jj], td[12 + jj], td[15 + jj], tt[jj], tt[3 + jj], tt[6 + jj], tt[9 + jj], tt[12 + jj], tt[15 + jj]);
     };
-    auto transform_xwrite = [&](int k0, int k1) __attribute__((always_inline)) {   // t[i][3h + jj] -> T[i * 6 + 3h + jj][lane & 31]
+    auto transform_swap = [&]() __attribute__((always_inline)) {   // -> td[ii * 6 + j] = t[3h + ii][j]
 #pragma unroll
-        for (int k = k0; k < k1; ++k) smem[tT + ((k / 3) * 6 + 3 * h_t + (k % 3)) * 32] = tt[k];
-    };
-    auto transform_xread = [&](int k0, int k1) __attribute__((always_inline)) {    // t[3h + ii][j] -> td[ii * 6 + j]
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int k = k0; k < k1; ++k) td[k] = smem[tT + ((3 * h_t + k / 6) * 6 + (k % 6)) * 32];
+            for (int jj = 0; jj < 3; ++jj) {
+                float y = tt[i * 3 + jj], x = tt[(i + 3) * 3 + jj];   // lower half keeps y, gets the upper half's y into x; upper half keeps x, gets the lower half's x into y
+                FS_W4_SWAP(y, x);
+                td[6 * i + jj] = y;
+                td[6 * i + 3 + jj] = x;
+            }
     };
     auto transform_cols = [&]() __attribute__((always_inline)) {   // V[i][:] = t[i][:] B for the lane's three rows: tt[ii * 6 + j]
 #pragma unroll
@@ -306,21 +349,31 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
             FS_W4_BT(td[6 * ii], td[6 * ii + 1], td[6 * ii + 2], td[6 * ii + 3], td[6 * ii + 4], td[6 * ii + 5], tt[6 * ii], tt[6 * ii + 1], tt[6 * ii + 2],
                      tt[6 * ii + 3], tt[6 * ii + 4], tt[6 * ii + 5]);
     };
-    auto transform_write = [&](float* Vl, int k0, int k1) __attribute__((always_inline)) {   // position (3h + ii) * 6 + j
+    auto transform_write = [&](int a_vn, int k0, int k1) __attribute__((always_inline)) {   // position (3h + ii) * 6 + j; a_vn: address of position 18 h
 #pragma unroll
-        for (int k = k0; k < k1; ++k) Vl[tdst + (18 * h_t + k) * (kNT * kCC)] = tt[k];
+        for (int k = k0; k < k1; ++k) FS_W4_LDS(float, a_vn + k * (kNT * kCC * 4)) = tt[k];
     };
 
-    f32x4 acc[32][2];    // positions 0..31: accumulator file
-    f32x4 accv[4][2];    // positions 32..35: ordinary vector registers (FS_W4_MFMA_V)
-#define FS_W4_ACC(pos, mb, r) ((pos) < 32 ? acc[(pos) & 31][mb][r] : accv[(pos) & 3][mb][r])
+    f32x4 acc[kNA][2];         // positions 0 .. kNA-1: accumulator file
+    f32x4 accv[36 - kNA][2];   // the rest: ordinary vector registers (FS_W4_MFMA_V)
+// (accumulator-file elements leave through a volatile v_accvgpr_read exactly where the output transform consumes them: left to
+// itself the scheduler hoists hundreds of these reads to the top of the epilogue and the register allocator spills loop
+// invariants to scratch memory -- reloaded before every sweep behind `s_waitcnt vmcnt(0)`, i.e. behind every load in flight)
+// (accumulator-file elements leave through a volatile v_accvgpr_read exactly where the output transform consumes them: left to
+// itself the scheduler hoists hundreds of these reads to the top of the epilogue, and the register allocator answers by
+// spilling the sweep's loop invariants to scratch memory -- reloaded before every sweep behind `s_waitcnt vmcnt(0)`)
+#ifdef FS_W4_PLAIN_ACC
+#define FS_W4_ACC(pos, mb, r) ((pos) < kNA ? acc[(pos) < kNA ? (pos) : 0][mb][r] : accv[(pos) >= kNA ? (pos) - kNA : 0][mb][r])
+#else
+#define FS_W4_ACC(pos, mb, r) ((pos) < kNA ? FS_ACC_READ(acc[(pos) < kNA ? (pos) : 0][mb][r]) : accv[(pos) >= kNA ? (pos) - kNA : 0][mb][r])
+#endif
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int pos = 0; pos < 32; ++pos)
+        for (int pos = 0; pos < kNA; ++pos)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) acc[pos][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int pos = 0; pos < 4; ++pos)
+        for (int pos = 0; pos < 36 - kNA; ++pos)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) accv[pos][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
@@ -334,60 +387,80 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
     //   10-15  LDS reads of the patch of step q+1 (the lane's 6 x 3 inputs), three per slot
     //   18     B^T d, 36 vector instructions in ONE gap (beside the fp32 matrix instruction every vector instruction costs its
     //          issue time, the first of a gap more: bunch them)
-    //   20-25  the halves' exchange: LDS writes of t        36-41 LDS reads of t
-    //   27-29  LDS writes of the patch of step q+2 (its loads went out during the previous sweep)
-    //   31-33  global loads of the patch of step q+3
-    //   44     (.) B, 36 vector instructions               46-54 LDS writes of V, two per slot
+    //   22     the halves' exchange (9 swaps) + (.) B (36 vector instructions)
+    //   24-32  LDS writes of V, two per slot
+    //   34-36  LDS writes of the patch of step q+2 (its loads went out during the previous sweep)
+    //   38-40  global loads of the patch of step q+3
     //   56-64  LDS writes of the filter quads
-    auto slice = [&](int sl, float* Un, float* Vn, const float* Pn, float* Pc) __attribute__((always_inline)) {
+    struct Addr {
+        int pa, pb;         // matrix operands of the current stage: U (+ half, lane), V (+ half, lane)
+        int un, vn, pn;     // next stage: the thread's filter quad 0, its V position 18 h, its patch block d[0][3h]
+        int pc[3];          // this stage's patch area: the thread's three pixels
+    };
+    auto stage_addrs = [&](int o0, int o1) __attribute__((always_inline)) {   // o0 / o1: float offsets of the current / the other stage
+        Addr A;
+        A.pa = FS_W4_ADDR(smem + o0 + chh * 128 + lane * 2);
+        A.pb = FS_W4_ADDR(smem + o0 + kUF + th * 64 + lane);
+        A.un = FS_W4_ADDR(smem + o1 + tid * 4);
+        A.vn = FS_W4_ADDR(smem + o1 + kUF + tdst + 18 * h_t * (kNT * kCC));
+        A.pn = FS_W4_ADDR(smem + o1 + kUF + kVF + tsrc);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) A.pc[i] = FS_W4_ADDR(smem + o0 + kUF + kVF + pdst[i]);
+        FS_W4_PIN(A.pa);
+        FS_W4_PIN(A.pb);
+        FS_W4_PIN(A.un);
+        FS_W4_PIN(A.vn);
+        FS_W4_PIN(A.pn);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) FS_W4_PIN(A.pc[i]);
+        return A;
+    };
+    auto slice = [&](int sl, const Addr& AD) __attribute__((always_inline)) {
         if (sl < 9) {
             if (!(FS_W4_ABL & 2)) issue_filter_one(CU.I, CU.chunk, sl);
         } else if (sl >= 10 && sl < 16) {
-            if (!(FS_W4_ABL & 1)) transform_read(Pn, 3 * (sl - 10), 3 * (sl - 10) + 3);
+            if (!(FS_W4_ABL & 1)) transform_read(AD.pn, 3 * (sl - 10), 3 * (sl - 10) + 3);
         } else if (sl == 18) {
             if (!(FS_W4_ABL & 1)) transform_rows();
-        } else if (sl >= 20 && sl < 26) {
-            if (!(FS_W4_ABL & 1)) transform_xwrite(3 * (sl - 20), 3 * (sl - 20) + 3);
-        } else if (sl >= 27 && sl < 30) {
-            if (!(FS_W4_ABL & 4)) commit_patch_one(Pc, sl - 27);
-        } else if (sl >= 31 && sl < 34) {
-            if (!(FS_W4_ABL & 4)) issue_patch_one(CP.I, CP.chunk, sl - 31);
-        } else if (sl >= 36 && sl < 42) {
-            if (!(FS_W4_ABL & 1)) transform_xread(3 * (sl - 36), 3 * (sl - 36) + 3);
-        } else if (sl == 44) {
-            if (!(FS_W4_ABL & 1)) transform_cols();
-        } else if (sl >= 46 && sl < 55) {
-            if (!(FS_W4_ABL & 1)) transform_write(Vn, 2 * (sl - 46), 2 * (sl - 46) + 2);
+        } else if (sl == 22) {
+            if (!(FS_W4_ABL & 1)) {
+                transform_swap();
+                transform_cols();
+            }
+        } else if (sl >= 24 && sl < 33) {
+            if (!(FS_W4_ABL & 1)) transform_write(AD.vn, 2 * (sl - 24), 2 * (sl - 24) + 2);
+        } else if (sl >= 34 && sl < 37) {
+            if (!(FS_W4_ABL & 4)) commit_patch_one(AD.pc[sl - 34], sl - 34);
+        } else if (sl >= 38 && sl < 41) {
+            if (!(FS_W4_ABL & 4)) issue_patch_one(CP.I, CP.chunk, sl - 38);
         } else if (sl >= 56 && sl < 65) {
-            if (!(FS_W4_ABL & 2)) commit_filter_one(Un, sl - 56);
+            if (!(FS_W4_ABL & 2)) commit_filter_one(AD.un, sl - 56);
         }
     };
-    auto sweep = [&](const float* Uc, const float* Vc, float* Un, float* Vn, const float* Pn, float* Pc) __attribute__((always_inline)) {
-        const float* pa = Uc + chh * 128 + lane * 2;
-        const float* pb = Vc + th * 64 + lane;
+    auto sweep = [&](const Addr& AD) __attribute__((always_inline)) {
         f32x2 A[3];
         float B[3];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            A[h] = *reinterpret_cast<const f32x2*>(pa + h * (kBN * kCC));
-            B[h] = pb[h * (kNT * kCC)];
+            A[h] = FS_W4_LDS(f32x2, AD.pa + h * (kBN * kCC * 4));
+            B[h] = FS_W4_LDS(float, AD.pb + h * (kNT * kCC * 4));
         }
         fs_static_for<0, 36>([&](auto POS) __attribute__((always_inline)) {
             constexpr int pos = decltype(POS)::value;
             constexpr int c = pos % 3, n2 = (pos + 2) % 3;
-            if constexpr (pos < 32) acc[pos & 31][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c].x, B[c], acc[pos & 31][0], 0, 0, 0);
-            else FS_W4_MFMA_V(accv[pos & 3][0], A[c].x, B[c]);
+            if constexpr (pos < kNA) acc[pos < kNA ? pos : 0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c].x, B[c], acc[pos < kNA ? pos : 0][0], 0, 0, 0);
+            else FS_W4_MFMA_V(accv[pos >= kNA ? pos - kNA : 0][0], A[c].x, B[c]);
             __builtin_amdgcn_sched_barrier(0);
             if (pos + 2 < 36 && !(FS_W4_ABL & 8)) {   // operands two positions ahead
-                A[n2] = *reinterpret_cast<const f32x2*>(pa + (pos + 2) * (kBN * kCC));
-                B[n2] = pb[(pos + 2) * (kNT * kCC)];
+                A[n2] = FS_W4_LDS(f32x2, AD.pa + (pos + 2) * (kBN * kCC * 4));
+                B[n2] = FS_W4_LDS(float, AD.pb + (pos + 2) * (kNT * kCC * 4));
             }
-            slice(2 * pos, Un, Vn, Pn, Pc);
+            slice(2 * pos, AD);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (pos < 32) acc[pos & 31][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c].y, B[c], acc[pos & 31][1], 0, 0, 0);
-            else FS_W4_MFMA_V(accv[pos & 3][1], A[c].y, B[c]);
+            if constexpr (pos < kNA) acc[pos < kNA ? pos : 0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c].y, B[c], acc[pos < kNA ? pos : 0][1], 0, 0, 0);
+            else FS_W4_MFMA_V(accv[pos >= kNA ? pos - kNA : 0][1], A[c].y, B[c]);
             __builtin_amdgcn_sched_barrier(0);
-            slice(2 * pos + 1, Un, Vn, Pn, Pc);
+            slice(2 * pos + 1, AD);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -396,49 +469,68 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
     // block mb, the four channels co0 + 32 chh + 16 mb + 4 g .. + 3 of all 36 positions: output transform in registers, one
     // 16-byte store per pixel and channel block.  Pixels outside the image (edge blocks) carry the out-of-range offset: loads
     // return 0, stores are dropped by the hardware range check.
-    auto epilogue = [&](const Item& I) __attribute__((always_inline)) {
-        const int tl = 16 * th + (lane & 15);
+    // FULL: the item's 16 x 32-pixel block lies inside the image (every VGG16 layer of a 256 x 256 batch): one lane base register,
+    // the pixel offsets are scalars.  Edge blocks swap the base for the out-of-range offset per pixel.
+    auto epilogue_body = [&](auto FULLT, const Item& I) __attribute__((always_inline)) {
+        constexpr bool full = decltype(FULLT)::value;
+        // (an opaque copy of the lane index: everything derived from it is computed HERE, once per item -- hoisted out of the item
+        // loop such values sit in registers across every sweep and push the staging state into scratch memory)
+        int ln = lane;
+        FS_W4_PIN(ln);
+        const int tl = 16 * th + (ln & 15);
         const int oy = I.oy0 + 4 * (tl >> 3), ox = I.ox0 + 4 * (tl & 7);
-        const int co = I.cob * kBN + chh * 32 + 4 * (lane >> 4);
+        const int co = I.cob * kBN + chh * 32 + 4 * (ln >> 4);
         const float* yb = a.y + ((size_t)I.n + (ks > 1 ? (size_t)I.z * a.N : 0)) * a.Ho * a.Wo * a.Cout;
         const unsigned img_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.Ho * a.Wo * a.Cout) * 4u);
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(yb)), 0, img_bytes, 0x00020000);
-        const int rowp = a.Wo * a.Cout;
-        const int obase = (oy * a.Wo + ox) * a.Cout + co;
-        unsigned voff[16];
-#pragma unroll
-        for (int px = 0; px < 16; ++px) {
-            const int py = px >> 2, pxx = px & 3;
-            const bool ok = oy + py < a.Ho && ox + pxx < a.Wo;
-            voff[px] = ok ? (unsigned)(obase + py * rowp + pxx * a.Cout) * 4u : kOOB;
-        }
-        const float* msn = a.mask_src ? uniform_ptr(a.mask_src + (size_t)I.n * a.Ho * a.Wo * a.Cout) : nullptr;
-        const bool relu_out = a.out_relu != 0;
-        float* pon = a.pool_out ? a.pool_out + (size_t)I.n * (a.Ho >> 1) * (a.Wo >> 1) * a.Cout : nullptr;
-        // Per channel block: issue its 16 mask loads, transform (~600 vector instructions: covers their latency), apply + store.
-        // Register budget outside the accumulator file: 64 mask + 64 outputs + 24 intermediates + 16 offsets.
+        const unsigned rowp4 = __builtin_amdgcn_readfirstlane((unsigned)(a.Wo * a.Cout) * 4u), col4 = __builtin_amdgcn_readfirstlane((unsigned)a.Cout * 4u);
+        const unsigned obase = (unsigned)((oy * a.Wo + ox) * a.Cout + co) * 4u;
+        const int ry = a.Ho - oy, cx = a.Wo - ox;   // valid rows / columns of the lane's tile (edge blocks)
+        auto voff = [&](int px) __attribute__((always_inline)) { return (full || ((px >> 2) < ry && (px & 3) < cx)) ? obase : kOOB; };
+        auto soff = [&](int px, int mb) __attribute__((always_inline)) { return (unsigned)(px >> 2) * rowp4 + (unsigned)(px & 3) * col4 + (unsigned)mb * 64u; };
+        const float* msn = EPI == 2 ? uniform_ptr(a.mask_src + (size_t)I.n * a.Ho * a.Wo * a.Cout) : nullptr;
+        const bool pool = EPI == 1 && a.pool_out != nullptr;
+        auto relu1 = [](float x) __attribute__((always_inline)) {   // ONE v_max_f32 (fmaxf comes with a canonicalising second instruction)
+#if defined(__HIP_DEVICE_COMPILE__)
+            float r;
+            asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+            return r;
+#else
+            return x > 0.f ? x : 0.f;
+#endif
+        };
+        // Per channel block: mask loads of pixels 0..7 | output transform (~600 vector instructions: covers their latency) | mask
+        // loads of pixels 8..15 | apply + store 0..7 | apply + store 8..15.  Register peak outside the accumulator file: 32 mask
+        // + 64 outputs + 30 intermediates during the transform, 64 + 64 behind it.
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             float4 mk[16];
-            if (msn) {
-                const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(msn), 0, img_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EPI == 2 ? msn : yb), 0, img_bytes, 0x00020000);
+            if (EPI == 2) {
 #pragma unroll
-                for (int px = 0; px < 16; ++px) mk[px] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(mr, voff[px], mb * 64, 0));
+                for (int px = 0; px < 8; ++px) mk[px] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(mr, voff(px), soff(px, mb), 0));
             }
             float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias) bs = *reinterpret_cast<const float4*>(a.bias + co + 16 * mb);
+            if (EPI == 1 && a.bias) bs = *reinterpret_cast<const float4*>(a.bias + co + 16 * mb);
             __builtin_amdgcn_sched_barrier(0);
             float o[16][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float s[4][6];   // A^T M: rows 0..3, columns 0..5
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
-                    FS_W4_AT(FS_W4_ACC(q, mb, r), FS_W4_ACC(6 + q, mb, r), FS_W4_ACC(12 + q, mb, r), FS_W4_ACC(18 + q, mb, r), FS_W4_ACC(24 + q, mb, r),
-                             FS_W4_ACC(30 + q, mb, r), s[0][q], s[1][q], s[2][q], s[3][q]);
+                for (int q = 0; q < 6; ++q) {
+                    const float m0 = FS_W4_ACC(q, mb, r), m1 = FS_W4_ACC(6 + q, mb, r), m2 = FS_W4_ACC(12 + q, mb, r), m3 = FS_W4_ACC(18 + q, mb, r),
+                                m4 = FS_W4_ACC(24 + q, mb, r), m5 = FS_W4_ACC(30 + q, mb, r);   // (each element read ONCE: the reads are volatile)
+                    FS_W4_AT(m0, m1, m2, m3, m4, m5, s[0][q], s[1][q], s[2][q], s[3][q]);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     FS_W4_AT(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[4 * i][r], o[4 * i + 1][r], o[4 * i + 2][r], o[4 * i + 3][r]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (EPI == 2) {
+#pragma unroll
+                for (int px = 8; px < 16; ++px) mk[px] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(mr, voff(px), soff(px, mb), 0));
             }
             __builtin_amdgcn_sched_barrier(0);
             const float bsv[4] = {bs.x, bs.y, bs.z, bs.w};
@@ -447,14 +539,20 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
                 const float mv[4] = {mk[px].x, mk[px].y, mk[px].z, mk[px].w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = o[px][r] + bsv[r];
-                    v = relu_out ? fmaxf(v, 0.f) : v;
-                    if (msn) v = mv[r] > 0.f ? v : 0.f;
+                    float v = o[px][r];
+                    if (EPI == 1) v = a.out_relu ? relu1(v + bsv[r]) : v + bsv[r];
+                    if (EPI == 2) v = mv[r] > 0.f ? v : 0.f;
                     o[px][r] = v;
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fs_u32x4, make_float4(o[px][0], o[px][1], o[px][2], o[px][3])), yr, voff[px], mb * 64, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fs_u32x4, make_float4(o[px][0], o[px][1], o[px][2], o[px][3])), yr, voff(px),
+                                                       soff(px, mb), 0);
             }
-            if (pon) {   // 2x2/2 max-pool: the tile's four windows (tiles sit on multiples of four; Ho, Wo even)
+            if (pool) {   // 2x2/2 max-pool: the tile's four windows (tiles sit on multiples of four; Ho, Wo even)
+                const float* pb_ = a.pool_out + (size_t)I.n * (a.Ho >> 1) * (a.Wo >> 1) * a.Cout;
+                const unsigned pimg = __builtin_amdgcn_readfirstlane((unsigned)((a.Ho >> 1) * (a.Wo >> 1) * a.Cout) * 4u);
+                const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(pb_)), 0, pimg, 0x00020000);
+                const unsigned pbase = (unsigned)(((oy >> 1) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + co) * 4u;
+                const unsigned prow4 = __builtin_amdgcn_readfirstlane((unsigned)((a.Wo >> 1) * a.Cout) * 4u);
 #pragma unroll
                 for (int wy = 0; wy < 2; ++wy)
 #pragma unroll
@@ -463,46 +561,55 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
                         float m4[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) m4[r] = fmaxf(fmaxf(o[p00][r], o[p00 + 1][r]), fmaxf(o[p00 + 4][r], o[p00 + 5][r]));
-                        const int qy = (oy >> 1) + 2 * 0 + wy, qx = (ox >> 1) + wx;
-                        if (2 * qy < a.Ho && 2 * qx < a.Wo)
-                            *reinterpret_cast<float4*>(pon + ((size_t)qy * (a.Wo >> 1) + qx) * a.Cout + co + 16 * mb) = make_float4(m4[0], m4[1], m4[2], m4[3]);
+                        const bool okp = full || (2 * wy < ry && 2 * wx < cx);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fs_u32x4, make_float4(m4[0], m4[1], m4[2], m4[3])), pr, okp ? pbase : kOOB,
+                                                               (unsigned)wy * prow4 + (unsigned)wx * col4 + (unsigned)mb * 64u, 0);
                     }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    auto epilogue = [&](const Item& I) __attribute__((always_inline)) {
+        if (I.oy0 + kBH <= a.Ho && I.ox0 + kBW <= a.Wo)
+            epilogue_body(std::true_type{}, I);
+        else
+            epilogue_body(std::false_type{}, I);
         zero_acc();
+        // Nothing of the epilogue may still be in flight at the loop header: loads and stores share ONE counter and complete out
+        // of order with each other, so with stores pending the compiler places `s_waitcnt vmcnt(0)` -- every filter load just
+        // issued included -- in front of the sweep's first use of a loaded register instead of an exact count.  The drain hides
+        // behind the 288 zeroing moves.
+#ifndef FS_W4_X1
+        FS_WAIT_VMEM();
+#endif
     };
 
     // ---- prologue: step 0 complete in stage 0 (patch, V, U), the patch of step 1 in stage 1, the patch of step 2 in registers
-    float* const U0 = smem;
-    float* const V0 = smem + kUF;
-    float* const P0 = smem + kUF + kVF;
+    const Addr AP0 = stage_addrs(kStageF, 0), AP1 = stage_addrs(0, kStageF);   // "next stage" = stage 0 / stage 1
     patch_offsets(CP.I, 1);
 #pragma unroll
     for (int i = 0; i < 3; ++i) issue_patch_one(CP.I, CP.chunk, i);
 #pragma unroll
     for (int i = 0; i < 9; ++i) issue_filter_one(CU.I, CU.chunk, i);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) commit_patch_one(P0, i);
+    for (int i = 0; i < 3; ++i) commit_patch_one(AP1.pc[i], i);   // (AP1's current stage is stage 0)
 #pragma unroll
-    for (int i = 0; i < 9; ++i) commit_filter_one(U0, i);
+    for (int i = 0; i < 9; ++i) commit_filter_one(AP0.un, i);
     if (cursor_next(CP) || !CP.live) patch_offsets(CP.I, CP.live);
 #pragma unroll
     for (int i = 0; i < 3; ++i) issue_patch_one(CP.I, CP.chunk, i);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) commit_patch_one(P0 + kStageF, i);
+    for (int i = 0; i < 3; ++i) commit_patch_one(AP0.pc[i], i);   // stage 1's patch area
     if (cursor_next(CP) || !CP.live) patch_offsets(CP.I, CP.live);
 #pragma unroll
     for (int i = 0; i < 3; ++i) issue_patch_one(CP.I, CP.chunk, i);
     cursor_next(CU);   // the filter cursor now points at step 1
     __syncthreads();
-    transform_read(P0, 0, 18);
+    transform_read(AP0.pn, 0, 18);
     transform_rows();
-    transform_xwrite(0, 18);
-    __builtin_amdgcn_wave_barrier();   // (the halves of a wave exchange through LDS: lockstep on the GPU, a fiber hand-off in the emulator)
-    transform_xread(0, 18);
+    transform_swap();
     transform_cols();
-    transform_write(V0, 0, 18);
+    transform_write(AP0.vn, 0, 18);
     __syncthreads();
     FS_WAIT_VMEM();
 #ifdef FS_WINO4_TRACE
@@ -521,7 +628,12 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
             const long long q0 = FS_W4_NOW();
 #endif
             const int o0 = (q & 1) ? kStageF : 0, o1 = kStageF - o0;
-            sweep(smem + o0, smem + o0 + kUF, smem + o1, smem + o1 + kUF, smem + o1 + kUF + kVF, smem + o0 + kUF + kVF);
+            const Addr AD = stage_addrs(o0, o1);
+            __builtin_amdgcn_sched_barrier(0);
+            sweep(AD);
+#if defined(FS_W4_X2) && defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
             cursor_next(CU);
 #ifdef FS_WINO4_TRACE
             const long long q1 = FS_W4_NOW();
@@ -584,7 +696,7 @@ void wino4_plan(const ConvArgs& a, ConvPlan* out) {
     p.TW = kBW;
     p.tiles_y = cdiv(a.Ho, kBH);
     p.tiles_x = cdiv(a.Wo, kBW);
-    p.lds_bytes = 4 * (2 * kStageF + 4 * 36 * 32);   // two stages + the waves' transform exchange scratch
+    p.lds_bytes = 4 * 2 * kStageF;
     p.ksplit = 1;
     const long items = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / kBN);
     const int nchunks = a.Cin / kCC;
@@ -601,10 +713,19 @@ int wino4_launch(const ConvArgs& a, hipStream_t s) {
     const ConvPlan& p = a.p;
     const long items = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / kBN) * (p.ksplit > 1 ? p.ksplit : 1);
     const int wgs = tune_int("FS_WINO4_WGS", 256);
-    static BigLds lds_attr;
-    lds_attr.ensure(reinterpret_cast<const void*>(wino4_conv_kernel));
     const long grid = items < wgs ? items : wgs;
-    hipLaunchKernelGGL(wino4_conv_kernel, dim3((unsigned)grid), dim3(256), (size_t)p.lds_bytes, s, a);
+    static BigLds lds_attr[3];
+    const int epi = p.ksplit > 1 ? 0 : (a.mask_src ? 2 : ((a.bias || a.out_relu || a.pool_out) ? 1 : 0));
+    if (epi == 0) {
+        lds_attr[0].ensure(reinterpret_cast<const void*>(wino4_conv_kernel<0>));
+        hipLaunchKernelGGL(wino4_conv_kernel<0>, dim3((unsigned)grid), dim3(256), (size_t)p.lds_bytes, s, a);
+    } else if (epi == 1) {
+        lds_attr[1].ensure(reinterpret_cast<const void*>(wino4_conv_kernel<1>));
+        hipLaunchKernelGGL(wino4_conv_kernel<1>, dim3((unsigned)grid), dim3(256), (size_t)p.lds_bytes, s, a);
+    } else {
+        lds_attr[2].ensure(reinterpret_cast<const void*>(wino4_conv_kernel<2>));
+        hipLaunchKernelGGL(wino4_conv_kernel<2>, dim3((unsigned)grid), dim3(256), (size_t)p.lds_bytes, s, a);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
