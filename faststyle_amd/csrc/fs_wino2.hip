@@ -715,11 +715,31 @@ __global__ __launch_bounds__(1024) void wino2_rem_epilogue_kernel(ConvArgs a) {
     float v[16], cs = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = 0.f;
-    for (int z = 0; z < ks; ++z) {
-        const float* pz = part + (size_t)z * (4 * kNT) * kBN;
-        cs += pz[0];   // shift of the one-pass statistics: the block's first pixel of the channel
+    // (every load of a thread in flight before the first add: with the partials walked one after the other the kernel paid one
+    // memory latency per partial -- 23 us for 20 MB at batch 32; rem_ks is a power of two <= 8, summed in the same fixed order)
+    auto sum_group = [&](auto KS, int z0) __attribute__((always_inline)) {   // partials z0 .. z0 + K - 1
+        constexpr int K = decltype(KS)::value;
+        float t[K][16], c0[K];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] += pz[(g * 16 + i) * kBN];
+        for (int z = 0; z < K; ++z) {
+            const float* pz = part + (size_t)(z0 + z) * (4 * kNT) * kBN;
+            c0[z] = pz[0];   // shift of the one-pass statistics: the block's first pixel of the channel
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t[z][i] = pz[(g * 16 + i) * kBN];
+        }
+#pragma unroll
+        for (int z = 0; z < K; ++z) {
+            cs += c0[z];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] += t[z][i];
+        }
+    };
+    if (ks == 2) {
+        sum_group(std::integral_constant<int, 2>{}, 0);
+    } else if ((ks & 3) == 0) {
+        for (int z0 = 0; z0 < ks; z0 += 4) sum_group(std::integral_constant<int, 4>{}, z0);
+    } else {
+        for (int z = 0; z < ks; ++z) sum_group(std::integral_constant<int, 1>{}, z);
     }
     const int Ha = a.Ho - 2 * a.add_pad, Wa = a.Wo - 2 * a.add_pad;
     if (a.stats) {

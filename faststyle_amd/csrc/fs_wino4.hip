@@ -52,6 +52,10 @@ constexpr unsigned kOOB = 0x80000000u;
 #ifndef FS_W4_NA
 #define FS_W4_NA 32
 #endif
+#ifndef FS_W4_MASK_EARLY
+#define FS_W4_MASK_EARLY 8
+#endif
+constexpr int kMaskEarly = FS_W4_MASK_EARLY;      // consumer-mask loads issued in front of the output transform (the rest behind it)
 constexpr int kNA = FS_W4_NA;                    // positions whose accumulators live in the accumulator file (the other 36 - kNA: vector registers)
 }  // namespace
 
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
             const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EPI == 2 ? msn : yb), 0, img_bytes, 0x00020000);
             if (EPI == 2) {
 #pragma unroll
-                for (int px = 0; px < 8; ++px) mk[px] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(mr, voff(px), soff(px, mb), 0));
+                for (int px = 0; px < kMaskEarly; ++px) mk[px] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(mr, voff(px), soff(px, mb), 0));
             }
             float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
             if (EPI == 1 && a.bias) bs = *reinterpret_cast<const float4*>(a.bias + co + 16 * mb);
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if (EPI == 2) {
 #pragma unroll
-                for (int px = 8; px < 16; ++px) mk[px] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(mr, voff(px), soff(px, mb), 0));
+                for (int px = kMaskEarly; px < 16; ++px) mk[px] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(mr, voff(px), soff(px, mb), 0));
             }
             __builtin_amdgcn_sched_barrier(0);
             const float bsv[4] = {bs.x, bs.y, bs.z, bs.w};

@@ -160,7 +160,16 @@ inline void run_block(Block& b, const std::function<void()>& body, Idx bid, Idx 
         while (b.stacks.size() < nt) b.stacks.push_back((char*)aligned_alloc(64, kStack));
     }
     b.waves.assign(nt / 64, Wave());
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define FS_EMU_ASAN 1
+#endif
+#endif
+#ifdef FS_EMU_ASAN   /* sanitized build (tests/emu_lib.build_emu_sanitized): the LDS block is EXACTLY the launch's size, so an out-of-range LDS index lands in a redzone */
+    if (smem != b.smem_cap || !b.smem) { free(b.smem); b.smem_cap = smem; b.smem = (char*)aligned_alloc(64, (smem + 63) / 64 * 64 ? (smem + 63) / 64 * 64 : 64); }
+#else
     if (smem + 64 > b.smem_cap) { free(b.smem); b.smem_cap = smem + 64; b.smem = (char*)aligned_alloc(64, (b.smem_cap + 63) / 64 * 64); }
+#endif
     memset(b.smem, 0xCD, smem);   // poison: reading unwritten LDS shows up as garbage
     for (unsigned t = 0; t < nt; ++t) {
         Fiber& f = b.fibers[t];

@@ -15,7 +15,39 @@ EMU_SO = os.path.join(EMU_DIR, "libfaststyle_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
+ASAN_RT = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"
+
+
+def build_emu_sanitized():
+    """The same sources with -fsanitize=address,undefined (tests/test_fuzz_emu.py runs tools/fuzz_emu.py against it in a
+    subprocess that preloads the ASan runtime): an out-of-range LDS or global index of a ragged-edge path is then an error
+    even where it does not change a compared value.  Device buffers are numpy allocations (ASan intercepts malloc once its
+    runtime is preloaded), a workgroup's LDS is a heap block of exactly the launch's size."""
+    so = os.path.join(EMU_DIR, "asan", "libfaststyle_emu_asan.so")
+    srcs = [os.path.join(fsbuild.CSRC, s) for s in fsbuild.SOURCES]
+    deps = srcs + [os.path.join(fsbuild.CSRC, h) for h in os.listdir(fsbuild.CSRC) if h.endswith(".h")] + \
+        [os.path.join(EMU_DIR, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "faststyle_hip.h"),
+         os.path.join(ROOT, "include", "faststyle_io.h")]
+    if os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(p) for p in deps):
+        return so
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    objs, procs = [], []
+    for s in srcs:
+        o = os.path.join(EMU_DIR, "asan", os.path.basename(s) + ".o")
+        objs.append(o)
+        procs.append(subprocess.Popen([CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-fsanitize=address,undefined",
+                                       "-fno-sanitize=float-divide-by-zero,float-cast-overflow", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                                       "-shared-libsan", "-Wno-psabi", "-Wno-pass-failed", "-I", EMU_DIR, "-I", fsbuild.CSRC, "-c", s, "-o", o]))
+    for p in procs:
+        if p.wait():
+            raise RuntimeError("sanitized emulator build failed")
+    subprocess.check_call([CLANG, "-shared", "-fsanitize=address,undefined", "-shared-libsan", "-o", so] + objs + ["-lpthread"])
+    return so
+
+
 def build_emu():
+    if os.environ.get("FS_EMU_SANITIZE") == "1":
+        return build_emu_sanitized()
     srcs = [os.path.join(fsbuild.CSRC, s) for s in fsbuild.SOURCES]
     deps = srcs + [os.path.join(fsbuild.CSRC, h) for h in os.listdir(fsbuild.CSRC) if h.endswith(".h")] + \
         [os.path.join(EMU_DIR, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "faststyle_hip.h"),

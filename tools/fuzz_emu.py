@@ -9,6 +9,7 @@
   * gram_stream_kernel / gram_reduce_kernel / gram_bwd_kernel (fs_gram.hip): every channel count they take, pixel counts
     that end inside a tile, several pixel ranges;
   * wino2_conv_kernel with bias / ReLU, wgrad2_kernel, conv3x3_to3_kernel on ragged shapes;
+  * wino4_conv_kernel (fs_wino4.hip, Winograd F(4x4,3x3)): raw / bias + ReLU / consumer-mask epilogues, ragged 16x32 blocks;
   * conv_s16_kernel (fs_s16.hip): the 9x9 3 -> 16 layer with mirror or zero padding and per-tile statistics, VGG conv1_1's
     form (3 -> 64, per-channel affine on load over zero padding, bias + ReLU); ragged tiles, several persistent grid sizes.
 Every case prints one line; a mismatch raises.  tests/ holds fixed-shape versions of the same checks."""
@@ -72,7 +73,7 @@ def main():
     up, down = e.mem.from_numpy, e.mem.to_numpy
     inst = [(16, 32, 3, 2), (32, 64, 2, 1), (32, 64, 3, 2), (64, 128, 2, 1), (64, 64, 3, 1)]
     for it in range(cases):
-        kind = it % 12
+        kind = it % 13
         if kind == 11:        # 16-channel-block streaming kernel (fs_s16.hip)
             n, h, w = int(rng.integers(1, 3)), int(rng.integers(9, 50)), int(rng.integers(9, 50))
             os.environ["FS_S16_WGS"] = str(int(rng.choice([1, 3, 512])))
@@ -156,6 +157,27 @@ def main():
             r = rel(g, want)
             print("case %3d gram_stream %s items %s  rel %.2e" % (it, f.shape, os.environ["FS_GRAM2_ITEMS"], r), flush=True)
             assert r < TOL and np.array_equal(g, g.transpose(0, 2, 1))
+        elif kind == 12:      # Winograd F(4x4,3x3) (fs_wino4.hip): SAME 3x3, the three epilogue forms, ragged 16x32 blocks, several items per workgroup
+            cin, cout = int(rng.choice([4, 8, 20, 64])), int(rng.choice([64, 128]))
+            n, h, w = int(rng.integers(1, 3)), int(rng.integers(1, 44)), int(rng.integers(1, 70))
+            os.environ["FS_WINO4_WGS"] = str(int(rng.choice([1, 3, 256])))
+            e.lib.fs_debug_reload_env()
+            x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+            wt = (rng.standard_normal((3, 3, cin, cout)) * 0.1).astype(np.float32)
+            epi = int(rng.integers(3))
+            kw, want = {}, nnops.conv2d(x.astype(np.float64), wt.astype(np.float64), 1, "SAME")
+            if epi == 1:
+                bias = rng.standard_normal((cout,)).astype(np.float32)
+                kw = dict(bias=up(bias), out_relu=1)
+                want = np.maximum(want + bias, 0.0)
+            elif epi == 2:
+                mask = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+                kw = dict(mask_src=up(mask))
+                want = np.where(mask > 0, want, 0.0)
+            y = down(e.conv2d(up(x), up(wt), 1, "SAME", winograd=4, **kw))
+            r = rel(y, want)
+            print("case %3d wino4 %s -> %d epilogue %d wgs %s  rel %.2e" % (it, x.shape, cout, epi, os.environ["FS_WINO4_WGS"], r), flush=True)
+            assert r < 5e-5
         elif kind == 8:       # second-generation Winograd kernel (fs_wino2.hip): SAME 3x3, bias + ReLU epilogue, ragged 16x16 blocks
             cin, cout = int(rng.choice([8, 16, 64, 128])), int(rng.choice([64, 128]))
             n, h, w = int(rng.integers(1, 3)), int(rng.integers(1, 40)), int(rng.integers(1, 40))
