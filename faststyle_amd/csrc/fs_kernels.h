@@ -473,6 +473,8 @@ void tune_reload();
 unsigned tune_epoch();   // bumped by tune_reload: cached plans made under older knob values are stale
 // does a launch of this size qualify?  (one workgroup reads N*C*T*groups records: beyond a few 10^4 a launch of its own,
 // spread over the chip, is faster)
+// (GPU-UNVERIFIED when on: its cross-XCD hand-off -- relaxed agent-scope atomics + a manual s_waitcnt -- is exercised by the
+// emulator tests only, which cannot model cache visibility.)
 inline bool fused_finalize_ok(int N, int C, int T, int groups) {
     // OFF by default -- measured on MI355X (round 3): correct, but SLOWER than the launch it replaces.  The merge runs on ONE
     // compute unit while the other 255 idle: with device-scope fences +36 us per unit, with coherent (sc1) record stores /

@@ -342,6 +342,9 @@ __global__ __launch_bounds__(256) void wino2_conv_kernel(ConvArgs a) {
 #ifndef FS_W2_DMA
 #define FS_W2_DMA 0   /* 1: the filter chunk goes global -> LDS by DMA (global_load_lds_dwordx4) -- no staging registers, no ds_write pass, but MEASURED SLOWER (sweep 5.9k -> 6.6k cycles per chunk): kept as a recorded experiment */
 #endif
+#if FS_W2_DMA && !defined(FS_LDS_BARRIER_OFF)
+#error "FS_W2_DMA: the filter stage arrives by global_load_lds (completes under vmcnt) -- build with -DFS_LDS_BARRIER_OFF so that the chunk barrier waits for it; FS_LDS_BARRIER orders LDS traffic only"
+#endif
 #ifndef FS_W2_ABL
 #define FS_W2_ABL 0   /* timing experiments (tools/conv_trace.py): 1 no input transform, 2 no filter commit, 4 no global loads, 8 no operand reads */
 #endif

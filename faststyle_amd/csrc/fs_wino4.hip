@@ -620,6 +620,16 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
     tr_pro = FS_W4_NOW() - tr_t0;
 #endif
 
+    // Optional stagger (FS_WINO4_STAGGER = s > 0, launches with >= 8 items per workgroup): workgroups of equal item lists run in
+    // lockstep -- every epilogue's 33 MB of stores (and the mask loads of the input gradients) hit HBM at the same moment, every
+    // sweep phase has none.  Workgroup v starts (v mod 8) * s / 64 of an item period late.
+    if (a.p.skew > 0 && my_items >= 8) {
+        const int period = (nchunks_all / ks) * 3600;   // cycles of one item, roughly
+        const long long wait = (long long)(vb & 7) * period * a.p.skew / 512;
+        const long long t_begin = __builtin_readcyclecounter();
+        while ((long long)__builtin_readcyclecounter() - t_begin < wait) __builtin_amdgcn_s_sleep(32);
+    }
+
     // ---- the flat pipeline over (item, chunk) steps: step q multiplies out of stage q & 1 while step q+1 is prepared into the
     // other stage (U, V), the patch of step q+2 lands in this stage's patch area and the patch loads of step q+3 go out
     int q = 0;
@@ -702,6 +712,7 @@ void wino4_plan(const ConvArgs& a, ConvPlan* out) {
     p.tiles_x = cdiv(a.Wo, kBW);
     p.lds_bytes = 4 * 2 * kStageF;
     p.ksplit = 1;
+    p.skew = tune_int("FS_WINO4_STAGGER", 0);
     const long items = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / kBN);
     const int nchunks = a.Cin / kCC;
     const int max_ks = tune_int("FS_WINO_KSPLIT", 4);
