@@ -696,7 +696,9 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
 bool wino4_eligible(const ConvArgs& a) {
     // the VGG16 form only: 3x3 stride 1 SAME, plain source, bias / ReLU / pool or consumer mask in the epilogue
     const bool pad_ok = a.pad_t == 1 && a.pad_l == 1 && a.Ho == a.H && a.Wo == a.W;
-    return a.w_wino4 && tune_int("FS_WINO_V", 4) >= 4 && a.KH == 3 && a.KW == 3 && a.stride == 1 && pad_ok && a.src_mode == SRC_PLAIN &&
+    // byte offsets inside one sample are 32-bit with the top bit reserved for "out of range"; the filter planes likewise
+    const bool fits = (double)a.H * a.W * (a.Cin > a.Cout ? a.Cin : a.Cout) * 4.0 < 2147483648.0 && 36.0 * a.Cin * a.Cout * 4.0 < 2147483648.0;
+    return fits && a.w_wino4 && tune_int("FS_WINO_V", 4) >= 4 && a.KH == 3 && a.KW == 3 && a.stride == 1 && pad_ok && a.src_mode == SRC_PLAIN &&
            a.Cin % kCC == 0 && a.Cout % kBN == 0 && !a.shuffle && !a.add_src && !a.in_a && !a.stats && !a.route_src && a.w_nstride == 0 &&
            a.dil_x <= 1 && (!a.pool_out || (!(a.Ho & 1) && !(a.Wo & 1)));
 }
