@@ -574,6 +574,8 @@ size_t fs_conv2d_wgrad_workspace_bytes(fs_wgrad_desc* d) {
     fs::WgradArgs a;
     if (fill_wgrad(d, &a)) return 0;
     if (is_gram2(a)) return fs::gram2_slab_floats(a.N, a.H * a.W, a.Cin) * sizeof(float);
+    fs::WgwArgs ww;
+    if (const size_t f = fs::wgw_plan(&a, 1, &ww)) return f * sizeof(float);      // Winograd filter gradient (fs_wgw.hip)
     fs::Wg2Args w2;
     if (const size_t f = fs::wgrad2_plan(&a, 1, &w2)) return f * sizeof(float);   // second-generation kernel (fs_wgrad2.hip)
     return (size_t)(a.per_sample ? a.N : 1) * a.p.n_slabs * a.p.K * a.Cout * sizeof(float);
@@ -587,6 +589,13 @@ int fs_conv2d_wgrad(fs_ctx* ctx, fs_wgrad_desc* d, void* ws, size_t ws_bytes) {
     if (is_gram2(a)) {
         if (ws_bytes < fs::gram2_slab_floats(a.N, a.H * a.W, a.Cin) * sizeof(float)) return fail(-3, "fs_conv2d_wgrad: workspace too small");
         const int rc2 = fs::gram2_launch(a.x, d->dw, (float*)ws, a.N, a.H * a.W, a.Cin, d->scale, ctx->stream);
+        return rc2 ? fail(rc2, "fs_conv2d_wgrad: launch failed (%d)", rc2) : 0;
+    }
+    fs::WgwArgs ww;
+    if (const size_t f = fs::wgw_plan(&a, 1, &ww)) {
+        if (ws_bytes < f * sizeof(float)) return fail(-3, "fs_conv2d_wgrad: workspace too small");
+        float* out[1] = {d->dw};
+        const int rc2 = fs::wgw_run(ww, (float*)ws, out, d->scale, ctx->stream);
         return rc2 ? fail(rc2, "fs_conv2d_wgrad: launch failed (%d)", rc2) : 0;
     }
     fs::Wg2Args w2;

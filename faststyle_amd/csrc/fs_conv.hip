@@ -807,7 +807,7 @@ const char* prof_family_name(int f) {
         "conv_igemm_kernel<32,1,1>", "wino_conv_kernel", "wino2_conv_kernel (VGG16 convs)", "wino2_conv_kernel (transform-net residual convs)",
         "conv_stream_kernel", "conv3x3_to3_kernel", "wgrad2_kernel", "conv_wgrad_kernel", "gram_stream_kernel",
         "conv_wgrad_kernel (Gram forward)", "gram_bwd_kernel", "conv_igemm_kernel (Gram backward, 1x1 per-sample filters)",
-        "wino2h_conv_kernel (transform-net residual convs, half items)", "conv_s16_kernel", "wino4_conv_kernel", ""};
+        "wino2h_conv_kernel (transform-net residual convs, half items)", "conv_s16_kernel", "wino4_conv_kernel", "wgw_kernel"};
     return f >= 0 && f < Profiler::kFamilies ? names[f] : "";
 }
 

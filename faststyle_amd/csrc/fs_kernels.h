@@ -187,6 +187,34 @@ struct Wg2Reduce {
     float scale;
     int n;
 };
+// ---- Winograd filter gradients F(3x3, 2x2) of the 3x3 stride-1 VALID 64 -> 64 convs (fs_wgw.hip): batched problems, one slab per workgroup
+struct WgwProb {
+    const float* x;       // [N,H,W,64]
+    const float* dy;      // [N,H-2,W-2,64]
+    const float* in_a;    // optional [N,64] on-load affine of x (+ ReLU): the producer's instance norm
+    const float* in_b;
+    int N, H, W, Ho, Wo, Ty, Tx;
+    int sps, steps;       // 16-tile steps per sample / of the problem
+    int wg_begin, wg_count;
+    size_t slab_off;      // offset of the problem's slabs inside the launch's scratch (floats)
+};
+struct WgwArgs {
+    int nprob, n_wg, in_nstride, in_relu;
+    float* slabs;
+    WgwProb prob[kW2MaxProb];
+};
+struct WgwReduce {
+    struct Job {
+        const float* slabs;
+        float* out;
+        int n_slabs;
+    } job[kW2MaxProb];
+    float scale;
+    int n;
+};
+bool wgw_eligible(const WgradArgs& a);
+size_t wgw_plan(const WgradArgs* probs, int n, WgwArgs* out);   // returns the slab scratch in floats (0: not eligible)
+int wgw_run(const WgwArgs& planned, float* slabs, float* const* dw, float scale, hipStream_t s);
 bool wgrad2_eligible(const WgradArgs& a);
 size_t wgrad2_plan(const WgradArgs* probs, int n, Wg2Args* out);   // returns the slab scratch in floats (0: not eligible)
 int wgrad2_run(const Wg2Args& planned, float* slabs, float* const* dw, float scale, hipStream_t s);
@@ -548,7 +576,7 @@ enum ProfFam {
     PF_IGEMM_32_2_2 = 0, PF_IGEMM_32_2_1 = 1, PF_IGEMM_16_4_1 = 2, PF_IGEMM_32_1_2 = 3, PF_IGEMM_32_1_1 = 4,
     PF_WINO = 5, PF_WINO2_VGG = 6, PF_WINO2_TNET = 7, PF_CSTREAM = 8, PF_C3 = 9, PF_WGRAD2 = 10, PF_WGRAD = 11,
     PF_GRAM_STREAM = 12, PF_GRAM_WGRAD = 13, PF_GRAM_BWD = 14, PF_GRAM_BWD_IGEMM = 15, PF_WINO2H_TNET = 16, PF_S16 = 17,
-    PF_WINO4 = 18, PF_RESERVED19 = 19
+    PF_WINO4 = 18, PF_WGW = 19
 };
 const char* prof_family_name(int f);
 struct Profiler {

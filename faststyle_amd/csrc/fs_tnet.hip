@@ -341,6 +341,9 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
         const size_t f2 = tune_int("FS_TNET_WGRAD_BATCH", 1) ? wgrad2_plan(probs, 10, &w2) : 0;
         L->res_batch = f2 > 0;
         if (f2 > max_slab) max_slab = f2;
+        WgwArgs ww;   // the Winograd filter-gradient kernel (fs_wgw.hip) takes the batch when it is eligible: its slabs are larger
+        const size_t f3 = L->res_batch ? wgw_plan(probs, 10, &ww) : 0;
+        if (f3 > max_slab) max_slab = f3;
         for (int i = 3; i <= 12; ++i)
             L->dzres[i - 3] = L->res_batch ? b.take((size_t)N * L->u[i].Hout * L->u[i].Wout * L->u[i].Cout) : 0;
     }
@@ -684,11 +687,16 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
             if (i == 3) {   // every residual dz exists: ten filter gradients, one launch + one reduction
                 if (fork && (hipEventRecord(aux->ev[i], s) != hipSuccess || hipStreamWaitEvent(ws_stream, aux->ev[i], 0) != hipSuccess))
                     return -20;
-                Wg2Args w2;
-                if (!wgrad2_plan(res_probs, 10, &w2)) return -21;
                 float* outs[10];
                 for (int k = 0; k < 10; ++k) outs[k] = grads + L.u[3 + k].w_off;
-                FS_TRY(wgrad2_run(w2, ws + L.slabs, outs, 1.0f, ws_stream));
+                WgwArgs ww;
+                if (wgw_plan(res_probs, 10, &ww)) {   // Winograd F(3x3, 2x2) filter gradients (fs_wgw.hip)
+                    FS_TRY(wgw_run(ww, ws + L.slabs, outs, 1.0f, ws_stream));
+                } else {
+                    Wg2Args w2;
+                    if (!wgrad2_plan(res_probs, 10, &w2)) return -21;
+                    FS_TRY(wgrad2_run(w2, ws + L.slabs, outs, 1.0f, ws_stream));
+                }
                 if (fork && hipEventRecord(aux->ev[16 + i], ws_stream) != hipSuccess) return -20;
             }
         } else {

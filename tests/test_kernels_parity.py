@@ -300,6 +300,42 @@ def test_wgrad_matches_oracle(eng, case, knob):
     assert rel(dw, want) < TOL
 
 
+WGW_CASES = [
+    # name, x shape, on-load affine (producer instance norm + ReLU), persistent grid (FS_WGW_WGS)
+    ("even", (2, 18, 22, 64), False, 256),
+    ("odd_extents", (3, 13, 17, 64), False, 256),          # odd Ho / Wo: a last tile row / column of one pixel, input tiles over the edge
+    ("affine_relu", (2, 14, 16, 64), True, 256),
+    ("few_workgroups", (2, 21, 19, 64), True, 3),          # several steps per workgroup, step ranges crossing samples
+    ("one_tile", (1, 3, 3, 64), False, 256),
+]
+
+
+@pytest.mark.parametrize("case", WGW_CASES, ids=[c[0] for c in WGW_CASES])
+def test_winograd_filter_gradient_matches_oracle(eng, knob, case):
+    """wgw_kernel + wgw_reduce_kernel (fs_wgw.hip, Winograd F(3x3, 2x2)): the filter gradient of a 3x3 stride-1 VALID 64 -> 64
+    conv -- the residual convs of the transform net (reference im_transf_net.py:250-276 under train.py:203's gradients) --
+    through fs_conv2d_wgrad, against the float64 oracle at the direct kernels' tolerance, and against the direct kernel."""
+    name, xs, affine, wgs = case
+    knob("FS_WGW_MIN_STEPS", 0)
+    knob("FS_WGW_WGS", wgs)
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(xs).astype(np.float32)
+    dy = rng.standard_normal((xs[0], xs[1] - 2, xs[2] - 2, 64)).astype(np.float32)
+    kw, xeff = {}, x.astype(np.float64)
+    if affine:
+        a = rng.uniform(0.5, 1.5, (xs[0], 64)).astype(np.float32)
+        b = rng.standard_normal((xs[0], 64)).astype(np.float32)
+        kw = dict(in_a=up(eng, a), in_b=up(eng, b), in_per_sample=1, in_relu=1)
+        xeff = np.maximum(x.astype(np.float64) * a[:, None, None, :] + b[:, None, None, :], 0.0)
+    dw = down(eng, eng.conv2d_wgrad(up(eng, x), up(eng, dy), 3, 1, "VALID", **kw))
+    want = nnops.conv2d_bwd_filter(xeff, dy.astype(np.float64), 3, 1, "VALID")
+    assert dw.shape == want.shape == (3, 3, 64, 64)
+    assert rel(dw, want) < TOL
+    knob("FS_WGW", 0)
+    direct = down(eng, eng.conv2d_wgrad(up(eng, x), up(eng, dy), 3, 1, "VALID", **kw))
+    assert rel(direct, want) < TOL and rel(dw, direct) < TOL and not np.array_equal(dw, direct)      # really the other algorithm
+
+
 @pytest.mark.parametrize("hw,c", [((16, 12), 64), ((9, 7), 128), ((5, 6), 512)])
 def test_gram_is_symmetric_psd_and_matches_oracle(eng, hw, c):
     rng = np.random.default_rng(7)
