@@ -13,10 +13,12 @@ SOURCES = ["fs_conv.hip", "fs_wino.hip", "fs_wino2.hip", "fs_wino2h.hip", "fs_wi
 OUT = os.path.join(HERE, "libfaststyle_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed"]
-# Per-source flags.  fs_wino4.hip: no SLP vectorisation -- with it (ROCm 7.2 clang) the packed-fp32 code of the output transform
-# produced WRONG values on gfx950 in two of the three epilogue instantiations (high halves of v_pk_* results, lanes 12-15 of every
-# row of 16; the CPU emulator build of the same source is right, tools/_dbg_w4.py shows it on the GPU), and packed fp32 beside
-# fp32 matrix instructions is slower anyway (MI355X_MICROARCH.md, price of one filler beside MFMAs).
+# Per-source flags.  fs_wino4.hip: no SLP vectorisation.  With it (ROCm 7.2 clang) two of the kernel's three epilogue
+# instantiations return WRONG values on gfx950 (a few per cent of the elements, always lanes 12-15 of a row of 16 and the odd
+# channel of a pair; tools/_dbg_w4.py on the GPU, exp build with -fslp-vectorize) while the CPU emulator build of the same source
+# is right and the third instantiation, equally packed, is right too.  The cause was not isolated (no undefined behaviour left in
+# the source; a code-generation or hazard problem around v_pk_add_f32 / v_pk_fma_f32).  Packed fp32 beside fp32 matrix
+# instructions is slower anyway (MI355X_MICROARCH.md, price of one filler beside MFMAs), so the kernel loses nothing.
 FILE_FLAGS = {"fs_wino4.hip": ["-fno-slp-vectorize"]}
 
 

@@ -540,7 +540,13 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
             const float bsv[4] = {bs.x, bs.y, bs.z, bs.w};
 #pragma unroll
             for (int px = 0; px < 16; ++px) {
-                const float mv[4] = {mk[px].x, mk[px].y, mk[px].z, mk[px].w};
+                float mv[4] = {1.f, 1.f, 1.f, 1.f};
+                if (EPI == 2) {   // (mk is loaded in this form only: no read of an indeterminate value in the others)
+                    mv[0] = mk[px].x;
+                    mv[1] = mk[px].y;
+                    mv[2] = mk[px].z;
+                    mv[3] = mk[px].w;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = o[px][r];
