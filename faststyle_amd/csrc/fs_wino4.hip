@@ -726,7 +726,8 @@ void wino4_plan(const ConvArgs& a, ConvPlan* out) {
     const int max_ks = tune_int("FS_WINO_KSPLIT", 4);
     if (a.split_ws && !a.pool_out) {
         int ks = 1;
-        while (ks < max_ks && items * ks < 256 && nchunks / (ks * 2) >= 16 && (size_t)(ks * 2) * a.N * a.Ho * a.Wo * a.Cout <= a.split_ws_floats) ks *= 2;
+        const int min_steps = tune_int("FS_WINO4_KSPLIT_MINSTEPS", 16);   // chunks (steps) a split item must keep
+        while (ks < max_ks && items * ks < 256 && nchunks / (ks * 2) >= min_steps && (size_t)(ks * 2) * a.N * a.Ho * a.Wo * a.Cout <= a.split_ws_floats) ks *= 2;
         p.ksplit = ks;
     }
     *out = p;
