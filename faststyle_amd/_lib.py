@@ -21,7 +21,7 @@ FS_FLAG_BF16 = 4
 FS_TNET_WS_Z, FS_TNET_WS_A, FS_TNET_WS_B, FS_TNET_WS_MEAN, FS_TNET_WS_RSTD, FS_TNET_WS_H = 0, 1, 2, 3, 4, 5
 FS_PAD_SAME, FS_PAD_VALID, FS_PAD_EXPLICIT = 0, 1, 2
 FS_SRC_PLAIN, FS_SRC_REFLECT, FS_SRC_DILATE2 = 0, 1, 2
-FS_PROFILE_FAMILIES = 20
+FS_PROFILE_FAMILIES = 21
 
 
 def profile_family_names(lib):
@@ -52,7 +52,8 @@ class fs_conv_desc(Structure):
                 ("in_a", c_void_p), ("in_b", c_void_p), ("in_per_sample", c_int), ("in_relu", c_int),
                 ("bias", c_void_p), ("out_relu", c_int), ("shuffle", c_int), ("stats", c_void_p),
                 ("add_src", c_void_p), ("add_pad", c_int), ("w_nstride", c_longlong), ("w_wino", c_void_p),
-                ("w_wino4", c_void_p), ("mask_src", c_void_p), ("pool_out", c_void_p)]
+                ("w_wino4", c_void_p), ("mask_src", c_void_p), ("pool_out", c_void_p),
+                ("w_wino4t", c_void_p)]
 
 
 class fs_wgrad_desc(Structure):
@@ -108,6 +109,7 @@ PROTOTYPES = {
     "fs_conv2d_plan": (c_int, [POINTER(fs_conv_desc), POINTER(c_int)]),
     "fs_wino_transform_filter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fs_wino4_transform_filter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "fs_wino4t_transform_filter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fs_instnorm_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "fs_instnorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

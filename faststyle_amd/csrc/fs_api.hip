@@ -459,6 +459,8 @@ static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
     a->mask_src = d->mask_src;
     a->w_wino4 = d->w_wino4;
     if (a->w_wino4 && !fs::wino4_eligible(*a)) a->w_wino4 = nullptr;   // (not a 3x3 stride-1 SAME conv of the supported shapes)
+    a->w_wino4t = d->w_wino4t;
+    if (a->w_wino4t && (a->w_wino4 || !fs::wino4t_eligible(*a))) a->w_wino4t = nullptr;
     if (fs::tune_int("FS_WINO_V", 2) >= 2) {   // the filter layout fs_wino_transform_filter produced (see there)
         a->w_wino2 = d->w_wino;
         if (a->w_wino2 && !fs::wino2_eligible(*a)) a->w_wino2 = nullptr;   // (not a 3x3 stride-1 conv of the supported shapes: direct kernel)
@@ -505,6 +507,13 @@ int fs_wino_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, flo
     if (Cin % 8) return fail(-2, "fs_wino_transform_filter: Cin must be a multiple of 8 (got %d)", Cin);
     const int rc = fs::tune_int("FS_WINO_V", 2) >= 2 ? fs::wt_wino2(w, U, Cin, Cout, ctx->stream) : fs::wt_wino(w, U, Cin, Cout, ctx->stream);
     return rc ? fail(rc, "fs_wino_transform_filter: launch failed (%d)", rc) : 0;
+}
+
+int fs_wino4t_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, float* U) {
+    if (!ctx || !w || !U) return fail(-1, "fs_wino4t_transform_filter: null argument");
+    if (Cin < 8 || Cout < 64 || (Cin % 8) || (Cout % 64)) return fail(-2, "fs_wino4t_transform_filter: Cin %% 8 == 0 and Cout %% 64 == 0 (got %dx%d)", Cin, Cout);
+    const int rc = fs::wt_wino4t(w, U, Cin, Cout, ctx->stream);
+    return rc ? fail(rc, "fs_wino4t_transform_filter: launch failed (%d)", rc) : 0;
 }
 
 int fs_wino4_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, float* U) {

@@ -24,7 +24,7 @@ enum SrcMode {
 
 struct ConvPlan {
     int variant;  // conv_igemm_kernel<MT,WM,WN>: 0 <32,2,2>  1 <32,2,1>  2 <16,4,1>  3 <32,1,2>  4 <32,1,1>;  5 wino_conv_kernel;  6 wino2_conv_kernel;
-                  // 7 conv_stream_kernel;  8 wino2h_conv_kernel;  9 conv_s16_kernel;  10 wino4_conv_kernel (F(4x4,3x3))
+                  // 7 conv_stream_kernel;  8 wino2h_conv_kernel;  9 conv_s16_kernel;  10 wino4_conv_kernel (F(4x4,3x3));  11 wino4t_conv_kernel (F(4x4,3x3), 16-tile items)
     int BN;       // output channels per workgroup
     int flat;     // Cin==3: K runs over (kw,ci) contiguously per kernel row
     int CC;       // input channels staged per chunk
@@ -80,6 +80,7 @@ struct ConvArgs {
     const float* w_wino;  // optional: the same filter Winograd-transformed, [16][Cin][Cout] (fs::wt_wino); enables variant 5
     const float* w_wino2; // optional: ... in the K-contiguous order [16][Cin/8][Cout][8] (fs::wt_wino2); enables variant 6
     const float* w_wino4; // optional: the filter transformed for F(4x4,3x3), [36][Cin/4][Cout/64][2][4][16][2] (fs::wt_wino4); enables variant 10
+    const float* w_wino4t; // optional: the filter transformed for F(4x4,3x3) in the register layout of fs_wino4t.hip, [Cin/8][Cout/16][18][64][4] (fs::wt_wino4t); enables variant 11
     float* y;        // [N,Ho,Wo,Cout], or [N,2Ho,2Wo,Cout/4] when shuffle
     int N, H, W, Cin;
     int Ho, Wo, Cout;
@@ -489,6 +490,12 @@ int wt_wino4(const float* w, float* U, int Cin, int Cout, hipStream_t s);       
 bool wino4_eligible(const ConvArgs& a);
 void wino4_plan(const ConvArgs& a, ConvPlan* out);
 int wino4_launch(const ConvArgs& a, hipStream_t s);
+int wt_wino4t(const float* w, float* U, int Cin, int Cout, hipStream_t s);                     // fs_wino4t.hip: F(4x4,3x3) with 16-tile items (transform-net residual convs), plan variant 11
+int wt_wino4t_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s);
+bool wino4t_eligible(const ConvArgs& a);
+long wino4t_items(const ConvArgs& a);
+void wino4t_plan(const ConvArgs& a, ConvPlan* out);
+int wino4t_launch(const ConvArgs& a, hipStream_t s);
 bool wino_eligible(const ConvArgs& a);
 void wino_plan(const ConvArgs& a, ConvPlan* out);
 int wino_launch(const ConvArgs& a, hipStream_t s);
@@ -576,11 +583,11 @@ enum ProfFam {
     PF_IGEMM_32_2_2 = 0, PF_IGEMM_32_2_1 = 1, PF_IGEMM_16_4_1 = 2, PF_IGEMM_32_1_2 = 3, PF_IGEMM_32_1_1 = 4,
     PF_WINO = 5, PF_WINO2_VGG = 6, PF_WINO2_TNET = 7, PF_CSTREAM = 8, PF_C3 = 9, PF_WGRAD2 = 10, PF_WGRAD = 11,
     PF_GRAM_STREAM = 12, PF_GRAM_WGRAD = 13, PF_GRAM_BWD = 14, PF_GRAM_BWD_IGEMM = 15, PF_WINO2H_TNET = 16, PF_S16 = 17,
-    PF_WINO4 = 18, PF_WGW = 19
+    PF_WINO4 = 18, PF_WGW = 19, PF_WINO4T = 20
 };
 const char* prof_family_name(int f);
 struct Profiler {
-    static const int kFamilies = 20;   // one per kernel symbol (ProfFam); fs_profile_family_name() names them
+    static const int kFamilies = 21;   // one per kernel symbol (ProfFam); fs_profile_family_name() names them
     struct Rec { hipEvent_t a, b; int fam; double flops; };
     Rec* recs = nullptr;
     int n = 0, cap = 0;

@@ -31,8 +31,8 @@ struct Unit {
     size_t z, stats, mean, rstd, a, b;  // workspace offsets (floats)
     int tiles;
     int wino;        // forward through a Winograd kernel: 1 wino(2)_conv_kernel (3x3 VALID residual convs on grids that fill the
-                     // chip with 64-tile items), 2 wino2h_conv_kernel (half items: smaller grids, batch 4 per GPU)
-    size_t wino_u;   // its transformed filter [16][Cin][Cout] in the workspace
+                     // chip with 64-tile items), 2 wino2h_conv_kernel (half items: smaller grids, batch 4 per GPU), 3 wino4t_conv_kernel (F(4x4,3x3))
+    size_t wino_u;   // its transformed filter ([16][Cin][Cout]; 36 * Cin * Cout floats for 3) in the workspace
     ConvPlan plan;
     WgradPlan wplan;
 };
@@ -51,7 +51,7 @@ struct TnetLayout {
     size_t wTu[16];   // per-unit input-gradient filters (flip+transpose / collapsed), all built by one wt_batch launch
     size_t g[3], dz[2], wT, dweff, inbwd, slabs;  // backward scratch (dz double-buffered: filter gradients run on a side stream)
     size_t wino_d[10]; // Winograd-transformed input-gradient filters of the residual convs (0: direct kernel)
-    int wino_dh[10];   // ... through the half-item kernel
+    int wino_dh[10];   // ... 1: through the half-item kernel, 2: through the 16-tile F(4x4) kernel (fs_wino4t.hip)
     size_t dzres[10]; // dz of the ten residual convs, kept until their filter gradients run as ONE launch (fs_wgrad2.hip)
     int res_batch;    // 1: that batched launch is planned (shapes eligible)
     size_t total_floats;

@@ -259,14 +259,24 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
                 h.half_items = 1;
                 if (wino2h_eligible(h) && wino2h_items(h) >= tune_int("FS_WINO2H_MIN_ITEMS", 96)) u.wino = 2;
             }
-            if (!u.wino) a.w_wino = a.w_wino2 = nullptr;
+            // ... and through the 16-tile Winograd F(4x4,3x3) kernel (fs_wino4t.hip: 36 products per 4x4 outputs instead of 64, filter
+            // operand global -> registers) wherever its items occupy a fair part of the chip.  FS_TNET_WINO4=0 disables, =2 forces.
+            const int w4 = tune_int("FS_TNET_WINO4", 1);
+            if (mode && w4 && u.kind == 0 && i >= 3 && i <= 12) {
+                ConvArgs t = a;
+                t.w_wino = t.w_wino2 = nullptr;
+                t.w_wino4t = reinterpret_cast<const float*>(16);
+                if (wino4t_eligible(t) && (w4 == 2 || wino4t_items(t) >= tune_int("FS_WINO4T_MIN_ITEMS", 64))) u.wino = 3;
+            }
+            if (!u.wino || u.wino == 3) a.w_wino = a.w_wino2 = nullptr;
+            if (u.wino == 3) a.w_wino4t = reinterpret_cast<const float*>(16);
             a.stats = nullptr;
         }
         a.half_items = u.wino == 2;
         a.rem_ws = reinterpret_cast<float*>(16);   // (planning looks at the capacity only)
         a.rem_ws_floats = (size_t)kRemUnits * 16384;
         u.plan = conv_plan(a);
-        u.wino_u = u.wino ? b.take((size_t)16 * u.Cin * u.Cc) : 0;
+        u.wino_u = u.wino ? b.take((size_t)(u.wino == 3 ? 36 : 16) * u.Cin * u.Cc) : 0;
         u.tiles = u.kind == 2 ? cdiv(u.Hout * u.Wout, 256) : u.plan.tiles_y * u.plan.tiles_x;
         const size_t act = (size_t)N * u.Hout * u.Wout * u.Cout;
         u.z = b.take(act);
@@ -322,7 +332,24 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
             h.half_items = 1;
             if (wino2h_eligible(h) && wino2h_items(h) >= tune_int("FS_WINO2H_MIN_ITEMS", 96)) on = L->wino_dh[i - 3] = 1;
         }
-        L->wino_d[i - 3] = on ? b.take((size_t)16 * 64 * 64) : 0;
+        if (const int w4 = L->wino_mode ? tune_int("FS_TNET_WINO4", 1) : 0) {   // the 16-tile F(4x4) kernel (see the forward units)
+            ConvArgs h{};   // the 3x3 'full' conv of dz that unit_dgrad launches
+            h.N = N;
+            h.H = u.Hout;
+            h.W = u.Wout;
+            h.Cin = h.Cout = 64;
+            h.Ho = u.Hin;
+            h.Wo = u.Win;
+            h.KH = h.KW = 3;
+            h.stride = 1;
+            h.pad_t = h.pad_l = 2;
+            h.w_wino4t = reinterpret_cast<const float*>(16);
+            if (wino4t_eligible(h) && (w4 == 2 || wino4t_items(h) >= tune_int("FS_WINO4T_MIN_ITEMS", 64))) {
+                on = true;
+                L->wino_dh[i - 3] = 2;
+            }
+        }
+        L->wino_d[i - 3] = on ? b.take((size_t)(L->wino_dh[i - 3] == 2 ? 36 : 16) * 64 * 64) : 0;
     }
     L->inbwd = b.take(max_inbwd);
     for (int i = 0; i < 16; ++i) {
@@ -408,14 +435,16 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
     }
     FS_TRY(wt_batch(wb, s));
     {   // Winograd-transformed filters of the residual convs that use wino_conv_kernel (one launch)
-        WinoBatch nb{};
+        WinoBatch nb{}, nb4{};
         for (int i = 3; i <= 12; ++i)
             if (L.u[i].wino) {
-                nb.w[nb.n] = params + L.u[i].w_off;
-                nb.U[nb.n] = ws + L.u[i].wino_u;
-                ++nb.n;
+                WinoBatch& t = L.u[i].wino == 3 ? nb4 : nb;   // (3: the register layout of fs_wino4t.hip)
+                t.w[t.n] = params + L.u[i].w_off;
+                t.U[t.n] = ws + L.u[i].wino_u;
+                ++t.n;
             }
         FS_TRY(tune_int("FS_WINO_V", 2) >= 2 ? wt_wino2_batch(nb, 64, 64, s) : wt_wino_batch(nb, 64, 64, s));
+        FS_TRY(wt_wino4t_batch(nb4, 64, 64, s));
     }
     // units whose conv kernel is persistent (fs_wino2 / fs_wino2h / fs_cstream) and whose record count is small merge their
     // own instance-norm statistics (the last workgroup to finish; FinArgs in fs_kernels.h): no in_finalize launch
@@ -441,8 +470,9 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
         a.in_nstride = src_a ? u.Cin : 0;
         a.in_relu = src_a ? 1 : 0;
         a.w = (u.kind == 1 || (u.kind == 3 && i < 15)) ? ws + L.weff[i - 13] : ((u.kind == 2 || u.kind == 3) ? ws + L.wfold : params + u.w_off);
-        a.w_wino = (u.wino && tune_int("FS_WINO_V", 2) < 2) ? ws + u.wino_u : nullptr;
-        a.w_wino2 = (u.wino && tune_int("FS_WINO_V", 2) >= 2) ? ws + u.wino_u : nullptr;
+        a.w_wino = (u.wino && u.wino != 3 && tune_int("FS_WINO_V", 2) < 2) ? ws + u.wino_u : nullptr;
+        a.w_wino2 = (u.wino && u.wino != 3 && tune_int("FS_WINO_V", 2) >= 2) ? ws + u.wino_u : nullptr;
+        a.w_wino4t = u.wino == 3 ? ws + u.wino_u : nullptr;
         a.half_items = u.wino == 2;
         a.y = u.kind == 2 ? ws + L.zfold : ws + u.z;
         a.stats = u.kind == 2 ? nullptr : ws + u.stats;
@@ -506,8 +536,12 @@ static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, c
     {
         const int ui = (int)(&u - L.u);
         if (ui >= 3 && ui <= 12 && L.wino_d[ui - 3]) {
-            a.w_wino2 = ws + L.wino_d[ui - 3];
-            a.half_items = L.wino_dh[ui - 3];
+            if (L.wino_dh[ui - 3] == 2) {
+                a.w_wino4t = ws + L.wino_d[ui - 3];
+            } else {
+                a.w_wino2 = ws + L.wino_d[ui - 3];
+                a.half_items = L.wino_dh[ui - 3];
+            }
         }
     }
     a.add_src = add_src;
@@ -638,14 +672,16 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
                 wb.add(u.kind == 1 ? WT_UPDGRAD : WT_FLIPT, params + u.w_off, ws + L.wTu[i], K, K, u.Cin, u.Cout);
         }
         FS_TRY(wt_batch(wb, s));
-        WinoBatch nb{};   // ... and the Winograd transforms of the residual ones ([3][3][Cout][Cin] as the kernel's HWIO)
+        WinoBatch nb{}, nb4{};   // ... and the Winograd transforms of the residual ones ([3][3][Cout][Cin] as the kernel's HWIO)
         for (int i = 3; i <= 12; ++i)
             if (L.wino_d[i - 3]) {
-                nb.w[nb.n] = ws + L.wTu[i];
-                nb.U[nb.n] = ws + L.wino_d[i - 3];
-                ++nb.n;
+                WinoBatch& t = L.wino_dh[i - 3] == 2 ? nb4 : nb;
+                t.w[t.n] = ws + L.wTu[i];
+                t.U[t.n] = ws + L.wino_d[i - 3];
+                ++t.n;
             }
         FS_TRY(wt_wino2_batch(nb, 64, 64, s));
+        FS_TRY(wt_wino4t_batch(nb4, 64, 64, s));
     }
     const float* g = dy;         // gradient wrt the current unit's output activation (or h_k)
     const float* res_g = nullptr;  // d h_k, kept alive until the block's first conv adds it to its dgrad

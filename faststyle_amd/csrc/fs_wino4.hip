@@ -21,14 +21,15 @@
 //   * the two LDS stages hold, per chunk, the transformed filter U (36 KB, a straight 16-byte copy of the pre-transformed
 //     filter in HBM, fs::wt_wino4), the transformed input V (18 KB) and the raw 18 x 34 x 4 patch (channel-planar, plane pitch
 //     = 1 mod 32: the transform's reads and the loaders' writes are conflict-free);
-//   * WAVE SPECIALISATION for the staging of the next chunk, threaded through the 72 matrix-instruction slots of the sweep:
-//     waves 0-1 transform (one 6x6 block per thread: 36 LDS reads, 144 vector instructions bunched into four gaps, 36 LDS
-//     writes), waves 2-3 load (the 36 KB filter chunk: 18 x 16-byte loads + LDS writes per thread, the patch of the
-//     chunk after next: 5 loads + 20 LDS writes) -- both about 1.1k cycles beside the 2.3k of matrix instructions, because
-//     beside the fp32 matrix instruction every vector-ALU / vector-memory instruction costs its issue time (tools/mfma_overlap.hip);
+//   * the staging of the next chunk is threaded through the 72 matrix-instruction slots of the sweep as straight-line slices,
+//     the SAME instruction stream in every wave (no role branches, no conditional loads): 9 filter quads global -> registers
+//     -> LDS, the input transform of one 6x6 block per lane PAIR (18 LDS reads, 72 vector instructions bunched into two gaps,
+//     9 lane-half swaps, 18 LDS writes), 3 patch quads of the chunk after next -- about 1.2k cycles beside the 2.3k of matrix
+//     instructions, because beside the fp32 matrix instruction every vector-ALU / vector-memory instruction costs its issue
+//     time (tools/mfma_overlap.hip);
 //   * epilogue per item: bias + ReLU (+ the 2x2 max-pool of the tile's four windows) for the forward, the consumer's
 //     ReLU mask for the input gradients; split-K (raw partials) where the launch cannot fill the chip.
-#include "fs_kernels.h"
+#include "fs_wino4.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -66,35 +67,12 @@ __global__ __launch_bounds__(256) void wt_wino4_kernel(const float* __restrict__
     const size_t cc = (size_t)Cin * Cout;
     if (i >= cc) return;
     const int ci = (int)(i / Cout), co = (int)(i - (size_t)ci * Cout);
-    double g[3][3], t[6][3];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) g[kh][kw] = (double)w[(size_t)(kh * 3 + kw) * cc + i];
-    auto row6 = [](double a, double b, double c, double (&o)[6]) {   // G [a b c]^T
-        o[0] = a / 4.0;
-        o[1] = -(a + b + c) / 6.0;
-        o[2] = -(a - b + c) / 6.0;
-        o[3] = a / 24.0 + b / 12.0 + c / 6.0;
-        o[4] = a / 24.0 - b / 12.0 + c / 6.0;
-        o[5] = c;
-    };
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-        double o[6];
-        row6(g[0][kw], g[1][kw], g[2][kw], o);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) t[r][kw] = o[r];
-    }
+    double o[36];
+    wino4_filter_transform(w, cc, i, o);
     const int c64 = co & 63;
     float* dst = U + ((size_t)(ci >> 2) * (Cout >> 6) + (co >> 6)) * 256 + (c64 >> 5) * 128 + (ci & 3) * 32 + (c64 & 15) * 2 + ((c64 >> 4) & 1);
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        double o[6];
-        row6(t[r][0], t[r][1], t[r][2], o);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) dst[(size_t)(r * 6 + q) * cc] = (float)o[q];
-    }
+    for (int k = 0; k < 36; ++k) dst[(size_t)k * cc] = (float)o[k];
 }
 
 int wt_wino4(const float* w, float* U, int Cin, int Cout, hipStream_t s) {
@@ -115,73 +93,6 @@ extern "C" int fs_debug_wino4_trace(long long* out, int n_wg) {
 #ifndef FS_W4_ABL
 #define FS_W4_ABL 0   /* timing experiments (results wrong): 1 no input transform, 2 no filter loads / commit, 4 no patch loads / commit, 8 no operand reads */
 #endif
-
-// 36 positions x 2 channel blocks x 4 registers = 288 accumulator registers, but the accumulator file holds 256 and the
-// compiler's matrix-instruction form takes its C/D operand from that file only (asked for more, it funnels EVERY accumulator
-// through one quad with v_accvgpr copies).  So positions 0..31 use the builtin (256 AGPRs), positions 32..35 an
-// inline-assembly v_mfma with C/D in ordinary vector registers (legal on gfx90a+).  No software wait states are needed: an
-// accumulator is next read 72 matrix instructions later, or in the epilogue behind a barrier.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define FS_W4_MFMA_V(accq, av, bv) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accq) : "v"(av), "v"(bv))
-#else
-#define FS_W4_MFMA_V(accq, av, bv) (accq) = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), (accq), 0, 0, 0)
-#endif
-// v_permlane32_swap_b32 (gfx950): lanes 32..63 of the first register trade places with lanes 0..31 of the second -- the two halves of a wave exchange a
-// register pair in ONE instruction, no LDS round trip
-#if defined(__HIP_DEVICE_COMPILE__)
-#define FS_W4_SWAP(va_, vb_)                                                                                               \
-    do {                                                                                                                   \
-        const auto r_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(va_), __float_as_uint(vb_), false, false);        \
-        (va_) = __uint_as_float(r_[0]);                                                                                    \
-        (vb_) = __uint_as_float(r_[1]);                                                                                    \
-    } while (0)
-#elif defined(FS_EMULATOR)
-#define FS_W4_SWAP(va_, vb_)                                                     \
-    do {                                                                         \
-        const float as_ = __shfl_xor((va_), 32), bs_ = __shfl_xor((vb_), 32);    \
-        if ((threadIdx.x & 63) < 32) (vb_) = as_;                                \
-        else (va_) = bs_;                                                        \
-    } while (0)
-#else
-#define FS_W4_SWAP(va_, vb_) ((void)0)
-#endif
-// LDS accesses through COMPLETE byte addresses held in pinned vector registers (the lesson of fs_wgrad2.hip): with pointer
-// arithmetic on the shared array the backend re-derives "array base + stage + lane part + row" in front of the accesses -- six
-// vector adds per sweep for the patch rows alone, each ~12 cycles beside the matrix instructions.  One base register per
-// stream (computed before the sweep's first matrix instruction), everything else an immediate offset.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define FS_W4_ADDR(p) ((int)(size_t)(const __attribute__((address_space(3))) char*)(p))
-#define FS_W4_LDS(T, addr) (*(__attribute__((address_space(3))) T*)(size_t)(unsigned)(addr))
-#define FS_W4_PIN(x) asm volatile("" : "+v"(x))
-#else   /* emulator / host pass: addresses are byte offsets from the workgroup's LDS array */
-#define FS_W4_ADDR(p) ((int)(reinterpret_cast<const char*>(p) - reinterpret_cast<const char*>(smem)))
-#define FS_W4_LDS(T, addr) (*reinterpret_cast<T*>(reinterpret_cast<char*>(smem) + (addr)))
-#define FS_W4_PIN(x) ((void)0)
-#endif
-// B^T x for one 6-vector (input transform, one dimension): 12 instructions
-#define FS_W4_BT(d0, d1, d2, d3, d4, d5, t0, t1, t2, t3, t4, t5) \
-    do {                                                         \
-        const float a_ = fmaf(-4.f, d2, d4);                     \
-        const float b_ = fmaf(-4.f, d1, d3);                     \
-        const float c_ = d4 - d2;                                \
-        const float e_ = d3 - d1;                                \
-        t0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));                  \
-        t1 = a_ + b_;                                            \
-        t2 = a_ - b_;                                            \
-        t3 = fmaf(2.f, e_, c_);                                  \
-        t4 = fmaf(-2.f, e_, c_);                                 \
-        t5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));                  \
-    } while (0)
-// A^T m for one 6-vector (output transform, one dimension): 10 instructions
-#define FS_W4_AT(m0, m1, m2, m3, m4, m5, y0, y1, y2, y3) \
-    do {                                                 \
-        const float p_ = m1 + m2, q_ = m1 - m2;          \
-        const float r_ = m3 + m4, s_ = m3 - m4;          \
-        y0 = m0 + p_ + r_;                               \
-        y1 = fmaf(2.f, s_, q_);                          \
-        y2 = fmaf(4.f, r_, p_);                          \
-        y3 = fmaf(8.f, s_, q_) + m5;                     \
-    } while (0)
 
 // EPI: the epilogue form, a compile-time constant (a run-time choice costs a select per stored element): 0 raw (split-K partials,
 // the input gradient in front of a max-pool), 1 bias + ReLU (+ the fused 2x2 max-pool) -- the forward convs, 2 the consumer's
@@ -360,9 +271,6 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
 
     f32x4 acc[kNA][2];         // positions 0 .. kNA-1: accumulator file
     f32x4 accv[36 - kNA][2];   // the rest: ordinary vector registers (FS_W4_MFMA_V)
-// (accumulator-file elements leave through a volatile v_accvgpr_read exactly where the output transform consumes them: left to
-// itself the scheduler hoists hundreds of these reads to the top of the epilogue and the register allocator spills loop
-// invariants to scratch memory -- reloaded before every sweep behind `s_waitcnt vmcnt(0)`, i.e. behind every load in flight)
 // (accumulator-file elements leave through a volatile v_accvgpr_read exactly where the output transform consumes them: left to
 // itself the scheduler hoists hundreds of these reads to the top of the epilogue, and the register allocator answers by
 // spilling the sweep's loop invariants to scratch memory -- reloaded before every sweep behind `s_waitcnt vmcnt(0)`)

@@ -475,7 +475,12 @@ class Engine(object):
         d.add_pad = int(kw.get("add_pad", 0))
         d.w_nstride = int(kw.get("w_nstride", 0))
         d.mask_src = p(kw.get("mask_src"))
-        if kw.get("winograd") == 4:     # F(4x4,3x3) (fs_wino4.hip)
+        if kw.get("winograd") == "4t":     # F(4x4,3x3), 16-tile items (fs_wino4t.hip)
+            U = self.mem.empty((36, Cin, Cout))
+            L.check(self.lib, self.lib.fs_wino4t_transform_filter(self.ctx, p(w), Cin, Cout, p(U)), "fs_wino4t_transform_filter")
+            d.w_wino4t = p(U)
+            self._keep = [U]
+        elif kw.get("winograd") == 4:     # F(4x4,3x3) (fs_wino4.hip)
             U = self.mem.empty((36, Cin, Cout))
             L.check(self.lib, self.lib.fs_wino4_transform_filter(self.ctx, p(w), Cin, Cout, p(U)), "fs_wino4_transform_filter")
             d.w_wino4 = p(U)

@@ -35,7 +35,7 @@ const char* fs_version(void);
  * out[f*3+{0,1,2}] = {launches, FLOPs executed, milliseconds} of row f; fs_profile_family_name(f) is the kernel symbol the
  * row belongs to (one row per symbol, so a row can be re-derived from a `rocprofv3 --kernel-trace --stats` summary; the
  * one symbol shared by two workloads, wino2_conv_kernel, has a row per caller), "" for unused rows. */
-#define FS_PROFILE_FAMILIES 20
+#define FS_PROFILE_FAMILIES 21
 int fs_profile_begin(fs_ctx* ctx);
 int fs_profile_end(fs_ctx* ctx, double out[3 * FS_PROFILE_FAMILIES]);
 const char* fs_profile_family_name(int family);
@@ -188,6 +188,12 @@ typedef struct {
                             * convs (the gradient of vgg16.py:48's tf.nn.relu folded into the conv in front of it) */
     float* pool_out;       /* optional [N,Ho/2,Wo/2,Cout] (Winograd kernels only, even Ho and Wo): tf.nn.max_pool 2x2/2 of the
                             * stored result (vgg16.py:68,104,154) written by the same launch */
+    const float* w_wino4t; /* optional: the filter as transformed by fs_wino4t_transform_filter (36*Cin*Cout floats): a 3x3 stride-1
+                            * conv with padding 0, 1 or 2 (VALID / SAME / 'full'), Cin % 8 == 0, Cout % 64 == 0, no bias / activation /
+                            * mask / pool then runs on the 16-tile Winograd F(4x4,3x3) kernel (fs_wino4t.hip) -- the one fs_tnet_forward
+                            * / fs_tnet_backward run the ten residual convs (im_transf_net.py:250-276) and their input gradients on:
+                            * in_a / in_b (+ in_relu) on load with padding 0, stats, add_src as for the other kernels.  w_wino4 wins
+                            * when both are given; other shapes fall through. */
 } fs_conv_desc;
 /* U = G g G^T for every (ci, co) filter g = w[:, :, ci, co] of a 3x3 HWIO filter (Lavin & Gray F(2x2,3x3)), 16 values per
  * filter, in the order the Winograd kernels stage them; the caller owns U (16*Cin*Cout floats; Cin % 8 == 0).
@@ -196,6 +202,8 @@ int fs_wino_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, flo
 /* The same for F(4x4,3x3) (interpolation points 0, +-1, +-2, infinity; computed in float64, rounded once): 36 values per
  * filter, U holds 36*Cin*Cout floats; Cin % 4 == 0, Cout % 64 == 0. */
 int fs_wino4_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, float* U);
+/* ... in the register layout of the 16-tile kernel (fs_conv_desc.w_wino4t); Cin % 8 == 0, Cout % 64 == 0. */
+int fs_wino4t_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, float* U);
 /* tf.nn.conv2d (im_transf_net.py:115, vgg16.py:47) on the matrix cores. */
 int fs_conv2d_fwd(fs_ctx* ctx, fs_conv_desc* d);
 /* resolves Ho/Wo/pads and returns the per-image tile count the launch will use */

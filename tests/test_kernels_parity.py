@@ -159,6 +159,76 @@ def test_winograd_f4x4_accuracy_on_a_deep_reduction(eng):
     assert e_w < 5e-5 and rms < 1e-5, (e_d, e_w, rms)
 
 
+WINO4T_CASES = [
+    # name, x shape, Cout, padding (explicit: (pad, pad, Ho, Wo) | "VALID" | "SAME"), extra
+    ("one_item_valid", (1, 18, 18, 8), 64, "VALID", None),
+    ("ragged_valid_2img", (2, 23, 39, 16), 64, "VALID", None),          # 21x37 outputs: partial 16x16 items, a last tile row / column of 1 pixel
+    ("same_two_coblocks", (1, 20, 20, 8), 128, "SAME", None),
+    ("full_pad_with_add", (2, 19, 21, 64), 64, "FULL", "add"),           # the input-gradient form: padding 2, the residual gradient added in the interior
+    ("multi_item_grid5", (3, 34, 36, 24), 64, "VALID", "grid5"),         # 12 items on a persistent grid of 5: several items per workgroup, odd chunk count
+    ("tiny", (1, 3, 3, 8), 64, "VALID", None),
+]
+
+
+@pytest.mark.parametrize("case", WINO4T_CASES, ids=[c[0] for c in WINO4T_CASES])
+def test_winograd_f4x4_16tile_conv_matches_oracle(eng, knob, case):
+    """wino4t_conv_kernel (fs_wino4t.hip: Winograd F(4x4,3x3) on 16-tile items with the filter operand global -> registers; the
+    residual convs of the transform net, im_transf_net.py:250-276, and their input gradients) through fs_conv2d_fwd with a
+    caller-transformed filter (fs_wino4t_transform_filter).  float64 oracle, 5e-5 of the output's magnitude as for fs_wino4.hip."""
+    name, xs, cout, pad, extra = case
+    if extra == "grid5":
+        knob("FS_WINO4T_WGS", 5)
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(xs).astype(np.float32)
+    w = (rng.standard_normal((3, 3, xs[3], cout)) * 0.1).astype(np.float32)
+    kw = {}
+    if pad == "FULL":
+        padding = (2, 2, xs[1] + 2, xs[2] + 2)
+        want = nnops.conv2d(np.pad(x.astype(np.float64), ((0, 0), (2, 2), (2, 2), (0, 0))), w.astype(np.float64), 1, "VALID")
+    else:
+        padding = pad
+        want = nnops.conv2d(x.astype(np.float64), w.astype(np.float64), 1, pad)
+    if extra == "add":
+        add = rng.standard_normal((xs[0], xs[1] - 2, xs[2] - 2, cout)).astype(np.float32)
+        kw.update(add_src=up(eng, add), add_pad=2)
+        want[:, 2:-2, 2:-2, :] += add
+    direct = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, padding, **kw))
+    y = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, padding, winograd="4t", **kw))
+    assert y.shape == want.shape
+    assert rel(y, want) < 5e-5
+    assert rel(y, direct) < 5e-5 and not np.array_equal(y, direct)      # really the other algorithm
+
+
+def test_winograd_f4x4_16tile_residual_block_form(eng):
+    """The residual-block form on the 16-tile F(4x4) kernel: VALID padding, per-item statistics of the raw output ->
+    instnorm_finalize, then the producer's instance norm + ReLU applied on load by the next conv (im_transf_net.py:250-276)."""
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((2, 37, 41, 64)).astype(np.float32) + 0.5        # 35x39 outputs: ragged 16x16 items
+    w1 = (rng.standard_normal((3, 3, 64, 64)) * 0.1).astype(np.float32)
+    w2 = (rng.standard_normal((3, 3, 64, 64)) * 0.1).astype(np.float32)
+    gamma = (1 + 0.3 * rng.standard_normal(64)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(64)).astype(np.float32)
+    z, stats, tiles = eng.conv2d(up(eng, x), up(eng, w1), 1, "VALID", want_stats=True, winograd="4t")
+    assert tiles == 3 * 3
+    st = down(eng, stats)
+    z64 = nnops.conv2d(x.astype(np.float64), w1.astype(np.float64), 1, "VALID")
+    for (n, by, bx) in [(0, 0, 0), (1, 2, 2), (0, 1, 2)]:                  # records {mean, M2, count} of an interior, a corner and an edge item
+        blk = z64[n, 16 * by:16 * by + 16, 16 * bx:16 * bx + 16, :]
+        rec = st[n, by * 3 + bx]
+        assert np.all(rec[:, 2] == blk.shape[0] * blk.shape[1])
+        assert np.abs(rec[:, 0] - blk.mean(axis=(0, 1))).max() < 1e-4 * np.abs(z64).max()
+        assert np.abs(rec[:, 1] - ((blk - blk.mean(axis=(0, 1))) ** 2).sum(axis=(0, 1))).max() < 1e-4 * ((blk - blk.mean(axis=(0, 1))) ** 2).sum(axis=(0, 1)).max()
+    mean, rstd, a, b = eng.instnorm_finalize(stats, tiles, 64, 1, up(eng, gamma), up(eng, beta))
+    y = down(eng, eng.conv2d(z, up(eng, w2), 1, "VALID", in_a=a, in_b=b, in_per_sample=1, in_relu=1, winograd="4t"))
+    n64, (xhat, rs, _) = nnops.inst_norm(z64, gamma.astype(np.float64), beta.astype(np.float64))
+    assert rel(down(eng, z), z64) < 5e-5
+    assert rel(down(eng, mean), z64.mean(axis=(1, 2))) < 5e-5
+    assert rel(down(eng, rstd), rs[:, 0, 0, :]) < 5e-5
+    want = nnops.conv2d(nnops.relu(n64), w2.astype(np.float64), 1, "VALID")
+    assert y.shape == want.shape == (2, 33, 37, 64)
+    assert rel(y, want) < 1e-4
+
+
 def test_winograd_accuracy_is_that_of_the_direct_kernel(eng):
     """F(2x2,3x3) only adds / subtracts / halves in its transforms: on post-ReLU-like data with a deep reduction
     (256 input channels) its error against the fp64 oracle stays within 2x of the direct fp32 kernel's."""

@@ -162,6 +162,30 @@ def test_tnet_residual_convs_through_the_winograd_kernel(eng, shape, wgs, knob):
     assert grads_close(eng, g, want, 2e-4) == []
 
 
+@pytest.mark.parametrize("shape,wgs", [((2, 48, 56), 0), ((1, 45, 67), 0), ((3, 52, 44), 3)])
+def test_tnet_residual_convs_through_the_16tile_f4x4_kernel(eng, shape, wgs, knob):
+    """fs_wino4t.hip: what 720p frames and the training batches select by themselves (>= 64 items of 16x16 pixels) -- the ten
+    residual convs and their ten input gradients through the 16-tile Winograd F(4x4,3x3) kernel (instance norm + ReLU on load,
+    per-item statistics; 'full' padding + the residual gradient in the backward).  FS_TNET_WINO4=2 selects it at test sizes,
+    FS_WINO4T_WGS=3 makes workgroups walk several items.  Same oracle, same tolerances as every other path (measured: 2.5e-6 .. 4.4e-6
+    of the pixel range with the shipped weights -- 64-channel reductions keep F(4x4)'s larger transform constants harmless)."""
+    knob("FS_TNET_WINO4", 2)
+    if wgs:
+        knob("FS_WINO4T_WGS", wgs)
+    rng = np.random.default_rng(9)
+    P = tnet.strip_scope(starry())
+    flat = eng.mem.from_numpy(eng.flatten_params(P, scope=""))
+    x = rng.uniform(0, 255, shape + (3,)).astype(np.float32)
+    y = eng.mem.to_numpy(eng.tnet_forward(flat, eng.mem.from_numpy(x)))
+    yo = tnet.create_net(x.astype(np.float64), f64(P))
+    print("F(4x4) residual convs, shipped weights: max pixel error %.2e of the range" % (np.abs(y - yo).max() / 255.0))
+    assert np.abs(y - yo).max() / 255.0 < 2e-5
+    yk, yok, g, want = run_fwd_bwd(eng, kink_free_params(), shape, seed=0)
+    print("   kink-free weights: %.2e" % (np.abs(yk - yok).max() / 255.0))
+    assert np.abs(yk - yok).max() / 255.0 < 2e-5
+    assert grads_close(eng, g, want, 2e-4) == []
+
+
 @pytest.mark.parametrize("shape,block", [((2, 48, 56), 0), ((1, 45, 67), 1), ((3, 52, 44), 2), ((2, 56, 72), -1)])
 def test_tnet_residual_convs_through_the_half_item_winograd_kernel(eng, shape, block, knob):
     """fs_wino2h.hip: what a batch of 4 at 256x256 selects by itself (100..252 items on 256 CUs) -- the ten residual convs and
