@@ -472,13 +472,11 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
         else
             epilogue_body(std::false_type{}, I);
     };
-    auto next_item = [&]() __attribute__((always_inline)) {   // between two items of a workgroup
-        zero_acc();
-        // nothing of the epilogue may still be in flight at the loop header (loads and stores share ONE counter and complete out of
-        // order: with stores pending the compiler waits for vmcnt(0) -- every filter load included -- at the sweep's first use of a
-        // loaded register instead of an exact count); part of the drain hides behind the zeroing moves
-        FS_WAIT_VMEM();
-    };
+    // (No vector-memory drain between items or behind the prologue, unlike fs_wino4.hip: with the filter quads consumed one sweep
+    // after their loads the compiler keeps exact vmcnt counts in the sweep either way (checked in the ISA: vmcnt(20) / vmcnt(22)), and
+    // an exact count is safe with the epilogue's stores still in flight -- loads return in order among themselves, so "at most N
+    // operations outstanding" implies that a load with N younger LOADS behind it has arrived, whatever the stores do.)
+    auto next_item = [&]() __attribute__((always_inline)) { zero_acc(); };
 
     // ---- prologue: step 0 complete in stage 0 (patch, V) and in registers (filter), the patch of step 1 in stage 1, the patch of step 2
     // in registers.  Every load of steps 0 and 1 goes out before the first wait (patches first: they are needed first, and
@@ -512,7 +510,6 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
     transform_cols();
     transform_write(AP0.vn, 0, 18);
     __syncthreads();
-    FS_WAIT_VMEM();
 #ifdef FS_WINO4T_TRACE
     tr_pro = FS_W4T_NOW() - tr_t0;
 #endif
@@ -548,7 +545,7 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
         const long long e0 = FS_W4T_NOW();
 #endif
         epilogue(cur_it);
-        next_item();   // (also behind the last item: skipping it there -- `if (it + 1 < my_items)` -- makes the compiler restructure the item loop, 512 registers + scratch)
+        next_item();   // (also behind the last item: an `if (it + 1 < my_items)` makes the compiler restructure the item loop -- 512 registers + scratch)
 #ifdef FS_WINO4T_TRACE
         tr_epi += FS_W4T_NOW() - e0;
 #endif
