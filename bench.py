@@ -276,6 +276,8 @@ def main():
     fam = dict((n, i) for i, n in enumerate(names))
     F_WINO, F_WINO2_VGG, F_WINO2_TNET = fam["wino_conv_kernel"], fam["wino2_conv_kernel (VGG16 convs)"], fam["wino2_conv_kernel (transform-net residual convs)"]
     F_WINO4 = fam["wino4_conv_kernel"]
+    F_WINO4T_TNET, F_WINO4T_VGG = fam["wino4t_conv_kernel (transform-net residual convs)"], fam["wino4t_conv_kernel (VGG16 convs)"]
+    WINO_F4 = (F_WINO4, F_WINO4T_TNET, F_WINO4T_VGG)
     F_GRAM_FWD = (fam["gram_stream_kernel"], fam["conv_wgrad_kernel (Gram forward)"])
     F_GRAM_BWD = (fam["gram_bwd_kernel"], fam["conv_igemm_kernel (Gram backward, 1x1 per-sample filters)"])
     WINO_F2 = (F_WINO, F_WINO2_VGG, F_WINO2_TNET)
@@ -526,7 +528,7 @@ def main():
                                              "time of the section by HIP events in an eager pass (every kernel of it, not only MFMA ones)"},
                 "per_kernel": per_kernel,
             }
-            wf = [F_WINO4, F_WINO, F_WINO2_VGG, F_WINO2_TNET]
+            wf = [F_WINO4T_VGG, F_WINO4T_TNET, F_WINO4, F_WINO, F_WINO2_VGG, F_WINO2_TNET]
             w_fl, w_ms, w_n = (sum(tot[3 * f + k] for f in wf) for k in (1, 2, 0))
             if w_ms:
                 rep["winograd_family"] = {"kernels": [names[f] for f in wf if tot[3 * f + 2] > 0], "launches_per_step": round(w_n / P, 1),
@@ -538,6 +540,8 @@ def main():
         dom = per_kernel[names[di]]
         traffic, traffic_src = None, None
         sym = names[di].split(" (")[0]                     # the kernel symbol of the dominant row
+        if sym == "wino4t_conv_kernel":                    # (its 32-tile VGG16 instances and 16-tile transform-net instances are folded separately)
+            sym += "<2>" if di == F_WINO4T_VGG else "<1>"
         tpath = newest_profile("hbm_traffic_pmc.json")
         if tpath:
             tj = json.load(open(tpath))
@@ -563,7 +567,7 @@ def main():
                        "style_image": "starry_night_crop.jpg 640x938"},
             "roofline": {"bound": "mfma",
                          "kernel": names[di] + (": fp32 MFMA, Winograd F(4x4,3x3) 3x3 conv; achieved = FLOPs EXECUTED (36 products per "
-                                                "4x4 outputs instead of 144: a quarter of the direct form's, 0.5625 of F(2x2,3x3)'s)" if di == F_WINO4 else
+                                                "4x4 outputs instead of 144: a quarter of the direct form's, 0.5625 of F(2x2,3x3)'s)" if di in WINO_F4 else
                                                 ": fp32 MFMA, Winograd F(2x2,3x3) 3x3 conv; achieved = FLOPs EXECUTED (16 products per "
                                                 "2x2 outputs instead of 36)" if di in WINO_F2 else ": fp32 MFMA"),
                          "achieved": dom["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac"],
@@ -573,7 +577,7 @@ def main():
                          "timed_with": "HIP events on the launch stream, eager pass of %d steps right after the timed region; every row "
                                        "of per_kernel is ONE kernel symbol (template instances summed), so row ms = launches x the "
                                        "average duration of that symbol in profiles/*kernel_stats*" % args.profile_steps,
-                         "direct_form_equivalent_tflops": round(dom["tflops"] * (4.0 if di == F_WINO4 else 2.25), 2) if di in WINO_F2 + (F_WINO4,) else None,
+                         "direct_form_equivalent_tflops": round(dom["tflops"] * (4.0 if di in WINO_F4 else 2.25), 2) if di in WINO_F2 + WINO_F4 else None,
                          "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
                          "winograd_family": rep.get("winograd_family"),
                          "per_kernel": per_kernel},

@@ -470,7 +470,7 @@ static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
     }
     a->p = fs::conv_plan(*a);
     if (d->pool_out) {   // only the Winograd epilogues hold whole pooling windows
-        if (!(a->p.variant == 5 || a->p.variant == 6 || a->p.variant == 10) || a->p.ksplit > 1 || (a->Ho & 1) || (a->Wo & 1))
+        if (!(a->p.variant == 5 || a->p.variant == 6 || a->p.variant == 10 || a->p.variant == 11) || a->p.ksplit > 1 || (a->Ho & 1) || (a->Wo & 1))
             return fail(-2, "fs_conv2d: pool_out needs a Winograd-eligible conv with even Ho, Wo");
         a->pool_out = d->pool_out;
     }

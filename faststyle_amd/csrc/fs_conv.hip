@@ -808,7 +808,7 @@ const char* prof_family_name(int f) {
         "conv_stream_kernel", "conv3x3_to3_kernel", "wgrad2_kernel", "conv_wgrad_kernel", "gram_stream_kernel",
         "conv_wgrad_kernel (Gram forward)", "gram_bwd_kernel", "conv_igemm_kernel (Gram backward, 1x1 per-sample filters)",
         "wino2h_conv_kernel (transform-net residual convs, half items)", "conv_s16_kernel", "wino4_conv_kernel", "wgw_kernel",
-        "wino4t_conv_kernel (transform-net residual convs)"};
+        "wino4t_conv_kernel (transform-net residual convs)", "wino4t_conv_kernel (VGG16 convs)"};
     return f >= 0 && f < Profiler::kFamilies ? names[f] : "";
 }
 
@@ -1117,7 +1117,7 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
         else if (p.variant == 7) fam = PF_CSTREAM;
         else if (p.variant == 9) fam = PF_S16;
         else if (p.variant == 10) fam = PF_WINO4;
-        else if (p.variant == 11) fam = PF_WINO4T;
+        else if (p.variant == 11) fam = a.prof_tag ? PF_WINO4T_TNET : PF_WINO4T_VGG;
         else if (p.variant == 8) fam = PF_WINO2H_TNET;
         else if (p.variant == 6) fam = a.prof_tag ? PF_WINO2_TNET : PF_WINO2_VGG;
         prof->begin(fam, fl, s);

@@ -583,11 +583,11 @@ enum ProfFam {
     PF_IGEMM_32_2_2 = 0, PF_IGEMM_32_2_1 = 1, PF_IGEMM_16_4_1 = 2, PF_IGEMM_32_1_2 = 3, PF_IGEMM_32_1_1 = 4,
     PF_WINO = 5, PF_WINO2_VGG = 6, PF_WINO2_TNET = 7, PF_CSTREAM = 8, PF_C3 = 9, PF_WGRAD2 = 10, PF_WGRAD = 11,
     PF_GRAM_STREAM = 12, PF_GRAM_WGRAD = 13, PF_GRAM_BWD = 14, PF_GRAM_BWD_IGEMM = 15, PF_WINO2H_TNET = 16, PF_S16 = 17,
-    PF_WINO4 = 18, PF_WGW = 19, PF_WINO4T = 20
+    PF_WINO4 = 18, PF_WGW = 19, PF_WINO4T_TNET = 20, PF_WINO4T_VGG = 21
 };
 const char* prof_family_name(int f);
 struct Profiler {
-    static const int kFamilies = 21;   // one per kernel symbol (ProfFam); fs_profile_family_name() names them
+    static const int kFamilies = 22;   // one per kernel symbol (ProfFam); fs_profile_family_name() names them
     struct Rec { hipEvent_t a, b; int fam; double flops; };
     Rec* recs = nullptr;
     int n = 0, cap = 0;

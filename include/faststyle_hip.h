@@ -35,7 +35,7 @@ const char* fs_version(void);
  * out[f*3+{0,1,2}] = {launches, FLOPs executed, milliseconds} of row f; fs_profile_family_name(f) is the kernel symbol the
  * row belongs to (one row per symbol, so a row can be re-derived from a `rocprofv3 --kernel-trace --stats` summary; the
  * one symbol shared by two workloads, wino2_conv_kernel, has a row per caller), "" for unused rows. */
-#define FS_PROFILE_FAMILIES 21
+#define FS_PROFILE_FAMILIES 22
 int fs_profile_begin(fs_ctx* ctx);
 int fs_profile_end(fs_ctx* ctx, double out[3 * FS_PROFILE_FAMILIES]);
 const char* fs_profile_family_name(int family);

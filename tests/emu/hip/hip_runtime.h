@@ -312,21 +312,23 @@ inline float shfl_idx(float v, int src) {
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) fsemu::mfma_32x32x16_bf16((a), (b), (c))
 #define __builtin_amdgcn_s_getreg(imm) 0u   /* hardware id register: slot 0 everywhere */
 
-/* buffer resources: a (base, size) pair; loads beyond the size return zeros, as the hardware range check does */
+/* buffer resources: a (base, size) pair; loads beyond the size return zeros, as the hardware range check does.  The kernels mark a
+ * DELIBERATELY dropped access with the offset 0x80000000 or with an EMPTY buffer (size 0); any other out-of-range access is a bug
+ * and aborts. */
 namespace fsemu {
 struct buffer_rsrc { const unsigned char* base; unsigned nbytes; };
 static inline uint4 raw_buffer_load_b128(buffer_rsrc r, unsigned voff, unsigned soff) {
     uint4 v{0u, 0u, 0u, 0u};
     const unsigned long long end = (unsigned long long)voff + soff + 16ull;
     if (voff < 0x80000000u && end <= r.nbytes) memcpy(&v, r.base + voff + soff, 16);
-    else if (voff < 0x80000000u) { fprintf(stderr, "emu: buffer load out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
+    else if (voff < 0x80000000u && r.nbytes) { fprintf(stderr, "emu: buffer load out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
     return v;
 }
 static inline unsigned raw_buffer_load_b32(buffer_rsrc r, unsigned voff, unsigned soff) {
     unsigned v = 0u;
     const unsigned long long end = (unsigned long long)voff + soff + 4ull;
     if (voff < 0x80000000u && end <= r.nbytes) memcpy(&v, r.base + voff + soff, 4);
-    else if (voff < 0x80000000u) { fprintf(stderr, "emu: buffer load out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
+    else if (voff < 0x80000000u && r.nbytes) { fprintf(stderr, "emu: buffer load out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
     return v;
 }
 struct uint3_emu { unsigned x, y, z; };
@@ -334,7 +336,7 @@ static inline uint3_emu raw_buffer_load_b96(buffer_rsrc r, unsigned voff, unsign
     uint3_emu v{0u, 0u, 0u};
     const unsigned long long end = (unsigned long long)voff + soff + 12ull;
     if (voff < 0x80000000u && end <= r.nbytes) memcpy(&v, r.base + voff + soff, 12);
-    else if (voff < 0x80000000u) { fprintf(stderr, "emu: buffer load out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
+    else if (voff < 0x80000000u && r.nbytes) { fprintf(stderr, "emu: buffer load out of range (%u+%u of %u)\n", voff, soff, r.nbytes); abort(); }
     return v;
 }
 static inline void raw_buffer_store_b32(unsigned v, buffer_rsrc r, unsigned voff, unsigned soff) {

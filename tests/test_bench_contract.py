@@ -30,8 +30,8 @@ def test_bench_json_contract():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.05 < r["frac"] < 1.0
     assert r["traffic"] is None or r["traffic"] > 1e6
-    # one row per kernel SYMBOL (wino2 split by caller), each with its own frac
-    assert set(r["per_kernel"]) >= {"wino4_conv_kernel", "wino2_conv_kernel (transform-net residual convs)",
+    # one row per kernel SYMBOL (wino4t split by caller), each with its own frac
+    assert set(r["per_kernel"]) >= {"wino4t_conv_kernel (VGG16 convs)", "wino4t_conv_kernel (transform-net residual convs)",
                                     "wgrad2_kernel", "gram_stream_kernel", "gram_bwd_kernel", "conv_stream_kernel"}
     for row in r["per_kernel"].values():
         assert abs(row["frac"] - row["tflops"] / 157.3) < 1e-3 and abs(row["ms_per_step"] * 1e3 - row["launches_per_step"] * row["avg_launch_us"]) < 2.0

@@ -160,24 +160,36 @@ def test_winograd_f4x4_accuracy_on_a_deep_reduction(eng):
 
 
 WINO4T_CASES = [
-    # name, x shape, Cout, padding (explicit: (pad, pad, Ho, Wo) | "VALID" | "SAME"), extra
-    ("one_item_valid", (1, 18, 18, 8), 64, "VALID", None),
-    ("ragged_valid_2img", (2, 23, 39, 16), 64, "VALID", None),          # 21x37 outputs: partial 16x16 items, a last tile row / column of 1 pixel
-    ("same_two_coblocks", (1, 20, 20, 8), 128, "SAME", None),
-    ("full_pad_with_add", (2, 19, 21, 64), 64, "FULL", "add"),           # the input-gradient form: padding 2, the residual gradient added in the interior
-    ("multi_item_grid5", (3, 34, 36, 24), 64, "VALID", "grid5"),         # 12 items on a persistent grid of 5: several items per workgroup, odd chunk count
-    ("tiny", (1, 3, 3, 8), 64, "VALID", None),
+    # name, x shape, Cout, padding ("VALID" | "SAME" | "FULL" = padding 2), extra, tile blocks per item (FS_WINO4T_TB)
+    ("one_item_valid", (1, 18, 18, 8), 64, "VALID", None, 1),
+    ("ragged_valid_2img", (2, 23, 39, 16), 64, "VALID", None, 1),       # 21x37 outputs: partial 16x16 items, a last tile row / column of 1 pixel
+    ("same_two_coblocks", (1, 20, 20, 8), 128, "SAME", None, 1),
+    ("full_pad_with_add", (2, 19, 21, 64), 64, "FULL", "add", 1),        # the input-gradient form: padding 2, the residual gradient added in the interior
+    ("multi_item_grid5", (3, 34, 36, 24), 64, "VALID", "grid5", 1),      # 12 items on a persistent grid of 5: several items per workgroup, odd chunk count
+    ("tiny", (1, 3, 3, 8), 64, "VALID", None, 1),
+    ("tb2_one_block", (1, 16, 32, 8), 64, "SAME", None, 2),              # 32-tile items (16 x 32 pixels): the VGG16 forms
+    ("tb2_ragged_bias_relu", (2, 21, 37, 8), 64, "SAME", "bias_relu", 2),
+    ("tb2_two_coblocks_pool", (1, 24, 40, 16), 128, "SAME", "pool", 2),
+    ("tb2_mask_multi_item", (3, 20, 36, 16), 128, "SAME", "mask", 2),    # 12 items on a grid of 5
+    ("tb2_full_pad_with_add", (2, 19, 45, 24), 64, "FULL", "add", 2),
+    ("tb1_bias_relu_pool", (1, 18, 20, 8), 64, "SAME", "pool", 1),
+    ("tb1_mask", (2, 17, 19, 16), 64, "SAME", "mask", 1),
+    ("tb2_split_k", (1, 16, 32, 128), 64, "SAME", "ksplit", 2),          # one item: the planner splits the 16 steps over 4 workgroups (raw partials + splitk epilogue)
 ]
 
 
 @pytest.mark.parametrize("case", WINO4T_CASES, ids=[c[0] for c in WINO4T_CASES])
 def test_winograd_f4x4_16tile_conv_matches_oracle(eng, knob, case):
-    """wino4t_conv_kernel (fs_wino4t.hip: Winograd F(4x4,3x3) on 16-tile items with the filter operand global -> registers; the
-    residual convs of the transform net, im_transf_net.py:250-276, and their input gradients) through fs_conv2d_fwd with a
-    caller-transformed filter (fs_wino4t_transform_filter).  float64 oracle, 5e-5 of the output's magnitude as for fs_wino4.hip."""
-    name, xs, cout, pad, extra = case
-    if extra == "grid5":
+    """wino4t_conv_kernel (fs_wino4t.hip: Winograd F(4x4,3x3) with the filter operand global -> registers; 16-tile items for the
+    residual convs of the transform net, im_transf_net.py:250-276, and their input gradients, 32-tile items for the VGG16 convs,
+    libs/vgg16.py:45-173) through fs_conv2d_fwd with a caller-transformed filter (fs_wino4t_transform_filter).  float64 oracle,
+    5e-5 of the output's magnitude as for fs_wino4.hip."""
+    name, xs, cout, pad, extra, tb = case
+    knob("FS_WINO4T_TB", tb)
+    if extra == "grid5" or name == "tb2_mask_multi_item":
         knob("FS_WINO4T_WGS", 5)
+    if extra == "ksplit":
+        knob("FS_WINO4_KSPLIT_MINSTEPS", 8)
     rng = np.random.default_rng(21)
     x = rng.standard_normal(xs).astype(np.float32)
     w = (rng.standard_normal((3, 3, xs[3], cout)) * 0.1).astype(np.float32)
@@ -192,29 +204,44 @@ def test_winograd_f4x4_16tile_conv_matches_oracle(eng, knob, case):
         add = rng.standard_normal((xs[0], xs[1] - 2, xs[2] - 2, cout)).astype(np.float32)
         kw.update(add_src=up(eng, add), add_pad=2)
         want[:, 2:-2, 2:-2, :] += add
+    if extra in ("bias_relu", "pool"):
+        bias = rng.standard_normal(cout).astype(np.float32)
+        kw.update(bias=up(eng, bias), out_relu=1)
+        want = np.maximum(want + bias, 0.0)
+    if extra == "mask":
+        mask = rng.standard_normal(want.shape).astype(np.float32)
+        kw["mask_src"] = up(eng, mask)
+        want = np.where(mask > 0, want, 0.0)
     direct = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, padding, **kw))
-    y = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, padding, winograd="4t", **kw))
+    out = eng.conv2d(up(eng, x), up(eng, w), 1, padding, winograd="4t", want_pool=(extra == "pool"), **kw)
+    y = down(eng, out[0] if extra == "pool" else out)
     assert y.shape == want.shape
     assert rel(y, want) < 5e-5
     assert rel(y, direct) < 5e-5 and not np.array_equal(y, direct)      # really the other algorithm
+    if extra == "pool":
+        assert np.array_equal(down(eng, out[1]), nnops.max_pool_2x2(y)[0])   # the pooled tensor is the max over the STORED values, bit for bit
 
 
-def test_winograd_f4x4_16tile_residual_block_form(eng):
+@pytest.mark.parametrize("tb", [1, 2])
+def test_winograd_f4x4_16tile_residual_block_form(eng, knob, tb):
     """The residual-block form on the 16-tile F(4x4) kernel: VALID padding, per-item statistics of the raw output ->
     instnorm_finalize, then the producer's instance norm + ReLU applied on load by the next conv (im_transf_net.py:250-276)."""
+    knob("FS_WINO4T_TB", tb)
+    BW = 16 * tb
     rng = np.random.default_rng(23)
-    x = rng.standard_normal((2, 37, 41, 64)).astype(np.float32) + 0.5        # 35x39 outputs: ragged 16x16 items
+    x = rng.standard_normal((2, 37, 41, 64)).astype(np.float32) + 0.5        # 35x39 outputs: ragged items
     w1 = (rng.standard_normal((3, 3, 64, 64)) * 0.1).astype(np.float32)
     w2 = (rng.standard_normal((3, 3, 64, 64)) * 0.1).astype(np.float32)
     gamma = (1 + 0.3 * rng.standard_normal(64)).astype(np.float32)
     beta = (0.2 * rng.standard_normal(64)).astype(np.float32)
     z, stats, tiles = eng.conv2d(up(eng, x), up(eng, w1), 1, "VALID", want_stats=True, winograd="4t")
-    assert tiles == 3 * 3
+    assert tiles == 3 * (3 if tb == 1 else 2)
     st = down(eng, stats)
     z64 = nnops.conv2d(x.astype(np.float64), w1.astype(np.float64), 1, "VALID")
-    for (n, by, bx) in [(0, 0, 0), (1, 2, 2), (0, 1, 2)]:                  # records {mean, M2, count} of an interior, a corner and an edge item
-        blk = z64[n, 16 * by:16 * by + 16, 16 * bx:16 * bx + 16, :]
-        rec = st[n, by * 3 + bx]
+    nbx = 3 if tb == 1 else 2
+    for (n, by, bx) in [(0, 0, 0), (1, 2, nbx - 1), (0, 1, nbx - 1)]:      # records {mean, M2, count} of an interior, a corner and an edge item
+        blk = z64[n, 16 * by:16 * by + 16, BW * bx:BW * bx + BW, :]
+        rec = st[n, by * nbx + bx]
         assert np.all(rec[:, 2] == blk.shape[0] * blk.shape[1])
         assert np.abs(rec[:, 0] - blk.mean(axis=(0, 1))).max() < 1e-4 * np.abs(z64).max()
         assert np.abs(rec[:, 1] - ((blk - blk.mean(axis=(0, 1))) ** 2).sum(axis=(0, 1))).max() < 1e-4 * ((blk - blk.mean(axis=(0, 1))) ** 2).sum(axis=(0, 1)).max()

@@ -32,7 +32,7 @@ CASES = {
 
 def main():
     names = sys.argv[1:] or list(CASES)
-    modes = [int(m) for m in os.environ.get("MODES", "4,2").split(",")]
+    modes = [m if m == "4t" else int(m) for m in os.environ.get("MODES", "4t,4").split(",")]   # 4t: fs_wino4t.hip, 4: fs_wino4.hip, 2: F(2x2), 0: direct
     iters = int(os.environ.get("ITERS", "20"))
     e = engine.Engine()
     p = e.mem.ptr
@@ -54,7 +54,12 @@ def main():
                 d.bias, d.out_relu = p(bias), 1
             if epi == "mask":
                 d.mask_src = p(mask)
-            if mode == 4:
+            if mode == "4t":
+                U = e.mem.empty((36, Ci, Co))
+                L.check(e.lib, e.lib.fs_wino4t_transform_filter(e.ctx, p(w), Ci, Co, p(U)), "wino4t transform")
+                d.w_wino4t = p(U)
+                keep.append(U)
+            elif mode == 4:
                 U = e.mem.empty((36, Ci, Co))
                 L.check(e.lib, e.lib.fs_wino4_transform_filter(e.ctx, p(w), Ci, Co, p(U)), "wino4 transform")
                 d.w_wino4 = p(U)
@@ -67,7 +72,7 @@ def main():
             tiles = ctypes.c_int()
             y = e.mem.empty((N, H, W, Co))
             d.y = p(y)
-            if epi == "pool" and mode in (2, 4) and not (mode == 2 and Ci > 128):
+            if epi == "pool" and mode in (2, 4, "4t") and not (mode == 2 and Ci > 128):
                 pool = e.mem.empty((N, H // 2, W // 2, Co))
                 d.pool_out = p(pool)
                 keep.append(pool)
@@ -84,13 +89,14 @@ def main():
             ms = t0.elapsed_time(t1) / iters
             fl = 2.0 * N * H * W * 9 * Ci * Co
             outs[mode] = y
-            print("%-18s mode %d %8.1f us  direct-equivalent %7.2f TFLOP/s  executed %6.2f TFLOP/s" % (
-                nm, mode, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 * ({4: 0.25, 2: 16.0 / 36.0}.get(mode, 1.0))), flush=True)
-            if mode == 4 and hasattr(e.lib, "fs_debug_wino4_trace"):   # -DFS_WINO4_TRACE build: phases of the last launch
+            print("%-18s mode %-2s %8.1f us  direct-equivalent %7.2f TFLOP/s  executed %6.2f TFLOP/s" % (
+                nm, mode, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 * ({4: 0.25, "4t": 0.25, 2: 16.0 / 36.0}.get(mode, 1.0))), flush=True)
+            tracer = {4: "fs_debug_wino4_trace", "4t": "fs_debug_wino4t_trace"}.get(mode)
+            if tracer and hasattr(e.lib, tracer):   # -DFS_WINO4_TRACE / -DFS_WINO4T_TRACE build: phases of the last launch
                 import numpy as np
                 buf = np.zeros((4096, 8), dtype=np.int64)
-                e.lib.fs_debug_wino4_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
-                assert e.lib.fs_debug_wino4_trace(buf.ctypes.data, 4096) == 0
+                getattr(e.lib, tracer).argtypes = [ctypes.c_void_p, ctypes.c_int]
+                assert getattr(e.lib, tracer)(buf.ctypes.data, 4096) == 0
                 live = buf[buf[:, 6] > 0]
                 life = (live[:, 6] - live[:, 0]).astype(float)
                 steps = live[:, 5].astype(float)
@@ -100,11 +106,11 @@ def main():
                           100 * live[:, 2].mean() / life.mean(), (live[:, 2] / steps).mean(), 100 * live[:, 3].mean() / life.mean(),
                           100 * live[:, 4].mean() / life.mean(), (live[:, 4] / live[:, 7]).mean()))
         if os.environ.get("CHECK") and len(outs) > 1:
-            ks = sorted(outs)
+            ks = list(outs)
             ref = outs[ks[0]].double()
             for k in ks[1:]:
                 err = float((outs[k].double() - ref).abs().max() / ref.abs().max())
-                print("   max |mode %d - mode %d| / max = %.2e" % (k, ks[0], err))
+                print("   max |mode %s - mode %s| / max = %.2e" % (k, ks[0], err))
 
 
 if __name__ == "__main__":
