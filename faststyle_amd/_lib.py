@@ -18,6 +18,7 @@ FS_VGG_NLAYERS = 10
 FS_FLAG_SAVE_FOR_BWD = 1
 FS_FLAG_UPSAMPLE_DECONV = 2
 FS_FLAG_BF16 = 4
+FS_FLAG_PARAMS_FROZEN = 8
 FS_TNET_WS_Z, FS_TNET_WS_A, FS_TNET_WS_B, FS_TNET_WS_MEAN, FS_TNET_WS_RSTD, FS_TNET_WS_H = 0, 1, 2, 3, 4, 5
 FS_PAD_SAME, FS_PAD_VALID, FS_PAD_EXPLICIT = 0, 1, 2
 FS_SRC_PLAIN, FS_SRC_REFLECT, FS_SRC_DILATE2 = 0, 1, 2

@@ -20,6 +20,11 @@ struct fs_ctx {
     fs::TnetLayout tnet;
     unsigned tnet_epoch = 0;   // fs::tune_epoch() the layout was planned under
     bool tnet_valid;
+    // the last fs_tnet_forward (fp32) that rebuilt the re-laid-out filters inside its workspace: FS_FLAG_PARAMS_FROZEN skips the rebuild on a match
+    const float* fwd_params = nullptr;
+    const void* fwd_ws = nullptr;
+    unsigned fwd_serial = 0;     // tnet_serial at that call
+    unsigned tnet_serial = 0;    // bumped whenever the cached layout is re-planned
     fs::BTnetLayout* btnet;  // bf16 inference layout (allocated on first use)
     hipStream_t side;      // second stream for the filter-gradient branch of fs_tnet_backward
     hipEvent_t ev[34];
@@ -178,6 +183,7 @@ static const fs::TnetLayout* get_layout(fs_ctx* ctx, int N, int H, int W, int fl
         fs::tnet_layout(N, H, W, deconv, &ctx->tnet);
         ctx->tnet_valid = true;
         ctx->tnet_epoch = fs::tune_epoch();
+        ++ctx->tnet_serial;
     }
     return &ctx->tnet;
 }
@@ -215,8 +221,16 @@ int fs_tnet_forward(fs_ctx* ctx, const float* params, const float* x, int N, int
     const fs::TnetLayout* L = get_layout(ctx, N, H, W, flags);
     if (ws_bytes < L->total_floats * sizeof(float))
         return fail(-3, "fs_tnet_forward: workspace too small (%zu < %zu bytes)", ws_bytes, L->total_floats * sizeof(float));
-    const int rc = fs::tnet_forward(*L, params, x, y, (float*)ws, ctx->stream);
-    return rc ? fail(rc, "fs_tnet_forward: launch failed (%d)", rc) : 0;
+    const bool reuse = (flags & FS_FLAG_PARAMS_FROZEN) && ctx->fwd_params == params && ctx->fwd_ws == ws && ctx->fwd_serial == ctx->tnet_serial;
+    const int rc = fs::tnet_forward(*L, params, x, y, (float*)ws, ctx->stream, reuse);
+    if (rc) {
+        ctx->fwd_params = nullptr;
+        return fail(rc, "fs_tnet_forward: launch failed (%d)", rc);
+    }
+    ctx->fwd_params = params;
+    ctx->fwd_ws = ws;
+    ctx->fwd_serial = ctx->tnet_serial;
+    return 0;
 }
 
 int fs_tnet_backward(fs_ctx* ctx, const float* params, const float* x, const float* dy, int N, int H, int W, float* grads,

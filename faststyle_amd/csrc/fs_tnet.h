@@ -60,7 +60,8 @@ struct TnetLayout {
 void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L);
 int tnet_wino_mode();  // current FS_TNET_WINO
 WgradArgs unit_wgrad_args(const Unit& u, int N);
-int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s);
+// reuse_filters: the re-laid-out filters in ws are those of the previous call (FS_FLAG_PARAMS_FROZEN): skip the kernels that build them
+int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s, bool reuse_filters = false);
 // Optional second stream + events: the filter gradients of unit i only need dz_i, so they run concurrently
 // with the input-gradient chain of the units below (both are small launches at batch 4).
 struct StreamAux {

@@ -420,7 +420,7 @@ WgradArgs unit_wgrad_args(const Unit& u, int N) {
         if (rc_) return rc_; \
     } while (0)
 
-int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s) {
+int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s, bool reuse_filters) {
     const int N = L.N;
     // collapsed resize-conv filters (weights may have changed since the last call: training)
     WtBatch wb{};
@@ -433,8 +433,8 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
         wb.add(WT_UPFWD, params + L.u[14].w_off, ws + L.weff[1], 3, 3, 32, 16);
         wb.add(WT_FOLD5FWD, params + L.u[15].w_off, ws + L.wfold, 9, 9, 16, 3);
     }
-    FS_TRY(wt_batch(wb, s));
-    {   // Winograd-transformed filters of the residual convs that use wino_conv_kernel (one launch)
+    if (!reuse_filters) FS_TRY(wt_batch(wb, s));
+    if (!reuse_filters) {   // Winograd-transformed filters of the residual convs that use wino_conv_kernel (one launch)
         WinoBatch nb{}, nb4{};
         for (int i = 3; i <= 12; ++i)
             if (L.u[i].wino) {

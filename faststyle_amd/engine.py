@@ -222,9 +222,10 @@ class Engine(object):
         assert upsample_method in ("resize", "deconv")
         return L.FS_FLAG_UPSAMPLE_DECONV if upsample_method == "deconv" else 0
 
-    def tnet_forward(self, params, x, save_for_bwd=False, upsample_method="resize", bf16=False):
+    def tnet_forward(self, params, x, save_for_bwd=False, upsample_method="resize", bf16=False, frozen=False):
         """create_net(x, upsample_method): x [N,H,W,3] float32 RGB 0..255 -> y [N,Ho,Wo,3].
-        bf16=True: the mixed-precision inference path (FS_FLAG_BF16; ~1e-2 of the pixel range off the fp32 path)."""
+        bf16=True: the mixed-precision inference path (FS_FLAG_BF16; ~1e-2 of the pixel range off the fp32 path).
+        frozen=True: `params` is not modified between calls (FS_FLAG_PARAMS_FROZEN: the filter re-layouts run once per sequence)."""
         self._sync_stream()
         N, H, W, C = (int(s) for s in x.shape)
         assert C == 3
@@ -234,7 +235,7 @@ class Engine(object):
         p = self.mem.ptr
         L.check(self.lib, self.lib.fs_tnet_forward(self.ctx, p(params), p(x), N, H, W, p(y), p(ws), nbytes,
                                                    (L.FS_FLAG_SAVE_FOR_BWD if save_for_bwd else 0) |
-                                                   (L.FS_FLAG_BF16 if bf16 else 0) |
+                                                   (L.FS_FLAG_BF16 if bf16 else 0) | (L.FS_FLAG_PARAMS_FROZEN if frozen and not bf16 else 0) |
                                                    self._method_flag(upsample_method)), "fs_tnet_forward")
         return y
 

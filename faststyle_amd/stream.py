@@ -36,7 +36,7 @@ class FrameStylizer(object):
     def _device_pass(self):
         e = self.eng
         e.u8_to_f32(self._in_u8, self._in_f32)
-        self._y = e.tnet_forward(self.variables, self._in_f32, upsample_method=self.method, bf16=self.bf16)
+        self._y = e.tnet_forward(self.variables, self._in_f32, upsample_method=self.method, bf16=self.bf16, frozen=True)   # one checkpoint, many frames
         e.f32_to_u8(self._y, self._out_u8, swap_rb=self.swap_rb)
 
     def _capture(self):

@@ -50,6 +50,12 @@ const char* fs_profile_family_name(int family);
                                     * is ~1e-2 of the pixel range -- NOT the 1e-3 parity bar, which only the fp32 path meets. */
 #define FS_FLAG_UPSAMPLE_DECONV 2 /* --upsample_method deconv (im_transf_net.py:57-63): the three upsample_* filters are
                                      [K,K,Cout,Cin] conv2d_transpose filters (same element counts and offsets) */
+#define FS_FLAG_PARAMS_FROZEN 8   /* fs_tnet_forward, fp32: the caller promises that `params` holds the values it held at this context's
+                                   * previous fs_tnet_forward call and that nobody wrote to `ws` in between (stylize_image.py /
+                                   * stylize_webcam.py: one checkpoint, many frames).  The re-laid-out filters (collapsed resize-conv,
+                                   * folded output layer, Winograd transforms) live in `ws`; when params pointer, ws pointer and
+                                   * plan are those of the previous call the kernels that rebuild them are skipped -- any other
+                                   * call rebuilds them as usual, so the first call of a sequence is always complete. */
 
 /* name / offset (floats) / shape of the idx-th parameter tensor in the flat buffer; the order is
  * the key order of the TF bundle (models/<style>_final.ckpt.index), without the "img_t_net/" scope. */

@@ -40,7 +40,10 @@ for CFG in "720 1280 1 fp32" "1080 1920 8 bf16"; do
     timeout 200 rocprofv3 --kernel-trace --pmc $C -d $O/pmc_${T}_$C --output-format csv -- python $R/tools/fwd720.py $1 $2 $3 $4 > /dev/null 2>&1
   done
 done
+# 4. matrix-core utilisation counters of the b32 step (one pass; tools/pmc_mfma.py folds them per kernel symbol)
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -d $O/pmc_mfma --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-stylize --no-b4 --no-graph > /dev/null 2>&1
 cd $R
+python tools/pmc_mfma.py $O/pmc_mfma $O/mfma_util_b32.json "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES (one pass) on MI355X; python bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-stylize --no-b4 --no-graph (train step, batch 32); per-launch averages" > $O/mfma_util_b32.txt 2>&1
 PROV="rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) on MI355X, per-launch average over all launches of the kernel. Counters are KiB; gfx950 correction (MI355X_MICROARCH.md HBM section): FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled. traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024."
 python tools/pmc_traffic.py $O/pmc_b32_FETCH_SIZE $O/pmc_b32_WRITE_SIZE $O/hbm_traffic_pmc.json "$PROV Command: python bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-stylize --no-b4 --no-graph (train step, batch 32)." 32 > $O/traffic_b32.txt
 python tools/pmc_traffic.py $O/pmc_720p_b1_fp32_FETCH_SIZE $O/pmc_720p_b1_fp32_WRITE_SIZE $O/hbm_traffic_720p_fp32.json "$PROV Command: python tools/fwd720.py 720 1280 1 fp32 (23 forward passes)." - 23 > $O/traffic_720p.txt

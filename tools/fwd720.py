@@ -18,12 +18,12 @@ N = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 BF16 = len(sys.argv) > 4 and sys.argv[4] == "bf16"      # ("fp32": the default path)
 x = torch.rand((N, H, Wd, 3), device="cuda") * 255
 for _ in range(3):
-    e.tnet_forward(flat, x, bf16=BF16)
+    e.tnet_forward(flat, x, bf16=BF16, frozen=True)   # one checkpoint, many frames (stylize_image.py / stylize_webcam.py)
 torch.cuda.synchronize()
 t = time.perf_counter()
 it = 20
 for _ in range(it):
-    e.tnet_forward(flat, x, bf16=BF16)
+    e.tnet_forward(flat, x, bf16=BF16, frozen=True)   # one checkpoint, many frames (stylize_image.py / stylize_webcam.py)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / it
 print("forward %s %dx%dx%d: %.3f ms  %.1f fps" % ("bf16" if BF16 else "fp32", N, H, Wd, dt * 1e3, N / dt))
