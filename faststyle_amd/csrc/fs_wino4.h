@@ -46,10 +46,13 @@
 #define FS_W4_ADDR(p) ((int)(size_t)(const __attribute__((address_space(3))) char*)(p))
 #define FS_W4_LDS(T, addr) (*(__attribute__((address_space(3))) T*)(size_t)(unsigned)(addr))
 #define FS_W4_PIN(x) asm volatile("" : "+v"(x))
+/* a 4-byte LDS store the compiler may NOT pair with a neighbour (ds_write2_b32 has 8-bit offsets: pairs at large strides need a vector add for their base) */
+#define FS_W4_LDS_STORE1(addr, v) (*(volatile __attribute__((address_space(3))) float*)(size_t)(unsigned)(addr) = (v))
 #else   /* emulator / host pass: addresses are byte offsets from the workgroup's LDS array */
 #define FS_W4_ADDR(p) ((int)(reinterpret_cast<const char*>(p) - reinterpret_cast<const char*>(smem)))
 #define FS_W4_LDS(T, addr) (*reinterpret_cast<T*>(reinterpret_cast<char*>(smem) + (addr)))
 #define FS_W4_PIN(x) ((void)0)
+#define FS_W4_LDS_STORE1(addr, v) (FS_W4_LDS(float, addr) = (v))
 #endif
 // B^T x for one 6-vector (input transform, one dimension): 12 instructions
 #define FS_W4_BT(d0, d1, d2, d3, d4, d5, t0, t1, t2, t3, t4, t5) \

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
     };
     auto transform_write = [&](int a_vn, int k0, int k1) __attribute__((always_inline)) {   // position (3h + ii) * 6 + j of the lane's sub-chunk
 #pragma unroll
-        for (int k = k0; k < k1; ++k) FS_W4_LDS(float, a_vn + k * (kVB * 4)) = tt[k];
+        for (int k = k0; k < k1; ++k) FS_W4_LDS_STORE1(a_vn + k * (kVB * 4), tt[k]);
     };
 
     // accumulators: [position][tile block].  TB = 2 needs 288 registers: positions >= kNA live in ordinary vector registers (fs_wino4.h)
