@@ -307,9 +307,19 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
 #pragma unroll
         for (int nn = 0; nn < NB; ++nn) breg[j][nn] = Sn[(2 * j + kq) * C + co0 + nn * 32 + lm];
 
+    // (the row blocks of a wave span more than 64 KB: one base register per 64 KB, each behind an opaque copy, keeps every read at
+    // "register + 16-bit immediate" -- folded onto ONE base, half of the reads got a v_add each between the matrix instructions)
+    constexpr int MPB = (65536 / (32 * S * 4)) > 0 ? (65536 / (32 * S * 4)) : 1;   // row blocks per base register
+    constexpr int NBASE = (WM + MPB - 1) / MPB;
+    int laneB[NBASE];
+#pragma unroll
+    for (int g = 0; g < NBASE; ++g) {
+        laneB[g] = ((mw * WM + g * MPB) * 32 + lm) * S + kq;
+        if (g > 0) FS_OPAQUE(laneB[g]);
+    }
     int laneA[WM];
 #pragma unroll
-    for (int m = 0; m < WM; ++m) laneA[m] = ((mw * WM + m) * 32 + lm) * S + kq;
+    for (int m = 0; m < WM; ++m) laneA[m] = laneB[m / MPB] + (m % MPB) * 32 * S;
 
     const float* Fn = a.F + (size_t)n * a.HW * C;
     {

@@ -343,6 +343,23 @@ __device__ __forceinline__ f32x2 fs_pk_fma(f32x2 a, f32x2 b, f32x2 c) {   // a *
 #define FS_LDS_BARRIER() __syncthreads()
 #endif
 
+// LDS accesses beside matrix instructions.  A vector-ALU instruction between two fp32 v_mfma costs ~20 cycles there (same fp32 units), an LDS
+// instruction next to nothing -- so address arithmetic must not reach the vector ALU:
+//   FS_LDS_LOAD1 / FS_LDS_STORE1: a 4-byte access the compiler may NOT pair with a neighbour (ds_read2_b32 / ds_write2_b32 take 8-bit offsets in
+//     units of 4 bytes: a pair further than 1020 bytes from the base register gets a v_add for its own base; the unpaired access has a 16-bit
+//     byte offset).  Measured on fs_wino4t.hip: 18 such adds per step removed = -5 % of the step.
+//   FS_OPAQUE(x): the value behind an opaque copy -- the compiler cannot fold a second base register back into "first base + constant"
+//     (offsets past 65535 bytes would again cost a v_add each).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FS_LDS_LOAD1(ptr) (*(const volatile __attribute__((address_space(3))) float*)(ptr))
+#define FS_LDS_STORE1(ptr, v) (*(volatile __attribute__((address_space(3))) float*)(ptr) = (v))
+#define FS_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define FS_LDS_LOAD1(ptr) (*(ptr))
+#define FS_LDS_STORE1(ptr, v) (*(ptr) = (v))
+#define FS_OPAQUE(x) ((void)0)
+#endif
+
 // Wait for every vector-memory operation of this wave (s_waitcnt vmcnt(0); gfx9 encoding, the other counters left at their
 // maxima).  Placed at the END of a pipeline prologue: the compiler inserts waits statically, so a load that is still pending
 // on ONE path into a loop header (the prologue's) costs a vmcnt(0) in EVERY iteration if its destination register is

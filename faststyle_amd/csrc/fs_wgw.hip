@@ -183,10 +183,10 @@ __global__ __launch_bounds__(256) void wgw_kernel(WgwArgs a) {
     const float* pb = Dl + ((4 * wave) * kST + kq) * kC + lm;
     auto sweep = [&]() __attribute__((always_inline)) {
         float A[2][2], B[2][2];
-        A[0][0] = pa[0];
-        A[0][1] = pa[32];
-        B[0][0] = pb[0];
-        B[0][1] = pb[32];
+        A[0][0] = FS_LDS_LOAD1(pa);   // (unpaired 4-byte reads, 16-bit immediates: no address arithmetic between the matrix instructions)
+        A[0][1] = FS_LDS_LOAD1(pa + 32);
+        B[0][0] = FS_LDS_LOAD1(pb);
+        B[0][1] = FS_LDS_LOAD1(pb + 32);
 #pragma unroll
         for (int q = 0; q < 32; ++q) {   // q = pair j (0..7) * 4 + position p
             const int c = q & 1, nx = c ^ 1, p = q & 3;
@@ -194,10 +194,10 @@ __global__ __launch_bounds__(256) void wgw_kernel(WgwArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if (q + 1 < 32) {
                 const int off = ((q + 1) & 3) * (kST * kC) + ((q + 1) >> 2) * (2 * kC);
-                A[nx][0] = pa[off];
-                A[nx][1] = pa[off + 32];
-                B[nx][0] = pb[off];
-                B[nx][1] = pb[off + 32];
+                A[nx][0] = FS_LDS_LOAD1(pa + off);
+                A[nx][1] = FS_LDS_LOAD1(pa + off + 32);
+                B[nx][0] = FS_LDS_LOAD1(pb + off);
+                B[nx][1] = FS_LDS_LOAD1(pb + off + 32);
             }
             __builtin_amdgcn_sched_barrier(0);
             acc[p][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[c][0], B[c][1], acc[p][0][1], 0, 0, 0);
