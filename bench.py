@@ -446,12 +446,21 @@ def main():
             eng.release_pins(held)
             n = shape[0]
             fps = world * iters * n / dt
-            gf_exec, gf_written, mb = FWD_WORK[(shape[1], shape[2])]
+            gf_direct, gf_written, mb = FWD_WORK[(shape[1], shape[2])]
             if bf16:
                 mb = mb / 2
+            # FLOPs EXECUTED: on the fp32 path the ten residual convs run as Winograd F(4x4,3x3) (fs_wino4t.hip; every shape timed here has
+            # >= 64 items) -- 36 products per 4x4 outputs instead of 144.  (Until round 4 this figure counted them in direct form.)
+            gf_exec = gf_direct
+            if not bf16:
+                hr, wr = (shape[1] + 80) // 4, (shape[2] + 80) // 4            # residual input extent (im_transf_net.py:34-45)
+                for k in range(1, 11):
+                    ho, wo = hr - 2 * k, wr - 2 * k
+                    gf_exec += (2.0 * -(-ho // 4) * -(-wo // 4) * 36 - 2.0 * ho * wo * 9) * 64 * 64 / 1e9
             per_gpu = fps / world
             rep = {"fps": round(fps, 1), "ms_per_batch": round(1e3 * dt / iters, 3), "batch_per_gpu": n, "iters": iters,
-                   "tflops_executed": round(gf_exec * per_gpu / 1e3, 2), "tflops_as_written": round(gf_written * per_gpu / 1e3, 2),
+                   "tflops_executed": round(gf_exec * per_gpu / 1e3, 2), "tflops_direct_form": round(gf_direct * per_gpu / 1e3, 2),
+                   "tflops_as_written": round(gf_written * per_gpu / 1e3, 2),
                    "min_traffic_TBps": round(mb * per_gpu / 1e6, 3), "frac_hbm_peak_min_traffic": round(mb * per_gpu / 1e6 / PEAK_HBM_TBS, 4),
                    "hip_graph": bool(graph and not args.no_graph)}
             if bf16:     # two roofs: the bf16 matrix cores (2.5 PFLOP/s dense) and HBM -- this leg is built around bytes
