@@ -139,7 +139,7 @@ def test_tnet_forward_with_two_level_statistics_merge(eng, knob):
     assert np.abs(y - yo).max() / 255.0 < 2e-5
 
 
-@pytest.mark.parametrize("shape,wgs", [((2, 48, 56), 0), ((1, 45, 67), 0), ((2, 48, 56), 6), ((3, 52, 44), 10)])
+@pytest.mark.parametrize("shape,wgs", [((1, 45, 67), 0), ((2, 48, 56), 6), ((3, 52, 44), 10)])
 def test_tnet_residual_convs_through_the_winograd_kernel(eng, shape, wgs, knob):
     """FS_TNET_WINO=2 forces what 720p / 1080p frames (and large training batches) select by themselves: the ten 3x3
     VALID residual convs through wino_conv_kernel -- producer instance norm + ReLU on load, per-block statistics --
@@ -186,7 +186,7 @@ def test_tnet_residual_convs_through_the_16tile_f4x4_kernel(eng, shape, wgs, kno
     assert grads_close(eng, g, want, 2e-4) == []
 
 
-@pytest.mark.parametrize("shape,block", [((2, 48, 56), 0), ((1, 45, 67), 1), ((3, 52, 44), 2), ((2, 56, 72), -1)])
+@pytest.mark.parametrize("shape,block", [((1, 45, 67), 1), ((3, 52, 44), 2), ((2, 56, 72), -1)])   # (a fallback path since round 4: below 64 items of 16x16 pixels)
 def test_tnet_residual_convs_through_the_half_item_winograd_kernel(eng, shape, block, knob):
     """fs_wino2h.hip: what a batch of 4 at 256x256 selects by itself (100..252 items on 256 CUs) -- the ten residual convs and
     their ten input gradients through the half-item Winograd kernel (<= 32 tiles x 64 channels, waves split by channel block

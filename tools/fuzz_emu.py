@@ -73,7 +73,7 @@ def main():
     up, down = e.mem.from_numpy, e.mem.to_numpy
     inst = [(16, 32, 3, 2), (32, 64, 2, 1), (32, 64, 3, 2), (64, 128, 2, 1), (64, 64, 3, 1)]
     for it in range(cases):
-        kind = it % 13
+        kind = it % 14
         if kind == 11:        # 16-channel-block streaming kernel (fs_s16.hip)
             n, h, w = int(rng.integers(1, 3)), int(rng.integers(9, 50)), int(rng.integers(9, 50))
             os.environ["FS_S16_WGS"] = str(int(rng.choice([1, 3, 512])))
@@ -177,6 +177,42 @@ def main():
             y = down(e.conv2d(up(x), up(wt), 1, "SAME", winograd=4, **kw))
             r = rel(y, want)
             print("case %3d wino4 %s -> %d epilogue %d wgs %s  rel %.2e" % (it, x.shape, cout, epi, os.environ["FS_WINO4_WGS"], r), flush=True)
+            assert r < 5e-5
+        elif kind == 13:      # register-fed Winograd F(4x4,3x3) (fs_wino4t.hip): 16- / 32-tile items, padding 0 / 1 / 2, every epilogue form, ragged blocks
+            cin, cout = int(rng.choice([8, 16, 24, 64])), int(rng.choice([64, 128]))
+            pad = int(rng.integers(3))
+            n, h, w = int(rng.integers(1, 3)), int(rng.integers(3 - pad, 40)), int(rng.integers(3 - pad, 70))
+            os.environ["FS_WINO4T_WGS"] = str(int(rng.choice([1, 3, 256])))
+            os.environ["FS_WINO4T_TB"] = str(int(rng.choice([1, 2])))
+            e.lib.fs_debug_reload_env()
+            x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+            wt = (rng.standard_normal((3, 3, cin, cout)) * 0.1).astype(np.float32)
+            ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
+            want = nnops.conv2d(np.pad(x.astype(np.float64), ((0, 0), (pad, pad), (pad, pad), (0, 0))), wt.astype(np.float64), 1, "VALID")
+            epi = int(rng.integers(5))
+            kw, stats = {}, False
+            if epi == 1:
+                bias = rng.standard_normal((cout,)).astype(np.float32)
+                kw = dict(bias=up(bias), out_relu=1)
+                want = np.maximum(want + bias, 0.0)
+            elif epi == 2:
+                mask = rng.standard_normal((n, ho, wo, cout)).astype(np.float32)
+                kw = dict(mask_src=up(mask))
+                want = np.where(mask > 0, want, 0.0)
+            elif epi == 3 and ho > 4 and wo > 4:
+                add = rng.standard_normal((n, ho - 4, wo - 4, cout)).astype(np.float32)
+                kw = dict(add_src=up(add), add_pad=2)
+                want[:, 2:-2, 2:-2, :] += add
+            elif epi == 4:
+                stats = True
+            out = e.conv2d(up(x), up(wt), 1, (pad, pad, ho, wo), winograd="4t", want_stats=stats, **kw)
+            y = down(out[0] if stats else out)
+            r = rel(y, want)
+            if stats:
+                mean, var = merge_stats(down(out[1]))
+                r = max(r, rel(mean, want.mean(axis=(1, 2))), rel(var, want.var(axis=(1, 2))))
+            print("case %3d wino4t %s -> %d pad %d epilogue %d tb %s wgs %s  rel %.2e" % (it, x.shape, cout, pad, epi, os.environ["FS_WINO4T_TB"],
+                                                                                       os.environ["FS_WINO4T_WGS"], r), flush=True)
             assert r < 5e-5
         elif kind == 8:       # second-generation Winograd kernel (fs_wino2.hip): SAME 3x3, bias + ReLU epilogue, ragged 16x16 blocks
             cin, cout = int(rng.choice([8, 16, 64, 128])), int(rng.choice([64, 128]))

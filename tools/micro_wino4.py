@@ -91,12 +91,16 @@ def main():
             outs[mode] = y
             print("%-18s mode %-2s %8.1f us  direct-equivalent %7.2f TFLOP/s  executed %6.2f TFLOP/s" % (
                 nm, mode, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 * ({4: 0.25, "4t": 0.25, 2: 16.0 / 36.0}.get(mode, 1.0))), flush=True)
-            tracer = {4: "fs_debug_wino4_trace", "4t": "fs_debug_wino4t_trace"}.get(mode)
-            if tracer and hasattr(e.lib, tracer):   # -DFS_WINO4_TRACE / -DFS_WINO4T_TRACE build: phases of the last launch
+            buf = None
+            if mode == 4 and hasattr(e.lib, "fs_debug_wino4_trace"):   # -DFS_WINO4_TRACE build: phases of the last launch
                 import numpy as np
                 buf = np.zeros((4096, 8), dtype=np.int64)
-                getattr(e.lib, tracer).argtypes = [ctypes.c_void_p, ctypes.c_int]
-                assert getattr(e.lib, tracer)(buf.ctypes.data, 4096) == 0
+                e.lib.fs_debug_wino4_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
+                assert e.lib.fs_debug_wino4_trace(buf.ctypes.data, 4096) == 0
+            elif mode == "4t":                                          # -DFS_WINO4T_TRACE build
+                from micro_wino4t import read_wino4t_trace
+                buf = read_wino4t_trace(e.lib)
+            if buf is not None:
                 live = buf[buf[:, 6] > 0]
                 life = (live[:, 6] - live[:, 0]).astype(float)
                 steps = live[:, 5].astype(float)
