@@ -16,7 +16,7 @@
 //     bytes per step through 9 loads + 9 LDS writes + 36 LDS reads for HALF the matrix instructions).  A filter quad is
 //     reloaded for the next step right behind the last matrix instruction that reads it (one register set);
 //   * LDS holds only the transformed input V (72 blocks of [k][tile], skewed: conflict-free for the transform's writes and the
-//     operand reads) and the raw 18 x (16 TB + 2) x 8 patch (channel-planar) -- 33 KB (TB = 1) / 63 KB (TB = 2) per stage;
+//     operand reads) and the raw 18 x (16 TB + 2) x 8 patch (channel-planar) -- 33 KB (TB = 1) / 67 KB (TB = 2) per stage;
 //   * input transform of the tiles x 8 channels of a step on lane pairs with v_permlane32_swap, as in fs_wino4.hip (TB = 2: two passes);
 //   * on load: the producer's instance norm + ReLU (AFF; padding 0 only); epilogue forms: raw (also split-K partials), raw +
 //     per-item instance-norm partials {mean, M2, count}, + the residual gradient added in the interior, bias + ReLU (+ the fused

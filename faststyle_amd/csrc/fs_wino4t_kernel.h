@@ -49,6 +49,9 @@ static inline int wino4t_trace_read(long long* out, int n_wg) {
 }
 #define FS_W4T_NOW() ((long long)__builtin_readcyclecounter())
 #endif
+#ifndef FS_W4T_EARLY_TB2_MASK
+#define FS_W4T_EARLY_TB2_MASK 8   /* 32-tile items, consumer-mask epilogue: mask loads issued in front of the output transform (of 16 per tile block) */
+#endif
 #ifndef FS_W4T_ABL
 #define FS_W4T_ABL 0   /* timing experiments (results wrong): 1 no input transform, 2 no filter loads, 4 no patch loads / commit, 8 no operand reads */
 #endif
@@ -67,7 +70,8 @@ template <int TB, int EPI, bool AFF>
 __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
     using GEO = Geo<TB>;
     constexpr int kBW = GEO::kBW, kPW = GEO::kPW, kPR = GEO::kPR, kPix = GEO::kPix, kSink = GEO::kSink, kPlane = GEO::kPlane, kNPV = GEO::kNPV, kVB = GEO::kVB,
-                  kVF = GEO::kVF, kStageF = GEO::kStageF, kEarly = GEO::kEarly;
+                  kVF = GEO::kVF, kStageF = GEO::kStageF;
+    constexpr int kEarly = (TB == 2 && EPI == 4) ? FS_W4T_EARLY_TB2_MASK : GEO::kEarly;
     constexpr bool kDefer = GEO::kDefer;
     HIP_DYNAMIC_SHARED(float, smem)
 #ifdef FS_WINO4T_TRACE
