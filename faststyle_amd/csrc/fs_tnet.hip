@@ -343,6 +343,7 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
             h.KH = h.KW = 3;
             h.stride = 1;
             h.pad_t = h.pad_l = 2;
+            h.prof_tag = 1;   // (as unit_dgrad sets it: the planner keeps 16-tile items for the transform net)
             h.w_wino4t = reinterpret_cast<const float*>(16);
             if (wino4t_eligible(h) && (w4 == 2 || wino4t_items(h) >= tune_int("FS_WINO4T_MIN_ITEMS", 64))) {
                 on = true;
