@@ -81,6 +81,7 @@ struct ConvArgs {
     const float* w_wino2; // optional: ... in the K-contiguous order [16][Cin/8][Cout][8] (fs::wt_wino2); enables variant 6
     const float* w_wino4; // optional: the filter transformed for F(4x4,3x3), [36][Cin/4][Cout/64][2][4][16][2] (fs::wt_wino4); enables variant 10
     const float* w_wino4t; // optional: the filter transformed for F(4x4,3x3) in the register layout of fs_wino4t.hip, [Cin/8][Cout/16][18][64][4] (fs::wt_wino4t); enables variant 11
+    const float* w_wino4u; // optional, with w_wino4t: the same filter in the layout of the 128-channel item form of fs_wino4t.hip, [Cin/8][Cout/32][36][64][4] (fs::wt_wino4u)
     float* y;        // [N,Ho,Wo,Cout], or [N,2Ho,2Wo,Cout/4] when shuffle
     int N, H, W, Cin;
     int Ho, Wo, Cout;
@@ -509,6 +510,7 @@ void wino4_plan(const ConvArgs& a, ConvPlan* out);
 int wino4_launch(const ConvArgs& a, hipStream_t s);
 int wt_wino4t(const float* w, float* U, int Cin, int Cout, hipStream_t s);                     // fs_wino4t.hip: F(4x4,3x3) with 16-tile items (transform-net residual convs), plan variant 11
 int wt_wino4t_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s);
+int wt_wino4u(const float* w, float* U, int Cin, int Cout, hipStream_t s);                      // ... for its 128-channel item form (ConvArgs::w_wino4u)
 bool wino4t_eligible(const ConvArgs& a);
 long wino4t_items(const ConvArgs& a);
 void wino4t_plan(const ConvArgs& a, ConvPlan* out);

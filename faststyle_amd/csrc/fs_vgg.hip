@@ -63,7 +63,9 @@ static size_t wino4_offset(int l, bool dgrad) {  // l >= 1
 }
 // (... and once more in the register layout of fs_wino4t.hip, the kernel the training step runs them on since the second half of round 4)
 static size_t wino4t_offset(int l, bool dgrad) { return wino4_offset(l, dgrad) + (wino4_offset(FS_VGG_NLAYERS, false) - wino4_offset(1, false)); }
-size_t vgg_prepared_floats() { return wino4t_offset(FS_VGG_NLAYERS, false); }
+// (... and in the layout of its 128-channel item form, for the layers that have the channels)
+static size_t wino4u_offset(int l, bool dgrad) { return wino4t_offset(l, dgrad) + (wino4_offset(FS_VGG_NLAYERS, false) - wino4_offset(1, false)); }
+size_t vgg_prepared_floats() { return wino4u_offset(FS_VGG_NLAYERS, false); }
 // FS_WINO_V >= 5 (default): the F(4x4) convs through fs_wino4t.hip (32-tile items, filter operand global -> registers); 4: through fs_wino4.hip
 static bool vgg_use_4t() { return tune_int("FS_WINO_V", 5) >= 5; }
 // debugging aid: FS_VGG_WINO_MASK selects the layers that may take the Winograd kernel (bit l: forward of layer l,
@@ -89,6 +91,8 @@ int vgg_prepare(const float* const w[FS_VGG_NLAYERS], float* prepared, hipStream
         FS_TRY(wt_wino4(prepared + prepared_offset(l), prepared + wino4_offset(l, true), kCout[l], kCin[l], s));
         FS_TRY(wt_wino4t(w[l], prepared + wino4t_offset(l, false), kCin[l], kCout[l], s));
         FS_TRY(wt_wino4t(prepared + prepared_offset(l), prepared + wino4t_offset(l, true), kCout[l], kCin[l], s));
+        if (kCout[l] % 128 == 0) FS_TRY(wt_wino4u(w[l], prepared + wino4u_offset(l, false), kCin[l], kCout[l], s));
+        if (kCin[l] % 128 == 0) FS_TRY(wt_wino4u(prepared + prepared_offset(l), prepared + wino4u_offset(l, true), kCout[l], kCin[l], s));
     }
     return 0;
 }
@@ -192,7 +196,7 @@ void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, 
 }
 
 // pool: optional destination of the 2x2/2 max-pool of the result; *pooled tells whether the conv launch produced it
-static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, const float* w_wino, const float* w_wino2, const float* w_wino4, const float* w_wino4t, const float* bias, const float* ab,
+static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, const float* w_wino, const float* w_wino2, const float* w_wino4, const float* w_wino4t, const float* w_wino4u, const float* bias, const float* ab,
                     float* y, float* split_ws, size_t split_ws_floats, hipStream_t s, float* pool = nullptr, bool* pooled = nullptr) {
     ConvArgs a{};
     a.x = x;
@@ -201,6 +205,7 @@ static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, 
     a.w_wino2 = w_wino2;
     a.w_wino4 = w_wino4;
     a.w_wino4t = w_wino4t;
+    a.w_wino4u = w_wino4u;
     a.y = y;
     a.N = N;
     a.H = a.Ho = H;
@@ -239,7 +244,8 @@ static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS],
         const bool wl = prepared && l >= 1 && wino_layer_on(l);
         FS_TRY(vgg_conv(src, nb, L.Hl[l], L.Wl[l], l, w[l], wl ? prepared + wino_offset(l, false) : nullptr,
                         wl ? prepared + wino2_offset(l, false) : nullptr, (wl && !vgg_use_4t()) ? prepared + wino4_offset(l, false) : nullptr,
-                        (wl && vgg_use_4t()) ? prepared + wino4t_offset(l, false) : nullptr, b[l],
+                        (wl && vgg_use_4t()) ? prepared + wino4t_offset(l, false) : nullptr,
+                        (wl && vgg_use_4t() && kCout[l] % 128 == 0) ? prepared + wino4u_offset(l, false) : nullptr, b[l],
                         ws + L.ab, ws + L.act[l], ws + L.splitws, L.splitws_floats, s,
                         (pool_after(l) && l < L.lmax) ? ws + L.pool[pool_index(l)] : nullptr, &pooled));
         src = ws + L.act[l];
@@ -401,6 +407,7 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         a.w_wino2 = (l >= 1 && wino_layer_on(16 + l)) ? prepared + wino2_offset(l, true) : nullptr;
         a.w_wino4 = (l >= 1 && wino_layer_on(16 + l) && !vgg_use_4t()) ? prepared + wino4_offset(l, true) : nullptr;
         a.w_wino4t = (l >= 1 && wino_layer_on(16 + l) && vgg_use_4t()) ? prepared + wino4t_offset(l, true) : nullptr;
+        a.w_wino4u = (a.w_wino4t && kCin[l] % 128 == 0) ? prepared + wino4u_offset(l, true) : nullptr;
         a.N = N;
         a.H = a.Ho = H;
         a.W = a.Wo = W;

@@ -45,6 +45,31 @@ __global__ __launch_bounds__(256) void wt_wino4t_kernel(WinoBatch b, int Cin, in
     }
 }
 
+// The 128-channel item form (M = 3 of the kernel): U4u[ci/8][co/32][q (36)][lane = (ci%4) * 16 + co%16][e], quad q = slot / 2, e = (slot % 2) * 2 + (co/16) % 2
+// -- the wave that owns channels co/32 * 32 .. +31 reads, per slot, the A operands of its two 16-channel blocks from one quad.
+__global__ __launch_bounds__(256) void wt_wino4u_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t cc = (size_t)Cin * Cout;
+    if (i >= cc) return;
+    const int ci = (int)(i / Cout), co = (int)(i - (size_t)ci * Cout);
+    double o[36];
+    wino4_filter_transform(w, cc, i, o);
+    float* dst = U + ((size_t)(ci >> 3) * (Cout >> 5) + (co >> 5)) * (36 * 256) + ((ci & 3) * 16 + (co & 15)) * 4 + ((co >> 4) & 1);
+    const int sub = (ci >> 2) & 1;
+#pragma unroll
+    for (int pos = 0; pos < 36; ++pos) {
+        const int slot = sub * 36 + pos;
+        dst[(slot >> 1) * 256 + (slot & 1) * 2] = (float)o[pos];
+    }
+}
+
+int wt_wino4u(const float* w, float* U, int Cin, int Cout, hipStream_t s) {
+    if (Cin % kCC || Cout % (2 * kBN)) return -1;
+    const size_t cc = (size_t)Cin * Cout;
+    hipLaunchKernelGGL(wt_wino4u_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, w, U, Cin, Cout);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 int wt_wino4t_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s) {
     if (Cin % kCC || Cout % kBN || b.n < 0 || b.n > 12) return -1;
     if (b.n == 0) return 0;
@@ -102,11 +127,20 @@ static int wino4t_pick_tb(const ConvArgs& a) {
 
 long wino4t_items(const ConvArgs& a) { return wino4t_items_tb(a, wino4t_pick_tb(a)); }
 
+// The 128-channel item form (16 tiles x 128 channels; the filter in the layout of wt_wino4u): where 32-tile items would be taken and the
+// layer has the channels for it -- same item count, but ONE input-transform pass per 144 matrix instructions instead of two.
+// FS_WINO4T_CB = 1 disables it.
+static bool wino4t_use_cb2(const ConvArgs& a) {
+    const int e = wino4t_epi(a, 1);
+    return a.w_wino4u && a.Cout % (2 * kBN) == 0 && !a.in_a && (e == 0 || e == 3 || e == 4) && tune_int("FS_WINO4T_CB", 2) >= 2 && wino4t_pick_tb(a) == 2;
+}
+
 void wino4t_plan(const ConvArgs& a, ConvPlan* out) {
     ConvPlan p{};
-    const int tb = wino4t_pick_tb(a);
+    const bool cb2 = wino4t_use_cb2(a);
+    const int tb = cb2 ? 1 : wino4t_pick_tb(a);
     p.variant = 11;
-    p.BN = kBN;
+    p.BN = cb2 ? 2 * kBN : kBN;
     p.CC = kCC;
     p.TH = kBH;
     p.TW = 16 * tb;
@@ -114,7 +148,7 @@ void wino4t_plan(const ConvArgs& a, ConvPlan* out) {
     p.tiles_x = cdiv(a.Wo, p.TW);
     p.lds_bytes = 4 * 2 * (tb == 1 ? Geo<1>::kStageF : Geo<2>::kStageF);
     p.ksplit = 1;
-    const long items = wino4t_items_tb(a, tb);
+    const long items = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / p.BN);
     const int nchunks = a.Cin / kCC;
     const int max_ks = tune_int("FS_WINO_KSPLIT", 4);
     if (a.split_ws && !a.pool_out && !a.stats && !a.in_a) {   // split-K where the launch cannot fill the chip (the rule of fs_wino4.hip; a step here is 8 channels)
@@ -128,6 +162,7 @@ void wino4t_plan(const ConvArgs& a, ConvPlan* out) {
 
 // (the other instantiations: fs_wino4t1b.hip, fs_wino4t2.hip, fs_wino4t2b.hip)
 int wino4t_launch_1b(const ConvArgs& a, int epi, long grid, hipStream_t s);
+int wino4t_launch_1c(const ConvArgs& a, int epi, long grid, hipStream_t s);
 int wino4t_launch_2a(const ConvArgs& a, int epi, long grid, hipStream_t s);
 int wino4t_launch_2b(const ConvArgs& a, int epi, long grid, hipStream_t s);
 
@@ -137,9 +172,10 @@ int wino4t_launch(const ConvArgs& a, hipStream_t s) {
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
     const int epi = wino4t_epi(a, ks);
     if (epi < 0 || (tb != 1 && tb != 2) || (a.in_a && epi > 1)) return -7;
-    const long items = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / kBN) * ks;
+    const long items = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / p.BN) * ks;
     const int wgs = tune_int("FS_WINO4T_WGS", 256);
     const long grid = items < wgs ? items : wgs;
+    if (p.BN == 2 * kBN) return (tb == 1 && a.w_wino4u) ? wino4t_launch_1c(a, epi, grid, s) : -7;
     const bool part_a = a.in_a || epi <= 1;
     if (tb == 1) return part_a ? wino4t_launch_part_a<1>(a, epi, grid, s) : wino4t_launch_1b(a, epi, grid, s);
     return part_a ? wino4t_launch_2a(a, epi, grid, s) : wino4t_launch_2b(a, epi, grid, s);

@@ -64,15 +64,23 @@ __device__ __forceinline__ float quad_elem(const float4& v) {
     else return v.w;
 }
 
-// TB: tile blocks of 16 per item.  EPI: 0 raw (also split-K partials), 1 raw + instance-norm partials of the item (a.stats), 2 + a.add_src in
+// M: item form -- 1: 16 tiles x 64 channels; 2: 32 tiles (two tile blocks) x 64 channels; 3: 16 tiles x 128 channels (two CHANNEL blocks per
+// wave: the input transform of a step serves twice the products; 36 filter quads per step through an 18-register window).
+// EPI: 0 raw (also split-K partials), 1 raw + instance-norm partials of the item (a.stats), 2 + a.add_src in
 // the interior, 3 bias + ReLU (+ a.pool_out), 4 a.mask_src.  AFF: a.in_a / a.in_b + ReLU on load.
-template <int TB, int EPI, bool AFF>
+template <int M, int EPI, bool AFF>
 __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
+    constexpr int TB = M == 2 ? 2 : 1;      // tile blocks of 16 per item (geometry)
+    constexpr bool CB2 = M == 3;            // two channel blocks of 16 per wave
+    constexpr int NB = M == 1 ? 1 : 2;      // accumulator blocks per position
+    constexpr int kBNi = CB2 ? 2 * kBN : kBN;   // output channels per item
+    constexpr int QPS = CB2 ? 36 : 18;      // filter quads per step and wave
+    static_assert(!(CB2 && (EPI == 1 || EPI == 2 || AFF)), "the 128-channel form carries the VGG16 epilogues only");
     using GEO = Geo<TB>;
     constexpr int kBW = GEO::kBW, kPW = GEO::kPW, kPR = GEO::kPR, kPix = GEO::kPix, kSink = GEO::kSink, kPlane = GEO::kPlane, kNPV = GEO::kNPV, kVB = GEO::kVB,
                   kVF = GEO::kVF, kStageF = GEO::kStageF;
     constexpr int kEarly = (TB == 2 && EPI == 4) ? FS_W4T_EARLY_TB2_MASK : GEO::kEarly;
-    constexpr bool kDefer = GEO::kDefer;
+    constexpr bool kDefer = NB == 2;   // (288 accumulator registers: the epilogue needs the staging registers)
     HIP_DYNAMIC_SHARED(float, smem)
 #ifdef FS_WINO4T_TRACE
     const long long tr_t0 = FS_W4T_NOW();
@@ -92,10 +100,10 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
     // the virtual index gives every XCD a contiguous range of items (the channel blocks of a pixel block and neighbouring blocks
     // share patch rows in its L2)
     const int blocks = p.tiles_y * p.tiles_x;
-    const int ncob = a.Cout / kBN;
+    const int ncob = a.Cout / kBNi;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
     const int nchunks_all = a.Cin / kCC;
-    const int nco16 = a.Cout >> 4;
+    const int nblk = CB2 ? a.Cout >> 5 : a.Cout >> 4;   // filter blocks of the layer (one per wave)
     const int total_items = a.N * blocks * ncob * ks;
     const int G = (int)gridDim.x;
     const int vb = (G & 7) ? (int)blockIdx.x : (((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3));
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
     const unsigned u_bytes = __builtin_amdgcn_readfirstlane((unsigned)(36 * a.Cin * a.Cout) * 4u);
     const unsigned ab_bytes = __builtin_amdgcn_readfirstlane((unsigned)a.Cin * 4u);
     unsigned load_on = 1u;   // 0 during the LAST sweep of an item: every staging load of that sweep gets an empty buffer (see next_item)
-    const float* ub = uniform_ptr(a.w_wino4t);
+    const float* ub = uniform_ptr(CB2 ? a.w_wino4u : a.w_wino4t);
     const unsigned uvo = (unsigned)lane * 16u;
     unsigned uvo_eff = uvo;   // kOOB while the step the filter loads are for does not exist
     auto patch_offsets = [&](const Item& I, int live) __attribute__((always_inline)) {   // once per item
@@ -230,11 +238,13 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
         FS_W4_LDS(float, a_pc + 3 * kPlane * 4) = act(v.w, sa.w, sb.w);
     };
     auto commit_patch_one = [&](int a_pc, int i) __attribute__((always_inline)) { commit_quad(a_pc, pv[i], fa, fb); };
-    auto issue_filter_one = [&](const Item& I, int chunk, int i) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ub), 0, load_on ? u_bytes : 0u, 0x00020000);
-        const unsigned so = (unsigned)(((chunk * nco16 + I.cob * 4 + wave) * 18 + i) * 1024);
-        uv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, uvo_eff, so, 0));
+    // quad `quad` (of QPS) of step (I, chunk) into register set `dst`; on = 0: against an empty buffer (zeros, no traffic)
+    auto issue_filter_q = [&](const Item& I, int chunk, int quad, int dst, unsigned on, unsigned vo) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ub), 0, on ? u_bytes : 0u, 0x00020000);
+        const unsigned so = (unsigned)(((chunk * nblk + I.cob * 4 + wave) * QPS + quad) * 1024);
+        uv[dst] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, vo, so, 0));
     };
+    auto issue_filter_one = [&](const Item& I, int chunk, int i) __attribute__((always_inline)) { issue_filter_q(I, chunk, i, i, load_on, uvo_eff); };
     // input transform V = B^T d B of the tiles x 8 channels of a step on PAIRS of lanes.  Half h does B^T d for columns 3h .. 3h+2, the
     // halves trade nine registers (v_permlane32_swap), half h does (.) B for rows 3h .. 3h+2.
     //   TB = 1: one pass; wave w owns tile rows 2 (w & 1), +1 and channels 4 (w >> 1) .. +3; lane = (half h, channel c, tile row tyl, tile column tx)
@@ -278,20 +288,20 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
     };
 
     // accumulators: [position][tile block].  TB = 2 needs 288 registers: positions >= kNA live in ordinary vector registers (fs_wino4.h)
-    constexpr int kNAcc = TB == 1 ? 36 : kNA;
-    f32x4 acc[kNAcc][TB];
-    f32x4 accv[TB == 1 ? 1 : 36 - kNA][TB];
+    constexpr int kNAcc = NB == 1 ? 36 : kNA;
+    f32x4 acc[kNAcc][NB];
+    f32x4 accv[NB == 1 ? 1 : 36 - kNA][NB];
 #define FS_W4T_ACC(pos, tb, r) ((pos) < kNAcc ? FS_ACC_READ(acc[(pos) < kNAcc ? (pos) : 0][tb][r]) : accv[(pos) >= kNAcc ? (pos) - kNAcc : 0][tb][r])
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int pos = 0; pos < kNAcc; ++pos)
 #pragma unroll
-            for (int tb = 0; tb < TB; ++tb) acc[pos][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (TB == 2) {
+            for (int tb = 0; tb < NB; ++tb) acc[pos][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (NB == 2) {
 #pragma unroll
             for (int pos = 0; pos < 36 - kNA; ++pos)
 #pragma unroll
-                for (int tb = 0; tb < TB; ++tb) accv[pos][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int tb = 0; tb < NB; ++tb) accv[pos][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
@@ -351,6 +361,8 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
         if constexpr ((pos) < kNAcc) FS_W4_MFMA_A(acc[(pos) < kNAcc ? (pos) : 0][tb], av, bv);       \
         else FS_W4_MFMA_V(accv[(pos) >= kNAcc ? (pos) - kNAcc : 0][tb], av, bv);       \
     } while (0)
+    Item cur_I = CU.I;     // the step being multiplied (M = 3 reloads the second half of ITS filter quads during the sweep)
+    int cur_chunk = 0;
     auto sweep = [&](const Addr& AD) __attribute__((always_inline)) {
         float B[3][TB];
         auto read_b = [&](int slot, int into) __attribute__((always_inline)) {
@@ -367,19 +379,38 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
         fs_static_for<0, 72>([&](auto SLOT) __attribute__((always_inline)) {
             constexpr int s = decltype(SLOT)::value;
             constexpr int pos = s % 36, c = s % 3, n2 = (s + 2) % 3;
-            const float av = quad_elem<(s & 3)>(uv[s >> 2]);
-            FS_W4T_MFMA(pos, 0, av, B[c][0]);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (TB == 2) {
+            if constexpr (CB2) {
+                // quad g = s / 2 of the step's 36 holds slots 2g, 2g+1 for both channel blocks; it lives in register set g % 18 and is replaced,
+                // right behind its last use, by quad (g + 18) % 36 -- of THIS step for g < 18, of the next step beyond
+                constexpr int g = s >> 1, e0 = (s & 1) * 2;
+                FS_W4T_MFMA(pos, 0, quad_elem<e0>(uv[g % 18]), B[c][0]);
+                __builtin_amdgcn_sched_barrier(0);
                 slice(2 * s, AD);
                 __builtin_amdgcn_sched_barrier(0);
-                FS_W4T_MFMA(pos, TB - 1, av, B[c][TB - 1]);
+                FS_W4T_MFMA(pos, 1, quad_elem<e0 + 1>(uv[g % 18]), B[c][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 2 < 72 && !(FS_W4T_ABL & 8)) read_b(s + 2, n2);
+                slice(2 * s + 1, AD);
+                if ((s & 1) == 1 && !(FS_W4T_ABL & 2)) {
+                    if constexpr (g < 18) issue_filter_q(cur_I, cur_chunk, g + 18, g, 1u, uvo);
+                    else issue_filter_q(CU.I, CU.chunk, g - 18, g - 18, load_on, uvo_eff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                const float av = quad_elem<(s & 3)>(uv[s >> 2]);
+                FS_W4T_MFMA(pos, 0, av, B[c][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (TB == 2) {
+                    slice(2 * s, AD);
+                    __builtin_amdgcn_sched_barrier(0);
+                    FS_W4T_MFMA(pos, TB - 1, av, B[c][TB - 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (s + 2 < 72 && !(FS_W4T_ABL & 8)) read_b(s + 2, n2);   // operands two slots ahead
+                slice(TB * s + TB - 1, AD);
+                if ((s & 3) == 3 && !(FS_W4T_ABL & 2)) issue_filter_one(CU.I, CU.chunk, s >> 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (s + 2 < 72 && !(FS_W4T_ABL & 8)) read_b(s + 2, n2);   // operands two slots ahead
-            slice(TB * s + TB - 1, AD);
-            if ((s & 3) == 3 && !(FS_W4T_ABL & 2)) issue_filter_one(CU.I, CU.chunk, s >> 2);
-            __builtin_amdgcn_sched_barrier(0);
         });
     };
 
@@ -399,7 +430,6 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
         int ln = lane;
         FS_W4_PIN(ln);
         const int j = ln & 15;
-        const int co = I.cob * kBN + wave * 16 + 4 * (ln >> 4);
         const float* yb = a.y + ((size_t)I.n + (ks > 1 ? (size_t)I.z * a.N : 0)) * a.Ho * a.Wo * a.Cout;
         const unsigned img_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.Ho * a.Wo * a.Cout) * 4u);
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(yb)), 0, img_bytes, 0x00020000);
@@ -412,14 +442,15 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
         const float* adn = EPI == 2 ? a.add_src + (size_t)I.n * Ha * Wa * a.Cout : (EPI == 4 ? a.mask_src + (size_t)I.n * Ha * Wa * a.Cout : yb);
         const unsigned add_bytes = __builtin_amdgcn_readfirstlane((unsigned)(Ha * Wa * a.Cout) * 4u);
         const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(adn)), 0, add_bytes, 0x00020000);
-        float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI == 3 && a.bias) bs = *reinterpret_cast<const float4*>(a.bias + co);
-        const float bsv[4] = {bs.x, bs.y, bs.z, bs.w};
         const bool pool = EPI == 3 && a.pool_out != nullptr;
         float cs[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};   // EPI 1
-        fs_static_for<0, TB>([&](auto TBI) __attribute__((always_inline)) {
-            constexpr int tb = decltype(TBI)::value;
-            const int t = 16 * tb + j;
+        fs_static_for<0, NB>([&](auto TBI) __attribute__((always_inline)) {
+            constexpr int tb = decltype(TBI)::value;          // accumulator block: tile block (M = 2) or channel block (M = 3)
+            const int t = CB2 ? j : 16 * tb + j;
+            const int co = I.cob * kBNi + wave * (CB2 ? 32 : 16) + (CB2 ? 16 * tb : 0) + 4 * (ln >> 4);
+            float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (EPI == 3 && a.bias) bs = *reinterpret_cast<const float4*>(a.bias + co);
+            const float bsv[4] = {bs.x, bs.y, bs.z, bs.w};
             const int oy = I.oy0 + 4 * (TB == 1 ? (t >> 2) : (t >> 3)), ox = I.ox0 + 4 * (TB == 1 ? (t & 3) : (t & 7));
             const unsigned obase = (unsigned)((oy * a.Wo + ox) * a.Cout + co) * 4u;
             const int ry = a.Ho - oy, cx = a.Wo - ox;   // valid rows / columns of the lane's tile (edge blocks)
@@ -524,6 +555,7 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
             if (j == 0) {
                 const int th_valid = min(kBH, a.Ho - I.oy0), tw_valid = min(kBW, a.Wo - I.ox0);
                 const float cnt = (float)(th_valid * tw_valid);
+                const int co = I.cob * kBNi + wave * 16 + 4 * (ln >> 4);
                 float* st = a.stats + ((size_t)(I.n * blocks + I.br) * a.Cout + co) * 3;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -612,6 +644,8 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
         const Item cur_it = decode(it);
         for (int chunk = cur_it.cbeg; chunk < cur_it.cend; ++chunk, ++q) {
             load_on = (!kDefer || chunk + 1 < cur_it.cend) ? 1u : 0u;
+            cur_I = cur_it;
+            cur_chunk = chunk;
             uvo_eff = CU.live ? uvo : kOOB;
             if (cursor_next(CP) || !CP.live) patch_offsets(CP.I, CP.live);   // (the offsets change once per item)
 #ifdef FS_WINO4T_TRACE
@@ -658,11 +692,11 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
 #undef FS_W4T_MFMA
 }
 
-template <int TB, int EPI, bool AFF>
+template <int M, int EPI, bool AFF>
 static int wino4t_launch_as(const ConvArgs& a, long grid, hipStream_t s) {
     static BigLds lds_attr;
-    lds_attr.ensure(reinterpret_cast<const void*>(wino4t_conv_kernel<TB, EPI, AFF>));
-    hipLaunchKernelGGL((wino4t_conv_kernel<TB, EPI, AFF>), dim3((unsigned)grid), dim3(256), (size_t)a.p.lds_bytes, s, a);
+    lds_attr.ensure(reinterpret_cast<const void*>(wino4t_conv_kernel<M, EPI, AFF>));
+    hipLaunchKernelGGL((wino4t_conv_kernel<M, EPI, AFF>), dim3((unsigned)grid), dim3(256), (size_t)a.p.lds_bytes, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -679,6 +713,15 @@ static int wino4t_launch_part_b(const ConvArgs& a, int epi, long grid, hipStream
         case 2: return wino4t_launch_as<TB, 2, false>(a, grid, s);
         case 3: return wino4t_launch_as<TB, 3, false>(a, grid, s);
         default: return wino4t_launch_as<TB, 4, false>(a, grid, s);
+    }
+}
+// the 128-channel item form (M = 3): raw (split-K partials, input gradients in front of a pool), bias + ReLU (+ pool), consumer mask
+static inline int wino4t_launch_part_c(const ConvArgs& a, int epi, long grid, hipStream_t s) {
+    switch (epi) {
+        case 0: return wino4t_launch_as<3, 0, false>(a, grid, s);
+        case 3: return wino4t_launch_as<3, 3, false>(a, grid, s);
+        case 4: return wino4t_launch_as<3, 4, false>(a, grid, s);
+        default: return -7;
     }
 }
 

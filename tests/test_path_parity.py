@@ -342,11 +342,15 @@ def test_instnorm_backward_modes(eng, mode, shape):
         assert np.abs(eng.mem.to_numpy(got) - wnt).max() / np.abs(wnt).max() < 5e-5
 
 
-@pytest.mark.parametrize("force_ksplit", [0, 3])
+@pytest.mark.parametrize("force_ksplit", [0, 3, "big_items"])
 def test_perceptual_loss_and_gradient_match_oracle(eng, knob, force_ksplit):
     """force_ksplit=3 drives every eligible VGG conv (forward and dgrad) through the split-K kernel path +
-    splitk_epilogue_kernel (bias/ReLU, tap add + ReLU mask), which otherwise only triggers at 256x256."""
-    if force_ksplit:
+    splitk_epilogue_kernel (bias/ReLU, tap add + ReLU mask), which otherwise only triggers at 256x256.
+    "big_items": the item forms the batch-32 step takes by itself -- FS_WINO4T_TB=2 selects 32-tile items for the 64-channel
+    layers and the 128-channel form (two channel blocks per wave, filter layout of wt_wino4u) for every layer that has them."""
+    if force_ksplit == "big_items":
+        knob("FS_WINO4T_TB", 2)
+    elif force_ksplit:
         knob("FS_CONV_FORCE_KSPLIT", force_ksplit)
     rng = np.random.default_rng(1)
     Wv = perceptual.synthetic_vgg_weights(seed=3)

@@ -32,7 +32,7 @@ def read_wino4t_trace(lib):
     units with a buffer each (fs_debug_wino4t_trace_1a / 1b / 2a / 2b); the buffer holding the latest end timestamp is the one."""
     import numpy as np
     best = None
-    for unit in ("1a", "1b", "2a", "2b"):
+    for unit in ("1a", "1b", "1c", "2a", "2b"):
         fn = getattr(lib, "fs_debug_wino4t_trace_" + unit, None)
         if fn is None:
             continue

@@ -20,8 +20,9 @@ from collections import defaultdict
 
 def short(name):
     m = re.search(r"wino4t_conv_kernel<(\d)", name)
-    if m:   # the 16-tile (transform net) and the 32-tile (VGG16) instances of fs_wino4t.hip are different workloads
-        return "wino4t_conv_kernel<%s>" % m.group(1)
+    if m:   # the 16-tile x 64-channel instances (<1>: transform net, small VGG16 grids) and the big-item instances (<2>: 32 tiles x 64 channels,
+        #     <3>: 16 tiles x 128 channels -- the VGG16 launches of the training batches, folded together as "<2>") are different workloads
+        return "wino4t_conv_kernel<%s>" % ("1" if m.group(1) == "1" else "2")
     m = re.search(r"(conv_igemm_kernel<[^>]*>|conv_wgrad_kernel<[^>]*>|wgrad2_kernel<[^>]*>|conv_stream_kernel<[^>]*>|gram_stream_kernel<[^>]*>|"
                   r"gram_bwd_kernel<[^>]*>|conv_bf16_\w+<[^>]*>|conv_bstream_kernel<[^>]*>|[a-z_0-9]+_kernel)", name)
     s = m.group(1) if m else name[:60]
