@@ -10,9 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_streaming_kernels_on_random_shapes():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_emu.py"), "28", "3"], cwd=ROOT, capture_output=True,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_emu.py"), "30", "3"], cwd=ROOT, capture_output=True,
                          text=True, timeout=1500)
-    assert out.returncode == 0 and "fuzz_emu: 28 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+    assert out.returncode == 0 and "fuzz_emu: 30 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
 
 
 def test_random_shapes_under_address_and_undefined_behaviour_sanitizers():

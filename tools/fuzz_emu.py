@@ -10,6 +10,8 @@
     that end inside a tile, several pixel ranges;
   * wino2_conv_kernel with bias / ReLU, wgrad2_kernel, conv3x3_to3_kernel on ragged shapes;
   * wino4_conv_kernel (fs_wino4.hip, Winograd F(4x4,3x3)): raw / bias + ReLU / consumer-mask epilogues, ragged 16x32 blocks;
+  * wino4t_conv_kernel (fs_wino4t*.hip): 16- / 32-tile items, paddings 0 / 1 / 2, every epilogue form through fs_conv2d_fwd; its 128-channel
+    item form through the whole VGG16 section (fs_perceptual_loss against the oracle's loss and gradient);
   * conv_s16_kernel (fs_s16.hip): the 9x9 3 -> 16 layer with mirror or zero padding and per-tile statistics, VGG conv1_1's
     form (3 -> 64, per-channel affine on load over zero padding, bias + ReLU); ragged tiles, several persistent grid sizes.
 Every case prints one line; a mismatch raises.  tests/ holds fixed-shape versions of the same checks."""
@@ -73,7 +75,7 @@ def main():
     up, down = e.mem.from_numpy, e.mem.to_numpy
     inst = [(16, 32, 3, 2), (32, 64, 2, 1), (32, 64, 3, 2), (64, 128, 2, 1), (64, 64, 3, 1)]
     for it in range(cases):
-        kind = it % 14
+        kind = it % 15
         if kind == 11:        # 16-channel-block streaming kernel (fs_s16.hip)
             n, h, w = int(rng.integers(1, 3)), int(rng.integers(9, 50)), int(rng.integers(9, 50))
             os.environ["FS_S16_WGS"] = str(int(rng.choice([1, 3, 512])))
@@ -214,6 +216,33 @@ def main():
             print("case %3d wino4t %s -> %d pad %d epilogue %d tb %s wgs %s  rel %.2e" % (it, x.shape, cout, pad, epi, os.environ["FS_WINO4T_TB"],
                                                                                        os.environ["FS_WINO4T_WGS"], r), flush=True)
             assert r < 5e-5
+        elif kind == 14:      # the VGG16 section through the big-item forms of fs_wino4t.hip (32 tiles x 64 channels, 16 tiles x 128 channels)
+            from faststyle_amd import engine as fs_engine
+            os.environ["FS_WINO4T_TB"] = "2"
+            os.environ["FS_WINO4T_WGS"] = str(int(rng.choice([3, 256])))
+            e.lib.fs_debug_reload_env()
+            e.reset_workspaces()
+            Wv = perceptual.synthetic_vgg_weights(seed=3)
+            e.vgg_load(Wv)
+            cfg = fs_engine.default_loss_cfg()
+            n, h, w = 1, int(rng.integers(16, 34)), int(rng.integers(16, 42))
+            style = rng.uniform(0, 255, (1, 24, 32, 3)).astype(np.float32)
+            tg = e.style_targets(up(style), cfg)
+            y = rng.uniform(0, 255, (n, h, w, 3)).astype(np.float32)
+            xc = rng.uniform(0, 255, (n, h, w, 3)).astype(np.float32)
+            losses, dy = e.perceptual_loss(up(y), up(xc), tg, cfg)
+            W64 = dict((k, v.astype(np.float64)) for k, v in Wv.items())
+            tgo = perceptual.target_grams(style.astype(np.float64), W64, cfg["style_layers"])
+            feats = perceptual.vgg16(xc.astype(np.float64), W64, upto="conv3_3")
+            lo, dyo = perceptual.perceptual_loss(y.astype(np.float64), [feats["conv3_3"]], tgo, W64, beta=0.0)
+            r = abs(float(down(losses)[0]) - lo["loss"]) / abs(lo["loss"])
+            g, go = down(dy).ravel().astype(np.float64), dyo.ravel()
+            cos = float(np.dot(g, go) / (np.linalg.norm(g) * np.linalg.norm(go)))
+            os.environ.pop("FS_WINO4T_TB")
+            e.lib.fs_debug_reload_env()
+            e.reset_workspaces()
+            print("case %3d vgg section, big items %s wgs %s  loss rel %.2e  gradient cos %.7f" % (it, y.shape, os.environ["FS_WINO4T_WGS"], r, cos), flush=True)
+            assert r < 1e-4 and cos > 0.9999
         elif kind == 8:       # second-generation Winograd kernel (fs_wino2.hip): SAME 3x3, bias + ReLU epilogue, ragged 16x16 blocks
             cin, cout = int(rng.choice([8, 16, 64, 128])), int(rng.choice([64, 128]))
             n, h, w = int(rng.integers(1, 3)), int(rng.integers(1, 40)), int(rng.integers(1, 40))
