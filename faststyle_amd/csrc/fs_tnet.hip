@@ -659,7 +659,9 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
     const int N = L.N;
     // (no fork while the per-kernel profiler is recording: two streams sharing the chip would charge each kernel with its
     // neighbour's time -- bench.py's per-kernel table wants every launch alone)
-    const bool fork = aux && aux->side && aux->nev >= 34 && !Profiler::current();
+    // ... and no fork for small batches: at batch 4 the fork / join events cost more than the overlap returns (same lease, FS_NO_SIDE_STREAM = 0 / 1:
+    // 1100 against 1133 images/s; at batch 32 the fork is worth 1.2 %).  FS_SIDE_MIN_PIXELS: smallest N * H * W that forks.
+    const bool fork = aux && aux->side && aux->nev >= 34 && !Profiler::current() && (long)N * L.H * L.W >= (long)tune_int("FS_SIDE_MIN_PIXELS", 1000000);
     hipStream_t ws_stream = fork ? aux->side : s;  // stream of the filter-gradient branch
     {  // every input-gradient filter of the step in one launch (the parameters are fixed during a backward)
         WtBatch wb{};

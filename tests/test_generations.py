@@ -86,3 +86,26 @@ def test_forward_kernel_choices_agree_on_arbitrary_frames(knobs, shape):
     for name in ("wino2", "wino1"):
         assert ys[name].shape == ys["direct"].shape
         assert np.abs(ys[name] - ys["direct"]).max() < 2e-5 * 255, (name, shape)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 100, 76), (5, 64, 80)], ids=["2x100x76", "5x64x80"])
+def test_filter_gradient_branch_on_the_second_stream_changes_nothing(knobs, shape):
+    """fs_tnet_backward forks the filter gradients onto a second stream for batches of >= FS_SIDE_MIN_PIXELS pixels (the training
+    batches; below that the fork costs more than it returns).  The fork only changes WHERE kernels run: forced on at a small shape
+    (FS_SIDE_MIN_PIXELS=0) the 48 gradient tensors must equal the single-stream ones bit for bit."""
+    e = get_engine("hip")
+    n, h, w = shape
+    rng = np.random.default_rng(n + h + w)
+    P = tnet.init_params(seed=0)
+    x = rng.uniform(0, 255, (n, h, w, 3)).astype(np.float32)
+    grads = {}
+    for name, kn in (("forked", {"FS_SIDE_MIN_PIXELS": 0}), ("one_stream", {"FS_SIDE_MIN_PIXELS": 1 << 30})):
+        knobs(kn)
+        flat = e.mem.from_numpy(e.flatten_params(P, scope=""))
+        xd = e.mem.from_numpy(x)
+        y = e.tnet_forward(flat, xd, save_for_bwd=True)
+        dy = e.mem.from_numpy(np.random.default_rng(7).standard_normal(tuple(int(v) for v in y.shape)).astype(np.float32))
+        grads[name] = e.mem.to_numpy(e.tnet_backward(flat, xd, dy))
+    assert np.isfinite(grads["forked"]).all() and np.linalg.norm(grads["forked"]) > 0
+    assert np.array_equal(grads["forked"], grads["one_stream"])
