@@ -1071,6 +1071,16 @@ int vgg_consts(float* ab, hipStream_t s) {
 __global__ void loss_total_kernel(float* l) {
     if (threadIdx.x == 0) l[0] = l[1] + l[2] + l[3];
 }
+// n <= 64 words = 0 (instead of hipMemsetAsync: see fs_perceptual_loss)
+__global__ void zero_words_kernel(unsigned* p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
+}
+int zero_words(void* p, int n, hipStream_t s) {
+    if (n < 0 || n > 64) return -1;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned*>(p), n);
+    return launch_status();
+}
+int loss_zero(float* losses, hipStream_t s) { return zero_words(losses, 4, s); }
 int loss_total(float* losses, hipStream_t s) {
     hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, s, losses);
     return launch_status();

@@ -468,6 +468,7 @@ int apply_res(const float* z, const float* a, const float* b, const float* skip,
               int skip_relu, float* out, int N, int H, int W, int C, hipStream_t s);
 int apply_tanh(const float* z, const float* a, const float* b, float* y, int N, int HW, int C, hipStream_t s);
 int reduce_slabs(const float* slabs, int groups, int n_wg, size_t count, float scale, float* out, hipStream_t s);
+int zero_words(void* p, int n, hipStream_t s);   // n <= 64 32-bit words = 0 -- a kernel instead of hipMemsetAsync (memset nodes misbehave in single-stream graph replays: fs_perceptual_loss)
 // output-pixel tile (TH x TW <= max_px) with the best fill / halo trade-off for an Ho x Wo image (fs_conv.hip)
 // Winograd F(2x2,3x3) path (fs_wino.hip)
 int wt_wino(const float* w, float* U, int Cin, int Cout, hipStream_t s);

@@ -457,7 +457,7 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
                    fused_finalize_ok(N, u.Cout, u.tiles, u.kind == 1 ? 4 : 1);
         any_fused = any_fused || fused[i];
     }
-    if (any_fused && hipMemsetAsync(ws + L.fin_counter, 0, 64, s) != hipSuccess) return -10;
+    if (any_fused) FS_TRY(zero_words(ws + L.fin_counter, 16, s));   // (a kernel: memset nodes misbehave in single-stream graph replays, see fs_perceptual_loss)
     const float* src = x;
     const float* src_a = nullptr;
     const float* src_b = nullptr;

@@ -32,5 +32,6 @@ int vgg_features(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const
                  int n_layers, const int* layers, float* const* out, float* ws, hipStream_t s);
 int vgg_consts(float* ab, hipStream_t s);
 int loss_total(float* losses, hipStream_t s);
+int loss_zero(float* losses, hipStream_t s);   // losses[0..3] = 0 (a kernel, not a memset node: see fs_perceptual_loss)
 
 }  // namespace fs

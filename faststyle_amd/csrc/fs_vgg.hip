@@ -307,7 +307,10 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
     if (L.cmax >= 0 &&
         hipMemcpyAsync(ws + L.xin + img, content, img * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return -10;
-    if (hipMemsetAsync(losses, 0, 4 * sizeof(float), s) != hipSuccess) return -10;
+    // (a kernel, not hipMemsetAsync: replayed from a single-stream hipGraph -- the training step of a small batch -- the 16-byte memset NODE left
+    // a stale 8-byte value in losses[2..3] from the second replay on (ROCm 7.2; found when the filter-gradient fork became batch-dependent;
+    // with the fork in the graph the same node behaved).  No memset on any capturable path of the library any more.)
+    FS_TRY(loss_zero(losses, s));
     FS_TRY(vgg_forward(L, w, b, prepared, ws, s));
 
     // ---- losses ----

@@ -109,3 +109,28 @@ def test_filter_gradient_branch_on_the_second_stream_changes_nothing(knobs, shap
         grads[name] = e.mem.to_numpy(e.tnet_backward(flat, xd, dy))
     assert np.isfinite(grads["forked"]).all() and np.linalg.norm(grads["forked"]) > 0
     assert np.array_equal(grads["forked"], grads["one_stream"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("min_pixels", [1 << 30, 0], ids=["one_stream", "forked"])
+def test_graph_replayed_train_steps_report_the_eager_losses(knobs, min_pixels):
+    """Trainer(use_graph=True) replays ONE captured hipGraph per step; the four reported scalars and the parameters after three steps
+    must be those of the eager loop, bit for bit, with and without the second-stream fork inside the graph.  (Regression: the loss
+    buffer used to be cleared by hipMemsetAsync -- as a node of a single-stream graph it left garbage in losses[2..3] from the second
+    replay on; the training batches always forked, so only `tv_loss` of small-batch runs ever showed it.)"""
+    from faststyle_amd import trainer, vgg16, im_transf_net
+    e = get_engine("hip")
+    knobs({"FS_SIDE_MIN_PIXELS": min_pixels})
+    rng = np.random.default_rng(3)
+    Wv = vgg16.synthetic_weights(3)
+    style = rng.uniform(0, 255, (1, 64, 64, 3)).astype(np.float32)
+    params = e.flatten_params(im_transf_net.initial_variables(seed=0), scope="")
+    xs = [rng.uniform(0, 255, (2, 128, 128, 3)).astype(np.float32) for _ in range(3)]
+    got = {}
+    for use_graph in (False, True):
+        tr = trainer.Trainer(e, params.copy(), Wv, style, engine.default_loss_cfg(), use_graph=use_graph)
+        ls = [e.mem.to_numpy(tr.step(e.mem.from_numpy(x))).copy() for x in xs]
+        assert (tr.graph is not None) == use_graph
+        got[use_graph] = (np.stack(ls), tr.params_numpy())
+    assert np.isfinite(got[True][0]).all() and (got[True][0][:, 3] == 0).all()          # beta = 0: no TV term
+    assert np.array_equal(got[True][0], got[False][0]) and np.array_equal(got[True][1], got[False][1])
