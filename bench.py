@@ -414,8 +414,10 @@ def main():
 
         def fwd_leg(shape, bf16, warm, iters, graph):
             x = torch.rand(shape, device="cuda", generator=g) * 255.0
-            run = lambda: eng.tnet_forward(flat, x, bf16=bf16, frozen=True)   # inference: the checkpoint does not change between frames
-            held = []
+            # inference: the checkpoint does not change between frames (frozen) -- in a workspace of this leg's own, as the streaming driver
+            # does: the captured graph skips the filter re-layouts, so nobody else may write where they live
+            wsp = eng.new_tnet_workspace(shape[0], shape[1], shape[2], bf16)
+            run = lambda: eng.tnet_forward(flat, x, bf16=bf16, frozen=True, workspace=wsp)
             for _ in range(warm):
                 run()
             sync()
@@ -432,7 +434,6 @@ def main():
                     fg = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(fg, capture_error_mode="thread_local"):
                         run()
-                    held = eng.pin_last_used(tnet=True)       # the graph replays into this workspace: no eviction under it
                     run = fg.replay
                     run()
                     sync()
@@ -443,7 +444,8 @@ def main():
                 run()
             sync()
             dt = max_over_ranks(time.perf_counter() - t0)
-            eng.release_pins(held)
+            del wsp
+            eng.invalidate_frozen()
             n = shape[0]
             fps = world * iters * n / dt
             gf_direct, gf_written, mb = FWD_WORK[(shape[1], shape[2])]

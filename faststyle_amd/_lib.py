@@ -84,6 +84,7 @@ PROTOTYPES = {
     "fs_tnet_out_shape": (c_int, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "fs_tnet_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "fs_tnet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_int]),
+    "fs_tnet_invalidate": (c_int, [c_void_p]),
     "fs_tnet_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
                                  c_int]),
     "fs_vgg_prepared_floats": (c_size_t, []),

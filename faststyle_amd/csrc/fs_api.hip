@@ -25,6 +25,12 @@ struct fs_ctx {
     const void* fwd_ws = nullptr;
     unsigned fwd_serial = 0;     // tnet_serial at that call
     unsigned tnet_serial = 0;    // bumped whenever the cached layout is re-planned
+    // the last few workspaces an fp32 fs_tnet_forward filled, and how: fs_tnet_backward refuses a workspace whose forward had another shape / method
+    struct FwdRec {
+        const void* ws = nullptr;
+        int N = 0, H = 0, W = 0, deconv = 0;
+    } fwd_recs[8];
+    int fwd_rec_next = 0;
     fs::BTnetLayout* btnet;  // bf16 inference layout (allocated on first use)
     hipStream_t side;      // second stream for the filter-gradient branch of fs_tnet_backward
     hipEvent_t ev[34];
@@ -230,6 +236,25 @@ int fs_tnet_forward(fs_ctx* ctx, const float* params, const float* x, int N, int
     ctx->fwd_params = params;
     ctx->fwd_ws = ws;
     ctx->fwd_serial = ctx->tnet_serial;
+    {   // remember how this workspace was filled (fs_tnet_backward checks it)
+        fs_ctx::FwdRec* r = nullptr;
+        for (auto& q : ctx->fwd_recs)
+            if (q.ws == ws) r = &q;
+        if (!r) r = &ctx->fwd_recs[ctx->fwd_rec_next++ & 7];
+        r->ws = ws;
+        r->N = N;
+        r->H = H;
+        r->W = W;
+        r->deconv = (flags & FS_FLAG_UPSAMPLE_DECONV) ? 1 : 0;
+    }
+    return 0;
+}
+
+int fs_tnet_invalidate(fs_ctx* ctx) {
+    if (!ctx) return fail(-1, "fs_tnet_invalidate: null ctx");
+    ctx->fwd_params = nullptr;   // the next FS_FLAG_PARAMS_FROZEN call rebuilds the re-laid-out filters whatever its pointers
+    ctx->fwd_ws = nullptr;
+    for (auto& q : ctx->fwd_recs) q = fs_ctx::FwdRec();
     return 0;
 }
 
@@ -238,7 +263,12 @@ int fs_tnet_backward(fs_ctx* ctx, const float* params, const float* x, const flo
     if (!ctx || !params || !x || !dy || !grads || !ws) return fail(-1, "fs_tnet_backward: null argument");
     if (N < 1 || H < 41 || W < 41) return fail(-2, "fs_tnet_backward: need N>=1 and H,W>=41");
     const fs::TnetLayout* L = get_layout(ctx, N, H, W, flags);
-    if (ws_bytes < L->total_floats * sizeof(float)) return fail(-3, "fs_tnet_backward: workspace too small");
+    if (ws_bytes < L->total_floats * sizeof(float))
+        return fail(-3, "fs_tnet_backward: workspace too small (%zu < %zu bytes)", ws_bytes, L->total_floats * sizeof(float));
+    for (const auto& q : ctx->fwd_recs)   // a workspace this context filled with ANOTHER shape / upsample method holds nothing this backward can read
+        if (q.ws == ws && (q.N != N || q.H != H || q.W != W || q.deconv != ((flags & FS_FLAG_UPSAMPLE_DECONV) ? 1 : 0)))
+            return fail(-5, "fs_tnet_backward: the workspace was filled by fs_tnet_forward(N=%d, %dx%d, %s) -- this call is (N=%d, %dx%d, %s)", q.N, q.H,
+                        q.W, q.deconv ? "deconv" : "resize", N, H, W, (flags & FS_FLAG_UPSAMPLE_DECONV) ? "deconv" : "resize");
     fs::StreamAux aux{ctx->side, ctx->ev, 34};
     const int rc = fs::tnet_backward(*L, params, x, dy, grads, (float*)ws, ctx->stream, ctx->have_side ? &aux : nullptr);
     return rc ? fail(rc, "fs_tnet_backward: launch failed (%d)", rc) : 0;
@@ -397,7 +427,9 @@ int fs_vgg_features(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const flo
 
 int fs_loss_sqdiff(fs_ctx* ctx, const float* x, const float* t, size_t t_period, size_t n, float scale, float* out, void* scratch) {
     if (!ctx || !x || !t || !out || !scratch || !t_period) return fail(-1, "fs_loss_sqdiff: null argument");
-    return fs::sqdiff_loss(x, t, t_period, n, scale, 0.f, nullptr, out, 0, (float*)scratch, ctx->stream);
+    if (n % t_period || n / t_period > 1024) return fail(-2, "fs_loss_sqdiff: n = %zu must be 1 .. 1024 whole periods of %zu", n, t_period);
+    const int rc = fs::sqdiff_loss(x, t, t_period, n, scale, 0.f, nullptr, out, 0, (float*)scratch, ctx->stream);
+    return rc ? fail(rc, "fs_loss_sqdiff: launch failed (%d)", rc) : 0;
 }
 int fs_loss_tv(fs_ctx* ctx, const float* x, int N, int H, int W, int C, float* out, void* scratch) {
     if (!ctx || !x || !out || !scratch) return fail(-1, "fs_loss_tv: null argument");
@@ -551,8 +583,11 @@ int fs_instnorm_bwd(fs_ctx* ctx, const float* gin, const float* z, const float* 
     if (!ctx || !gin || !z || !mean || !rstd || !a || !b || !dz || !dgamma || !dbeta || !ws)
         return fail(-1, "fs_instnorm_bwd: null argument");
     if (C > 256) return fail(-2, "fs_instnorm_bwd: C <= 256");
-    if (ws_bytes < fs_instnorm_bwd_workspace_bytes(N, HW, C)) return fail(-3, "fs_instnorm_bwd: workspace too small");
-    return fs::in_bwd(gin, z, mean, rstd, a, b, mode, dz, dgamma, dbeta, (float*)ws, N, HW, C, ctx->stream);
+    if (N < 1 || HW < 1 || C < 1 || mode < 0 || mode > 2) return fail(-2, "fs_instnorm_bwd: bad shape / mode (N=%d HW=%d C=%d mode=%d)", N, HW, C, mode);
+    if (ws_bytes < fs_instnorm_bwd_workspace_bytes(N, HW, C))
+        return fail(-3, "fs_instnorm_bwd: workspace too small (%zu < %zu bytes)", ws_bytes, fs_instnorm_bwd_workspace_bytes(N, HW, C));
+    const int rc = fs::in_bwd(gin, z, mean, rstd, a, b, mode, dz, dgamma, dbeta, (float*)ws, N, HW, C, ctx->stream);
+    return rc ? fail(rc, "fs_instnorm_bwd: launch failed (%d)", rc) : 0;
 }
 
 static int fill_wgrad(fs_wgrad_desc* d, fs::WgradArgs* a) {

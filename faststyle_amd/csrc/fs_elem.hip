@@ -632,18 +632,183 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* gin, con
     }
 }
 
-// scratch: N*chunks*C*2 + N*C*2 floats
-int in_bwd(const float* gin, const float* z, const float* mean, const float* rstd, const float* a, const float* b, int mode,
-           float* dz, float* dgamma, float* dbeta, float* scratch, int N, int HW, int C, hipStream_t s) {
-    if (C > 256) return -1;
+// ---- round 5: the per-sample sums arrive as RECORDS, the final reduction is the apply kernel's prologue.
+// rec [N][T][C][2] = {sum g, sum g * xhat} per (sample, pixel block, channel): written by the epilogue of the kernel that PRODUCED gin
+// (fs_wino4t_kernel.h, EPI 5 / 6: the residual input gradients -- the producer holds g in registers and reads z once, so the
+// in_bwd_partial4 pass over g AND z disappears) or by in_bwd_partial4_kernel itself (same format, T = chunks).  A workgroup owns
+// 256 UNR consecutive float4 of ONE sample, UNR (4 or 8) per thread: it ISSUES its 2 UNR element loads first, then sums the sample's T records in
+// a fixed order while they travel (thread = (record lane, float4 column of a record row), RL = 256 / (C/2) lanes stride over the rows,
+// fixed-order combine through LDS: deterministic and independent of the batch size) -- one memory latency per workgroup, as in the
+// kernel without a prologue.  Block 0 of a sample leaves S[n][C][2] for in_bwd_params_kernel (dgamma / dbeta of all units, ONE launch per step).
+template <int UNR>
+__global__ __launch_bounds__(256) void in_bwd_apply_rec_kernel(const float* __restrict__ gin, const float* __restrict__ z,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ a, const float* __restrict__ b, int mode,
+                                                               const float* __restrict__ rec, int T, float* __restrict__ S_out,
+                                                               float* __restrict__ dz, int HW, int C) {
+    __shared__ float4 red[256];
+    __shared__ float Ssh[512];   // [C][2]
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int per4 = (HW * C) >> 2;
+    const int j0 = blockIdx.x * (UNR * 256) + tid;
+    const size_t base = (size_t)n * HW * C;
+    float4 zz[UNR], gg[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const int j = j0 + u * 256;
+        const int jc = j < per4 ? j : 0;   // clamped: a valid address, the value is discarded below
+        zz[u] = *reinterpret_cast<const float4*>(z + base + (size_t)jc * 4);
+        gg[u] = *reinterpret_cast<const float4*>(gin + base + (size_t)jc * 4);
+    }
+    const bool fixed_c = (1024 % C) == 0;   // the thread's channel quad is the same for its four elements (stride 256 float4 = 1024 floats)
+    float av[4], bv[4], mv[4], rv[4];
+    auto params = [&](int c) {
+        const int k = n * C + c;
+        const float4 a4 = *reinterpret_cast<const float4*>(a + k), b4 = *reinterpret_cast<const float4*>(b + k);
+        const float4 m4 = *reinterpret_cast<const float4*>(mean + k), r4 = *reinterpret_cast<const float4*>(rstd + k);
+        av[0] = a4.x, av[1] = a4.y, av[2] = a4.z, av[3] = a4.w;
+        bv[0] = b4.x, bv[1] = b4.y, bv[2] = b4.z, bv[3] = b4.w;
+        mv[0] = m4.x, mv[1] = m4.y, mv[2] = m4.z, mv[3] = m4.w;
+        rv[0] = r4.x, rv[1] = r4.y, rv[2] = r4.z, rv[3] = r4.w;
+    };
+    const int c_fixed = (j0 * 4) % C;
+    if (fixed_c) params(c_fixed);
+    {
+        const int row4 = C >> 1;            // float4 per record row (C % 4 == 0, C <= 256)
+        const int RL = 256 / row4;          // record lanes
+        const int r = tid / row4, col = tid - r * row4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < RL) {
+            const float4* rp = reinterpret_cast<const float4*>(rec) + (size_t)n * T * row4 + col;
+            int t = r;
+            for (; t + 3 * RL < T; t += 4 * RL) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = rp[(size_t)(t + u * RL) * row4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc.x += v[u].x;
+                    acc.y += v[u].y;
+                    acc.z += v[u].z;
+                    acc.w += v[u].w;
+                }
+            }
+            for (; t < T; t += RL) {
+                const float4 v = rp[(size_t)t * row4];
+                acc.x += v.x;
+                acc.y += v.y;
+                acc.z += v.z;
+                acc.w += v.w;
+            }
+        }
+        red[tid] = acc;
+        __syncthreads();
+        if (tid < row4) {
+            float4 tsum = red[tid];
+            for (int k = 1; k < RL; ++k) {
+                const float4 q = red[k * row4 + tid];
+                tsum.x += q.x;
+                tsum.y += q.y;
+                tsum.z += q.z;
+                tsum.w += q.w;
+            }
+            *reinterpret_cast<float4*>(Ssh + 4 * tid) = tsum;
+            if (blockIdx.x == 0) *reinterpret_cast<float4*>(S_out + (size_t)n * C * 2 + 4 * tid) = tsum;
+        }
+        __syncthreads();
+    }
+    const float inv = 1.0f / (float)HW;
+    float s1v[4], s2v[4];
+    auto sums = [&](int c) {
+        const float4 sA = *reinterpret_cast<const float4*>(Ssh + 2 * c), sB = *reinterpret_cast<const float4*>(Ssh + 2 * c + 4);
+        s1v[0] = sA.x * inv, s1v[1] = sA.z * inv, s1v[2] = sB.x * inv, s1v[3] = sB.z * inv;
+        s2v[0] = sA.y * inv, s2v[1] = sA.w * inv, s2v[2] = sB.y * inv, s2v[3] = sB.w * inv;
+    };
+    if (fixed_c) sums(c_fixed);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const int j = j0 + u * 256;
+        if (j >= per4) continue;
+        if (!fixed_c) {
+            params((j * 4) % C);
+            sums((j * 4) % C);
+        }
+        const float zv[4] = {zz[u].x, zz[u].y, zz[u].z, zz[u].w}, gv[4] = {gg[u].x, gg[u].y, gg[u].z, gg[u].w};
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float g = in_bwd_g(gv[q], zv[q], av[q], bv[q], mode);
+            const float xh = (zv[q] - mv[q]) * rv[q];
+            o[q] = av[q] * (g - s1v[q] - xh * s2v[q]);
+        }
+        *reinterpret_cast<float4*>(dz + base + (size_t)j * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dbeta[c] = sum_n S1, dgamma[c] = sum_n S2 (fixed order) of every unit whose in_bwd ran on records: one launch per step, one block per unit
+__global__ __launch_bounds__(256) void in_bwd_params_kernel(InbParams p) {
+    const InbParams::U& u = p.u[blockIdx.x];
+    for (int c = threadIdx.x; c < u.C; c += 256) {
+        float g1 = 0.f, g2 = 0.f;
+        for (int m = 0; m < p.N; ++m) {
+            const float2 v = *reinterpret_cast<const float2*>(u.S + ((size_t)m * u.C + c) * 2);
+            g1 += v.x;
+            g2 += v.y;
+        }
+        u.dbeta[c] = g1;
+        u.dgamma[c] = g2;
+    }
+}
+
+int in_bwd_params(const InbParams& p, hipStream_t s) {
+    if (p.n <= 0) return 0;
+    if (p.n > 16) return -1;
+    hipLaunchKernelGGL(in_bwd_params_kernel, dim3(p.n), dim3(256), 0, s, p);
+    return launch_status();
+}
+
+// how many pixels one partial-sum block of in_bwd covers
+static int in_bwd_chunk_px(int N, int HW) {
     // enough blocks to cover the HBM latency: ~2k blocks of >= 128 pixels (64 measures 0.6 % slower on the step:
     // twice the partial records for the final reduction)
     int chunk_px = cdiv(HW * N, 2048);
     if (chunk_px < 128) chunk_px = 128;
-    {   // tuning aid: pixels per partial-sum block (multiples of 64 only: the scratch is sized for 64)
-        const int v = tune_int("FS_INBWD_CHUNK", 0);
-        if (v >= 64) chunk_px = v;
+    const int v = tune_int("FS_INBWD_CHUNK", 0);   // tuning aid: pixels per partial-sum block (multiples of 64 only: the scratch is sized for 64)
+    if (v >= 64) chunk_px = v;
+    return chunk_px;
+}
+
+// The records path: rec == nullptr -> in_bwd_partial4_kernel writes them into `scratch` first (T = chunks, when there are few enough for
+// a prologue: FS_INBWD_REC_MAXT per sample); returns 1 when the shape is not taken (the caller falls back to in_bwd).  dgamma / dbeta
+// come from in_bwd_params over S_out.
+int in_bwd_rec(const float* gin, const float* z, const float* mean, const float* rstd, const float* a, const float* b, int mode,
+               float* dz, const float* rec, int T, float* S_out, float* scratch, int N, int HW, int C, hipStream_t s) {
+    if (C > 256 || C % 4 || (size_t)HW * C >= ((size_t)1 << 31) || !tune_int("FS_INBWD_REC", 1)) return 1;
+    if (!rec) {
+        // a coarser chunking than in_bwd's where needed (the prologue of every apply workgroup reads ALL of its sample's records): <= max_t
+        // chunks per sample
+        const int max_t = tune_int("FS_INBWD_REC_MAXT", 96);
+        int chunk_px = in_bwd_chunk_px(N, HW);
+        if (cdiv(HW, chunk_px) > max_t) chunk_px = cdiv(cdiv(HW, max_t), 64) * 64;
+        const int chunks = cdiv(HW, chunk_px);
+        hipLaunchKernelGGL(in_bwd_partial4_kernel, dim3(chunks, N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, scratch, HW, C, chunk_px);
+        rec = scratch;
+        T = chunks;
     }
+    const int per4 = (HW * C) >> 2;
+    // eight float4 per thread halve the prologue's share; four where that would leave fewer than ~4 workgroups per CU
+    if ((long)cdiv(per4, 2048) * N >= 1024)
+        hipLaunchKernelGGL(in_bwd_apply_rec_kernel<8>, dim3(cdiv(per4, 2048), N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, rec, T, S_out, dz, HW, C);
+    else
+        hipLaunchKernelGGL(in_bwd_apply_rec_kernel<4>, dim3(cdiv(per4, 1024), N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, rec, T, S_out, dz, HW, C);
+    return launch_status();
+}
+
+// scratch: N*chunks*C*2 + N*C*2 floats
+int in_bwd(const float* gin, const float* z, const float* mean, const float* rstd, const float* a, const float* b, int mode,
+           float* dz, float* dgamma, float* dbeta, float* scratch, int N, int HW, int C, hipStream_t s) {
+    if (C > 256) return -1;
+    const int chunk_px = in_bwd_chunk_px(N, HW);
     const int chunks = cdiv(HW, chunk_px);
     float* partial = scratch;
     float* S = scratch + (size_t)N * chunks * C * 2;

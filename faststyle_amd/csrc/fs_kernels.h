@@ -113,6 +113,17 @@ struct ConvArgs {
     int half_items;          // 1: with w_wino2, prefer the half-item Winograd kernel (fs_wino2h.hip: grids too small for 64-tile items)
     float* split_ws;         // optional scratch for split-K partials (split_ws_floats capacity); enables ksplit plans
     size_t split_ws_floats;
+    // optional (fs_wino4t.hip, raw / add_src epilogues -- the residual input gradients of the transform net): y is the gradient g wrt the OUTPUT
+    // of an instance-norm unit whose raw conv output is inb_z [N,Ho,Wo,Cout]; the epilogue also leaves that unit's instance-norm-backward
+    // partial sums inb_rec [N][tiles][Cout][2] = {sum g', sum g' * xhat} per item (g' = g where relu(a z + b) > 0 when inb_relu, else g;
+    // xhat = (z - mean) * rstd; im_transf_net.py:218-247 adjoint) -- what in_bwd_partial4_kernel computes in a pass of its own over g and z
+    const float* inb_z;
+    const float* inb_mean;   // [N][Cout] each
+    const float* inb_rstd;
+    const float* inb_a;
+    const float* inb_b;
+    int inb_relu;
+    float* inb_rec;
     ConvPlan p;
 };
 
@@ -547,6 +558,20 @@ int u8_to_f32(const unsigned char* src, float* dst, size_t n, hipStream_t s);
 int f32_to_u8(const float* src, unsigned char* dst, size_t npix, int swap_rb, hipStream_t s);
 int in_bwd(const float* gin, const float* z, const float* mean, const float* rstd, const float* a, const float* b, int mode,
            float* dz, float* dgamma, float* dbeta, float* scratch, int N, int HW, int C, hipStream_t s);
+// ... with the per-sample sums taken from records [N][T][C][2] (rec == nullptr: computed here into `scratch`), reduced in the apply kernel's
+// prologue; S_out [N][C][2] feeds in_bwd_params (dgamma / dbeta of up to 16 units in one launch).  Returns 1 when the shape is not taken.
+int in_bwd_rec(const float* gin, const float* z, const float* mean, const float* rstd, const float* a, const float* b, int mode,
+               float* dz, const float* rec, int T, float* S_out, float* scratch, int N, int HW, int C, hipStream_t s);
+struct InbParams {
+    struct U {
+        const float* S;   // [N][C][2]
+        float* dgamma;
+        float* dbeta;
+        int C;
+    } u[16];
+    int n, N;
+};
+int in_bwd_params(const InbParams& p, hipStream_t s);
 size_t in_bwd_scratch_floats(int N, int HW, int C);
 int maxpool(const float* x, float* y, int N, int H, int W, int C, hipStream_t s);
 int vgg_bwd_route(const float* out, const float* d_above, const float* d_tap, int pooled, float* d_pre, int N, int H, int W,

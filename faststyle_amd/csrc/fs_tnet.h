@@ -52,6 +52,9 @@ struct TnetLayout {
     size_t g[3], dz[2], wT, dweff, inbwd, slabs;  // backward scratch (dz double-buffered: filter gradients run on a side stream)
     size_t wino_d[10]; // Winograd-transformed input-gradient filters of the residual convs (0: direct kernel)
     int wino_dh[10];   // ... 1: through the half-item kernel, 2: through the 16-tile F(4x4) kernel (fs_wino4t.hip)
+    size_t inb_rec;   // instance-norm-backward partial-sum records [N][items][64][2] written by the epilogue of a residual input-gradient launch
+                      // (fs_wino4t_kernel.h EPI 5 / 6) for the unit below it; one buffer, consumed by that unit's in_bwd_rec right after
+    size_t inb_S[16]; // per unit: the per-sample sums [N][Cout][2] in_bwd_rec leaves for in_bwd_params (dgamma / dbeta of all units in one launch)
     size_t dzres[10]; // dz of the ten residual convs, kept until their filter gradients run as ONE launch (fs_wgrad2.hip)
     int res_batch;    // 1: that batched launch is planned (shapes eligible)
     size_t total_floats;

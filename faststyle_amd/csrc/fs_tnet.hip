@@ -353,6 +353,15 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
         L->wino_d[i - 3] = on ? b.take((size_t)(L->wino_dh[i - 3] == 2 ? 36 : 16) * 64 * 64) : 0;
     }
     L->inbwd = b.take(max_inbwd);
+    {
+        size_t max_rec = 0;
+        for (int i = 2; i <= 11; ++i) {   // units whose output gradient a residual input-gradient launch writes (16 x 16-pixel items)
+            const size_t r = (size_t)N * cdiv(L->u[i].Hout, 16) * cdiv(L->u[i].Wout, 16) * L->u[i].Cout * 2;
+            if (r > max_rec) max_rec = r;
+        }
+        L->inb_rec = b.take(max_rec);
+        for (int i = 0; i < 16; ++i) L->inb_S[i] = b.take((size_t)N * L->u[i].Cout * 2);
+    }
     for (int i = 0; i < 16; ++i) {
         Unit& u = L->u[i];
         WgradArgs wa = unit_wgrad_args(u, N);
@@ -525,9 +534,12 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
 
 // ---------------------------------------------------------------- backward
 // dgrad helper: d(input of unit u) from dz (gradient of u's raw conv output)
+// below / below_relu / rec_tiles: the unit whose OUTPUT gradient `dst` is (its instance-norm backward runs next): when the launch is a
+// 16-tile F(4x4) one its epilogue also leaves that unit's partial sums in ws + L.inb_rec and *rec_tiles = records per sample (else 0)
 static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, const float* dz, float* dst,
-                      const float* add_src, float* ws, hipStream_t s) {
+                      const float* add_src, float* ws, hipStream_t s, const Unit* below = nullptr, int below_relu = 0, int* rec_tiles = nullptr) {
     const int N = L.N;
+    if (rec_tiles) *rec_tiles = 0;
     ConvArgs a{};
     a.prof_tag = 1;
     a.N = N;
@@ -605,6 +617,23 @@ static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, c
     a.rem_ws = ws + L.rem_ws;
     a.rem_ws_floats = (size_t)kRemUnits * 16384;
     a.p = conv_plan(a);
+    if (below && rec_tiles && a.w_wino4t && a.p.variant == 11 && a.p.TW == 16 && a.p.ksplit <= 1 && a.Ho == below->Hout && a.Wo == below->Wout &&
+        a.Cout == below->Cout && tune_int("FS_INBWD_FUSED", 1)) {
+        ConvArgs f = a;
+        f.inb_z = ws + below->z;
+        f.inb_mean = ws + below->mean;
+        f.inb_rstd = ws + below->rstd;
+        f.inb_a = ws + below->a;
+        f.inb_b = ws + below->b;
+        f.inb_relu = below_relu;
+        f.inb_rec = ws + L.inb_rec;
+        const ConvPlan pf = conv_plan(f);
+        if (pf.variant == 11 && pf.TW == 16 && pf.ksplit <= 1 && pf.tiles_y == a.p.tiles_y && pf.tiles_x == a.p.tiles_x) {
+            f.p = pf;
+            *rec_tiles = pf.tiles_y * pf.tiles_x;
+            return conv_launch(f, s);
+        }
+    }
     return conv_launch(a, s);
 }
 
@@ -689,6 +718,9 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
     const float* g = dy;         // gradient wrt the current unit's output activation (or h_k)
     const float* res_g = nullptr;  // d h_k, kept alive until the block's first conv adds it to its dgrad
     int dz_reader[2] = {-1, -1};   // event (side stream) of the last filter gradient that read dz[0] / dz[1]
+    int rec_tiles = 0;             // > 0: the launch that wrote g left the unit's instance-norm-backward records in ws + L.inb_rec (per sample)
+    InbParams ibp{};               // units whose dgamma / dbeta come from in_bwd_params at the end
+    ibp.N = N;
     WgradArgs res_probs[10];       // the residual units' filter-gradient problems, launched together after unit 3
     for (int i = 15; i >= 0; --i) {
         const Unit& u = L.u[i];
@@ -700,8 +732,24 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
         const bool res1 = i >= 3 && i <= 11 && ((i - 3) & 1) == 0;  // first conv of a block
         if (res2) res_g = g;
         const int mode = i == 15 ? 2 : (res2 ? 0 : 1);
-        FS_TRY(in_bwd(g, ws + u.z, ws + u.mean, ws + u.rstd, ws + u.a, ws + u.b, mode, dz, grads + u.g_off, grads + u.b_off,
-                      ws + L.inbwd, N, u.Hout * u.Wout, u.Cout, s));
+        {
+            // per-sample sums from records (the producer's epilogue, or a partial-sum pass here), reduced in the apply kernel's prologue;
+            // 1: shape not taken -> the three-launch form
+            int rc = in_bwd_rec(g, ws + u.z, ws + u.mean, ws + u.rstd, ws + u.a, ws + u.b, mode, dz, rec_tiles > 0 ? ws + L.inb_rec : nullptr, rec_tiles,
+                                ws + L.inb_S[i], ws + L.inbwd, N, u.Hout * u.Wout, u.Cout, s);
+            if (rc == 0) {
+                InbParams::U& q = ibp.u[ibp.n++];
+                q.S = ws + L.inb_S[i];
+                q.dgamma = grads + u.g_off;
+                q.dbeta = grads + u.b_off;
+                q.C = u.Cout;
+            } else if (rc == 1) {
+                rc = in_bwd(g, ws + u.z, ws + u.mean, ws + u.rstd, ws + u.a, ws + u.b, mode, dz, grads + u.g_off, grads + u.b_off, ws + L.inbwd, N,
+                            u.Hout * u.Wout, u.Cout, s);
+            }
+            FS_TRY(rc);
+            rec_tiles = 0;
+        }
         // the tensor this unit's conv consumed
         const float* xin;
         const float *xa = nullptr, *xb = nullptr;
@@ -757,10 +805,15 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
                 break;
             }
         }
-        FS_TRY(unit_dgrad(L, u, params, dz, dst, res1 ? res_g : nullptr, ws, s));
+        {
+            const int j = i - 1;   // the unit whose instance-norm backward consumes dst next
+            const bool j_res2 = j >= 4 && j <= 12 && ((j - 3) & 1);
+            FS_TRY(unit_dgrad(L, u, params, dz, dst, res1 ? res_g : nullptr, ws, s, &L.u[j], j_res2 ? 0 : 1, &rec_tiles));
+        }
         if (res1) res_g = nullptr;
         g = dst;
     }
+    FS_TRY(in_bwd_params(ibp, s));
     if (fork) {  // join: every filter gradient done before the caller's stream proceeds (events 16..31 are ordered on the side stream)
         if (hipStreamWaitEvent(s, aux->ev[16 + 0], 0) != hipSuccess) return -20;
     }

@@ -93,7 +93,8 @@ extern "C" int fs_debug_wino4t_trace_1a(long long* out, int n_wg) { return wino4
 // which epilogue form a launch takes (-1: none fits)
 static int wino4t_epi(const ConvArgs& a, int ksplit) {
     const bool act = a.bias || a.out_relu || a.pool_out;
-    if (ksplit > 1) return 0;
+    if (ksplit > 1) return a.inb_rec ? -1 : 0;
+    if (a.inb_rec) return (act || a.mask_src || a.stats || a.in_a || !a.inb_z || !a.inb_mean || !a.inb_rstd || (a.inb_relu && (!a.inb_a || !a.inb_b))) ? -1 : (a.add_src ? 6 : 5);
     if (a.stats) return (act || a.mask_src || a.add_src) ? -1 : 1;
     if (a.add_src) return (act || a.mask_src) ? -1 : 2;
     if (a.mask_src) return act ? -1 : 4;
@@ -151,7 +152,7 @@ void wino4t_plan(const ConvArgs& a, ConvPlan* out) {
     const long items = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / p.BN);
     const int nchunks = a.Cin / kCC;
     const int max_ks = tune_int("FS_WINO_KSPLIT", 4);
-    if (a.split_ws && !a.pool_out && !a.stats && !a.in_a) {   // split-K where the launch cannot fill the chip (the rule of fs_wino4.hip; a step here is 8 channels)
+    if (a.split_ws && !a.pool_out && !a.stats && !a.in_a && !a.inb_rec) {   // split-K where the launch cannot fill the chip (the rule of fs_wino4.hip; a step here is 8 channels)
         int ks = 1;
         const int min_steps = tune_int("FS_WINO4_KSPLIT_MINSTEPS", 16) / 2;
         while (ks < max_ks && items * ks < 256 && nchunks / (ks * 2) >= min_steps && (size_t)(ks * 2) * a.N * a.Ho * a.Wo * a.Cout <= a.split_ws_floats) ks *= 2;
@@ -163,6 +164,7 @@ void wino4t_plan(const ConvArgs& a, ConvPlan* out) {
 // (the other instantiations: fs_wino4t1b.hip, fs_wino4t2.hip, fs_wino4t2b.hip)
 int wino4t_launch_1b(const ConvArgs& a, int epi, long grid, hipStream_t s);
 int wino4t_launch_1c(const ConvArgs& a, int epi, long grid, hipStream_t s);
+int wino4t_launch_1d(const ConvArgs& a, int epi, long grid, hipStream_t s);
 int wino4t_launch_2a(const ConvArgs& a, int epi, long grid, hipStream_t s);
 int wino4t_launch_2b(const ConvArgs& a, int epi, long grid, hipStream_t s);
 
@@ -177,6 +179,7 @@ int wino4t_launch(const ConvArgs& a, hipStream_t s) {
     const long grid = items < wgs ? items : wgs;
     if (p.BN == 2 * kBN) return (tb == 1 && a.w_wino4u) ? wino4t_launch_1c(a, epi, grid, s) : -7;
     const bool part_a = a.in_a || epi <= 1;
+    if (epi >= 5) return tb == 1 ? wino4t_launch_1d(a, epi, grid, s) : -7;   // (instance-norm-backward partial sums: 16-tile items only)
     if (tb == 1) return part_a ? wino4t_launch_part_a<1>(a, epi, grid, s) : wino4t_launch_1b(a, epi, grid, s);
     return part_a ? wino4t_launch_2a(a, epi, grid, s) : wino4t_launch_2b(a, epi, grid, s);
 }

@@ -8,6 +8,6 @@ namespace fs {
 extern "C" int fs_debug_wino4t_trace_1c(long long* out, int n_wg) { return wino4t_trace_read(out, n_wg); }
 #endif
 
-int wino4t_launch_1c(const ConvArgs& a, int epi, long grid, hipStream_t s) { return wino4t_launch_part_c(a, epi, grid, s); }
+int wino4t_launch_1c(const ConvArgs& a, int epi, long grid, hipStream_t s) { return wino4t_launch_part_c<3>(a, epi, grid, s); }
 
 }  // namespace fs

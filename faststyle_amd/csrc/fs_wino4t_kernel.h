@@ -52,6 +52,9 @@ static inline int wino4t_trace_read(long long* out, int n_wg) {
 #ifndef FS_W4T_EARLY_TB2_MASK
 #define FS_W4T_EARLY_TB2_MASK 8   /* 32-tile items, consumer-mask epilogue: mask loads issued in front of the output transform (of 16 per tile block) */
 #endif
+#ifndef FS_W4T_INB_DEFER
+#define FS_W4T_INB_DEFER 1   /* EPI 5 / 6: an item's last sweep loads nothing (as the 32-tile forms): the filter registers are free for the epilogue's 32 quads of loads */
+#endif
 #ifndef FS_W4T_ABL
 #define FS_W4T_ABL 0   /* timing experiments (results wrong): 1 no input transform, 2 no filter loads, 4 no patch loads / commit, 8 no operand reads */
 #endif
@@ -67,7 +70,8 @@ __device__ __forceinline__ float quad_elem(const float4& v) {
 // M: item form -- 1: 16 tiles x 64 channels; 2: 32 tiles (two tile blocks) x 64 channels; 3: 16 tiles x 128 channels (two CHANNEL blocks per
 // wave: the input transform of a step serves twice the products; 36 filter quads per step through an 18-register window).
 // EPI: 0 raw (also split-K partials), 1 raw + instance-norm partials of the item (a.stats), 2 + a.add_src in
-// the interior, 3 bias + ReLU (+ a.pool_out), 4 a.mask_src.  AFF: a.in_a / a.in_b + ReLU on load.
+// the interior, 3 bias + ReLU (+ a.pool_out), 4 a.mask_src, 5 raw + the instance-norm-BACKWARD partial sums of the unit whose output
+// gradient the launch writes (a.inb_*, round 5), 6 = 2 + the same.  AFF: a.in_a / a.in_b + ReLU on load.
 template <int M, int EPI, bool AFF>
 __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
     constexpr int TB = M == 2 ? 2 : 1;      // tile blocks of 16 per item (geometry)
@@ -76,11 +80,14 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
     constexpr int kBNi = CB2 ? 2 * kBN : kBN;   // output channels per item
     constexpr int QPS = CB2 ? 36 : 18;      // filter quads per step and wave
     static_assert(!(CB2 && (EPI == 1 || EPI == 2 || AFF)), "the 128-channel form carries the VGG16 epilogues only");
+    static_assert(!((EPI == 5 || EPI == 6) && (M != 1 || AFF)), "the instance-norm-backward epilogues exist for 16-tile items only");
+    constexpr bool kAdd = EPI == 2 || EPI == 6, kInb = EPI == 5 || EPI == 6;
     using GEO = Geo<TB>;
     constexpr int kBW = GEO::kBW, kPW = GEO::kPW, kPR = GEO::kPR, kPix = GEO::kPix, kSink = GEO::kSink, kPlane = GEO::kPlane, kNPV = GEO::kNPV, kVB = GEO::kVB,
                   kVF = GEO::kVF, kStageF = GEO::kStageF;
-    constexpr int kEarly = (TB == 2 && EPI == 4) ? FS_W4T_EARLY_TB2_MASK : GEO::kEarly;
-    constexpr bool kDefer = NB == 2;   // (288 accumulator registers: the epilogue needs the staging registers)
+    constexpr int kEarly = (TB == 2 && EPI == 4) ? FS_W4T_EARLY_TB2_MASK : (((EPI == 5 || EPI == 6) && FS_W4T_INB_DEFER) ? 16 : GEO::kEarly);
+    // (288 accumulator registers: the epilogue needs the staging registers; the instance-norm-backward forms keep 32 quads of loads beside the 64 outputs)
+    constexpr bool kDefer = NB == 2 || ((EPI == 5 || EPI == 6) && FS_W4T_INB_DEFER);
     HIP_DYNAMIC_SHARED(float, smem)
 #ifdef FS_WINO4T_TRACE
     const long long tr_t0 = FS_W4T_NOW();
@@ -425,6 +432,22 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
         return x > 0.f ? x : 0.f;
 #endif
     };
+    // sum over the 16 lanes of a row (= the 16 tiles of a tile block), result in every lane.  On the GPU four DPP adds (quad_perm xor 1, xor 2, then
+    // row_half_mirror and row_mirror: after two steps a quad's lanes are equal, so "the mirrored lane" carries the other quad's / half's sum --
+    // the same pairs as the xor butterfly, bit-identical to it) instead of four ds_bpermute round trips.
+    auto row16_sum = [](float v) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));   // row_mirror
+        return v;
+#else
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m);
+        return v;
+#endif
+    };
     auto epilogue_body = [&](auto FULLT, const Item& I) __attribute__((always_inline)) {
         constexpr bool full = decltype(FULLT)::value;
         int ln = lane;
@@ -437,9 +460,12 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
         auto soff = [&](int px) __attribute__((always_inline)) { return (unsigned)(px >> 2) * rowp4 + (unsigned)(px & 3) * col4; };
         // second source of the epilogue: the residual gradient (EPI 2: [N][Ho - 2 add_pad][Wo - 2 add_pad][Cout], added where it exists) or the
         // consumer's ReLU mask (EPI 4: [N][Ho][Wo][Cout])
-        const int Ha = EPI == 2 ? a.Ho - 2 * a.add_pad : a.Ho, Wa = EPI == 2 ? a.Wo - 2 * a.add_pad : a.Wo;
-        const int apad = EPI == 2 ? a.add_pad : 0;
-        const float* adn = EPI == 2 ? a.add_src + (size_t)I.n * Ha * Wa * a.Cout : (EPI == 4 ? a.mask_src + (size_t)I.n * Ha * Wa * a.Cout : yb);
+        const int Ha = kAdd ? a.Ho - 2 * a.add_pad : a.Ho, Wa = kAdd ? a.Wo - 2 * a.add_pad : a.Wo;
+        const int apad = kAdd ? a.add_pad : 0;
+        const float* adn = kAdd ? a.add_src + (size_t)I.n * Ha * Wa * a.Cout : (EPI == 4 ? a.mask_src + (size_t)I.n * Ha * Wa * a.Cout : yb);
+        // EPI 5 / 6: z of the unit whose output gradient this is, [N][Ho][Wo][Cout]
+        const __amdgpu_buffer_rsrc_t zr =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(kInb ? a.inb_z + (size_t)I.n * a.Ho * a.Wo * a.Cout : yb)), 0, img_bytes, 0x00020000);
         const unsigned add_bytes = __builtin_amdgcn_readfirstlane((unsigned)(Ha * Wa * a.Cout) * 4u);
         const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(adn)), 0, add_bytes, 0x00020000);
         const bool pool = EPI == 3 && a.pool_out != nullptr;
@@ -458,7 +484,9 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
             auto voff = [&](int px) __attribute__((always_inline)) { return inside(px) ? obase : kOOB; };
             float4 ad[16];
             auto add_load = [&](int px) __attribute__((always_inline)) {
-                if (EPI == 2) {
+                if (EPI == 5) {
+                    ad[px] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(zr, voff(px), soff(px), 0));
+                } else if (kAdd) {
                     const int ay = oy + (px >> 2) - apad, ax = ox + (px & 3) - apad;
                     const bool ok = ay >= 0 && ay < Ha && ax >= 0 && ax < Wa;
                     ad[px] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ar, ok ? (unsigned)((ay * Wa + ax) * a.Cout + co) * 4u : kOOB, 0, 0));
@@ -466,9 +494,15 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
                     ad[px] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ar, voff(px), soff(px), 0));
                 }
             };
-            if (EPI == 2 || EPI == 4) {
+            float4 zz[EPI == 6 ? 16 : 1];   // EPI 6: z beside the residual-gradient quads (EPI 5 keeps z in ad[])
+            auto z_load = [&](int px) __attribute__((always_inline)) {
+                if (EPI == 6) zz[px] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(zr, voff(px), soff(px), 0));
+            };
+            if (kAdd || EPI == 4 || EPI == 5) {
 #pragma unroll
                 for (int px = 0; px < kEarly; ++px) add_load(px);
+#pragma unroll
+                for (int px = 0; px < kEarly; ++px) z_load(px);
             }
             __builtin_amdgcn_sched_barrier(0);
             float o[16][4];
@@ -486,11 +520,45 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
                     FS_W4_AT(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[4 * i][r], o[4 * i + 1][r], o[4 * i + 2][r], o[4 * i + 3][r]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (EPI == 2 || EPI == 4) {
+            if (kAdd || EPI == 4 || EPI == 5) {
 #pragma unroll
                 for (int px = kEarly; px < 16; ++px) add_load(px);
+#pragma unroll
+                for (int px = kEarly; px < 16; ++px) z_load(px);
+            }
+            // EPI 5 / 6: the per-(sample, channel) constants of the lane's four channels
+            float4 ib_m = make_float4(0.f, 0.f, 0.f, 0.f), ib_a = ib_m, ib_b = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (kInb) {
+                const size_t k = (size_t)I.n * a.Cout + co;
+                ib_m = *reinterpret_cast<const float4*>(a.inb_mean + k);
+                if (a.inb_relu) {
+                    ib_a = *reinterpret_cast<const float4*>(a.inb_a + k);
+                    ib_b = *reinterpret_cast<const float4*>(a.inb_b + k);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (kInb) {
+                // instance-norm backward of the unit that produced inb_z, partial sums of the item: s1 = sum g', s2 = sum g' (z - mean) (x rstd below),
+                // g' = g where the unit's activation passed (relu(a z + b) > 0; a = 0, b = 1 without a ReLU).  All of it IN FRONT of the item's
+                // stores: a load result needed while stores are in flight costs `s_waitcnt vmcnt(0)` (one counter, out of order between the
+                // two kinds) -- i.e. the write burst of all 256 workgroups: measured +4.5 us per item with the sums behind the stores.
+                const float mq[4] = {ib_m.x, ib_m.y, ib_m.z, ib_m.w}, aq[4] = {ib_a.x, ib_a.y, ib_a.z, ib_a.w}, bq[4] = {ib_b.x, ib_b.y, ib_b.z, ib_b.w};
+#pragma unroll
+                for (int px = 0; px < 16; ++px) {
+                    const float4 z4 = EPI == 6 ? zz[EPI == 6 ? px : 0] : ad[px];
+                    const float zq[4] = {z4.x, z4.y, z4.z, z4.w};
+                    const float av4[4] = {ad[px].x, ad[px].y, ad[px].z, ad[px].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (kAdd) o[px][r] += av4[r];
+                        const bool keep = inside(px) && fmaf(zq[r], aq[r], bq[r]) > 0.f;
+                        const float gq = keep ? o[px][r] : 0.f;
+                        s1[r] += gq;
+                        s2[r] = fmaf(gq, zq[r] - mq[r], s2[r]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int px = 0; px < 16; ++px) {
                 const float av4[4] = {ad[px].x, ad[px].y, ad[px].z, ad[px].w};
@@ -498,7 +566,7 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     v[r] = o[px][r];
-                    if (EPI == 2) v[r] += av4[r];
+                    if (kAdd && !kInb) v[r] += av4[r];
                     if (EPI == 3) v[r] = a.out_relu ? relu1(v[r] + bsv[r]) : v[r] + bsv[r];
                     if (EPI == 4) v[r] = av4[r] > 0.f ? v[r] : 0.f;
                     if (EPI == 3) o[px][r] = v[r];   // (the pool reads the stored values)
@@ -544,14 +612,26 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        if (kInb) {   // the 16 tiles of the item (= the 16 lanes of a row), fixed order; lane j = 0 of a row writes the item's record of its four channels
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s1[r] = row16_sum(s1[r]);
+                s2[r] = row16_sum(s2[r]);
+            }
+            if (j == 0) {
+                const int co = I.cob * kBNi + wave * 16 + 4 * (ln >> 4);
+                const float4 rs = *reinterpret_cast<const float4*>(a.inb_rstd + (size_t)I.n * a.Cout + co);
+                float* rc = a.inb_rec + ((size_t)(I.n * blocks + I.br) * a.Cout + co) * 2;
+                *reinterpret_cast<float4*>(rc) = make_float4(s1[0], s2[0] * rs.x, s1[1], s2[1] * rs.y);
+                *reinterpret_cast<float4*>(rc + 4) = make_float4(s1[2], s2[2] * rs.z, s1[3], s2[3] * rs.w);
+            }
+        }
         if (EPI == 1) {
 #pragma unroll
-            for (int m = 1; m < 16; m <<= 1)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s1[r] += __shfl_xor(s1[r], m);
-                    s2[r] += __shfl_xor(s2[r], m);
-                }
+            for (int r = 0; r < 4; ++r) {
+                s1[r] = row16_sum(s1[r]);
+                s2[r] = row16_sum(s2[r]);
+            }
             if (j == 0) {
                 const int th_valid = min(kBH, a.Ho - I.oy0), tw_valid = min(kBW, a.Wo - I.ox0);
                 const float cnt = (float)(th_valid * tw_valid);
@@ -715,8 +795,16 @@ static int wino4t_launch_part_b(const ConvArgs& a, int epi, long grid, hipStream
         default: return wino4t_launch_as<TB, 4, false>(a, grid, s);
     }
 }
+// 16-tile items with the instance-norm-backward partial sums (EPI 5 raw, 6 residual gradient): fs_wino4t1d.hip
+template <int TB>   // (a template like the other parts: instantiated only by the translation unit that calls it)
+static int wino4t_launch_part_d(const ConvArgs& a, int epi, long grid, hipStream_t s) {
+    static_assert(TB == 1, "16-tile items only");
+    return epi == 5 ? wino4t_launch_as<1, 5, false>(a, grid, s) : wino4t_launch_as<1, 6, false>(a, grid, s);
+}
 // the 128-channel item form (M = 3): raw (split-K partials, input gradients in front of a pool), bias + ReLU (+ pool), consumer mask
-static inline int wino4t_launch_part_c(const ConvArgs& a, int epi, long grid, hipStream_t s) {
+template <int M>
+static int wino4t_launch_part_c(const ConvArgs& a, int epi, long grid, hipStream_t s) {
+    static_assert(M == 3, "the 128-channel form");
     switch (epi) {
         case 0: return wino4t_launch_as<3, 0, false>(a, grid, s);
         case 3: return wino4t_launch_as<3, 3, false>(a, grid, s);

@@ -154,11 +154,21 @@ class Engine(object):
         """Drop least-recently-used, unpinned entries of `cache` until `incoming_bytes` more fit the budget."""
         def total():
             return sum(nb for _, nb in self._tnet_ws.values()) + sum(nb for _, nb in self._perc_ws.values())
+        dropped = False
         for key in list(cache):
             if len(cache) < self.MAX_CACHED_SHAPES and total() + incoming_bytes <= self.MAX_CACHED_BYTES:
                 break
             if self._pinned.get(id(cache[key][0]), 0) == 0:
                 cache.pop(key)
+                dropped = True
+        if dropped:
+            self.invalidate_frozen()
+
+    def invalidate_frozen(self):
+        """A workspace (or a parameter buffer) the library may remember by ADDRESS went away: the caching allocator can hand the same address
+        out again, so FS_FLAG_PARAMS_FROZEN must not trust pointer identity across this point (fs_tnet_invalidate)."""
+        if self.ctx:
+            self.lib.fs_tnet_invalidate(self.ctx)
 
     def pin_workspaces(self, entries, on=True):
         """entries: workspace tensors a captured hipGraph replays into; pinned entries survive cache eviction."""
@@ -216,21 +226,31 @@ class Engine(object):
         self._perc_ws.clear()
         self._pinned.clear()
         self._tnet_nbytes.clear()
+        self.invalidate_frozen()
+
+    def new_tnet_workspace(self, N, H, W, bf16=False):
+        """A transform-net workspace of the caller's own (not in the shape cache): what a hipGraph capturer with frozen=True replays into --
+        the re-laid-out filters inside it belong to ONE parameter set, and no other call of this engine may rewrite them (a shared, per-shape
+        workspace would be rewritten by any other same-shape forward: another FrameStylizer with another checkpoint, a Trainer, an eval)."""
+        nbytes = self._tnet_key(N, H, W, bf16)[4]
+        self.invalidate_frozen()          # (a fresh allocation may re-use an address the library remembers)
+        return (self.mem.empty((nbytes // 4,)), nbytes)
 
     @staticmethod
     def _method_flag(upsample_method):
         assert upsample_method in ("resize", "deconv")
         return L.FS_FLAG_UPSAMPLE_DECONV if upsample_method == "deconv" else 0
 
-    def tnet_forward(self, params, x, save_for_bwd=False, upsample_method="resize", bf16=False, frozen=False):
+    def tnet_forward(self, params, x, save_for_bwd=False, upsample_method="resize", bf16=False, frozen=False, workspace=None):
         """create_net(x, upsample_method): x [N,H,W,3] float32 RGB 0..255 -> y [N,Ho,Wo,3].
         bf16=True: the mixed-precision inference path (FS_FLAG_BF16; ~1e-2 of the pixel range off the fp32 path).
-        frozen=True: `params` is not modified between calls (FS_FLAG_PARAMS_FROZEN: the filter re-layouts run once per sequence)."""
+        frozen=True: `params` is not modified between calls (FS_FLAG_PARAMS_FROZEN: the filter re-layouts run once per sequence).
+        workspace: a (tensor, nbytes) pair from new_tnet_workspace() instead of the engine's shared per-shape one."""
         self._sync_stream()
         N, H, W, C = (int(s) for s in x.shape)
         assert C == 3
         Ho, Wo = self.tnet_out_shape(H, W)
-        ws, nbytes = self._tnet_workspace(N, H, W, bf16)
+        ws, nbytes = workspace if workspace is not None else self._tnet_workspace(N, H, W, bf16)
         y = self.mem.empty((N, Ho, Wo, 3))
         p = self.mem.ptr
         L.check(self.lib, self.lib.fs_tnet_forward(self.ctx, p(params), p(x), N, H, W, p(y), p(ws), nbytes,

@@ -29,18 +29,23 @@ class FrameStylizer(object):
         self._in_f32 = mem.empty(self.shape)
         self._out_u8 = mem.upload_u8(np.zeros(self.out_shape, np.uint8))
         self._graph = None
-        self._graph_keepalive = []       # the engine workspace the captured graph replays into (pinned, see _capture)
+        # A workspace of this stylizer's OWN: with frozen=True the re-laid-out filters of self.variables live inside it and the captured
+        # graph no longer rebuilds them -- nobody else may write there (the engine's shared per-shape workspace would be rewritten by any
+        # other same-shape forward, and every later replay would silently mix two models).
+        self._ws = eng.new_tnet_workspace(self.shape[0], self.shape[1], self.shape[2], bf16)
         self._use_graph = use_graph and hasattr(mem, "torch")
         self._y = None
 
     def _device_pass(self):
         e = self.eng
         e.u8_to_f32(self._in_u8, self._in_f32)
-        self._y = e.tnet_forward(self.variables, self._in_f32, upsample_method=self.method, bf16=self.bf16, frozen=True)   # one checkpoint, many frames
+        self._y = e.tnet_forward(self.variables, self._in_f32, upsample_method=self.method, bf16=self.bf16, frozen=True,   # one checkpoint, many frames
+                                 workspace=self._ws)
         e.f32_to_u8(self._y, self._out_u8, swap_rb=self.swap_rb)
 
     def _capture(self):
         torch = self.eng.mem.torch
+        self.eng.invalidate_frozen()                       # the warm-up below rebuilds the filters in self._ws whatever the library remembers
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up outside capture (one-time initialisation)
@@ -52,15 +57,11 @@ class FrameStylizer(object):
         # invalidate this thread's capture
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._device_pass()
-        self._graph = g
-        # the graph replays raw pointers into the engine's transform-net workspace of this shape: pin it against the
-        # engine's byte-bounded LRU eviction and keep it alive for as long as the graph lives
-        self._graph_keepalive = self.eng.pin_last_used(tnet=True)
+        self._graph = g                                    # (replays raw pointers into self._ws, which lives as long as this object)
 
     def release(self):
-        """Drop the captured graph and un-pin its workspace."""
+        """Drop the captured graph."""
         self._graph = None
-        self.eng.release_pins(self._graph_keepalive)
 
     def __del__(self):
         try:

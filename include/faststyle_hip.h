@@ -67,9 +67,14 @@ size_t fs_tnet_workspace_bytes(int N, int H, int W, int flags);
  * Replaces sess.run(Y, {X: img}) at stylize_image.py:75 and the forward half of train.py:256-275. */
 int fs_tnet_forward(fs_ctx* ctx, const float* params, const float* x, int N, int H, int W, float* y, void* ws,
                     size_t ws_bytes, int flags);
+/* Forget what FS_FLAG_PARAMS_FROZEN remembers (params pointer, workspace pointer, plan): the next fs_tnet_forward rebuilds the re-laid-out
+ * filters whatever its pointers are.  Call it whenever a workspace or a parameter buffer the context has seen is freed, re-used for something
+ * else or rewritten behind the library's back (an allocator handing the same address out again would otherwise look like "nothing changed"). */
+int fs_tnet_invalidate(fs_ctx* ctx);
 /* grads[FS_TNET_NPARAMS] = d loss / d params given dy = d loss / d y; `ws` must be the workspace a
  * fs_tnet_forward(..., FS_FLAG_SAVE_FOR_BWD) call on the same inputs just filled.  Replaces the
- * transform-net half of AdamOptimizer.minimize's gradient graph (train.py:203). */
+ * transform-net half of AdamOptimizer.minimize's gradient graph (train.py:203).  Error -5: this context filled `ws` with a forward of
+ * another shape or another upsample method. */
 int fs_tnet_backward(fs_ctx* ctx, const float* params, const float* x, const float* dy, int N, int H, int W, float* grads,
                      void* ws, size_t ws_bytes, int flags);
 

@@ -1,0 +1,168 @@
+"""Error paths of the C ABI (include/faststyle_hip.h: "every call returns 0 on success, a negative code on error; fs_last_error()
+holds the message") through ctypes -- on the CPU against the emulator build of the same sources, on the GPU against the product library.
+Every case returns BEFORE anything is launched or dereferenced, so the tensor arguments may be arbitrary non-null addresses."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from faststyle_amd import _lib as L
+from tests.backends import engine_params, get_engine
+
+P = ctypes.c_void_p
+
+
+@pytest.fixture(params=engine_params())
+def eng(request):
+    return get_engine(request.param)
+
+
+def err(e):
+    return (e.lib.fs_last_error() or b"").decode()
+
+
+def test_tnet_entry_points_reject_bad_arguments(eng):
+    e, lib, ctx = eng, eng.lib, eng.ctx
+    buf = e.mem.zeros((1024,))
+    p = e.mem.ptr(buf)
+    need = lib.fs_tnet_workspace_bytes(1, 64, 64, 0)
+    assert need > 0
+    # null tensor: -1
+    assert lib.fs_tnet_forward(ctx, None, p, 1, 64, 64, p, p, need, 0) == -1 and "null" in err(e)
+    # REFLECT-40 needs H, W >= 41: -2, the message carries the numbers
+    assert lib.fs_tnet_forward(ctx, p, p, 1, 40, 64, p, p, need, 0) == -2 and "41" in err(e) and "40" in err(e)
+    assert lib.fs_tnet_forward(ctx, p, p, 0, 64, 64, p, p, need, 0) == -2
+    # workspace one byte short: -3 with both sizes
+    assert lib.fs_tnet_forward(ctx, p, p, 1, 64, 64, p, p, need - 1, 0) == -3 and str(need) in err(e)
+    assert lib.fs_tnet_backward(ctx, p, p, p, 1, 64, 64, p, p, need - 1, 0) == -3 and str(need) in err(e)
+    # the bf16 mode is inference-only and covers the resize-conv models
+    assert lib.fs_tnet_forward(ctx, p, p, 1, 64, 64, p, p, need, L.FS_FLAG_BF16 | L.FS_FLAG_SAVE_FOR_BWD) == -2 and "BF16" in err(e)
+    assert lib.fs_tnet_forward(ctx, p, p, 1, 64, 64, p, p, need, L.FS_FLAG_BF16 | L.FS_FLAG_UPSAMPLE_DECONV) == -2
+    assert lib.fs_tnet_workspace_bytes(1, 64, 64, L.FS_FLAG_BF16 | L.FS_FLAG_SAVE_FOR_BWD) == 0
+    assert lib.fs_tnet_workspace_bytes(1, 40, 64, 0) == 0
+    # inspection entry points
+    off, dims = ctypes.c_size_t(), (ctypes.c_int * 4)()
+    assert lib.fs_tnet_ws_tensor(1, 64, 64, 0, 16, L.FS_TNET_WS_Z, ctypes.byref(off), ctypes.byref(dims)) == -2 and "16" in err(e)
+    assert lib.fs_tnet_ws_tensor(1, 64, 64, 0, 5, L.FS_TNET_WS_H, ctypes.byref(off), ctypes.byref(dims)) == -2
+    assert lib.fs_tnet_ws_tensor(1, 64, 64, L.FS_FLAG_BF16, 0, L.FS_TNET_WS_Z, ctypes.byref(off), ctypes.byref(dims)) == -2
+    name = ctypes.c_char_p()
+    assert lib.fs_tnet_param_info(48, ctypes.byref(name), None, None, None) == -1 and "48" in err(e)
+    assert lib.fs_tnet_invalidate(None) == -1
+
+
+def test_backward_refuses_a_workspace_filled_by_another_forward(eng):
+    """fs_tnet_backward reads what fs_tnet_forward left in the caller's workspace; handed a workspace this context filled with another
+    upsample method (FS_FLAG_UPSAMPLE_DECONV: other filter layouts, another launch sequence) or another shape it returns -5 instead of
+    gradients of garbage."""
+    from oracle import tnet
+    e, lib, ctx = eng, eng.lib, eng.ctx
+    N, H, W = 1, 44, 48
+    flat = e.mem.from_numpy(e.flatten_params(tnet.init_params(seed=0), scope=""))
+    x = e.mem.from_numpy(np.random.default_rng(0).uniform(0, 255, (N, H, W, 3)).astype(np.float32))
+    nbytes = max(lib.fs_tnet_workspace_bytes(N, H, W, L.FS_FLAG_SAVE_FOR_BWD),
+                 lib.fs_tnet_workspace_bytes(N, H, W, L.FS_FLAG_SAVE_FOR_BWD | L.FS_FLAG_UPSAMPLE_DECONV),
+                 lib.fs_tnet_workspace_bytes(2, H, W, L.FS_FLAG_SAVE_FOR_BWD))
+    ws = e.mem.zeros((nbytes // 4,))
+    Ho, Wo = e.tnet_out_shape(H, W)
+    y, dy, g = e.mem.zeros((N, Ho, Wo, 3)), e.mem.zeros((2, Ho, Wo, 3)), e.mem.zeros((L.FS_TNET_NPARAMS,))
+    p = e.mem.ptr
+    e._sync_stream()
+    assert lib.fs_tnet_forward(ctx, p(flat), p(x), N, H, W, p(y), p(ws), nbytes, L.FS_FLAG_SAVE_FOR_BWD) == 0
+    assert lib.fs_tnet_backward(ctx, p(flat), p(x), p(dy), N, H, W, p(g), p(ws), nbytes, L.FS_FLAG_UPSAMPLE_DECONV) == -5
+    assert "resize" in err(e) and "deconv" in err(e)
+    assert lib.fs_tnet_backward(ctx, p(flat), p(x), p(dy), 2, H, W, p(g), p(ws), nbytes, 0) == -5 and "N=2" in err(e)
+    assert lib.fs_tnet_backward(ctx, p(flat), p(x), p(dy), N, H, W, p(g), p(ws), nbytes, 0) == 0          # the matching call runs
+    assert np.isfinite(e.mem.to_numpy(g)).all()
+    lib.fs_tnet_invalidate(ctx)                                                                           # forgets the record: no refusal
+    assert lib.fs_tnet_backward(ctx, p(flat), p(x), p(dy), N, H, W, p(g), p(ws), nbytes, 0) == 0
+
+
+def test_loss_and_builder_entry_points_reject_bad_arguments(eng):
+    e, lib, ctx = eng, eng.lib, eng.ctx
+    buf = e.mem.zeros((1024,))
+    p = e.mem.ptr(buf)
+    vp = (P * L.FS_VGG_NLAYERS)(*([p] * L.FS_VGG_NLAYERS))
+    cfg = L.fs_loss_cfg()
+    cfg.n_content = 1
+    cfg.content_layer[0] = 6
+    cfg.n_style = 1
+    cfg.style_layer[0] = 10                      # conv4_3 is layer 9: out of range
+    assert lib.fs_perceptual_workspace_bytes(1, 64, 64, ctypes.byref(cfg)) == 0
+    assert lib.fs_perceptual_loss(ctx, ctypes.byref(vp), ctypes.byref(vp), p, ctypes.byref(cfg), p, p, 1, 64, 64, p, p, p, 1 << 30) == -2
+    assert "style layer" in err(e)
+    cfg.style_layer[0] = 9
+    cfg.n_content = 5
+    assert lib.fs_perceptual_loss(ctx, ctypes.byref(vp), ctypes.byref(vp), p, ctypes.byref(cfg), p, p, 1, 64, 64, p, p, p, 1 << 30) == -2
+    cfg.n_content = 1
+    # a style layer without its target Gram matrix
+    assert lib.fs_perceptual_loss(ctx, ctypes.byref(vp), ctypes.byref(vp), p, ctypes.byref(cfg), p, p, 1, 64, 64, p, p, p, 1 << 30) == -2
+    assert "target_gram[0]" in err(e)
+    cfg.target_gram[0] = p
+    need = lib.fs_perceptual_workspace_bytes(1, 64, 64, ctypes.byref(cfg))
+    assert need > 0
+    assert lib.fs_perceptual_loss(ctx, ctypes.byref(vp), ctypes.byref(vp), p, ctypes.byref(cfg), p, p, 1, 64, 64, p, p, p, need - 4) == -3
+    assert lib.fs_perceptual_loss(ctx, ctypes.byref(vp), ctypes.byref(vp), p, ctypes.byref(cfg), p, None, 1, 64, 64, p, p, p, need) == -1
+    gp = (P * 4)(p, p, p, p)
+    assert lib.fs_style_targets(ctx, ctypes.byref(vp), ctypes.byref(vp), ctypes.byref(cfg), p, 64, 64, ctypes.byref(gp), p, 16) == -3
+    lay = (ctypes.c_int * 1)(10)
+    op = (P * 1)(p)
+    assert lib.fs_vgg_features(ctx, ctypes.byref(vp), ctypes.byref(vp), p, 1, 64, 64, 1, lay, op, p, 1 << 30) == -2 and "10" in err(e)
+    assert lib.fs_vgg_features_workspace_bytes(1, 64, 64, 10) == 0
+    # Gram matrices: C a multiple of 4, of 128 beyond 128
+    assert lib.fs_gram_fwd(ctx, p, 1, 64, 130, p, p, 1 << 20) == -2 and "130" in err(e)
+    assert lib.fs_gram_workspace_bytes(1, 64, 130) == 0
+    assert lib.fs_gram_bwd(ctx, p, p, 1, 64, 64, p, p, 64) == -3
+    # Adam: t is the 1-based step
+    assert lib.fs_adam_tf_step(ctx, p, p, p, p, 16, 1e-3, 0.9, 0.999, 1e-8, 0) == -2 and "1-based" in err(e)
+    # losses.content_loss / style_loss: n must be whole periods
+    assert lib.fs_loss_sqdiff(ctx, p, p, 7, 16, 1.0, p, p) == -2 and "period" in err(e)
+    assert lib.fs_loss_sqdiff(ctx, p, p, 0, 16, 1.0, p, p) == -1
+
+
+def test_single_op_entry_points_reject_bad_arguments(eng):
+    e, lib, ctx = eng, eng.lib, eng.ctx
+    buf = e.mem.zeros((1024,))
+    p = e.mem.ptr(buf)
+
+    def desc(**kw):
+        d = L.fs_conv_desc()
+        d.x = d.w = d.y = p
+        d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride = 1, 16, 16, 8, 64, 3, 3, 1
+        d.pad_mode = L.FS_PAD_SAME
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+    d = desc(Cin=6)                                          # Cin: 3 or a multiple of 4
+    assert lib.fs_conv2d_fwd(ctx, ctypes.byref(d)) == -2 and "Cin" in err(e)
+    d = desc(shuffle=1, Cout=66)
+    assert lib.fs_conv2d_fwd(ctx, ctypes.byref(d)) == -2 and "shuffle" in err(e)
+    d = desc(pad_mode=L.FS_PAD_VALID, H=2, W=2)              # a 3x3 VALID conv of a 2x2 image has no output
+    assert lib.fs_conv2d_fwd(ctx, ctypes.byref(d)) == -2 and "empty" in err(e)
+    d = desc(pool_out=p)                                     # the fused max-pool exists in the Winograd epilogues only
+    assert lib.fs_conv2d_fwd(ctx, ctypes.byref(d)) == -2 and "pool_out" in err(e)
+    d = desc(x=None)
+    assert lib.fs_conv2d_fwd(ctx, ctypes.byref(d)) == -1
+    assert lib.fs_conv2d_fwd(None, ctypes.byref(desc())) == -1
+    # filter transforms: channel multiples of the kernels' steps
+    assert lib.fs_wino4t_transform_filter(ctx, p, 12, 64, p) == -2 and "12" in err(e)      # Cin % 8
+    assert lib.fs_wino4t_transform_filter(ctx, p, 8, 32, p) == -2                          # Cout % 64
+    assert lib.fs_wino4_transform_filter(ctx, p, 6, 64, p) == -2
+    assert lib.fs_wino_transform_filter(ctx, p, 12, 64, p) == -2
+    # instance-norm backward
+    assert lib.fs_instnorm_bwd(ctx, p, p, p, p, p, p, 1, 1, 64, 260, p, p, p, p, 1 << 30) == -2 and "256" in err(e)
+    need = lib.fs_instnorm_bwd_workspace_bytes(2, 4096, 64)
+    assert lib.fs_instnorm_bwd(ctx, p, p, p, p, p, p, 1, 2, 4096, 64, p, p, p, p, need - 4) == -3 and str(need) in err(e)
+    assert lib.fs_instnorm_bwd(ctx, p, p, p, p, p, p, 3, 2, 4096, 64, p, p, p, p, need) == -2
+    # filter gradients
+    w = L.fs_wgrad_desc()
+    w.x = w.dy = w.dw = p
+    w.N, w.H, w.W, w.Cin, w.Cout, w.KH, w.KW, w.stride = 1, 16, 16, 192, 64, 3, 3, 1
+    w.pad_mode = L.FS_PAD_SAME
+    assert lib.fs_conv2d_wgrad(ctx, ctypes.byref(w), p, 1 << 30) == -2 and "128" in err(e)
+    assert lib.fs_conv2d_wgrad_workspace_bytes(ctypes.byref(w)) == 0
+    w.Cin = 64
+    need = lib.fs_conv2d_wgrad_workspace_bytes(ctypes.byref(w))
+    assert need > 0 and lib.fs_conv2d_wgrad(ctx, ctypes.byref(w), p, need - 4) == -3
+    # u8 <-> f32 helpers: alignment contract
+    assert lib.fs_u8_to_f32(ctx, P(p + 1), 16, p) == -1 and "aligned" in err(e)
+    assert lib.fs_resize_bicubic_u8(ctx, p, 0, 4, p, 4, 4) == -1

@@ -10,8 +10,9 @@ if [ "$1" = build ]; then
   T=$(mktemp -d)
   git -C "$R" archive "$2" faststyle_amd/csrc include | tar -x -C "$T"
   for f in "$T"/faststyle_amd/csrc/*.hip; do
-    echo "/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-pass-failed -c $f -o $T/$(basename $f).o"
-  done | xargs -P 16 -I{} sh -c "{}"
+    X=""; case "$(basename $f)" in fs_wino4*) X="-fno-slp-vectorize";; esac   # (faststyle_amd/build.py FILE_FLAGS)
+    echo "/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-pass-failed $X -c $f -o $T/$(basename $f).o"
+  done | xargs -P 8 -I{} sh -c "{}"
   mkdir -p "$R/exp"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$T"/*.o -o "$R/exp/libbase.so"
   rm -rf "$T"
