@@ -58,6 +58,16 @@ def newest_profile(stem):
     return c[-1] if c else None
 
 
+def same_build(profile_json):
+    """A stored counter profile describes the running library only if it was collected from the same kernel sources
+    (tools/pmc_traffic.py stores faststyle_amd.build.source_digest()); otherwise its numbers are not quoted."""
+    try:
+        from faststyle_amd import build as fsbuild
+        return profile_json.get("csrc_sha16") is not None and profile_json.get("csrc_sha16") == fsbuild.source_digest()
+    except Exception:
+        return False
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -474,7 +484,9 @@ def main():
             if tp:
                 tj = json.load(open(tp))
                 passes = tj.get("forward_passes", 23)
-                if tj.get("kernels"):
+                if tj.get("kernels") and not same_build(tj):
+                    rep["hbm_counter_source"] = os.path.relpath(tp, ROOT) + " (NOT quoted: collected from other kernel sources than the running build)"
+                elif tj.get("kernels"):
                     tot_b = sum(k["traffic_bytes_per_launch"] * k["launches_sampled"] for k in tj["kernels"].values()) / passes
                     rep["hbm_counter_bytes_per_batch"] = int(tot_b)
                     rep["hbm_counter_TBps"] = round(tot_b / (dt / iters) / 1e12, 3)
@@ -557,8 +569,10 @@ def main():
         if tpath:
             tj = json.load(open(tpath))
             k = tj.get("kernels", {}).get(sym)
-            if k and tj.get("batch_per_gpu") == B:
+            if k and tj.get("batch_per_gpu") == B and same_build(tj):
                 traffic, traffic_src = k["traffic_bytes_per_launch"], os.path.relpath(tpath, ROOT)
+            elif k and tj.get("batch_per_gpu") == B:
+                traffic_src = os.path.relpath(tpath, ROOT) + " (NOT quoted: collected from other kernel sources than the running build)"
         out = {
             "metric": "images/sec train-step 256x256 b32 (+ Gram GFLOPs % MFMA peak); 720p stylize fps",
             "value": rep["images_per_sec"], "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -616,7 +630,23 @@ def main():
             out["stylize_1080p_b8_fp32_fps"] = fwd["stylize_1080p_b8_fp32"]["fps"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S)
+        # the headline figures once more as the LAST key of the line (and as the last stderr line): what a log tail shows
+        dg = {"b32_images_per_sec": out["value"], "b32_ms_per_step": out["ms_per_step"], "n_gpus": world,
+              "roofline_frac": out["roofline"]["frac"], "roofline_kernel": names[di].split(" (")[0],
+              "vgg_gram_frac_executed": out["vgg_gram_substep"]["frac_executed"], "step_frac_executed": out["step_frac_executed"]}
+        if b4_leg is not None:
+            dg["b4_per_gpu_images_per_sec"] = out["train_b4_per_gpu"]["images_per_sec"]
+            dg["b4_ms_per_step"] = out["train_b4_per_gpu"]["ms_per_step"]
+        if fwd:
+            dg["stylize_720p_fps"] = out["stylize_720p_fps"]
+            dg["stylize_1080p_b8_bf16_fps"] = out["stylize_1080p_b8_bf16_fps"]
+            dg["stylize_1080p_b8_fp32_fps"] = out["stylize_1080p_b8_fp32_fps"]
+        if "cpu_baseline" in out:
+            dg["cpu_baseline_images_per_sec"] = out["cpu_baseline"].get("value")
+        out["digest"] = dg
         print(json.dumps(out))
+        sys.stdout.flush()
+        print("bench digest: " + json.dumps(dg), file=sys.stderr)
     if launched:
         dist.destroy_process_group()
 

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "fs_gram_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t]),
     "fs_tnet_ws_tensor": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_size_t), POINTER(c_int * 4)]),
     "fs_perceptual_ws_tensor": (c_int, [c_int, c_int, c_int, POINTER(fs_loss_cfg), c_int, POINTER(c_size_t), POINTER(c_int * 4)]),
+    "fs_perceptual_ws_input": (c_int, [c_int, c_int, c_int, POINTER(fs_loss_cfg), POINTER(c_size_t), POINTER(c_size_t)]),
     "fs_loss_sqdiff": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_void_p, c_void_p]),
     "fs_loss_tv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fs_adam_tf_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,

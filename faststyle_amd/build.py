@@ -15,12 +15,26 @@ OBJDIR = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed"]
 # Per-source flags.  fs_wino4.hip: no SLP vectorisation.  With it (ROCm 7.2 clang) two of the kernel's three epilogue
 # instantiations return WRONG values on gfx950 (a few per cent of the elements, always lanes 12-15 of a row of 16 and the odd
-# channel of a pair; tools/_dbg_w4.py on the GPU, exp build with -fslp-vectorize) while the CPU emulator build of the same source
+# channel of a pair; tools/w4_slp_repro.py on the GPU, exp build with -fslp-vectorize) while the CPU emulator build of the same source
 # is right and the third instantiation, equally packed, is right too.  The cause was not isolated (no undefined behaviour left in
 # the source; a code-generation or hazard problem around v_pk_add_f32 / v_pk_fma_f32).  Packed fp32 beside fp32 matrix
 # instructions is slower anyway (MI355X_MICROARCH.md, price of one filler beside MFMAs), so the kernel loses nothing.
 FILE_FLAGS = {"fs_wino4.hip": ["-fno-slp-vectorize"], "fs_wino4t.hip": ["-fno-slp-vectorize"], "fs_wino4t1b.hip": ["-fno-slp-vectorize"], "fs_wino4t1c.hip": ["-fno-slp-vectorize"], "fs_wino4t1d.hip": ["-fno-slp-vectorize"], "fs_wino4t2.hip": ["-fno-slp-vectorize"],
               "fs_wino4t2b.hip": ["-fno-slp-vectorize"]}   # (fs_wino4t.hip: the same transforms, same precaution)
+
+
+def source_digest():
+    """sha256[:16] over the kernel sources (csrc/*.hip, csrc/*.h, the public headers): the identity of the build a stored measurement
+    (profiles/*hbm_traffic*.json) belongs to -- there is no .git on the GPU box, so a commit id is not available where profiles are collected."""
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + \
+        sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _newest(paths):

@@ -29,6 +29,8 @@ struct fs_ctx {
     struct FwdRec {
         const void* ws = nullptr;
         int N = 0, H = 0, W = 0, deconv = 0;
+        bool bwd_filters = false;   // that forward (FS_FLAG_SAVE_FOR_BWD) also built the backward's input-gradient filters, for these parameters
+        const float* params = nullptr;
     } fwd_recs[8];
     int fwd_rec_next = 0;
     fs::BTnetLayout* btnet;  // bf16 inference layout (allocated on first use)
@@ -228,7 +230,8 @@ int fs_tnet_forward(fs_ctx* ctx, const float* params, const float* x, int N, int
     if (ws_bytes < L->total_floats * sizeof(float))
         return fail(-3, "fs_tnet_forward: workspace too small (%zu < %zu bytes)", ws_bytes, L->total_floats * sizeof(float));
     const bool reuse = (flags & FS_FLAG_PARAMS_FROZEN) && ctx->fwd_params == params && ctx->fwd_ws == ws && ctx->fwd_serial == ctx->tnet_serial;
-    const int rc = fs::tnet_forward(*L, params, x, y, (float*)ws, ctx->stream, reuse);
+    const bool with_bwd = (flags & FS_FLAG_SAVE_FOR_BWD) && !reuse && fs::tune_int("FS_TNET_BWD_FILTERS_IN_FWD", 1);
+    const int rc = fs::tnet_forward(*L, params, x, y, (float*)ws, ctx->stream, reuse, with_bwd);
     if (rc) {
         ctx->fwd_params = nullptr;
         return fail(rc, "fs_tnet_forward: launch failed (%d)", rc);
@@ -246,6 +249,8 @@ int fs_tnet_forward(fs_ctx* ctx, const float* params, const float* x, int N, int
         r->H = H;
         r->W = W;
         r->deconv = (flags & FS_FLAG_UPSAMPLE_DECONV) ? 1 : 0;
+        r->bwd_filters = with_bwd;
+        r->params = params;
     }
     return 0;
 }
@@ -269,8 +274,14 @@ int fs_tnet_backward(fs_ctx* ctx, const float* params, const float* x, const flo
         if (q.ws == ws && (q.N != N || q.H != H || q.W != W || q.deconv != ((flags & FS_FLAG_UPSAMPLE_DECONV) ? 1 : 0)))
             return fail(-5, "fs_tnet_backward: the workspace was filled by fs_tnet_forward(N=%d, %dx%d, %s) -- this call is (N=%d, %dx%d, %s)", q.N, q.H,
                         q.W, q.deconv ? "deconv" : "resize", N, H, W, (flags & FS_FLAG_UPSAMPLE_DECONV) ? "deconv" : "resize");
+    bool filters_ready = false;   // the forward that filled this workspace built the input-gradient filters too (same parameters: same step)
+    for (auto& q : ctx->fwd_recs)
+        if (q.ws == ws && q.bwd_filters && q.params == params) {
+            filters_ready = true;
+            q.bwd_filters = false;   // (once: a second backward on the same workspace rebuilds them -- the caller may have updated `params` in place)
+        }
     fs::StreamAux aux{ctx->side, ctx->ev, 34};
-    const int rc = fs::tnet_backward(*L, params, x, dy, grads, (float*)ws, ctx->stream, ctx->have_side ? &aux : nullptr);
+    const int rc = fs::tnet_backward(*L, params, x, dy, grads, (float*)ws, ctx->stream, ctx->have_side ? &aux : nullptr, filters_ready);
     return rc ? fail(rc, "fs_tnet_backward: launch failed (%d)", rc) : 0;
 }
 
@@ -360,6 +371,17 @@ int fs_perceptual_ws_tensor(int N, int H, int W, const fs_loss_cfg* cfg, int lay
     dims[1] = L.Hl[layer];
     dims[2] = L.Wl[layer];
     dims[3] = cout[layer];
+    return 0;
+}
+
+// where fs_perceptual_loss stages its two inputs inside the caller's workspace (a caller that produces them there skips the copies)
+int fs_perceptual_ws_input(int N, int H, int W, const fs_loss_cfg* cfg, size_t* y_offset_floats, size_t* content_offset_floats) {
+    if (int rc = check_cfg(cfg)) return rc;
+    if (N < 1 || H < 1 || W < 1 || !y_offset_floats || !content_offset_floats) return fail(-1, "fs_perceptual_ws_input: bad argument");
+    fs::VggLayout L;
+    fs::vgg_layout(N, H, W, *cfg, true, &L);
+    *y_offset_floats = L.xin;
+    *content_offset_floats = L.cmax >= 0 ? L.xin + (size_t)N * H * W * 3 : (size_t)-1;   // (size_t)-1: no content layer, `content` is not read
     return 0;
 }
 

@@ -976,6 +976,48 @@ int sqdiff_loss(const float* x, const float* t, size_t t_period, size_t total, f
     return launch_status();
 }
 
+// The same element pass without the final sum: partial[0 .. *n_partial) are left for loss_finish (fs_perceptual_loss: every loss term of a
+// step is summed by ONE launch at the end instead of a sum_partials launch per term).  partial: room for 1024 floats.
+int sqdiff_partials(const float* x, const float* t, size_t t_period, size_t total, float gscale, float* grad, float* partial, int* n_partial,
+                    hipStream_t s) {
+    const int periods = (int)(total / t_period);
+    if (periods < 1 || periods > 1024 || (size_t)periods * t_period != total) return -1;
+    int bx = (int)min((size_t)(1024 / periods > 0 ? 1024 / periods : 1), (t_period + 255) / 256);
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(bx, periods), dim3(256), 0, s, x, t, t_period, gscale, grad, partial);
+    *n_partial = bx * periods;
+    return launch_status();
+}
+
+// losses = {total, content, style, beta * tv} (reference train.py:184) from the partial sums of every term: job j adds
+// scale_j * sum(partial_j[0 .. n_j)) to losses[slot_j]; one workgroup, fixed order (deterministic); all four scalars are WRITTEN (no
+// clear beforehand, no read-modify-write across launches).
+__global__ __launch_bounds__(256) void loss_finish_kernel(LossFinish f) {
+    __shared__ float sh[4];
+    float tot[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < f.n; ++j) {
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < f.job[j].n; i += 256) acc += f.job[j].partial[i];
+        const float v = block_sum(acc, sh) * f.job[j].scale;
+        const int slot = f.job[j].slot;
+        tot[1] += slot == 1 ? v : 0.f;
+        tot[2] += slot == 2 ? v : 0.f;
+        tot[3] += slot == 3 ? v : 0.f;
+    }
+    if (threadIdx.x == 0) {
+        f.losses[1] = tot[1];
+        f.losses[2] = tot[2];
+        f.losses[3] = tot[3];
+        f.losses[0] = tot[1] + tot[2] + tot[3];
+    }
+}
+
+int loss_finish(const LossFinish& f, hipStream_t s) {
+    if (f.n < 0 || f.n > LossFinish::kMax) return -1;
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, f);
+    return launch_status();
+}
+
 // TV loss (reference losses.py:70-97): sum of squared forward differences along H and W, and
 // its gradient scaled by gscale, ACCUMULATED into grad (grad += gscale * dTV/dx) when grad != null.
 __global__ __launch_bounds__(256) void tv_kernel(const float* x, int H, int W, int C, size_t total, float gscale,
@@ -1005,6 +1047,14 @@ __global__ __launch_bounds__(256) void tv_kernel(const float* x, int H, int W, i
     }
     const float tot = block_sum(acc, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+int tv_partials(const float* x, int N, int H, int W, int C, float gscale, float* grad, float* partial, int* n_partial, hipStream_t s) {
+    const size_t total = (size_t)N * H * W * C;
+    const int blocks = (int)min((size_t)1024, (total + 255) / 256);
+    hipLaunchKernelGGL(tv_kernel, dim3(blocks), dim3(256), 0, s, x, H, W, C, total, gscale, grad, partial);
+    *n_partial = blocks;
+    return launch_status();
 }
 
 int tv_loss(const float* x, int N, int H, int W, int C, float lscale, float gscale, float* grad, float* loss_out,
@@ -1232,10 +1282,6 @@ int vgg_consts(float* ab, hipStream_t s) {
     hipLaunchKernelGGL(vgg_consts_kernel, dim3(1), dim3(64), 0, s, ab);
     return launch_status();
 }
-// losses = {total, content, style, beta*tv}   (reference train.py:184)
-__global__ void loss_total_kernel(float* l) {
-    if (threadIdx.x == 0) l[0] = l[1] + l[2] + l[3];
-}
 // n <= 64 words = 0 (instead of hipMemsetAsync: see fs_perceptual_loss)
 __global__ void zero_words_kernel(unsigned* p, int n) {
     if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
@@ -1243,11 +1289,6 @@ __global__ void zero_words_kernel(unsigned* p, int n) {
 int zero_words(void* p, int n, hipStream_t s) {
     if (n < 0 || n > 64) return -1;
     hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned*>(p), n);
-    return launch_status();
-}
-int loss_zero(float* losses, hipStream_t s) { return zero_words(losses, 4, s); }
-int loss_total(float* losses, hipStream_t s) {
-    hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, s, losses);
     return launch_status();
 }
 }  // namespace fs

@@ -255,6 +255,92 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(GramArgs a, float scal
     }
 }
 
+// The same reduction for SEVERAL layers in one launch, with the style-loss terms of losses.py:61-64 on the way (round 5: a train step had a
+// reduce, a squared-difference and a sum launch per style layer -- twelve launches of a few microseconds of work each):
+//   G = scale * sum of slabs (+ mirror image), S = gscale * (G - Gt), partial[block] = sum over the block's elements of (G - Gt)^2 with every
+//   element of the full C x C matrix counted once (a mirrored element counts twice).
+// grid (16, sum of the jobs' pairs, N); blocks beyond a job's tile size return.
+namespace {
+struct GramFinishArgs {
+    struct J {
+        GramArgs a;
+        const float* Gt;
+        float* G;
+        float* S;
+        float* partial;
+        float scale, gscale;
+        int pair0;   // first blockIdx.y of the job
+    } j[4];
+    int n;
+};
+}  // namespace
+__global__ __launch_bounds__(256) void gram_finish_kernel(GramFinishArgs f) {
+    __shared__ float sh[4];
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < f.n && (int)blockIdx.y >= f.j[k].pair0) q = k;
+    const GramFinishArgs::J& J_ = f.j[q];
+    const GramArgs& a = J_.a;
+    const int CG = a.CG;
+    const int bx = (CG * CG / 4 + 255) / 256;
+    if ((int)blockIdx.x >= bx) return;   // (uniform per block)
+    const int pair_id = (int)blockIdx.y - J_.pair0;
+    const int e4 = (int)blockIdx.x * 256 + (int)threadIdx.x;   // float4 index inside the tile
+    const int r = (e4 * 4) / CG, c = (e4 * 4) - r * CG;
+    int pair = pair_id, I = 0;
+    while (pair >= a.groups - I) {
+        pair -= a.groups - I;
+        ++I;
+    }
+    const int J = I + pair, n = (int)blockIdx.z;
+    const bool active = e4 * 4 < CG * CG && !(I == J && CG == 128 && (r >> 5) > (c >> 5));
+    float acc = 0.f;
+    if (active) {
+        const float* p = a.slabs + (((size_t)n * a.pairs + pair_id) * a.splits) * CG * CG + (size_t)r * CG + c;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < a.splits; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * CG * CG);
+            s.x += v.x;
+            s.y += v.y;
+            s.z += v.z;
+            s.w += v.w;
+        }
+        s.x *= J_.scale;
+        s.y *= J_.scale;
+        s.z *= J_.scale;
+        s.w *= J_.scale;
+        const size_t cc = (size_t)a.C * a.C;
+        float* Gn = J_.G + (size_t)n * cc;
+        float* Sn = J_.S + (size_t)n * cc;
+        const int gr = I * CG + r, gc = J * CG + c;
+        const float4 t = *reinterpret_cast<const float4*>(J_.Gt + (size_t)gr * a.C + gc);
+        const float d[4] = {s.x - t.x, s.y - t.y, s.z - t.z, s.w - t.w};
+        const float g = J_.gscale;
+        *reinterpret_cast<float4*>(Gn + (size_t)gr * a.C + gc) = s;
+        *reinterpret_cast<float4*>(Sn + (size_t)gr * a.C + gc) = make_float4(g * d[0], g * d[1], g * d[2], g * d[3]);
+        const bool mirror = I != J || (CG == 128 && (r >> 5) < (c >> 5));   // (blocks ON the diagonal hold both halves already)
+        if (mirror) {
+            const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Gn[(size_t)(gc + e) * a.C + gr] = sv[e];
+                // (the target is symmetric up to rounding, the product of another kernel: the mirrored element takes ITS target)
+                const float dm = sv[e] - J_.Gt[(size_t)(gc + e) * a.C + gr];
+                Sn[(size_t)(gc + e) * a.C + gr] = g * dm;
+                acc = fmaf(dm, dm, acc);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fmaf(d[e], d[e], acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) J_.partial[((size_t)n * a.pairs + pair_id) * bx + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Gradient of the style loss through a Gram matrix (the adjoint of utils.py:76-82 behind train.py:203):
 //     dF[n] = F[n] . S[n]   (+ an optional addend: the content-loss gradient of a layer that carries both terms),
@@ -464,12 +550,56 @@ size_t gram2_slab_floats(int N, int HW, int C) {
     return (size_t)N * a.pairs * a.splits * a.CG * a.CG;
 }
 
+int gram2_finish_partials(int N, int C) {
+    GramArgs a;
+    if (!gram2_shape(N, 1, C, &a)) return 0;   // (pairs and the tile size do not depend on HW)
+    return N * a.pairs * ((a.CG * a.CG / 4 + 255) / 256);
+}
+
+int gram2_finish_batch(const GramFinishJob* jobs, int n, int N, hipStream_t s) {
+    if (n < 1 || n > 4) return -1;
+    GramFinishArgs f{};
+    f.n = n;
+    int pairs = 0;
+    for (int k = 0; k < n; ++k) {
+        GramFinishArgs::J& j = f.j[k];
+        if (!gram2_shape(N, jobs[k].HW, jobs[k].C, &j.a)) return -1;
+        j.a.slabs = const_cast<float*>(jobs[k].slabs);
+        j.Gt = jobs[k].Gt;
+        j.G = jobs[k].G;
+        j.S = jobs[k].S;
+        j.partial = jobs[k].partial;
+        j.scale = jobs[k].scale;
+        j.gscale = jobs[k].gscale;
+        j.pair0 = pairs;
+        pairs += j.a.pairs;
+    }
+    hipLaunchKernelGGL(gram_finish_kernel, dim3(16, (unsigned)pairs, (unsigned)N), dim3(256), 0, s, f);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+static int gram2_stream_impl(const GramArgs& a, int N, int HW, hipStream_t s);
+
+int gram2_stream(const float* F, float* slabs, int N, int HW, int C, hipStream_t s) {
+    GramArgs a;
+    if (!gram2_shape(N, HW, C, &a)) return -1;
+    a.F = F;
+    a.slabs = slabs;
+    return gram2_stream_impl(a, N, HW, s);
+}
+
 // G[n] = scale * F[n]^T F[n]; slabs: gram2_slab_floats(N, HW, C) floats of scratch
 int gram2_launch(const float* F, float* G, float* slabs, int N, int HW, int C, float scale, hipStream_t s) {
     GramArgs a;
     if (!gram2_shape(N, HW, C, &a)) return -1;
     a.F = F;
     a.slabs = slabs;
+    if (const int rc = gram2_stream_impl(a, N, HW, s)) return rc;
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)cdiv(a.CG * a.CG / 4, 256), (unsigned)a.pairs, (unsigned)N), dim3(256), 0, s, a, scale, G);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+static int gram2_stream_impl(const GramArgs& a, int N, int HW, hipStream_t s) {
     const size_t lds = a.CG == 64 ? (size_t)256 * 68 * sizeof(float) : (size_t)2 * 64 * 132 * sizeof(float);
     Profiler* prof = Profiler::current();
     // FLOPs EXECUTED: diagonal 128-channel tiles multiply 10 of their 16 blocks
@@ -485,8 +615,6 @@ int gram2_launch(const float* F, float* G, float* slabs, int N, int HW, int C, f
         hipLaunchKernelGGL(gram_stream_kernel<128>, dim3((unsigned)(N * a.pairs * a.splits)), dim3(256), lds, s, a);
     }
     if (prof) prof->end(s);
-    if (hipGetLastError() != hipSuccess) return -3;
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)cdiv(a.CG * a.CG / 4, 256), (unsigned)a.pairs, (unsigned)N), dim3(256), 0, s, a, scale, G);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

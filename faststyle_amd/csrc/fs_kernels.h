@@ -230,7 +230,8 @@ size_t wgw_plan(const WgradArgs* probs, int n, WgwArgs* out);   // returns the s
 int wgw_run(const WgwArgs& planned, float* slabs, float* const* dw, float scale, hipStream_t s);
 bool wgrad2_eligible(const WgradArgs& a);
 size_t wgrad2_plan(const WgradArgs* probs, int n, Wg2Args* out);   // returns the slab scratch in floats (0: not eligible)
-int wgrad2_run(const Wg2Args& planned, float* slabs, float* const* dw, float scale, hipStream_t s);
+int wgrad2_run(const Wg2Args& planned, float* slabs, float* const* dw, float scale, hipStream_t s, Wg2Reduce* defer = nullptr);
+int wgrad2_reduce(const Wg2Reduce& r, hipStream_t s);
 
 ConvPlan conv_plan(const ConvArgs& a);
 int conv_launch(const ConvArgs& a, hipStream_t s);
@@ -483,9 +484,9 @@ int zero_words(void* p, int n, hipStream_t s);   // n <= 64 32-bit words = 0 -- 
 // output-pixel tile (TH x TW <= max_px) with the best fill / halo trade-off for an Ho x Wo image (fs_conv.hip)
 // Winograd F(2x2,3x3) path (fs_wino.hip)
 int wt_wino(const float* w, float* U, int Cin, int Cout, hipStream_t s);
-struct WinoBatch {  // several filters of one shape in one launch (the 10 residual convs of the transform net)
-    const float* w[12];
-    float* U[12];
+struct WinoBatch {  // several filters of one shape in one launch (the 10 residual convs of the transform net; forward + input-gradient filters: 20)
+    const float* w[24];
+    float* U[24];
     int n;
 };
 int wt_wino_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s);
@@ -580,6 +581,36 @@ int sqdiff_loss(const float* x, const float* t, size_t t_period, size_t total, f
                 float* loss_out, int accumulate, float* scratch, hipStream_t s);
 int tv_loss(const float* x, int N, int H, int W, int C, float lscale, float gscale, float* grad, float* loss_out,
             float* scratch, hipStream_t s);
+// the element passes of the two losses without their final sums (partial: 1024 floats each), and the ONE launch that turns the partial sums
+// of all terms of a step into losses[4] = {total, content, style, beta * tv} (fs_perceptual_loss)
+int sqdiff_partials(const float* x, const float* t, size_t t_period, size_t total, float gscale, float* grad, float* partial, int* n_partial,
+                    hipStream_t s);
+int tv_partials(const float* x, int N, int H, int W, int C, float gscale, float* grad, float* partial, int* n_partial, hipStream_t s);
+struct LossFinish {
+    static const int kMax = 10;
+    struct Job {
+        const float* partial;
+        int n, slot;   // slot 1 content, 2 style, 3 tv
+        float scale;
+    } job[kMax];
+    int n;
+    float* losses;
+};
+int loss_finish(const LossFinish& f, hipStream_t s);
+// Gram matrices of several layers finished by ONE launch (fs_gram.hip): per job the slab reduction of gram2_launch, the mirror image, and the
+// style-loss terms of losses.py:61-64 on the way -- S = gscale * (G - Gt) (the filter of the Gram gradient) and the partial sums of (G - Gt)^2
+int gram2_stream(const float* F, float* slabs, int N, int HW, int C, hipStream_t s);   // the matrix part of gram2_launch only
+struct GramFinishJob {
+    const float* slabs;
+    const float* Gt;      // [C][C] target
+    float* G;             // [N][C][C]
+    float* S;             // [N][C][C]
+    float* partial;       // gram2_finish_partials(N, C) floats
+    int HW, C;
+    float scale, gscale;
+};
+int gram2_finish_partials(int N, int C);
+int gram2_finish_batch(const GramFinishJob* jobs, int n, int N, hipStream_t s);
 int axpby(const float* x, const float* y, float a, float b, float* out, size_t n, hipStream_t s);
 int adam_tf(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s);
 // Several filter re-layouts in ONE launch (blockIdx.y = job): the ~18 per-step re-layouts of the transform net

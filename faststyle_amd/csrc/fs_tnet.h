@@ -49,12 +49,14 @@ struct TnetLayout {
     size_t fin_counter; // 16 unsigned: the "last workgroup" counters of the fused instance-norm finalize (fs_kernels.h FinArgs)
     size_t fwd_floats;
     size_t wTu[16];   // per-unit input-gradient filters (flip+transpose / collapsed), all built by one wt_batch launch
+    size_t dweff2;    // the collapsed filter gradient of the SECOND resize-conv unit (both units' reductions are pending at once since round 5)
     size_t g[3], dz[2], wT, dweff, inbwd, slabs;  // backward scratch (dz double-buffered: filter gradients run on a side stream)
     size_t wino_d[10]; // Winograd-transformed input-gradient filters of the residual convs (0: direct kernel)
     int wino_dh[10];   // ... 1: through the half-item kernel, 2: through the 16-tile F(4x4) kernel (fs_wino4t.hip)
     size_t inb_rec;   // instance-norm-backward partial-sum records [N][items][64][2] written by the epilogue of a residual input-gradient launch
                       // (fs_wino4t_kernel.h EPI 5 / 6) for the unit below it; one buffer, consumed by that unit's in_bwd_rec right after
     size_t inb_S[16]; // per unit: the per-sample sums [N][Cout][2] in_bwd_rec leaves for in_bwd_params (dgamma / dbeta of all units in one launch)
+    size_t slab_u[16]; // per unit: slabs of its own filter-gradient launch (the six non-residual units' reductions run as ONE launch at the end)
     size_t dzres[10]; // dz of the ten residual convs, kept until their filter gradients run as ONE launch (fs_wgrad2.hip)
     int res_batch;    // 1: that batched launch is planned (shapes eligible)
     size_t total_floats;
@@ -64,7 +66,10 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L);
 int tnet_wino_mode();  // current FS_TNET_WINO
 WgradArgs unit_wgrad_args(const Unit& u, int N);
 // reuse_filters: the re-laid-out filters in ws are those of the previous call (FS_FLAG_PARAMS_FROZEN): skip the kernels that build them
-int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s, bool reuse_filters = false);
+// with_bwd_filters: also build the input-gradient filters tnet_backward needs (same launches: the parameters cannot change between the forward
+// and the backward of a step) -- tnet_backward(..., filters_ready = true) then skips its own two re-layout launches
+int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s, bool reuse_filters = false,
+                 bool with_bwd_filters = false);
 // Optional second stream + events: the filter gradients of unit i only need dz_i, so they run concurrently
 // with the input-gradient chain of the units below (both are small launches at batch 4).
 struct StreamAux {
@@ -73,6 +78,6 @@ struct StreamAux {
     int nev;
 };
 int tnet_backward(const TnetLayout& L, const float* params, const float* x, const float* dy, float* grads, float* ws,
-                  hipStream_t s, const StreamAux* aux);
+                  hipStream_t s, const StreamAux* aux, bool filters_ready = false);
 
 }  // namespace fs

@@ -312,6 +312,7 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
                                       : b.take((size_t)(L->u[i].kind == 1 ? 9 : (L->u[i].stride == 2 ? 16 : L->u[i].K * L->u[i].K)) *
                                                L->u[i].Cin * L->u[i].Cout);
     L->dweff = b.take(4 * 64 * 128);
+    L->dweff2 = b.take(4 * 64 * 128);
     for (int i = 3; i <= 12; ++i) {   // residual input gradients (3x3 'full' convs of dz) through the Winograd kernel when its blocks fill the chip
         const Unit& u = L->u[i];
         const long blocks = (long)N * cdiv(u.Hin, 16) * cdiv(u.Win, 16);
@@ -362,6 +363,7 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
         L->inb_rec = b.take(max_rec);
         for (int i = 0; i < 16; ++i) L->inb_S[i] = b.take((size_t)N * L->u[i].Cout * 2);
     }
+    size_t slab_each[16];
     for (int i = 0; i < 16; ++i) {
         Unit& u = L->u[i];
         WgradArgs wa = unit_wgrad_args(u, N);
@@ -370,6 +372,7 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
         Wg2Args w2;
         if (const size_t f2 = wgrad2_plan(&wa, 1, &w2)) sl = f2;   // second-generation kernel where eligible (fs_wgrad2.hip)
         if (sl > max_slab) max_slab = sl;
+        slab_each[i] = sl;
     }
     {   // the ten residual filter gradients as one launch: every dz is kept until the last one exists
         WgradArgs probs[10];
@@ -385,6 +388,8 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
             L->dzres[i - 3] = L->res_batch ? b.take((size_t)N * L->u[i].Hout * L->u[i].Wout * L->u[i].Cout) : 0;
     }
     L->slabs = b.take(max_slab);
+    for (int i = 0; i < 16; ++i)   // (the residual units share L->slabs when their filter gradients run as one launch)
+        L->slab_u[i] = (L->res_batch && i >= 3 && i <= 12) ? L->slabs : b.take(slab_each[i]);
     L->total_floats = b.off;
 }
 
@@ -430,7 +435,27 @@ WgradArgs unit_wgrad_args(const Unit& u, int N) {
         if (rc_) return rc_; \
     } while (0)
 
-int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s, bool reuse_filters) {
+// the input-gradient filters of the backward pass (flip-transposed / collapsed / phase-decomposed; the residual ones also Winograd-transformed)
+static void bwd_filter_jobs(const TnetLayout& L, const float* params, float* ws, WtBatch* wb, WinoBatch* nb, WinoBatch* nb4) {
+    for (int i = 1; i < 16; ++i) {
+        const Unit& u = L.u[i];
+        if (u.kind == 3) continue;  // conv2d_transpose units use the stored filter as is
+        const int K = u.kind == 1 ? 3 : u.K;  // (a resize-conv unit carries its collapsed 2x2 tap count in K)
+        if (u.kind == 0 && u.stride == 2)  // phase-decomposed stride-2 input gradient (KH/KW fields = forward pads)
+            wb->add(WT_S2DGRAD, params + u.w_off, ws + L.wTu[i], u.pad_t, u.pad_l, u.Cin, u.Cout);
+        else
+            wb->add(u.kind == 1 ? WT_UPDGRAD : WT_FLIPT, params + u.w_off, ws + L.wTu[i], K, K, u.Cin, u.Cout);
+    }
+    for (int i = 3; i <= 12; ++i)   // ... and the Winograd transforms of the residual ones ([3][3][Cout][Cin] as the kernel's HWIO)
+        if (L.wino_d[i - 3]) {
+            WinoBatch& t = L.wino_dh[i - 3] == 2 ? *nb4 : *nb;
+            t.w[t.n] = ws + L.wTu[i];
+            t.U[t.n] = ws + L.wino_d[i - 3];
+            ++t.n;
+        }
+}
+
+int tnet_forward(const TnetLayout& L, const float* params, const float* x, float* y, float* ws, hipStream_t s, bool reuse_filters, bool with_bwd_filters) {
     const int N = L.N;
     // collapsed resize-conv filters (weights may have changed since the last call: training)
     WtBatch wb{};
@@ -443,9 +468,8 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
         wb.add(WT_UPFWD, params + L.u[14].w_off, ws + L.weff[1], 3, 3, 32, 16);
         wb.add(WT_FOLD5FWD, params + L.u[15].w_off, ws + L.wfold, 9, 9, 16, 3);
     }
-    if (!reuse_filters) FS_TRY(wt_batch(wb, s));
     if (!reuse_filters) {   // Winograd-transformed filters of the residual convs that use wino_conv_kernel (one launch)
-        WinoBatch nb{}, nb4{};
+        WinoBatch nb{}, nb4{}, nbd{};
         for (int i = 3; i <= 12; ++i)
             if (L.u[i].wino) {
                 WinoBatch& t = L.u[i].wino == 3 ? nb4 : nb;   // (3: the register layout of fs_wino4t.hip)
@@ -453,7 +477,11 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
                 t.U[t.n] = ws + L.u[i].wino_u;
                 ++t.n;
             }
+        // a training step: the backward's input-gradient filters ride in the same launches (two launches less per step)
+        if (with_bwd_filters) bwd_filter_jobs(L, params, ws, &wb, &nbd, &nb4);
+        FS_TRY(wt_batch(wb, s));
         FS_TRY(tune_int("FS_WINO_V", 2) >= 2 ? wt_wino2_batch(nb, 64, 64, s) : wt_wino_batch(nb, 64, 64, s));
+        if (with_bwd_filters) FS_TRY(wt_wino2_batch(nbd, 64, 64, s));
         FS_TRY(wt_wino4t_batch(nb4, 64, 64, s));
     }
     // units whose conv kernel is persistent (fs_wino2 / fs_wino2h / fs_cstream) and whose record count is small merge their
@@ -662,29 +690,44 @@ static void unit_wgrad_problem(const TnetLayout& L, const Unit& u, const float* 
     *out = a;
 }
 
-static int unit_wgrad(const TnetLayout& L, const Unit& u, const float* xin, const float* xa, const float* xb,
-                      const float* dz, float* grads, float* ws, hipStream_t s) {
-    WgradArgs a;
-    unit_wgrad_problem(L, u, xin, xa, xb, dz, ws, &a);
-    if (u.kind == 2)  // the Z buffer of the forward is free by now
-        FS_TRY(unfold5(dz, ws + L.zfold, L.N, u.Hout, u.Wout, s));
-    // where the reduced gradient goes: the parameter-gradient buffer, or a scratch the unit's filter re-layout reads
-    float* dst = u.kind == 2 ? ws + L.dwfold : (u.kind == 1 ? ws + L.dweff : grads + u.w_off);
-    Wg2Args w2;
-    if (wgrad2_plan(&a, 1, &w2)) {
-        float* out[1] = {dst};
-        FS_TRY(wgrad2_run(w2, ws + L.slabs, out, 1.0f, s));
-    } else {
-        FS_TRY(wgrad_launch(a, s));
-        FS_TRY(reduce_slabs(ws + L.slabs, 1, a.p.n_slabs, (size_t)a.p.K * a.Cout, 1.0f, dst, s));
-    }
+// the filter re-layout behind a unit's reduced filter gradient (collapsed resize-conv -> 3x3, kw-folded output layer -> 9x9)
+static int unit_wgrad_fold(const TnetLayout& L, const Unit& u, float* grads, float* ws, hipStream_t s) {
     if (u.kind == 2) return wt_fold5_back(ws + L.dwfold, grads + u.w_off, u.Cin, s);
-    if (u.kind == 1) return wt_upconv_wgrad_fold(ws + L.dweff, grads + u.w_off, u.Cin, u.Cout, s);
+    if (u.kind == 1) return wt_upconv_wgrad_fold(ws + ((&u - L.u) == 14 ? L.dweff2 : L.dweff), grads + u.w_off, u.Cin, u.Cout, s);
     return 0;
 }
 
+// defer: the slab reduction of a second-generation launch is appended there (one reduction launch for all units at the end of the backward);
+// *fold_later = 1 then tells the caller to run the unit's filter re-layout (kind 1 / 2) behind that reduction
+static int unit_wgrad(const TnetLayout& L, const Unit& u, const float* xin, const float* xa, const float* xb,
+                      const float* dz, float* grads, float* ws, hipStream_t s, Wg2Reduce* defer = nullptr, int* fold_later = nullptr) {
+    WgradArgs a;
+    unit_wgrad_problem(L, u, xin, xa, xb, dz, ws, &a);
+    float* const slabs = ws + L.slab_u[&u - L.u];
+    a.slabs = slabs;
+    if (fold_later) *fold_later = 0;
+    if (u.kind == 2)  // the Z buffer of the forward is free by now
+        FS_TRY(unfold5(dz, ws + L.zfold, L.N, u.Hout, u.Wout, s));
+    // where the reduced gradient goes: the parameter-gradient buffer, or a scratch the unit's filter re-layout reads
+    float* dst = u.kind == 2 ? ws + L.dwfold : (u.kind == 1 ? ws + ((&u - L.u) == 14 ? L.dweff2 : L.dweff) : grads + u.w_off);
+    Wg2Args w2;
+    if (wgrad2_plan(&a, 1, &w2)) {
+        float* out[1] = {dst};
+        const int before = defer ? defer->n : 0;
+        FS_TRY(wgrad2_run(w2, slabs, out, 1.0f, s, defer));
+        if (defer && defer->n > before && fold_later) {
+            *fold_later = 1;
+            return 0;
+        }
+    } else {
+        FS_TRY(wgrad_launch(a, s));
+        FS_TRY(reduce_slabs(slabs, 1, a.p.n_slabs, (size_t)a.p.K * a.Cout, 1.0f, dst, s));
+    }
+    return unit_wgrad_fold(L, u, grads, ws, s);
+}
+
 int tnet_backward(const TnetLayout& L, const float* params, const float* x, const float* dy, float* grads, float* ws,
-                  hipStream_t s, const StreamAux* aux) {
+                  hipStream_t s, const StreamAux* aux, bool filters_ready) {
     const int N = L.N;
     // (no fork while the per-kernel profiler is recording: two streams sharing the chip would charge each kernel with its
     // neighbour's time -- bench.py's per-kernel table wants every launch alone)
@@ -692,29 +735,17 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
     // 1100 against 1133 images/s; at batch 32 the fork is worth 1.2 %).  FS_SIDE_MIN_PIXELS: smallest N * H * W that forks.
     const bool fork = aux && aux->side && aux->nev >= 34 && !Profiler::current() && (long)N * L.H * L.W >= (long)tune_int("FS_SIDE_MIN_PIXELS", 1000000);
     hipStream_t ws_stream = fork ? aux->side : s;  // stream of the filter-gradient branch
-    {  // every input-gradient filter of the step in one launch (the parameters are fixed during a backward)
+    if (!filters_ready) {  // every input-gradient filter of the step in one launch (a forward with FS_FLAG_SAVE_FOR_BWD has built them already)
         WtBatch wb{};
-        for (int i = 1; i < 16; ++i) {
-            const Unit& u = L.u[i];
-            if (u.kind == 3) continue;  // conv2d_transpose units use the stored filter as is
-            const int K = u.kind == 1 ? 3 : u.K;  // (a resize-conv unit carries its collapsed 2x2 tap count in K)
-            if (u.kind == 0 && u.stride == 2)  // phase-decomposed stride-2 input gradient (KH/KW fields = forward pads)
-                wb.add(WT_S2DGRAD, params + u.w_off, ws + L.wTu[i], u.pad_t, u.pad_l, u.Cin, u.Cout);
-            else
-                wb.add(u.kind == 1 ? WT_UPDGRAD : WT_FLIPT, params + u.w_off, ws + L.wTu[i], K, K, u.Cin, u.Cout);
-        }
+        WinoBatch nb{}, nb4{};
+        bwd_filter_jobs(L, params, ws, &wb, &nb, &nb4);
         FS_TRY(wt_batch(wb, s));
-        WinoBatch nb{}, nb4{};   // ... and the Winograd transforms of the residual ones ([3][3][Cout][Cin] as the kernel's HWIO)
-        for (int i = 3; i <= 12; ++i)
-            if (L.wino_d[i - 3]) {
-                WinoBatch& t = L.wino_dh[i - 3] == 2 ? nb4 : nb;
-                t.w[t.n] = ws + L.wTu[i];
-                t.U[t.n] = ws + L.wino_d[i - 3];
-                ++t.n;
-            }
         FS_TRY(wt_wino2_batch(nb, 64, 64, s));
         FS_TRY(wt_wino4t_batch(nb4, 64, 64, s));
     }
+    Wg2Reduce red{};               // the slab reductions of the non-residual units' filter gradients: ONE launch behind the last of them
+    int fold_units[16], n_fold = 0;
+    const bool defer_on = tune_int("FS_WGRAD_DEFER", 1) != 0;
     const float* g = dy;         // gradient wrt the current unit's output activation (or h_k)
     const float* res_g = nullptr;  // d h_k, kept alive until the block's first conv adds it to its dgrad
     int dz_reader[2] = {-1, -1};   // event (side stream) of the last filter gradient that read dz[0] / dz[1]
@@ -790,7 +821,9 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
             if (fork) {  // dz_i ready -> side stream computes dW_i while this stream continues with the input gradient
                 if (hipEventRecord(aux->ev[i], s) != hipSuccess || hipStreamWaitEvent(ws_stream, aux->ev[i], 0) != hipSuccess) return -20;
             }
-            FS_TRY(unit_wgrad(L, u, xin, xa, xb, dz, grads, ws, ws_stream));
+            int fold_later = 0;
+            FS_TRY(unit_wgrad(L, u, xin, xa, xb, dz, grads, ws, ws_stream, defer_on ? &red : nullptr, &fold_later));
+            if (fold_later) fold_units[n_fold++] = i;
             if (fork) {
                 if (hipEventRecord(aux->ev[16 + i], ws_stream) != hipSuccess) return -20;
                 dz_reader[i & 1] = 16 + i;
@@ -814,8 +847,10 @@ int tnet_backward(const TnetLayout& L, const float* params, const float* x, cons
         g = dst;
     }
     FS_TRY(in_bwd_params(ibp, s));
-    if (fork) {  // join: every filter gradient done before the caller's stream proceeds (events 16..31 are ordered on the side stream)
-        if (hipStreamWaitEvent(s, aux->ev[16 + 0], 0) != hipSuccess) return -20;
+    FS_TRY(wgrad2_reduce(red, ws_stream));
+    for (int k = 0; k < n_fold; ++k) FS_TRY(unit_wgrad_fold(L, L.u[fold_units[k]], grads, ws, ws_stream));
+    if (fork) {  // join: every filter gradient (and the reduction above) done before the caller's stream proceeds
+        if (hipEventRecord(aux->ev[32], ws_stream) != hipSuccess || hipStreamWaitEvent(s, aux->ev[32], 0) != hipSuccess) return -20;
     }
     return 0;
 }

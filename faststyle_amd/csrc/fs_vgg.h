@@ -14,6 +14,8 @@ struct VggLayout {
     int Hl[FS_VGG_NLAYERS], Wl[FS_VGG_NLAYERS];
     size_t xin, ab, act[FS_VGG_NLAYERS], pool[3];
     size_t gram[4], sm[4], slabs;
+    size_t gslab[4];   // per style layer: the partial slabs of its streaming Gram kernel (the four layers are finished by ONE launch: all must exist at once)
+    size_t lossp, lossp_floats;   // partial sums of every loss term of a step, summed by loss_finish
     size_t d_pre, d_in[2], d_tap, d_tap2, scratch;
     size_t splitws, splitws_floats;  // split-K partial sums of the deep, small-grid convs (conv4_x at batch 4)
     size_t total_floats;
@@ -31,7 +33,5 @@ int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], cons
 int vgg_features(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS], const float* x,
                  int n_layers, const int* layers, float* const* out, float* ws, hipStream_t s);
 int vgg_consts(float* ab, hipStream_t s);
-int loss_total(float* losses, hipStream_t s);
-int loss_zero(float* losses, hipStream_t s);   // losses[0..3] = 0 (a kernel, not a memset node: see fs_perceptual_loss)
 
 }  // namespace fs

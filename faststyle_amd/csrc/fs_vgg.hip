@@ -162,8 +162,19 @@ void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, 
         if (sl > max_slab) max_slab = sl;
         const size_t sl2 = gram2_slab_floats(N, L->Hl[l] * L->Wl[l], C);   // the streaming kernel's partial slabs (fs_gram.hip)
         if (sl2 > max_slab) max_slab = sl2;
+        L->gslab[i] = b.take(sl2 ? sl2 : 4);
     }
     L->slabs = b.take(max_slab);
+    {   // room for every term's partial sums: a style term up to max(its finish launch's blocks, 1024), content terms and the TV term 1024 each
+        size_t n = 1024;
+        for (int i = 0; i < cfg.n_style; ++i) {
+            const size_t g = (size_t)gram2_finish_partials(N, kCout[cfg.style_layer[i]]);
+            n += g > 1024 ? g : 1024;
+        }
+        n += (size_t)1024 * (cfg.n_content > 0 ? cfg.n_content : 0);
+        L->lossp_floats = n;
+        L->lossp = b.take(n);
+    }
     L->d_pre = b.take(max_act);
     L->d_in[0] = b.take(max_act);
     L->d_in[1] = b.take(max_act);
@@ -303,25 +314,71 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
                     float* dy, float* ws, hipStream_t s) {
     const int N = L.N;
     const size_t img = (size_t)N * L.H * L.W * 3;
-    if (hipMemcpyAsync(ws + L.xin, y, img * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -10;
-    if (L.cmax >= 0 &&
+    // [y ; content] as one 2N batch at ws + L.xin.  A caller that keeps the two tensors THERE (fs_perceptual_ws_input: the transform net writes y
+    // into the workspace, the input batch lives in it) saves both staging copies.
+    if (y != ws + L.xin && hipMemcpyAsync(ws + L.xin, y, img * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -10;
+    if (L.cmax >= 0 && content != ws + L.xin + img &&
         hipMemcpyAsync(ws + L.xin + img, content, img * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return -10;
     // (a kernel, not hipMemsetAsync: replayed from a single-stream hipGraph -- the training step of a small batch -- the 16-byte memset NODE left
     // a stale 8-byte value in losses[2..3] from the second replay on (ROCm 7.2; found when the filter-gradient fork became batch-dependent;
     // with the fork in the graph the same node behaved).  No memset on any capturable path of the library any more.)
-    FS_TRY(loss_zero(losses, s));
+    // (round 5: the four scalars are WRITTEN once, by loss_finish at the end, from the partial sums every term leaves in ws + L.lossp -- the per-term
+    // sum launches, the clear and the total are gone)
     FS_TRY(vgg_forward(L, w, b, prepared, ws, s));
 
     // ---- losses ----
-    for (int i = 0; i < cfg.n_style; ++i) {
-        const int l = cfg.style_layer[i], C = kCout[l];
-        const float hwc = (float)L.Hl[l] * L.Wl[l] * C;
-        FS_TRY(gram_forward(L, l, ws + L.act[l], ws + L.gram[i], ws, s));
-        // loss += w * sum (G-Gt)^2 / c^2 ;  S = 4w/(c^2 hwc) (G - Gt)   (dF = F S, G symmetric)
-        const float wgt = cfg.style_weight[i];
-        FS_TRY(sqdiff_loss(ws + L.gram[i], cfg.target_gram[i], (size_t)C * C, (size_t)N * C * C, wgt / ((float)C * C),
-                           4.0f * wgt / ((float)C * C * hwc), ws + L.sm[i], losses + 2, 1, ws + L.scratch, s));
+    LossFinish lf{};
+    lf.losses = losses;
+    size_t lp_off = 0;
+    auto term = [&](int slot, int n_partial, float scale) -> float* {   // reserves the term's partial sums; nullptr: no room (never with <= 4 + 4 + 1 terms)
+        if (lf.n >= LossFinish::kMax || lp_off + (size_t)n_partial > L.lossp_floats) return nullptr;
+        float* p = ws + L.lossp + lp_off;
+        lf.job[lf.n].partial = p;
+        lf.job[lf.n].n = n_partial;
+        lf.job[lf.n].slot = slot;
+        lf.job[lf.n].scale = scale;
+        ++lf.n;
+        lp_off += (size_t)n_partial;
+        return p;
+    };
+    {
+        // Gram matrices: the matrix kernels layer by layer, then ONE launch that reduces the slabs of all layers, mirrors them, and leaves
+        // S = 4w/(c^2 hwc) (G - Gt) (dF = F S, G symmetric) and the partial sums of (G - Gt)^2 (loss += w * sum / c^2, losses.py:61-64)
+        bool batch = cfg.n_style > 0 && tune_int("FS_GRAM_FINISH_BATCH", 1);
+        for (int i = 0; i < cfg.n_style; ++i) {
+            const int l = cfg.style_layer[i];
+            batch = batch && gram2_eligible(N, L.Hl[l] * L.Wl[l], kCout[l]);
+        }
+        GramFinishJob jobs[4];
+        for (int i = 0; i < cfg.n_style; ++i) {
+            const int l = cfg.style_layer[i], C = kCout[l], HW = L.Hl[l] * L.Wl[l];
+            const float hwc = (float)HW * C;
+            const float wgt = cfg.style_weight[i];
+            if (batch) {
+                FS_TRY(gram2_stream(ws + L.act[l], ws + L.gslab[i], N, HW, C, s));
+                GramFinishJob& j = jobs[i];
+                j.slabs = ws + L.gslab[i];
+                j.Gt = cfg.target_gram[i];
+                j.G = ws + L.gram[i];
+                j.S = ws + L.sm[i];
+                j.HW = HW;
+                j.C = C;
+                j.scale = 1.0f / hwc;
+                j.gscale = 4.0f * wgt / ((float)C * C * hwc);
+                j.partial = term(2, gram2_finish_partials(N, C), wgt / ((float)C * C));
+                if (!j.partial) return -12;
+            } else {
+                FS_TRY(gram_forward(L, l, ws + L.act[l], ws + L.gram[i], ws, s));
+                float* pp = term(2, 1024, wgt / ((float)C * C));
+                if (!pp) return -12;
+                int np = 0;
+                FS_TRY(sqdiff_partials(ws + L.gram[i], cfg.target_gram[i], (size_t)C * C, (size_t)N * C * C, 4.0f * wgt / ((float)C * C * hwc), ws + L.sm[i], pp,
+                                       &np, s));
+                lf.job[lf.n - 1].n = np;
+            }
+        }
+        if (batch) FS_TRY(gram2_finish_batch(jobs, cfg.n_style, N, s));
     }
 
     // ---- backward ----
@@ -344,8 +401,11 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
                 const float hwc = (float)H * W * C;
                 const float wgt = cfg.content_weight[i];
                 // reference losses.py:32-37: w * sum_{b,h,w,c} (phi(Y)-phi_t)^2 / (h*w*c)
-                FS_TRY(sqdiff_loss(ws + L.act[l], ws + L.act[l] + act_n, act_n, act_n, wgt / hwc, 2.0f * wgt / hwc,
-                                   ws + L.d_tap, losses + 1, 1, ws + L.scratch, s));
+                float* pp = term(1, 1024, wgt / hwc);
+                if (!pp) return -12;
+                int np = 0;
+                FS_TRY(sqdiff_partials(ws + L.act[l], ws + L.act[l] + act_n, act_n, act_n, 2.0f * wgt / hwc, ws + L.d_tap, pp, &np, s));
+                lf.job[lf.n - 1].n = np;
                 tap = ws + L.d_tap;
             }
         for (int i = 0; i < cfg.n_style; ++i)
@@ -454,9 +514,14 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         pre_nxt = t;
     }
     // TV term on y itself (reference losses.py:70-97, train.py:183-184); beta defaults to 0
-    if (cfg.beta != 0.0f)
-        FS_TRY(tv_loss(y, N, L.H, L.W, 3, cfg.beta, cfg.beta, dy, losses + 3, ws + L.scratch, s));
-    return loss_total(losses, s);
+    if (cfg.beta != 0.0f) {
+        float* pp = term(3, 1024, cfg.beta);
+        if (!pp) return -12;
+        int np = 0;
+        FS_TRY(tv_partials(y, N, L.H, L.W, 3, cfg.beta, dy, pp, &np, s));
+        lf.job[lf.n - 1].n = np;
+    }
+    return loss_finish(lf, s);
 }
 
 }  // namespace fs

@@ -724,8 +724,20 @@ static void w2_launch(const Wg2Args& a, hipStream_t s) {
     hipLaunchKernelGGL((wgrad2_kernel<KM, KN, XVEC, SA, SD, SPR, THc, PWc, WPc>), dim3((unsigned)a.n_wg), dim3(256), (size_t)a.p.lds_bytes, s, a);
 }
 
-// Launches a planned batch (slab pointers are bound here) and the reduction into dw[i] (scale applied).
-int wgrad2_run(const Wg2Args& planned, float* slabs, float* const* dw, float scale, hipStream_t s) {
+// the slab reduction of one or several wgrad2_run calls (same scale) as ONE launch
+int wgrad2_reduce(const Wg2Reduce& r, hipStream_t s) {
+    if (r.n <= 0) return 0;
+    if (r.n > kW2MaxProb) return -1;
+    size_t max4 = 0;
+    for (int i = 0; i < r.n; ++i)
+        if (r.job[i].count / 4 > max4) max4 = r.job[i].count / 4;
+    hipLaunchKernelGGL(reduce_slabs_batch_kernel, dim3((unsigned)((max4 + 7) / 8), (unsigned)r.n), dim3(256), 0, s, r);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// Launches a planned batch (slab pointers are bound here) and the reduction into dw[i] (scale applied).  defer != nullptr: the reduction jobs
+// are APPENDED to *defer instead (same scale; the caller launches wgrad2_reduce once for several runs -- the slabs must stay until then).
+int wgrad2_run(const Wg2Args& planned, float* slabs, float* const* dw, float scale, hipStream_t s, Wg2Reduce* defer) {
     Wg2Args a = planned;
     const int waves_p = 4 / a.p.waves_k;
     Wg2Reduce r{};
@@ -784,8 +796,14 @@ int wgrad2_run(const Wg2Args& planned, float* slabs, float* const* dw, float sca
     }
 #undef FS_W2_GEO
     if (prof) prof->end(s);
-    hipLaunchKernelGGL(reduce_slabs_batch_kernel, dim3((unsigned)((max4 + 7) / 8), (unsigned)a.nprob), dim3(256), 0, s, r);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    if (hipGetLastError() != hipSuccess) return -3;
+    if (defer && defer->n + r.n <= kW2MaxProb && (defer->n == 0 || defer->scale == scale)) {
+        defer->scale = scale;
+        for (int i = 0; i < r.n; ++i) defer->job[defer->n++] = r.job[i];
+        return 0;
+    }
+    (void)max4;
+    return wgrad2_reduce(r, s);
 }
 
 }  // namespace fs

@@ -71,7 +71,7 @@ int wt_wino4u(const float* w, float* U, int Cin, int Cout, hipStream_t s) {
 }
 
 int wt_wino4t_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s) {
-    if (Cin % kCC || Cout % kBN || b.n < 0 || b.n > 12) return -1;
+    if (Cin % kCC || Cout % kBN || b.n < 0 || b.n > 24) return -1;
     if (b.n == 0) return 0;
     const size_t cc = (size_t)Cin * Cout;
     hipLaunchKernelGGL(wt_wino4t_kernel, dim3((unsigned)((cc + 255) / 256), (unsigned)b.n), dim3(256), 0, s, b, Cin, Cout);

@@ -94,6 +94,7 @@ class Engine(object):
         self._perc_ws = {}
         self._pinned = {}          # id(workspace tensor) -> pin count
         self._tnet_nbytes = {}     # (N, H, W, bf16) -> fs_tnet_workspace_bytes, see _tnet_key
+        self._perc_io = {}         # perceptual workspace key -> (y offset, content offset), see perceptual_inputs
         self._keep = []
 
     def close(self):
@@ -226,6 +227,7 @@ class Engine(object):
         self._perc_ws.clear()
         self._pinned.clear()
         self._tnet_nbytes.clear()
+        self._perc_io.clear()
         self.invalidate_frozen()
 
     def new_tnet_workspace(self, N, H, W, bf16=False):
@@ -241,17 +243,19 @@ class Engine(object):
         assert upsample_method in ("resize", "deconv")
         return L.FS_FLAG_UPSAMPLE_DECONV if upsample_method == "deconv" else 0
 
-    def tnet_forward(self, params, x, save_for_bwd=False, upsample_method="resize", bf16=False, frozen=False, workspace=None):
+    def tnet_forward(self, params, x, save_for_bwd=False, upsample_method="resize", bf16=False, frozen=False, workspace=None, out=None):
         """create_net(x, upsample_method): x [N,H,W,3] float32 RGB 0..255 -> y [N,Ho,Wo,3].
         bf16=True: the mixed-precision inference path (FS_FLAG_BF16; ~1e-2 of the pixel range off the fp32 path).
         frozen=True: `params` is not modified between calls (FS_FLAG_PARAMS_FROZEN: the filter re-layouts run once per sequence).
-        workspace: a (tensor, nbytes) pair from new_tnet_workspace() instead of the engine's shared per-shape one."""
+        workspace: a (tensor, nbytes) pair from new_tnet_workspace() instead of the engine's shared per-shape one.
+        out: write y into this [N,Ho,Wo,3] tensor (e.g. perceptual_inputs()[0]) instead of a fresh one."""
         self._sync_stream()
         N, H, W, C = (int(s) for s in x.shape)
         assert C == 3
         Ho, Wo = self.tnet_out_shape(H, W)
         ws, nbytes = workspace if workspace is not None else self._tnet_workspace(N, H, W, bf16)
-        y = self.mem.empty((N, Ho, Wo, 3))
+        y = out if out is not None else self.mem.empty((N, Ho, Wo, 3))
+        assert tuple(int(v) for v in y.shape) == (N, Ho, Wo, 3)
         p = self.mem.ptr
         L.check(self.lib, self.lib.fs_tnet_forward(self.ctx, p(params), p(x), N, H, W, p(y), p(ws), nbytes,
                                                    (L.FS_FLAG_SAVE_FOR_BWD if save_for_bwd else 0) |
@@ -326,6 +330,31 @@ class Engine(object):
                 "fs_style_targets")
         return grams
 
+    def _perceptual_workspace(self, N, H, W, cfg, c):
+        key = (N, H, W, tuple(cfg["content_layers"]), tuple(cfg["style_layers"]))
+        nbytes = self.lib.fs_perceptual_workspace_bytes(N, H, W, ctypes.byref(c))
+        if key not in self._perc_ws or self._perc_ws[key][1] != nbytes:
+            self._perc_ws.pop(key, None)
+            self._evict(self._perc_ws, nbytes)
+            self._perc_ws[key] = (self.mem.empty((nbytes // 4,)), nbytes)
+        else:
+            self._perc_ws[key] = self._perc_ws.pop(key)
+        return self._perc_ws[key]
+
+    def perceptual_inputs(self, N, H, W, cfg):
+        """(y, content) views INSIDE the (cached) perceptual workspace of this shape, where fs_perceptual_loss stages its two inputs
+        (fs_perceptual_ws_input): a caller that lets tnet_forward(out=y) write there and keeps its batch in `content` saves both
+        staging copies of a step.  content is None when cfg has no content layer.  The views die with the workspace (pin it)."""
+        c = self._cfg(cfg)
+        ws, _ = self._perceptual_workspace(N, H, W, cfg, c)
+        key = (N, H, W, tuple(cfg["content_layers"]), tuple(cfg["style_layers"]))
+        if key not in self._perc_io:      # (the offsets are a pure function of the key; an eager loop asks every step)
+            yo, co = ctypes.c_size_t(), ctypes.c_size_t()
+            L.check(self.lib, self.lib.fs_perceptual_ws_input(N, H, W, ctypes.byref(c), ctypes.byref(yo), ctypes.byref(co)), "fs_perceptual_ws_input")
+            self._perc_io[key] = (yo.value, None if co.value == ctypes.c_size_t(-1).value else co.value)
+        yo, co = self._perc_io[key]
+        return self.mem.view(ws, yo, (N, H, W, 3)), (None if co is None else self.mem.view(ws, co, (N, H, W, 3)))
+
     def perceptual_loss(self, y, content, target_grams, cfg):
         """loss = content + style + beta*tv (train.py:164-184) and dL/dy.
         Returns (losses[4] device tensor {loss, content, style, beta*tv}, dy)."""
@@ -336,15 +365,7 @@ class Engine(object):
             raise L.FaststyleError("content batch %s and net output %s differ: training sizes must be multiples "
                                    "of 4 (create_net maps H -> 4*ceil(ceil((H+80)/2)/2)-80)" % (tuple(content.shape), tuple(y.shape)))
         c = self._cfg(cfg, target_grams)
-        key = (N, H, W, tuple(cfg["content_layers"]), tuple(cfg["style_layers"]))
-        nbytes = self.lib.fs_perceptual_workspace_bytes(N, H, W, ctypes.byref(c))
-        if key not in self._perc_ws or self._perc_ws[key][1] != nbytes:
-            self._perc_ws.pop(key, None)
-            self._evict(self._perc_ws, nbytes)
-            self._perc_ws[key] = (self.mem.empty((nbytes // 4,)), nbytes)
-        else:
-            self._perc_ws[key] = self._perc_ws.pop(key)
-        ws, nbytes = self._perc_ws[key]
+        ws, nbytes = self._perceptual_workspace(N, H, W, cfg, c)
         losses = self.mem.empty((4,))
         dy = self.mem.empty((N, H, W, 3))
         p = self.mem.ptr

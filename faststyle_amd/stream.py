@@ -14,6 +14,8 @@ from . import _lib as L
 
 
 class FrameStylizer(object):
+    KEEP_GRAPH = False     # tests: keep the captured hipGraph_t so that its node types can be inspected
+
     def __init__(self, eng, variables, height, width, upsample_method="resize", batch=1, swap_rb=True, use_graph=True,
                  bf16=False):
         self.eng = eng
@@ -52,7 +54,7 @@ class FrameStylizer(object):
             self._device_pass()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph(keep_graph=True) if self.KEEP_GRAPH else torch.cuda.CUDAGraph()
         # thread_local: calls made by OTHER threads (e.g. the RCCL watchdog of a data-parallel run) must not
         # invalidate this thread's capture
         with torch.cuda.graph(g, capture_error_mode="thread_local"):

@@ -16,6 +16,8 @@ from . import engine as _engine
 
 
 class Trainer(object):
+    KEEP_GRAPH = False     # tests: keep the captured hipGraph_t (CUDAGraph.raw_cuda_graph()) so that its node types can be inspected
+
     def __init__(self, eng, params_flat, vgg_weights, style_img, cfg=None, learn_rate=1e-3, dist=None,
                  use_graph=False, upsample_method="resize"):
         """params_flat: np.float32 [424102] (ckpt order); style_img: np [1,Hs,Ws,3] RGB 0..255;
@@ -52,7 +54,12 @@ class Trainer(object):
 
     def _forward_backward(self, batch):
         e = self.eng
-        y = e.tnet_forward(self.params, batch, save_for_bwd=True, upsample_method=self.method)
+        # the transform net writes y where fs_perceptual_loss stages it (inside the perceptual workspace): no device copy of y; the captured step
+        # also keeps its input batch there (self._static_in, see _capture): no copy of the content half either
+        N, H, W, _ = (int(v) for v in batch.shape)
+        Ho, Wo = e.tnet_out_shape(H, W)
+        y_view = e.perceptual_inputs(N, Ho, Wo, self.cfg)[0] if (Ho, Wo) == (H, W) and hasattr(e.mem, "view") else None
+        y = e.tnet_forward(self.params, batch, save_for_bwd=True, upsample_method=self.method, out=y_view)
         losses, dy = e.perceptual_loss(y, batch, self.target_grams, self.cfg)
         e.tnet_backward(self.params, batch, dy, grads=self.grads, upsample_method=self.method)
         return losses
@@ -62,14 +69,20 @@ class Trainer(object):
         every one-time initialisation inside the library has already happened)."""
         import torch
         self._release_graph()
-        self._static_in = batch.clone()
+        N, H, W, _ = (int(v) for v in batch.shape)
+        content_view = self.eng.perceptual_inputs(N, H, W, self.cfg)[1] if self.eng.tnet_out_shape(H, W) == (H, W) and hasattr(self.eng.mem, "view") else None
+        if content_view is not None:          # the step's input lives where the content half of the VGG batch is staged
+            self._static_in = content_view
+            self._static_in.copy_(batch)
+        else:
+            self._static_in = batch.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self._forward_backward(self._static_in)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph(keep_graph=True) if self.KEEP_GRAPH else torch.cuda.CUDAGraph()
         # thread_local: calls made by OTHER threads (e.g. the RCCL watchdog of a data-parallel run) must not
         # invalidate this thread's capture
         with torch.cuda.graph(g, capture_error_mode="thread_local"):

@@ -158,6 +158,11 @@ int fs_adam_tf_step(fs_ctx* ctx, float* p, const float* g, float* m, float* v, s
 #define FS_TNET_WS_H 5
 int fs_tnet_ws_tensor(int N, int H, int W, int flags, int unit, int what, size_t* offset_floats, int dims[4]);
 int fs_perceptual_ws_tensor(int N, int H, int W, const fs_loss_cfg* cfg, int layer, size_t* offset_floats, int dims[4]);
+/* fs_perceptual_ws_input: where fs_perceptual_loss stages y and content ([y ; content] is ONE 2N batch through the shared VGG layers).  Passing
+ *   y == ws + *y_offset_floats and / or content == ws + *content_offset_floats skips the corresponding device copy: the transform net can write
+ *   its output, and the input pipeline its batch, straight into the workspace (train.py:250-256 without the sess.run round trip).
+ *   *content_offset_floats = (size_t)-1 when cfg has no content layer. */
+int fs_perceptual_ws_input(int N, int H, int W, const fs_loss_cfg* cfg, size_t* y_offset_floats, size_t* content_offset_floats);
 
 /* ---- single ops (used by the parity tests; same kernels the composite calls launch) --------- */
 #define FS_PAD_SAME 0

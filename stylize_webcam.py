@@ -63,9 +63,9 @@ def run_webcam(args):
     cap = cv2.VideoCapture(0)
     if args.resolution is not None:
         x_length, y_length = args.resolution
-        cap.set(3, x_length)  # 3 and 4 are OpenCV property IDs.
-        cap.set(4, y_length)
-    x_new, y_new = int(cap.get(3)), int(cap.get(4))
+        cap.set(cv2.CAP_PROP_FRAME_WIDTH, x_length)      # (the reference passes the raw property ids 3 and 4: stylize_webcam.py:52-53)
+        cap.set(cv2.CAP_PROP_FRAME_HEIGHT, y_length)
+    x_new, y_new = int(cap.get(cv2.CAP_PROP_FRAME_WIDTH)), int(cap.get(cv2.CAP_PROP_FRAME_HEIGHT))
     print('Resolution is: {0} by {1}'.format(x_new, y_new))
     print('Loading up model...')
     eng, variables = _load(args)

@@ -42,6 +42,10 @@ class TorchCpuMem(object):
     def device_index(self):
         return 0
 
+    def view(self, t, offset, shape):
+        n = int(np.prod(shape))
+        return t.view(-1)[offset:offset + n].view(*shape)
+
 
 def _make_trainer(use_dist):
     import ctypes

@@ -456,7 +456,7 @@ def test_hip_train_step_256_matches_oracle_and_batch_sum_property(knob_hip):
     sides -- a different summation order in a FORWARD conv flips ReLU ties: the half-item Winograd kernel a batch of 2
     selects for the residual convs is therefore also selected for the single samples, and the VGG Winograd convs run
     without split-K, which a batch of 1 and a batch of 2 would otherwise take with different factors on conv3_x / conv4_x;
-    tools/_dbg_w4.py shows the F(4x4) kernel bit-identical per sample whatever batch it rides in.  What remains differs by
+    tools/w4_slp_repro.py shows the F(4x4) kernel bit-identical per sample whatever batch it rides in.  What remains differs by
     construction with the batch size: the pixel chunks of the instance-norm backward's partial sums and the slab partition
     of the filter gradients -- last-bit differences that the mean subtraction of sixteen instance-norm backwards amplifies
     to ~1e-4 of the largest gradient.)"""

@@ -60,6 +60,14 @@ def main():
             families[fam] = {"kernels": ks, "launches_sampled": n,
                              "traffic_bytes_per_launch": int(sum(kernels[k]["traffic_bytes_per_launch"] * kernels[k]["launches_sampled"] for k in ks) / n)}
     doc = {"_provenance": prov, "kernels": kernels, "families": families}
+    try:     # the build these counters were taken from (bench.py quotes them only for the same sources)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from faststyle_amd import build as fsbuild
+        doc["csrc_sha16"] = fsbuild.source_digest()
+    except Exception as ex:
+        doc["csrc_sha16"] = None
+        print("pmc_traffic: no source digest (%s)" % ex, file=sys.stderr)
     if len(sys.argv) > 5 and sys.argv[5] != "-":
         doc["batch_per_gpu"] = int(sys.argv[5])
     if len(sys.argv) > 6:

@@ -1,3 +1,18 @@
+#!/usr/bin/env python
+"""Reproducer / guard for the two things learnt about the F(4x4,3x3) kernels on the GPU (round 4), on the product library:
+
+1. ROCm 7.2 clang's SLP vectoriser and fs_wino4.hip.  Built WITH -fslp-vectorize two of the kernel's three epilogue instantiations return wrong
+   values on gfx950 -- a few per cent of the elements, always lanes 12..15 of a row of 16 and the odd channel of a pair -- while the CPU
+   emulator build of the same source and the third, equally packed instantiation are right.  The first loop runs the raw / bias + ReLU /
+   consumer-mask forms against the float64 oracle and prints WHERE the bad elements sit (rows, columns, channels).  faststyle_amd/build.py
+   compiles every MFMA translation unit with -fno-slp-vectorize since round 5 (packed fp32 beside fp32 matrix instructions is an anti-lever
+   anyway); to reproduce:  python -c "from faststyle_amd import build; build.build(force=True, extra_flags=['-fslp-vectorize'], out='exp/libslp.so',
+   objdir='exp/obj_slp')"  then on the GPU  FASTSTYLE_HIP_LIB=exp/libslp.so python tools/w4_slp_repro.py .
+2. Per-sample results of the kernel do not depend on the batch a sample rides in (items are per sample; only the item -> workgroup map changes):
+   the second loop compares a sample alone with the same sample in a batch of two, bit for bit -- the reason the data-parallel identity tests
+   (tests/test_path_parity.py) can attribute their residual to the instance-norm / filter-gradient partial-sum partitions.
+
+GPU only:  gpurun -- 'python tools/w4_slp_repro.py'"""
 import numpy as np, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.backends import get_engine
