@@ -13,15 +13,17 @@ SOURCES = ["fs_conv.hip", "fs_wino.hip", "fs_wino2.hip", "fs_wino2h.hip", "fs_wi
 OUT = os.path.join(HERE, "libfaststyle_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed"]
-# Per-source flags.  fs_wino4.hip: no SLP vectorisation.  With it (ROCm 7.2 clang) two of the kernel's three epilogue
-# instantiations return WRONG values on gfx950 (a few per cent of the elements, always lanes 12-15 of a row of 16 and the odd
-# channel of a pair; tools/w4_slp_repro.py on the GPU, exp build with -fslp-vectorize) while the CPU emulator build of the same source
-# is right and the third instantiation, equally packed, is right too.  The cause was not isolated (no undefined behaviour left in
-# the source; a code-generation or hazard problem around v_pk_add_f32 / v_pk_fma_f32).  Packed fp32 beside fp32 matrix
-# instructions is slower anyway (MI355X_MICROARCH.md, price of one filler beside MFMAs), so the kernel loses nothing.
-FILE_FLAGS = {"fs_wino4.hip": ["-fno-slp-vectorize"], "fs_wino4t.hip": ["-fno-slp-vectorize"], "fs_wino4t1b.hip": ["-fno-slp-vectorize"], "fs_wino4t1c.hip": ["-fno-slp-vectorize"], "fs_wino4t1d.hip": ["-fno-slp-vectorize"], "fs_wino4t2.hip": ["-fno-slp-vectorize"],
-              "fs_wino4t2b.hip": ["-fno-slp-vectorize"]}   # (fs_wino4t.hip: the same transforms, same precaution)
-
+# No SLP vectorisation anywhere (round 5; round 4 had it off in the F(4x4) files only).  With it (ROCm 7.2 clang) two of the three epilogue
+# instantiations of fs_wino4.hip return WRONG values on gfx950 (a few per cent of the elements, always lanes 12-15 of a row of 16 and the odd
+# channel of a pair; tools/w4_slp_repro.py on the GPU with an -fslp-vectorize build) while the CPU emulator build of the same source is right and
+# the third instantiation, equally packed, is right too.  The cause was not isolated (no undefined behaviour left in the source; a code-generation
+# or hazard problem around v_pk_add_f32 / v_pk_fma_f32 -- see FS_W4_MFMA_SETTLE in csrc/fs_wino4.h for the hazard the compiler cannot see).
+# Packed fp32 beside fp32 matrix instructions is slower anyway (MI355X_MICROARCH.md: price of one filler beside MFMAs), the kernels that want a
+# packed instruction write it as inline assembly (fs_kernels.h: fs_pk_add / fs_wino_cols01), and the parity suite is the only guard against a
+# silently wrong vectorisation in the other twenty translation units: every one of them is compiled without it.  Measured: no change of the
+# bench line.
+FLAGS.append("-fno-slp-vectorize")
+FILE_FLAGS = {}
 
 def source_digest():
     """sha256[:16] over the kernel sources (csrc/*.hip, csrc/*.h, the public headers): the identity of the build a stored measurement
@@ -41,9 +43,12 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build(force=False, verbose=False, extra_flags=(), out=None, objdir=None):
+def build(force=False, verbose=False, extra_flags=(), out=None, objdir=None, file_flags=None):
+    """extra_flags: appended for every source (a later -f flag wins); file_flags: {source name: [flags]} appended for single sources
+    (experiments: e.g. the round-4 configuration is extra_flags=['-fslp-vectorize'], file_flags={f: ['-fno-slp-vectorize'] for the fs_wino4* files})."""
     out = out or OUT
     objdir = objdir or OBJDIR
+    file_flags = FILE_FLAGS if file_flags is None else file_flags
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + \
         [os.path.join(os.path.dirname(HERE), "include", "faststyle_hip.h")]
@@ -56,7 +61,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None, objdir=None):
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
-            jobs.append([hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(s), []) + list(extra_flags) + ["-I", CSRC, "-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + list(extra_flags) + file_flags.get(os.path.basename(s), []) + ["-I", CSRC, "-c", s, "-o", o])
     if not jobs and os.path.exists(out) and os.path.getmtime(out) >= _newest(objs):
         return out
 

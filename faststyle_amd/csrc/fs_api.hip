@@ -608,7 +608,22 @@ int fs_instnorm_bwd(fs_ctx* ctx, const float* gin, const float* z, const float* 
     if (N < 1 || HW < 1 || C < 1 || mode < 0 || mode > 2) return fail(-2, "fs_instnorm_bwd: bad shape / mode (N=%d HW=%d C=%d mode=%d)", N, HW, C, mode);
     if (ws_bytes < fs_instnorm_bwd_workspace_bytes(N, HW, C))
         return fail(-3, "fs_instnorm_bwd: workspace too small (%zu < %zu bytes)", ws_bytes, fs_instnorm_bwd_workspace_bytes(N, HW, C));
-    const int rc = fs::in_bwd(gin, z, mean, rstd, a, b, mode, dz, dgamma, dbeta, (float*)ws, N, HW, C, ctx->stream);
+    // the form the train step runs (round 5): partial sums as records, their reduction in the apply kernel's prologue, dgamma / dbeta from the
+    // per-sample sums it leaves -- where the shape is taken (C % 4 == 0); the three-launch form otherwise
+    float* S = (float*)ws + (size_t)N * fs::cdiv(HW, 64) * C * 2;   // (the tail of the workspace: [N][C][2])
+    int rc = fs::in_bwd_rec(gin, z, mean, rstd, a, b, mode, dz, nullptr, 0, S, (float*)ws, N, HW, C, ctx->stream);
+    if (rc == 0) {
+        fs::InbParams q{};
+        q.n = 1;
+        q.N = N;
+        q.u[0].S = S;
+        q.u[0].dgamma = dgamma;
+        q.u[0].dbeta = dbeta;
+        q.u[0].C = C;
+        rc = fs::in_bwd_params(q, ctx->stream);
+    } else if (rc == 1) {
+        rc = fs::in_bwd(gin, z, mean, rstd, a, b, mode, dz, dgamma, dbeta, (float*)ws, N, HW, C, ctx->stream);
+    }
     return rc ? fail(rc, "fs_instnorm_bwd: launch failed (%d)", rc) : 0;
 }
 

@@ -419,6 +419,7 @@ __global__ __launch_bounds__(256) void in_bwd_final_kernel(const float* partial,
 
 // C % 4 == 0: a thread owns 4 channels; the C/4 threads of a pixel read it as consecutive float4, a workgroup covers
 // 1024/C pixels per pass and keeps UNR passes of loads in flight (the scalar kernel above waits for every pixel).
+template <int UNR>
 __global__ __launch_bounds__(256) void in_bwd_partial4_kernel(const float* __restrict__ gin, const float* __restrict__ z,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ a, const float* __restrict__ b, int mode,
@@ -437,7 +438,6 @@ __global__ __launch_bounds__(256) void in_bwd_partial4_kernel(const float* __res
         const int p0 = chunk * chunk_px, p1 = min(HW, p0 + chunk_px);
         const float* zb = z + (size_t)n * HW * C + c;
         const float* gb = gin + (size_t)n * HW * C + c;
-        constexpr int UNR = 4;
         for (int pb = p0 + row; pb < p1; pb += UNR * rows) {
             float4 zz[UNR], gg[UNR];
 #pragma unroll
@@ -640,27 +640,33 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const float* gin, con
 // a fixed order while they travel (thread = (record lane, float4 column of a record row), RL = 256 / (C/2) lanes stride over the rows,
 // fixed-order combine through LDS: deterministic and independent of the batch size) -- one memory latency per workgroup, as in the
 // kernel without a prologue.  Block 0 of a sample leaves S[n][C][2] for in_bwd_params_kernel (dgamma / dbeta of all units, ONE launch per step).
-template <int UNR>
+// `span4` consecutive float4 of ONE sample per workgroup, walked in batches of 4 x 256 with the NEXT batch's loads in flight while the current one
+// is computed and stored (round 5, second version: with one batch per workgroup and all workgroups resident at once the launch ran in lockstep --
+// every CU loading, then every CU idle in the prologue, then every CU storing: 2.8 TB/s against 4.5 for the kernel without a prologue).
 __global__ __launch_bounds__(256) void in_bwd_apply_rec_kernel(const float* __restrict__ gin, const float* __restrict__ z,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ a, const float* __restrict__ b, int mode,
                                                                const float* __restrict__ rec, int T, float* __restrict__ S_out,
-                                                               float* __restrict__ dz, int HW, int C) {
+                                                               float* __restrict__ dz, int HW, int C, int span4) {
     __shared__ float4 red[256];
     __shared__ float Ssh[512];   // [C][2]
     const int n = blockIdx.y, tid = threadIdx.x;
+    constexpr int UNR = 4;
     const int per4 = (HW * C) >> 2;
-    const int j0 = blockIdx.x * (UNR * 256) + tid;
+    const int j0 = blockIdx.x * span4, j1 = min(per4, j0 + span4);
     const size_t base = (size_t)n * HW * C;
     float4 zz[UNR], gg[UNR];
+    auto issue = [&](int jb, float4 (&zd)[UNR], float4 (&gd)[UNR]) {
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-        const int j = j0 + u * 256;
-        const int jc = j < per4 ? j : 0;   // clamped: a valid address, the value is discarded below
-        zz[u] = *reinterpret_cast<const float4*>(z + base + (size_t)jc * 4);
-        gg[u] = *reinterpret_cast<const float4*>(gin + base + (size_t)jc * 4);
-    }
-    const bool fixed_c = (1024 % C) == 0;   // the thread's channel quad is the same for its four elements (stride 256 float4 = 1024 floats)
+        for (int u = 0; u < UNR; ++u) {
+            const int j = jb + u * 256;
+            const int jc = j < j1 ? j : j0;   // clamped: a valid address, the value is discarded below
+            zd[u] = *reinterpret_cast<const float4*>(z + base + (size_t)jc * 4);
+            gd[u] = *reinterpret_cast<const float4*>(gin + base + (size_t)jc * 4);
+        }
+    };
+    issue(j0 + tid, zz, gg);
+    const bool fixed_c = (1024 % C) == 0;   // the thread's channel quad is the same for all of its elements (stride 256 float4 = 1024 floats)
     float av[4], bv[4], mv[4], rv[4];
     auto params = [&](int c) {
         const int k = n * C + c;
@@ -671,7 +677,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_rec_kernel(const float* __re
         mv[0] = m4.x, mv[1] = m4.y, mv[2] = m4.z, mv[3] = m4.w;
         rv[0] = r4.x, rv[1] = r4.y, rv[2] = r4.z, rv[3] = r4.w;
     };
-    const int c_fixed = (j0 * 4) % C;
+    const int c_fixed = ((j0 + tid) * 4) % C;
     if (fixed_c) params(c_fixed);
     {
         const int row4 = C >> 1;            // float4 per record row (C % 4 == 0, C <= 256)
@@ -725,38 +731,68 @@ __global__ __launch_bounds__(256) void in_bwd_apply_rec_kernel(const float* __re
         s2v[0] = sA.y * inv, s2v[1] = sA.w * inv, s2v[2] = sB.y * inv, s2v[3] = sB.w * inv;
     };
     if (fixed_c) sums(c_fixed);
+    for (int jb = j0 + tid; jb < j1; jb += UNR * 256) {
+        float4 zn[UNR], gn[UNR];
+        const bool more = jb + UNR * 256 < j1;   // (uniform up to the block's last batch: a thread without a next batch loads clamped addresses)
+        if (jb - tid + UNR * 256 < j1) issue(jb + UNR * 256, zn, gn);
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-        const int j = j0 + u * 256;
-        if (j >= per4) continue;
-        if (!fixed_c) {
-            params((j * 4) % C);
-            sums((j * 4) % C);
-        }
-        const float zv[4] = {zz[u].x, zz[u].y, zz[u].z, zz[u].w}, gv[4] = {gg[u].x, gg[u].y, gg[u].z, gg[u].w};
-        float o[4];
+        for (int u = 0; u < UNR; ++u) {
+            const int j = jb + u * 256;
+            if (j >= j1) continue;
+            if (!fixed_c) {
+                params((j * 4) % C);
+                sums((j * 4) % C);
+            }
+            const float zv[4] = {zz[u].x, zz[u].y, zz[u].z, zz[u].w}, gv[4] = {gg[u].x, gg[u].y, gg[u].z, gg[u].w};
+            float o[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float g = in_bwd_g(gv[q], zv[q], av[q], bv[q], mode);
-            const float xh = (zv[q] - mv[q]) * rv[q];
-            o[q] = av[q] * (g - s1v[q] - xh * s2v[q]);
+            for (int q = 0; q < 4; ++q) {
+                const float g = in_bwd_g(gv[q], zv[q], av[q], bv[q], mode);
+                const float xh = (zv[q] - mv[q]) * rv[q];
+                o[q] = av[q] * (g - s1v[q] - xh * s2v[q]);
+            }
+            *reinterpret_cast<float4*>(dz + base + (size_t)j * 4) = make_float4(o[0], o[1], o[2], o[3]);
         }
-        *reinterpret_cast<float4*>(dz + base + (size_t)j * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        (void)more;
+        if (jb - tid + UNR * 256 < j1) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                zz[u] = zn[u];
+                gg[u] = gn[u];
+            }
+        }
     }
 }
 
 // dbeta[c] = sum_n S1, dgamma[c] = sum_n S2 (fixed order) of every unit whose in_bwd ran on records: one launch per step, one block per unit
 __global__ __launch_bounds__(256) void in_bwd_params_kernel(InbParams p) {
+    // thread = (sample lane, channel): 256 / C lanes stride over the samples with independent loads (a serial walk over N = 32 samples per
+    // channel was 32 dependent L2 round trips: 22 us at batch 32), then a fixed-order combine through LDS
+    __shared__ float2 sh[256];
     const InbParams::U& u = p.u[blockIdx.x];
-    for (int c = threadIdx.x; c < u.C; c += 256) {
+    const int C = u.C;
+    const int lanes = C >= 256 ? 1 : 256 / C;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int c = c0 + (int)threadIdx.x % (C < 256 ? C : 256), ln = C < 256 ? (int)threadIdx.x / C : 0;
         float g1 = 0.f, g2 = 0.f;
-        for (int m = 0; m < p.N; ++m) {
-            const float2 v = *reinterpret_cast<const float2*>(u.S + ((size_t)m * u.C + c) * 2);
-            g1 += v.x;
-            g2 += v.y;
+        if (ln < lanes && c < C)
+            for (int m = ln; m < p.N; m += lanes) {
+                const float2 v = *reinterpret_cast<const float2*>(u.S + ((size_t)m * C + c) * 2);
+                g1 += v.x;
+                g2 += v.y;
+            }
+        __syncthreads();
+        sh[threadIdx.x] = make_float2(g1, g2);
+        __syncthreads();
+        if (ln == 0 && c < C) {
+            for (int k = 1; k < lanes; ++k) {
+                const float2 q = sh[k * C + (int)threadIdx.x];
+                g1 += q.x;
+                g2 += q.y;
+            }
+            u.dbeta[c] = g1;
+            u.dgamma[c] = g2;
         }
-        u.dbeta[c] = g1;
-        u.dgamma[c] = g2;
     }
 }
 
@@ -791,16 +827,20 @@ int in_bwd_rec(const float* gin, const float* z, const float* mean, const float*
         int chunk_px = in_bwd_chunk_px(N, HW);
         if (cdiv(HW, chunk_px) > max_t) chunk_px = cdiv(cdiv(HW, max_t), 64) * 64;
         const int chunks = cdiv(HW, chunk_px);
-        hipLaunchKernelGGL(in_bwd_partial4_kernel, dim3(chunks, N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, scratch, HW, C, chunk_px);
+        if (tune_int("FS_INBWD_PUNR", 8) >= 8)   // (16 loads of 16 bytes in flight per thread: the pass is latency-bound per workgroup)
+            hipLaunchKernelGGL(in_bwd_partial4_kernel<8>, dim3(chunks, N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, scratch, HW, C, chunk_px);
+        else
+            hipLaunchKernelGGL(in_bwd_partial4_kernel<4>, dim3(chunks, N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, scratch, HW, C, chunk_px);
         rec = scratch;
         T = chunks;
     }
     const int per4 = (HW * C) >> 2;
-    // eight float4 per thread halve the prologue's share; four where that would leave fewer than ~4 workgroups per CU
-    if ((long)cdiv(per4, 2048) * N >= 1024)
-        hipLaunchKernelGGL(in_bwd_apply_rec_kernel<8>, dim3(cdiv(per4, 2048), N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, rec, T, S_out, dz, HW, C);
-    else
-        hipLaunchKernelGGL(in_bwd_apply_rec_kernel<4>, dim3(cdiv(per4, 1024), N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, rec, T, S_out, dz, HW, C);
+    // ~1024 workgroups per launch (four per CU, all resident): each walks per4 / (1024 / N) float4 of its sample in pipelined batches of 1024
+    int bps = tune_int("FS_INBWD_APPLY_WGS", 1024) / N;
+    if (bps < 1) bps = 1;
+    int span4 = cdiv(cdiv(per4, bps), 1024) * 1024;
+    if (span4 < 1024) span4 = 1024;
+    hipLaunchKernelGGL(in_bwd_apply_rec_kernel, dim3(cdiv(per4, span4), N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, rec, T, S_out, dz, HW, C, span4);
     return launch_status();
 }
 
@@ -814,7 +854,7 @@ int in_bwd(const float* gin, const float* z, const float* mean, const float* rst
     float* S = scratch + (size_t)N * chunks * C * 2;
     if (C % 4 == 0) {
         int nparams = 0;
-        hipLaunchKernelGGL(in_bwd_partial4_kernel, dim3(chunks, N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, partial, HW,
+        hipLaunchKernelGGL(in_bwd_partial4_kernel<4>, dim3(chunks, N), dim3(256), 0, s, gin, z, mean, rstd, a, b, mode, partial, HW,
                            C, chunk_px);
         if (N <= 16 && 16 % N == 0) {
             hipLaunchKernelGGL(in_bwd_final_all_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, partial, N, chunks, C, S, dgamma, dbeta);

@@ -7,14 +7,26 @@
 // 36 positions x 2 channel blocks x 4 registers = 288 accumulator registers, but the accumulator file holds 256 and the
 // compiler's matrix-instruction form takes its C/D operand from that file only (asked for more, it funnels EVERY accumulator
 // through one quad with v_accvgpr copies).  So positions 0..31 use the builtin (256 AGPRs), positions 32..35 an
-// inline-assembly v_mfma with C/D in ordinary vector registers (legal on gfx90a+).  No software wait states are needed: an
-// accumulator is next read 72 matrix instructions later, or in the epilogue behind a barrier.
+// inline-assembly v_mfma with C/D in ordinary vector registers (legal on gfx90a+).  Inside a sweep no software wait states are needed (an
+// accumulator is next touched 72 matrix instructions later); at the sweep / epilogue boundaries see FS_W4_MFMA_SETTLE below.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FS_W4_MFMA_V(accq, av, bv) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accq) : "v"(av), "v"(bv))
 #define FS_W4_MFMA_A(accq, av, bv) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(accq) : "v"(av), "v"(bv))
 #else
 #define FS_W4_MFMA_V(accq, av, bv) (accq) = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), (accq), 0, 0, 0)
 #define FS_W4_MFMA_A(accq, av, bv) (accq) = __builtin_amdgcn_mfma_f32_16x16x4f32((av), (bv), (accq), 0, 0, 0)
+#endif
+// The hazard recogniser of the compiler does not look inside inline assembly: it inserts no wait states between an inline-assembly matrix
+// instruction and a following v_accvgpr_read / vector-ALU read of its result (an 8-pass v_mfma_f32_16x16x4_f32 needs up to 11), nor between a
+// vector-ALU write of an accumulator (the zeroing) and a following inline-assembly MFMA that takes it as SrcC.  In both kernels a workgroup
+// barrier and tens of instructions separate the two -- but a barrier returns at once for the wave that arrives last and is no architectural
+// guarantee, and the unexplained wrong lanes of the -fslp-vectorize build (faststyle_amd/build.py, tools/w4_slp_repro.py) are what such a
+// hazard would look like.  FS_W4_MFMA_SETTLE(): 16 explicit wait states, placed ONCE per item in front of the epilogue's first accumulator
+// read and once behind the zeroing -- nothing measurable against an item of >= 30k cycles.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FS_W4_MFMA_SETTLE() asm volatile("s_nop 7\n\ts_nop 7" ::: "memory")
+#else
+#define FS_W4_MFMA_SETTLE() ((void)0)
 #endif
 // (FS_W4_MFMA_A: the same with C/D pinned to ONE accumulator-file quad.  fs_wino4t.hip's 144 accumulators leave the register
 // allocator room, and with the builtin it keeps a fifth of them in vector registers between their two visits per sweep: 112

@@ -290,6 +290,7 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
             for (int mb = 0; mb < 2; ++mb) accv[pos][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     zero_acc();
+    FS_W4_MFMA_SETTLE();
 
     Cursor CU = cursor_begin();   // filter cursor: step q+1 during sweep q
     Cursor CP = cursor_begin();   // patch cursor: the step whose patch loads are issued next / were issued last
@@ -488,11 +489,13 @@ __global__ __launch_bounds__(256) void wino4_conv_kernel(ConvArgs a) {
         }
     };
     auto epilogue = [&](const Item& I) __attribute__((always_inline)) {
+        FS_W4_MFMA_SETTLE();   // (the last inline-assembly matrix instructions of the item have written their accumulators)
         if (I.oy0 + kBH <= a.Ho && I.ox0 + kBW <= a.Wo)
             epilogue_body(std::true_type{}, I);
         else
             epilogue_body(std::false_type{}, I);
         zero_acc();
+        FS_W4_MFMA_SETTLE();   // (the zeroed accumulators are the next sweep's SrcC)
         // Nothing of the epilogue may still be in flight at the loop header: loads and stores share ONE counter and complete out
         // of order with each other, so with stores pending the compiler places `s_waitcnt vmcnt(0)` -- every filter load just
         // issued included -- in front of the sweep's first use of a loaded register instead of an exact count.  The drain hides

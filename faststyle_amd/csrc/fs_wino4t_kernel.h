@@ -648,6 +648,7 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     };
     auto epilogue = [&](const Item& I) __attribute__((always_inline)) {
+        FS_W4_MFMA_SETTLE();   // (the item's last inline-assembly matrix instructions have written their accumulators: fs_wino4.h)
         if (I.oy0 + kBH <= a.Ho && I.ox0 + kBW <= a.Wo)
             epilogue_body(std::true_type{}, I);
         else
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
             issue_affine(CP.I, CP.chunk);
         }
         zero_acc();
+        FS_W4_MFMA_SETTLE();   // (the zeroed accumulators are the next sweep's SrcC)
     };
 
     // ---- prologue: step 0 complete in stage 0 (patch, V) and in registers (filter), the patch of step 1 in stage 1, the patch of step 2
@@ -693,6 +695,7 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 18; ++i) issue_filter_one(CU.I, CU.chunk, i);
     zero_acc();
+    FS_W4_MFMA_SETTLE();
 #pragma unroll
     for (int i = 0; i < kNPV; ++i) commit_quad(AP1.pc[i], pv0[i], fa0, fb0);   // (AP1's current stage is stage 0)
 #pragma unroll
