@@ -54,7 +54,9 @@ class fs_conv_desc(Structure):
                 ("bias", c_void_p), ("out_relu", c_int), ("shuffle", c_int), ("stats", c_void_p),
                 ("add_src", c_void_p), ("add_pad", c_int), ("w_nstride", c_longlong), ("w_wino", c_void_p),
                 ("w_wino4", c_void_p), ("mask_src", c_void_p), ("pool_out", c_void_p),
-                ("w_wino4t", c_void_p)]
+                ("w_wino4t", c_void_p),
+                ("inb_z", c_void_p), ("inb_mean", c_void_p), ("inb_rstd", c_void_p), ("inb_a", c_void_p), ("inb_b", c_void_p),
+                ("inb_relu", c_int), ("inb_rec", c_void_p)]
 
 
 class fs_wgrad_desc(Structure):

@@ -528,6 +528,14 @@ static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
     a->w_wino4 = d->w_wino4;
     if (a->w_wino4 && !fs::wino4_eligible(*a)) a->w_wino4 = nullptr;   // (not a 3x3 stride-1 SAME conv of the supported shapes)
     a->w_wino4t = d->w_wino4t;
+    a->inb_z = d->inb_z;
+    a->inb_mean = d->inb_mean;
+    a->inb_rstd = d->inb_rstd;
+    a->inb_a = d->inb_a;
+    a->inb_b = d->inb_b;
+    a->inb_relu = d->inb_relu;
+    a->inb_rec = d->inb_rec;
+    a->tnet_plan = d->inb_rec ? 1 : 0;   // (the partial sums exist for 16-tile items: plan them whatever the grid)
     if (a->w_wino4t && (a->w_wino4 || !fs::wino4t_eligible(*a))) a->w_wino4t = nullptr;
     if (fs::tune_int("FS_WINO_V", 2) >= 2) {   // the filter layout fs_wino_transform_filter produced (see there)
         a->w_wino2 = d->w_wino;
@@ -537,6 +545,8 @@ static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
         if (a->w_wino && !fs::wino_eligible(*a)) a->w_wino = nullptr;
     }
     a->p = fs::conv_plan(*a);
+    if (d->inb_rec && !(a->w_wino4t && a->p.variant == 11 && a->p.TW == 16 && a->p.ksplit <= 1))
+        return fail(-2, "fs_conv2d: inb_rec needs an eligible w_wino4t conv (3x3 stride 1, raw or add_src epilogue, inb_z / inb_mean / inb_rstd set)");
     if (d->pool_out) {   // only the Winograd epilogues hold whole pooling windows
         if (!(a->p.variant == 5 || a->p.variant == 6 || a->p.variant == 10 || a->p.variant == 11) || a->p.ksplit > 1 || (a->Ho & 1) || (a->Wo & 1))
             return fail(-2, "fs_conv2d: pool_out needs a Winograd-eligible conv with even Ho, Wo");

@@ -208,9 +208,32 @@ int apply_res(const float* z, const float* a, const float* b, const float* skip,
 }
 
 // y = (255*tanh(a z + b) + 255)/2   reference im_transf_net.py:202-215
+// A thread owns 4 consecutive floats (16-byte load and store: the scalar form ran at 3.2 TB/s, 123 us per 1080p batch of 8); sample and channel
+// of the quad's first element by one division, the rest by comparison (a quad may straddle two samples when HW * C is not a multiple of 4).
+__global__ __launch_bounds__(256) void apply_tanh4_kernel(const float* __restrict__ z, const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ y, int per, int C, size_t total4) {
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total4; q += (size_t)gridDim.x * 256) {
+        const size_t i0 = q * 4;
+        const int n = (int)(i0 / (size_t)per);
+        const int r = (int)(i0 - (size_t)n * per);
+        int c = r % C;
+        const float4 zz = *reinterpret_cast<const float4*>(z + i0);
+        const float zv[4] = {zz.x, zz.y, zz.z, zz.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int nk = r + k >= per ? n + 1 : n;      // (r + k >= per: the next sample starts at channel 0 + ...)
+            const int ck = r + k >= per ? (r + k - per) % C : c;
+            const float v = fmaf(zv[k], a[nk * C + ck], b[nk * C + ck]);
+            o[k] = (255.0f * tanhf(v) + 255.0f) / 2.0f;
+            c = c + 1 == C ? 0 : c + 1;
+        }
+        *reinterpret_cast<float4*>(y + i0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
 __global__ __launch_bounds__(256) void apply_tanh_kernel(const float* z, const float* a, const float* b, float* y, int HW,
-                                                         int C, size_t total) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+                                                         int C, size_t first, size_t total) {
+    for (size_t i = first + (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const int n = (int)(i / ((size_t)HW * C));
         const float v = fmaf(z[i], a[n * C + c], b[n * C + c]);
@@ -220,8 +243,13 @@ __global__ __launch_bounds__(256) void apply_tanh_kernel(const float* z, const f
 
 int apply_tanh(const float* z, const float* a, const float* b, float* y, int N, int HW, int C, hipStream_t s) {
     const size_t total = (size_t)N * HW * C;
-    hipLaunchKernelGGL(apply_tanh_kernel, dim3((unsigned)min((size_t)2048, (total + 255) / 256)), dim3(256), 0, s, z, a, b,
-                       y, HW, C, total);
+    const bool vec = (size_t)HW * C < ((size_t)1 << 31) && !(((uintptr_t)z | (uintptr_t)y) & 15) && total >= 4;
+    const size_t total4 = vec ? total / 4 : 0;
+    if (total4)
+        hipLaunchKernelGGL(apply_tanh4_kernel, dim3((unsigned)min((size_t)8192, (total4 + 255) / 256)), dim3(256), 0, s, z, a, b, y, HW * C, C, total4);
+    if (total4 * 4 < total)   // the tail (< 4 elements), or everything when the quads are not aligned
+        hipLaunchKernelGGL(apply_tanh_kernel, dim3((unsigned)min((size_t)2048, (total - total4 * 4 + 255) / 256)), dim3(256), 0, s, z, a, b, y, HW, C,
+                           total4 * 4, total);
     return launch_status();
 }
 

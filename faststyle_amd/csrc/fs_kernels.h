@@ -106,7 +106,11 @@ struct ConvArgs {
     float* pool_out;        // optional [N,Ho/2,Wo/2,Cout] (Winograd kernels, even Ho/Wo, no split-K): max over every 2x2 output tile =
                             // tf.nn.max_pool 2x2/2 of the stored result (vgg16.py:68,104,154) straight from the epilogue's registers
     long long w_nstride;
-    int prof_tag;            // 1: launched by the transform net (profiler row; no effect on the computation)
+    int prof_tag;            // 1: launched by the transform net -- selects the PROFILER ROW only (no effect on the plan or the computation)
+    int tnet_plan;           // 1: plan as the transform net's launches are planned -- 16-tile items in fs_wino4t.hip whatever the grid (the layout allocated
+                             // statistics records and workspace for that tiling), the remainder split in fs_wino2.hip.  Every launch site of fs_tnet.hip sets it
+                             // together with prof_tag; the public fs_conv2d_fwd leaves both 0 (round 4 keyed the plan on prof_tag: a launch site that forgot the
+                             // "profiler" tag planned another tile count than the layout had allocated for)
     FinArgs fin;             // fused instance-norm finalize (with stats; persistent kernels only)
     float* rem_ws;           // optional scratch for the remainder split of fs_wino2 (rem_ws_floats capacity): the items of the last,
     size_t rem_ws_floats;    // partial round of a persistent launch are split over the reduction dimension across ALL workgroups

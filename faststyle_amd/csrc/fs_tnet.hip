@@ -105,6 +105,7 @@ static ConvArgs unit_args(const Unit& u, int N) {
     a.refl = u.refl;
     a.shuffle = u.kind == 1;
     a.prof_tag = 1;
+    a.tnet_plan = 1;
     return a;
 }
 
@@ -344,7 +345,8 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
             h.KH = h.KW = 3;
             h.stride = 1;
             h.pad_t = h.pad_l = 2;
-            h.prof_tag = 1;   // (as unit_dgrad sets it: the planner keeps 16-tile items for the transform net)
+            h.prof_tag = 1;
+            h.tnet_plan = 1;   // (as unit_dgrad sets it: the planner keeps 16-tile items for the transform net)
             h.w_wino4t = reinterpret_cast<const float*>(16);
             if (wino4t_eligible(h) && (w4 == 2 || wino4t_items(h) >= tune_int("FS_WINO4T_MIN_ITEMS", 64))) {
                 on = true;
@@ -570,6 +572,7 @@ static int unit_dgrad(const TnetLayout& L, const Unit& u, const float* params, c
     if (rec_tiles) *rec_tiles = 0;
     ConvArgs a{};
     a.prof_tag = 1;
+    a.tnet_plan = 1;
     a.N = N;
     a.x = dz;
     a.y = dst;

@@ -826,7 +826,7 @@ void wino2_plan(const ConvArgs& a, ConvPlan* out) {
     }
     // remainder split (transform-net launches; see wino2_conv_kernel<true>): whole rounds of whole items, the last partial
     // round split over the input-channel chunks so that it occupies the whole chip for a fraction of a round
-    if (a.rem_ws && a.prof_tag && p.ksplit == 1 && !a.bias && !a.out_relu && !a.mask_src && !a.pool_out && !a.fin.counter && tune_int("FS_WINO2_REM", 1)) {
+    if (a.rem_ws && a.tnet_plan && p.ksplit == 1 && !a.bias && !a.out_relu && !a.mask_src && !a.pool_out && !a.fin.counter && tune_int("FS_WINO2_REM", 1)) {
         const long G = tune_int("FS_WINO2_WGS", 256);
         if (items > G) {
             const long full = items / G * G, rem = items - full;

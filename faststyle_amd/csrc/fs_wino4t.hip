@@ -108,7 +108,9 @@ bool wino4t_eligible(const ConvArgs& a) {
     const bool fits = (double)a.H * a.W * a.Cin * 4.0 < 2147483648.0 && (double)a.Ho * a.Wo * a.Cout * 4.0 < 2147483648.0 && 36.0 * a.Cin * a.Cout * 4.0 < 2147483648.0;
     const bool aff_ok = !a.in_a || (a.pad_t == 0 && a.in_b && a.in_relu && (a.in_nstride == 0 || a.in_nstride == a.Cin) && !a.add_src && !a.mask_src && !a.bias &&
                                     !a.out_relu && !a.pool_out);
-    return fits && a.w_wino4t && a.KH == 3 && a.KW == 3 && a.stride == 1 && pad_ok && a.src_mode == SRC_PLAIN && a.Cin % kCC == 0 && a.Cout % kBN == 0 &&
+    // item / step indices are decoded with float reciprocals in the kernel ((int)((x + 0.5f) * inv_d)): exact below 2^22 -- larger launches take the other kernels
+    const bool count_ok = (double)a.N * cdiv(a.Ho, kBH) * cdiv(a.Wo, 16) * (a.Cout / kBN) * 4.0 /* split-K */ < 4194304.0;
+    return fits && count_ok && a.w_wino4t && a.KH == 3 && a.KW == 3 && a.stride == 1 && pad_ok && a.src_mode == SRC_PLAIN && a.Cin % kCC == 0 && a.Cout % kBN == 0 &&
            !a.shuffle && aff_ok && wino4t_epi(a, 1) >= 0 && !a.route_src && a.w_nstride == 0 && a.dil_x <= 1 && !a.fin.counter && a.Ho > 0 && a.Wo > 0 &&
            (!a.pool_out || (!(a.Ho & 1) && !(a.Wo & 1)));
 }
@@ -120,7 +122,7 @@ static long wino4t_items_tb(const ConvArgs& a, int tb) { return (long)a.N * cdiv
 static int wino4t_pick_tb(const ConvArgs& a) {
     const int forced = tune_int("FS_WINO4T_TB", 0);
     if (forced == 1 || forced == 2) return forced;
-    if (a.prof_tag == 1) return 1;   // the transform net's 8-step items: measured level at batch 32 (800 16-tile / 480 32-tile items), 16-tile items ahead everywhere else
+    if (a.tnet_plan == 1) return 1;   // the transform net's 8-step items: measured level at batch 32 (800 16-tile / 480 32-tile items), 16-tile items ahead everywhere else
     const int wgs = tune_int("FS_WINO4T_WGS", 256);
     const double c1 = (double)cdiv((int)wino4t_items_tb(a, 1), wgs), c2 = 1.8 * (double)cdiv((int)wino4t_items_tb(a, 2), wgs);
     return c2 <= c1 ? 2 : 1;

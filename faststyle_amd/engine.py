@@ -517,6 +517,7 @@ class Engine(object):
         d.add_pad = int(kw.get("add_pad", 0))
         d.w_nstride = int(kw.get("w_nstride", 0))
         d.mask_src = p(kw.get("mask_src"))
+        inb = kw.get("inb")      # (z, mean, rstd, a, b, relu): also leave the instance-norm-backward partial sums of the unit that produced z
         if kw.get("winograd") == "4t":     # F(4x4,3x3), 16-tile items (fs_wino4t.hip)
             U = self.mem.empty((36, Cin, Cout))
             L.check(self.lib, self.lib.fs_wino4t_transform_filter(self.ctx, p(w), Cin, Cout, p(U)), "fs_wino4t_transform_filter")
@@ -532,6 +533,10 @@ class Engine(object):
             L.check(self.lib, self.lib.fs_wino_transform_filter(self.ctx, p(w), Cin, Cout, p(U)), "fs_wino_transform_filter")
             d.w_wino = p(U)
             self._keep = [U]
+        if inb is not None:      # (set before planning: the launch is then planned with 16 x 16-pixel items whatever the grid)
+            d.inb_z, d.inb_mean, d.inb_rstd, d.inb_a, d.inb_b = (p(t) for t in inb[:5])
+            d.inb_relu = int(inb[5])
+            d.inb_rec = 16       # placeholder until the record count is known
         tiles = ctypes.c_int()
         L.check(self.lib, self.lib.fs_conv2d_plan(ctypes.byref(d), ctypes.byref(tiles)), "fs_conv2d_plan")
         if d.shuffle:
@@ -543,6 +548,10 @@ class Engine(object):
         if kw.get("want_pool"):
             pool = self.mem.empty((N, d.Ho // 2, d.Wo // 2, Cout))
             d.pool_out = p(pool)
+        rec = None
+        if inb is not None:
+            rec = self.mem.empty((N, tiles.value, Cout, 2))
+            d.inb_rec = p(rec)
         stats = None
         if kw.get("want_stats"):
             stats = self.mem.empty((N, tiles.value, Cout, 3))
@@ -550,6 +559,8 @@ class Engine(object):
         L.check(self.lib, self.lib.fs_conv2d_fwd(self.ctx, ctypes.byref(d)), "fs_conv2d_fwd")
         if pool is not None:
             return y, pool
+        if rec is not None:
+            return y, rec
         return (y, stats, tiles.value) if kw.get("want_stats") else y
 
     def instnorm_finalize(self, stats, tiles, C, groups, gamma, beta, eps=1e-3):

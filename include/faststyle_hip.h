@@ -210,6 +210,19 @@ typedef struct {
                             * / fs_tnet_backward run the ten residual convs (im_transf_net.py:250-276) and their input gradients on:
                             * in_a / in_b (+ in_relu) on load with padding 0, stats, add_src as for the other kernels.  w_wino4 wins
                             * when both are given; other shapes fall through. */
+    /* optional, with w_wino4t and a plan of 16 x 16-pixel items (fs_conv2d_plan: tiles_per_image = ceil(Ho/16) * ceil(Wo/16)), raw or add_src
+     * epilogue only: y is the gradient g wrt the OUTPUT of an instance-norm unit whose raw conv output is inb_z [N,Ho,Wo,Cout]; the launch also
+     * leaves that unit's instance-norm-backward partial sums (im_transf_net.py:218-247 adjoint) per item,
+     *   inb_rec[n][item][c] = { sum g', sum g' * (z - mean[n][c]) * rstd[n][c] },  g' = g where relu(a z + b) > 0 when inb_relu, else g,
+     * [N][tiles_per_image][Cout][2] floats -- what fs_tnet_backward has the residual input-gradient launches produce for the unit below them.
+     * Any other plan with inb_rec set is an error (-2). */
+    const float* inb_z;
+    const float* inb_mean; /* [N][Cout] each */
+    const float* inb_rstd;
+    const float* inb_a;    /* with inb_relu */
+    const float* inb_b;
+    int inb_relu;
+    float* inb_rec;
 } fs_conv_desc;
 /* U = G g G^T for every (ci, co) filter g = w[:, :, ci, co] of a 3x3 HWIO filter (Lavin & Gray F(2x2,3x3)), 16 values per
  * filter, in the order the Winograd kernels stage them; the caller owns U (16*Cin*Cout floats; Cin % 8 == 0).

@@ -256,6 +256,55 @@ def test_winograd_f4x4_16tile_residual_block_form(eng, knob, tb):
     assert rel(y, want) < 1e-4
 
 
+@pytest.mark.parametrize("form", ["raw_relu", "raw_linear", "add_relu", "add_linear_grid3"])
+def test_winograd_f4x4_16tile_input_gradient_leaves_the_instance_norm_backward_partial_sums(eng, knob, form):
+    """Round 5: the residual input-gradient launches of fs_tnet_backward (3x3 'full' convs of dz on fs_wino4t.hip, EPI 5 raw / EPI 6 + the residual
+    gradient) also leave, per 16 x 16-pixel item, the instance-norm-backward partial sums of the unit whose OUTPUT gradient they write:
+    {sum g', sum g' xhat}, g' = g where the unit's ReLU passed (im_transf_net.py:218-247 adjoint; what in_bwd_partial4_kernel computed in a pass of
+    its own over g and z).  Ragged 35 x 39 outputs: partial items, a last tile row / column of 3 pixels; 'grid3': several items per workgroup
+    (the deferred-load item loop).  g itself must equal the launch without the records bit for bit."""
+    relu = form.endswith("relu")
+    with_add = form.startswith("add")
+    if form.endswith("grid3"):
+        knob("FS_WINO4T_WGS", 3)
+    rng = np.random.default_rng(31)
+    N, H, W, C = 2, 33, 37, 64
+    dz = rng.standard_normal((N, H, W, C)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, C, C)) * 0.1).astype(np.float32)
+    Ho, Wo = H + 2, W + 2
+    z = (rng.standard_normal((N, Ho, Wo, C)) * 2 + 0.3).astype(np.float32)
+    mean = z.mean(axis=(1, 2)).astype(np.float32)
+    rstd = (1.0 / np.sqrt(z.astype(np.float64).var(axis=(1, 2)) + 1e-3)).astype(np.float32)
+    gamma = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32)
+    a = (gamma * rstd).astype(np.float32)
+    b = (0.2 * rng.standard_normal((N, C))).astype(np.float32)
+    kw = {}
+    if with_add:
+        add = rng.standard_normal((N, Ho - 4, Wo - 4, C)).astype(np.float32)
+        kw.update(add_src=up(eng, add), add_pad=2)
+    plain = down(eng, eng.conv2d(up(eng, dz), up(eng, w), 1, (2, 2, Ho, Wo), winograd="4t", **kw))
+    g_dev, rec_dev = eng.conv2d(up(eng, dz), up(eng, w), 1, (2, 2, Ho, Wo), winograd="4t",
+                                inb=(up(eng, z), up(eng, mean), up(eng, rstd), up(eng, a), up(eng, b), relu), **kw)
+    g, rec = down(eng, g_dev), down(eng, rec_dev)
+    assert np.array_equal(g, plain)
+    ty, tx = -(-Ho // 16), -(-Wo // 16)
+    assert rec.shape == (N, ty * tx, C, 2)
+    g64, z64 = g.astype(np.float64), z.astype(np.float64)
+    keep = (z64 * a[:, None, None, :] + b[:, None, None, :] > 0) if relu else np.ones_like(z64, bool)
+    gq = np.where(keep, g64, 0.0)
+    xhat = (z64 - mean[:, None, None, :]) * rstd[:, None, None, :]
+    scale1, scale2 = np.abs(gq).sum(axis=(1, 2)).max() / (ty * tx), np.abs(gq * xhat).sum(axis=(1, 2)).max() / (ty * tx)
+    for by in range(ty):
+        for bx in range(tx):
+            blk = (slice(None), slice(16 * by, 16 * by + 16), slice(16 * bx, 16 * bx + 16))
+            want1, want2 = gq[blk].sum(axis=(1, 2)), (gq * xhat)[blk].sum(axis=(1, 2))
+            assert np.abs(rec[:, by * tx + bx, :, 0] - want1).max() < 2e-5 * scale1 * 16, (by, bx)
+            assert np.abs(rec[:, by * tx + bx, :, 1] - want2).max() < 2e-5 * scale2 * 16, (by, bx)
+    # the whole-sample sums (what the apply kernel's prologue forms) against the float64 sums
+    assert np.abs(rec[..., 0].sum(axis=1) - gq.sum(axis=(1, 2))).max() < 2e-5 * np.abs(gq).sum(axis=(1, 2)).max()
+    assert np.abs(rec[..., 1].sum(axis=1) - (gq * xhat).sum(axis=(1, 2))).max() < 2e-5 * np.abs(gq * xhat).sum(axis=(1, 2)).max()
+
+
 def test_winograd_accuracy_is_that_of_the_direct_kernel(eng):
     """F(2x2,3x3) only adds / subtracts / halves in its transforms: on post-ReLU-like data with a deep reduction
     (256 input channels) its error against the fp64 oracle stays within 2x of the direct fp32 kernel's."""

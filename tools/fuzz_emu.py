@@ -10,7 +10,8 @@
     that end inside a tile, several pixel ranges;
   * wino2_conv_kernel with bias / ReLU, wgrad2_kernel, conv3x3_to3_kernel on ragged shapes;
   * wino4_conv_kernel (fs_wino4.hip, Winograd F(4x4,3x3)): raw / bias + ReLU / consumer-mask epilogues, ragged 16x32 blocks;
-  * wino4t_conv_kernel (fs_wino4t*.hip): 16- / 32-tile items, paddings 0 / 1 / 2, every epilogue form through fs_conv2d_fwd; its 128-channel
+  * wino4t_conv_kernel (fs_wino4t*.hip): 16- / 32-tile items, paddings 0 / 1 / 2, every epilogue form through fs_conv2d_fwd (round 5: incl. the two
+    forms that also leave instance-norm-backward partial sums); its 128-channel
     item form through the whole VGG16 section (fs_perceptual_loss against the oracle's loss and gradient);
   * conv_s16_kernel (fs_s16.hip): the 9x9 3 -> 16 layer with mirror or zero padding and per-tile statistics, VGG conv1_1's
     form (3 -> 64, per-channel affine on load over zero padding, bias + ReLU); ragged tiles, several persistent grid sizes.
@@ -75,7 +76,7 @@ def main():
     up, down = e.mem.from_numpy, e.mem.to_numpy
     inst = [(16, 32, 3, 2), (32, 64, 2, 1), (32, 64, 3, 2), (64, 128, 2, 1), (64, 64, 3, 1)]
     for it in range(cases):
-        kind = it % 15
+        kind = int(os.environ["FUZZ_KIND"]) if "FUZZ_KIND" in os.environ else it % 15   # (FUZZ_KIND=<n>: that kernel family only)
         if kind == 11:        # 16-channel-block streaming kernel (fs_s16.hip)
             n, h, w = int(rng.integers(1, 3)), int(rng.integers(9, 50)), int(rng.integers(9, 50))
             os.environ["FS_S16_WGS"] = str(int(rng.choice([1, 3, 512])))
@@ -191,8 +192,9 @@ def main():
             wt = (rng.standard_normal((3, 3, cin, cout)) * 0.1).astype(np.float32)
             ho, wo = h + 2 * pad - 2, w + 2 * pad - 2
             want = nnops.conv2d(np.pad(x.astype(np.float64), ((0, 0), (pad, pad), (pad, pad), (0, 0))), wt.astype(np.float64), 1, "VALID")
-            epi = int(rng.integers(5))
+            epi = int(rng.integers(7))
             kw, stats = {}, False
+            inb = None
             if epi == 1:
                 bias = rng.standard_normal((cout,)).astype(np.float32)
                 kw = dict(bias=up(bias), out_relu=1)
@@ -207,9 +209,29 @@ def main():
                 want[:, 2:-2, 2:-2, :] += add
             elif epi == 4:
                 stats = True
+            elif epi >= 5 and cout == 64:   # round 5: raw (5) / residual-gradient (6) epilogue + the instance-norm-backward partial sums of the unit below
+                if epi == 6 and ho > 4 and wo > 4:
+                    add = rng.standard_normal((n, ho - 4, wo - 4, cout)).astype(np.float32)
+                    kw = dict(add_src=up(add), add_pad=2)
+                    want[:, 2:-2, 2:-2, :] += add
+                zz = (rng.standard_normal((n, ho, wo, cout)) * 2).astype(np.float32)
+                mean, rstd = zz.mean(axis=(1, 2)).astype(np.float32), (rng.uniform(0.3, 2.0, (n, cout))).astype(np.float32)
+                ia, ib = rng.standard_normal((n, cout)).astype(np.float32), rng.standard_normal((n, cout)).astype(np.float32)
+                relu = bool(rng.integers(2))
+                inb = (zz, mean, rstd, ia, ib, relu)
+                kw["inb"] = (up(zz), up(mean), up(rstd), up(ia), up(ib), relu)
+                os.environ["FS_WINO4T_TB"] = "1"    # (the planner takes 16-tile items for these launches whatever the knob says: keep the printout honest)
             out = e.conv2d(up(x), up(wt), 1, (pad, pad, ho, wo), winograd="4t", want_stats=stats, **kw)
-            y = down(out[0] if stats else out)
+            y = down(out[0] if (stats or inb is not None) else out)
             r = rel(y, want)
+            if inb is not None:
+                zz, mean, rstd, ia, ib, relu = inb
+                rec = down(out[1]).astype(np.float64)
+                keep = (zz.astype(np.float64) * ia[:, None, None, :] + ib[:, None, None, :] > 0) if relu else np.ones(zz.shape, bool)
+                gq = np.where(keep, y.astype(np.float64), 0.0)
+                xh = (zz.astype(np.float64) - mean[:, None, None, :]) * rstd[:, None, None, :]
+                r = max(r, rel(rec[..., 0].sum(axis=1), gq.sum(axis=(1, 2))) * (np.abs(gq.sum(axis=(1, 2))).max() / max(np.abs(gq).sum(axis=(1, 2)).max(), 1e-30)),
+                        rel(rec[..., 1].sum(axis=1), (gq * xh).sum(axis=(1, 2))) * (np.abs((gq * xh).sum(axis=(1, 2))).max() / max(np.abs(gq * xh).sum(axis=(1, 2)).max(), 1e-30)))
             if stats:
                 mean, var = merge_stats(down(out[1]))
                 r = max(r, rel(mean, want.mean(axis=(1, 2))), rel(var, want.var(axis=(1, 2))))
