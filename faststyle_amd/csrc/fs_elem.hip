@@ -851,7 +851,7 @@ int in_bwd_rec(const float* gin, const float* z, const float* mean, const float*
     if (!rec) {
         // a coarser chunking than in_bwd's where needed (the prologue of every apply workgroup reads ALL of its sample's records): <= max_t
         // chunks per sample
-        const int max_t = tune_int("FS_INBWD_REC_MAXT", 96);
+        const int max_t = tune_int("FS_INBWD_REC_MAXT", 192);   // (96 / 192 / 384 measured: 225 / 217 / 217 us on the largest unit at batch 32, tools/micro_inbwd.py)
         int chunk_px = in_bwd_chunk_px(N, HW);
         if (cdiv(HW, chunk_px) > max_t) chunk_px = cdiv(cdiv(HW, max_t), 64) * 64;
         const int chunks = cdiv(HW, chunk_px);
