@@ -484,7 +484,9 @@ def test_hip_train_step_256_matches_oracle_and_batch_sum_property(knob_hip):
     la, ga = step(x[:1])
     lb, gb = step(x[1:])
     np.testing.assert_allclose(l2, la + lb, rtol=1e-4)
-    assert np.abs(g2 - (ga + gb)).max() / np.abs(g2).max() < 3e-4
+    dp_err = np.abs(g2 - (ga + gb)).max() / np.abs(g2).max()
+    print("data-parallel identity 2 x 256 x 256: max |g(batch) - sum g(sample)| / max |g| = %.2e (tolerance 3e-4)" % dp_err)   # (recorded in DESIGN.md section 2)
+    assert dp_err < 3e-4
     tgo = perceptual.target_grams(style, Wv, cfg["style_layers"])
     lo, go, _ = perceptual.train_step(P, x, tgo, Wv)
     np.testing.assert_allclose(l2[:3], [lo["loss"], lo["content_loss"], lo["style_loss"]], rtol=1e-3)
