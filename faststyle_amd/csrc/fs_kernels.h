@@ -36,6 +36,7 @@ struct ConvPlan {
     int ksplit;   // > 1: blockIdx.z splits the input-channel chunks; raw partials go to ConvArgs::split_ws
     int rem_full;     // wino2, remainder split: items [0, rem_full) are whole items (rem_full = a multiple of the persistent grid) ...
     int rem_ks;       // ... and each item behind them is split into rem_ks units over its input-channel chunks (0: no split)
+    int flat_tiles;   // fs_wino4t.hip: 16-tile items over the sample's FLATTENED row-major tile list (tiles_y = 1, tiles_x = items per sample) instead of 16 x 16-pixel blocks
     int xcd_swizzle;  // workgroup -> (tile, channel block) map that keeps sharers of an input patch on one XCD
     int skew;  // > 0: first-round workgroups in odd wave slots start late by skew x 2048 cycles (see conv_igemm_kernel)
 };

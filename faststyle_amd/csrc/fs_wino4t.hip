@@ -138,6 +138,22 @@ static bool wino4t_use_cb2(const ConvArgs& a) {
     return a.w_wino4u && a.Cout % (2 * kBN) == 0 && !a.in_a && (e == 0 || e == 3 || e == 4) && tune_int("FS_WINO4T_CB", 2) >= 2 && wino4t_pick_tb(a) == 2;
 }
 
+// The flattened form (M = 4 of the kernel, round 5): 16 consecutive tiles of the sample's row-major tile list per item -- ceil(tiles / 16) items per
+// sample instead of ceil(Ho / 16) ceil(Wo / 16), at the price of a 6 x 6 patch per tile (1.8x the patch loads).  Taken where it saves a whole ROUND
+// of the persistent grid (batch 32 at 256 x 256: 736 against 800 items = three rounds instead of four); the transform net's launches only (its
+// epilogue forms).  FS_WINO4T_FLAT = 0 never, 2 always (tests).
+static bool wino4t_use_flat(const ConvArgs& a, int tb, bool cb2) {
+    const int mode = tune_int("FS_WINO4T_FLAT", 1);
+    const int e = wino4t_epi(a, 1);
+    if (!mode || tb != 1 || cb2 || !(e == 0 || e == 1 || e == 2 || e == 5 || e == 6) || a.split_ws) return false;
+    if (mode == 2) return true;
+    if (!a.tnet_plan) return false;
+    const int wgs = tune_int("FS_WINO4T_WGS", 256);
+    const long ncob = a.Cout / kBN;
+    const long rect = (long)a.N * cdiv(a.Ho, kBH) * cdiv(a.Wo, 16) * ncob, flat = (long)a.N * cdiv(cdiv(a.Ho, 4) * cdiv(a.Wo, 4), 16) * ncob;
+    return cdiv((int)flat, wgs) < cdiv((int)rect, wgs);
+}
+
 void wino4t_plan(const ConvArgs& a, ConvPlan* out) {
     ConvPlan p{};
     const bool cb2 = wino4t_use_cb2(a);
@@ -150,11 +166,17 @@ void wino4t_plan(const ConvArgs& a, ConvPlan* out) {
     p.tiles_y = cdiv(a.Ho, kBH);
     p.tiles_x = cdiv(a.Wo, p.TW);
     p.lds_bytes = 4 * 2 * (tb == 1 ? Geo<1>::kStageF : Geo<2>::kStageF);
+    if (wino4t_use_flat(a, tb, cb2)) {
+        p.flat_tiles = 1;
+        p.tiles_y = 1;
+        p.tiles_x = cdiv(cdiv(a.Ho, 4) * cdiv(a.Wo, 4), 16);   // items (= statistics / partial-sum records) per sample
+        p.lds_bytes = 4 * 2 * Geo<1, true>::kStageF;
+    }
     p.ksplit = 1;
     const long items = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / p.BN);
     const int nchunks = a.Cin / kCC;
     const int max_ks = tune_int("FS_WINO_KSPLIT", 4);
-    if (a.split_ws && !a.pool_out && !a.stats && !a.in_a && !a.inb_rec) {   // split-K where the launch cannot fill the chip (the rule of fs_wino4.hip; a step here is 8 channels)
+    if (a.split_ws && !a.pool_out && !a.stats && !a.in_a && !a.inb_rec && !p.flat_tiles) {   // split-K where the launch cannot fill the chip (the rule of fs_wino4.hip; a step here is 8 channels)
         int ks = 1;
         const int min_steps = tune_int("FS_WINO4_KSPLIT_MINSTEPS", 16) / 2;
         while (ks < max_ks && items * ks < 256 && nchunks / (ks * 2) >= min_steps && (size_t)(ks * 2) * a.N * a.Ho * a.Wo * a.Cout <= a.split_ws_floats) ks *= 2;
@@ -167,6 +189,8 @@ void wino4t_plan(const ConvArgs& a, ConvPlan* out) {
 int wino4t_launch_1b(const ConvArgs& a, int epi, long grid, hipStream_t s);
 int wino4t_launch_1c(const ConvArgs& a, int epi, long grid, hipStream_t s);
 int wino4t_launch_1d(const ConvArgs& a, int epi, long grid, hipStream_t s);
+int wino4t_launch_4a(const ConvArgs& a, int epi, long grid, hipStream_t s);
+int wino4t_launch_4b(const ConvArgs& a, int epi, long grid, hipStream_t s);
 int wino4t_launch_2a(const ConvArgs& a, int epi, long grid, hipStream_t s);
 int wino4t_launch_2b(const ConvArgs& a, int epi, long grid, hipStream_t s);
 
@@ -179,6 +203,10 @@ int wino4t_launch(const ConvArgs& a, hipStream_t s) {
     const long items = (long)a.N * p.tiles_y * p.tiles_x * (a.Cout / p.BN) * ks;
     const int wgs = tune_int("FS_WINO4T_WGS", 256);
     const long grid = items < wgs ? items : wgs;
+    if (p.flat_tiles) {
+        if (tb != 1 || p.BN != kBN || ks != 1) return -7;
+        return (a.in_a || epi <= 1) ? wino4t_launch_4a(a, epi, grid, s) : wino4t_launch_4b(a, epi, grid, s);
+    }
     if (p.BN == 2 * kBN) return (tb == 1 && a.w_wino4u) ? wino4t_launch_1c(a, epi, grid, s) : -7;
     const bool part_a = a.in_a || epi <= 1;
     if (epi >= 5) return tb == 1 ? wino4t_launch_1d(a, epi, grid, s) : -7;   // (instance-norm-backward partial sums: 16-tile items only)

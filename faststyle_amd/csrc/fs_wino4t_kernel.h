@@ -17,7 +17,7 @@ constexpr int kBN = 64;                          // output channels per item
 constexpr unsigned kOOB = 0x80000000u;
 constexpr int kNA = 32;                          // TB = 2: positions whose accumulators live in the accumulator file (the other 4: vector registers, see fs_wino4.h)
 // geometry of an item with TB tile blocks of 16 (4 tile rows x 4 TB tile columns)
-template <int TB>
+template <int TB, bool FL = false>
 struct Geo {
     static constexpr int kBW = 16 * TB;                      // output columns per item
     static constexpr int kPW = kBW + 2;                      // patch columns
@@ -37,6 +37,29 @@ struct Geo {
     // meet two-way: 18 per pass)
     static constexpr int koff(int k) { return TB == 1 ? k * 16 + 8 * (k >> 1) : k * 32 + 16 * ((k + 1) >> 1); }
     static constexpr bool kDefer = TB == 2;                  // an item's last sweep loads nothing; next_item does (see there)
+};
+// FL (round 5): 16 tiles of a FLATTENED per-sample tile list -- any 16 consecutive tiles of the row-major tile grid, not a 4 x 4 block -- so every
+// tile stages its OWN 6 x 6 input patch (no shared halo): plane = [tile 16][36 pixels], tile pitch 37 and plane pitch = 8 mod 32 put the 8 tiles x
+// 4 channels of a transform half-wave on 32 distinct banks (5 t + 8 c mod 32).  Items per sample = ceil(tiles / 16) instead of
+// ceil(Ho / 16) ceil(Wo / 16): 23 instead of 25 at 74 x 74 -- at batch 32 the difference between three and four rounds of a 256-workgroup grid.
+template <>
+struct Geo<1, true> {
+    static constexpr int kBW = 16;
+    static constexpr int kPW = 6;                            // (a tile's patch is 6 x 6)
+    static constexpr int kPR = 6;                            // patch row pitch inside a tile's patch
+    static constexpr int kTP = 37;                           // tile pitch
+    static constexpr int kPix = 16 * 36;                     // 576 pixel slots
+    static constexpr int kSink = 16 * kTP;                   // 592
+    static constexpr int kPlane = 616;                       // (= 8 mod 32)
+    static constexpr int kNPV = 5;                           // 16-byte patch loads per thread and step (1152 of 1280 slots used)
+    static constexpr int kVB = 72;
+    static constexpr int kVF = 72 * kVB;
+    static constexpr int kPatchF = kCC * kPlane + 8;
+    static constexpr int kStageF = kVF + kPatchF;            // 10120 floats per stage
+    static constexpr int kSlots = 72;
+    static constexpr int kEarly = 8;
+    static constexpr int koff(int k) { return k * 16 + 8 * (k >> 1); }
+    static constexpr bool kDefer = false;
 };
 }  // namespace
 
@@ -68,7 +91,8 @@ __device__ __forceinline__ float quad_elem(const float4& v) {
 }
 
 // M: item form -- 1: 16 tiles x 64 channels; 2: 32 tiles (two tile blocks) x 64 channels; 3: 16 tiles x 128 channels (two CHANNEL blocks per
-// wave: the input transform of a step serves twice the products; 36 filter quads per step through an 18-register window).
+// wave: the input transform of a step serves twice the products; 36 filter quads per step through an 18-register window); 4: form 1 on a
+// flattened per-sample tile list (Geo<1, true>: a.p.flat_tiles, a.p.tiles_x = items per sample).
 // EPI: 0 raw (also split-K partials), 1 raw + instance-norm partials of the item (a.stats), 2 + a.add_src in
 // the interior, 3 bias + ReLU (+ a.pool_out), 4 a.mask_src, 5 raw + the instance-norm-BACKWARD partial sums of the unit whose output
 // gradient the launch writes (a.inb_*, round 5), 6 = 2 + the same.  AFF: a.in_a / a.in_b + ReLU on load.
@@ -76,13 +100,15 @@ template <int M, int EPI, bool AFF>
 __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
     constexpr int TB = M == 2 ? 2 : 1;      // tile blocks of 16 per item (geometry)
     constexpr bool CB2 = M == 3;            // two channel blocks of 16 per wave
-    constexpr int NB = M == 1 ? 1 : 2;      // accumulator blocks per position
+    constexpr bool FL = M == 4;             // flattened tile list, per-tile patches
+    constexpr int NB = (M == 1 || M == 4) ? 1 : 2;      // accumulator blocks per position
     constexpr int kBNi = CB2 ? 2 * kBN : kBN;   // output channels per item
     constexpr int QPS = CB2 ? 36 : 18;      // filter quads per step and wave
     static_assert(!(CB2 && (EPI == 1 || EPI == 2 || AFF)), "the 128-channel form carries the VGG16 epilogues only");
-    static_assert(!((EPI == 5 || EPI == 6) && (M != 1 || AFF)), "the instance-norm-backward epilogues exist for 16-tile items only");
+    static_assert(!((EPI == 5 || EPI == 6) && ((M != 1 && M != 4) || AFF)), "the instance-norm-backward epilogues exist for 16-tile items only");
+    static_assert(!(FL && (EPI == 3 || EPI == 4)), "the flattened form carries the transform net's epilogues");
     constexpr bool kAdd = EPI == 2 || EPI == 6, kInb = EPI == 5 || EPI == 6;
-    using GEO = Geo<TB>;
+    using GEO = Geo<TB, FL>;
     constexpr int kBW = GEO::kBW, kPW = GEO::kPW, kPR = GEO::kPR, kPix = GEO::kPix, kSink = GEO::kSink, kPlane = GEO::kPlane, kNPV = GEO::kNPV, kVB = GEO::kVB,
                   kVF = GEO::kVF, kStageF = GEO::kStageF;
     constexpr int kEarly = (TB == 2 && EPI == 4) ? FS_W4T_EARLY_TB2_MASK : (((EPI == 5 || EPI == 6) && FS_W4T_INB_DEFER) ? 16 : GEO::kEarly);
@@ -117,6 +143,8 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
     const int my_items = (vb < total_items) ? (total_items - 1 - vb) / G + 1 : 0;
     if (my_items == 0) return;
     const float inv_ks = 1.0f / (float)ks, inv_ncob = 1.0f / (float)ncob, inv_blocks = 1.0f / (float)blocks, inv_tx = 1.0f / (float)p.tiles_x;
+    const int gTx = (a.Wo + 3) >> 2, gT = ((a.Ho + 3) >> 2) * gTx;   // FL: the sample's grid of 4 x 4-pixel tiles, row-major
+    const float inv_gtx = 1.0f / (float)gTx;
     struct Item {
         int n, oy0, ox0, cob, br, cbeg, cend, z;
     };
@@ -182,8 +210,13 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < kNPV; ++i) {
         const int pix = (tid + 256 * i) >> 1;
-        const int py = pix / kPW;
-        pdst[i] = q_t * 4 * kPlane + (pix < kPix ? py * kPR + (pix - py * kPW) : kSink + (pix - kPix) % (kPlane - kSink));
+        if constexpr (FL) {   // pixel slot = (tile, pixel of its 6 x 6 patch)
+            const int tl = pix / 36;
+            pdst[i] = q_t * 4 * kPlane + (pix < kPix ? tl * GEO::kTP + (pix - 36 * tl) : kSink + (pix - kPix) % (kPlane - kSink));
+        } else {
+            const int py = pix / kPW;
+            pdst[i] = q_t * 4 * kPlane + (pix < kPix ? py * kPR + (pix - py * kPW) : kSink + (pix - kPix) % (kPlane - kSink));
+        }
         gvo[i] = kOOB;
     }
     const unsigned x_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * a.Cin) * 4u);
@@ -199,10 +232,20 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < kNPV; ++i) {
             const int pix = (t_ + 256 * i) >> 1;
-            const int py = (int)(((float)pix + 0.5f) * (1.0f / (float)kPW)), px = pix - py * kPW;
-            const int sy = I.oy0 - a.pad_t + py, sx = I.ox0 - a.pad_l + px;
-            const bool ok = live && pix < kPix && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W;
-            gvo[i] = ok ? (unsigned)((sy * a.W + sx) * a.Cin + 4 * (t_ & 1)) * 4u : kOOB;
+            if constexpr (FL) {
+                const int tl = (int)(((float)pix + 0.5f) * (1.0f / 36.0f)), pp = pix - 36 * tl;
+                const int py = (int)(((float)pp + 0.5f) * (1.0f / 6.0f)), px = pp - 6 * py;
+                const int t = 16 * I.br + tl;
+                const int ty = fdiv(t, inv_gtx), tx = t - ty * gTx;
+                const int sy = 4 * ty - a.pad_t + py, sx = 4 * tx - a.pad_l + px;
+                const bool ok = live && pix < kPix && t < gT && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W;
+                gvo[i] = ok ? (unsigned)((sy * a.W + sx) * a.Cin + 4 * (t_ & 1)) * 4u : kOOB;
+            } else {
+                const int py = (int)(((float)pix + 0.5f) * (1.0f / (float)kPW)), px = pix - py * kPW;
+                const int sy = I.oy0 - a.pad_t + py, sx = I.ox0 - a.pad_l + px;
+                const bool ok = live && pix < kPix && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W;
+                gvo[i] = ok ? (unsigned)((sy * a.W + sx) * a.Cin + 4 * (t_ & 1)) * 4u : kOOB;
+            }
         }
         avo = live ? (unsigned)(t_ & 1) * 16u : kOOB;
     };
@@ -257,8 +300,11 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
     //   TB = 1: one pass; wave w owns tile rows 2 (w & 1), +1 and channels 4 (w >> 1) .. +3; lane = (half h, channel c, tile row tyl, tile column tx)
     //   TB = 2: two passes (pass = the step's first / second four channels); wave w owns tile row w; lane = (half h, channel c, tile column tx of 8)
     const int h_t = lane >> 5, c_t = (lane >> 3) & 3;
-    const int tsrc = TB == 1 ? (4 * (wave >> 1) + c_t) * kPlane + (4 * (2 * (wave & 1) + ((lane >> 2) & 1))) * kPR + 4 * (lane & 3) + 3 * h_t
-                             : c_t * kPlane + (4 * wave) * kPR + 4 * (lane & 7) + 3 * h_t;
+    int tsrc_ = TB == 1 ? (4 * (wave >> 1) + c_t) * kPlane + (4 * (2 * (wave & 1) + ((lane >> 2) & 1))) * kPR + 4 * (lane & 3) + 3 * h_t
+                        : c_t * kPlane + (4 * wave) * kPR + 4 * (lane & 7) + 3 * h_t;
+    if constexpr (FL)   // the lane's tile (4 (2 (w & 1) + tile row bit) + tile column of the rectangular form = the same tile INDEX) has a patch of its own
+        tsrc_ = (4 * (wave >> 1) + c_t) * kPlane + ((2 * (wave & 1) + ((lane >> 2) & 1)) * 4 + (lane & 3)) * Geo<1, true>::kTP + 3 * h_t;
+    const int tsrc = tsrc_;
     const int tdst = TB == 1 ? ((wave >> 1) * 36 + 18 * h_t) * kVB + GEO::koff(c_t) + (2 * (wave & 1) + ((lane >> 2) & 1)) * 4 + (lane & 3)
                              : 18 * h_t * kVB + GEO::koff(c_t) + 2 * (8 * (wave & 1) + (lane & 7)) + (wave >> 1);
     constexpr int kPassSrc = 4 * kPlane * 4, kPassDst = 36 * kVB * 4;   // TB = 2: byte offsets of the second pass
@@ -352,7 +398,7 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
         } else if (sl >= 14 && sl < 23) transform_write(a_vn, 2 * (sl - 14), 2 * (sl - 14) + 2);
     };
     auto slice = [&](int sl, const Addr& AD) __attribute__((always_inline)) {
-        constexpr int c0 = TB == 1 ? 34 : 76, l0 = TB == 1 ? 38 : 86;
+        constexpr int c0 = TB == 1 ? 34 : 76, l0 = FL ? c0 + kNPV : (TB == 1 ? 38 : 86);   // (FL commits 5 quads: slots 34-38, its loads follow at 39-43, the affine at 44)
         if (sl >= 10 && sl < 33) transform_slice(sl - 10, AD.pn, AD.vn);
         else if (TB == 2 && sl >= 46 && sl < 69) transform_slice(sl - 46, AD.pn + kPassSrc, AD.vn + kPassDst);
         else if (sl >= c0 && sl < c0 + kNPV) {
@@ -477,9 +523,17 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
             float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
             if (EPI == 3 && a.bias) bs = *reinterpret_cast<const float4*>(a.bias + co);
             const float bsv[4] = {bs.x, bs.y, bs.z, bs.w};
-            const int oy = I.oy0 + 4 * (TB == 1 ? (t >> 2) : (t >> 3)), ox = I.ox0 + 4 * (TB == 1 ? (t & 3) : (t & 7));
+            int oy = I.oy0 + 4 * (TB == 1 ? (t >> 2) : (t >> 3)), ox = I.ox0 + 4 * (TB == 1 ? (t & 3) : (t & 7));
+            bool tile_ok = true;
+            if constexpr (FL) {   // tile 16 br + t of the sample's row-major tile grid
+                const int tg = 16 * I.br + t;
+                const int tyg = fdiv(tg, inv_gtx);
+                oy = 4 * tyg;
+                ox = 4 * (tg - tyg * gTx);
+                tile_ok = tg < gT;
+            }
             const unsigned obase = (unsigned)((oy * a.Wo + ox) * a.Cout + co) * 4u;
-            const int ry = a.Ho - oy, cx = a.Wo - ox;   // valid rows / columns of the lane's tile (edge blocks)
+            const int ry = tile_ok ? a.Ho - oy : 0, cx = tile_ok ? a.Wo - ox : 0;   // valid rows / columns of the lane's tile (edge blocks; a tile past the grid: none)
             auto inside = [&](int px) __attribute__((always_inline)) { return full || ((px >> 2) < ry && (px & 3) < cx); };
             auto voff = [&](int px) __attribute__((always_inline)) { return inside(px) ? obase : kOOB; };
             float4 ad[16];
@@ -632,9 +686,16 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
                 s1[r] = row16_sum(s1[r]);
                 s2[r] = row16_sum(s2[r]);
             }
+            float cnt_fl = 0.f;
+            if constexpr (FL) {   // pixels of the item: the lanes' valid tile areas, summed over the 16 tiles of a row
+                const int tg = 16 * I.br + j;
+                const int tyg = fdiv(tg, inv_gtx);
+                const int ryv = tg < gT ? min(4, a.Ho - 4 * tyg) : 0, cxv = tg < gT ? min(4, a.Wo - 4 * (tg - tyg * gTx)) : 0;
+                cnt_fl = row16_sum((float)(ryv * cxv));
+            }
             if (j == 0) {
                 const int th_valid = min(kBH, a.Ho - I.oy0), tw_valid = min(kBW, a.Wo - I.ox0);
-                const float cnt = (float)(th_valid * tw_valid);
+                const float cnt = FL ? cnt_fl : (float)(th_valid * tw_valid);
                 const int co = I.cob * kBNi + wave * 16 + 4 * (ln >> 4);
                 float* st = a.stats + ((size_t)(I.n * blocks + I.br) * a.Cout + co) * 3;
 #pragma unroll
@@ -649,7 +710,7 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
     };
     auto epilogue = [&](const Item& I) __attribute__((always_inline)) {
         FS_W4_MFMA_SETTLE();   // (the item's last inline-assembly matrix instructions have written their accumulators: fs_wino4.h)
-        if (I.oy0 + kBH <= a.Ho && I.ox0 + kBW <= a.Wo)
+        if (FL ? (!(a.Ho & 3) && !(a.Wo & 3) && 16 * I.br + 16 <= gT) : (I.oy0 + kBH <= a.Ho && I.ox0 + kBW <= a.Wo))
             epilogue_body(std::true_type{}, I);
         else
             epilogue_body(std::false_type{}, I);
@@ -803,6 +864,24 @@ template <int TB>   // (a template like the other parts: instantiated only by th
 static int wino4t_launch_part_d(const ConvArgs& a, int epi, long grid, hipStream_t s) {
     static_assert(TB == 1, "16-tile items only");
     return epi == 5 ? wino4t_launch_as<1, 5, false>(a, grid, s) : wino4t_launch_as<1, 6, false>(a, grid, s);
+}
+// the flattened 16-tile form (M = 4): the transform net's epilogues only -- fs_wino4t4a.hip (on-load norm forms + raw + statistics), fs_wino4t4b.hip
+// (residual gradient, instance-norm-backward partial sums)
+template <int M>
+static int wino4t_launch_part_fa(const ConvArgs& a, int epi, long grid, hipStream_t s) {
+    static_assert(M == 4, "the flattened form");
+    if (a.in_a) return epi == 1 ? wino4t_launch_as<4, 1, true>(a, grid, s) : wino4t_launch_as<4, 0, true>(a, grid, s);
+    return epi == 1 ? wino4t_launch_as<4, 1, false>(a, grid, s) : wino4t_launch_as<4, 0, false>(a, grid, s);
+}
+template <int M>
+static int wino4t_launch_part_fb(const ConvArgs& a, int epi, long grid, hipStream_t s) {
+    static_assert(M == 4, "the flattened form");
+    switch (epi) {
+        case 2: return wino4t_launch_as<4, 2, false>(a, grid, s);
+        case 5: return wino4t_launch_as<4, 5, false>(a, grid, s);
+        case 6: return wino4t_launch_as<4, 6, false>(a, grid, s);
+        default: return -7;
+    }
 }
 // the 128-channel item form (M = 3): raw (split-K partials, input gradients in front of a pool), bias + ReLU (+ pool), consumer mask
 template <int M>

@@ -175,6 +175,14 @@ WINO4T_CASES = [
     ("tb1_bias_relu_pool", (1, 18, 20, 8), 64, "SAME", "pool", 1),
     ("tb1_mask", (2, 17, 19, 16), 64, "SAME", "mask", 1),
     ("tb2_split_k", (1, 16, 32, 128), 64, "SAME", "ksplit", 2),          # one item: the planner splits the 16 steps over 4 workgroups (raw partials + splitk epilogue)
+    # round 5: the FLATTENED form (FS_WINO4T_FLAT=2: items = 16 consecutive tiles of the sample's row-major tile list, a 6 x 6 patch per tile)
+    ("flat_one_item_valid", (1, 18, 18, 8), 64, "VALID", None, 1),
+    ("flat_ragged_valid_2img", (2, 23, 39, 16), 64, "VALID", None, 1),  # 21 x 37 outputs: 6 x 10 = 60 tiles = 3.75 items per sample, ragged last tile row / column
+    ("flat_same_two_coblocks", (1, 20, 20, 8), 128, "SAME", None, 1),
+    ("flat_full_pad_with_add", (2, 19, 21, 64), 64, "FULL", "add", 1),
+    ("flat_multi_item_grid5", (3, 34, 36, 24), 64, "VALID", "grid5", 1),
+    ("flat_tiny", (1, 3, 3, 8), 64, "VALID", None, 1),
+    ("flat_wide_strip", (1, 7, 70, 8), 64, "VALID", None, 1),           # 2 x 17 tiles: an item spans both tile rows
 ]
 
 
@@ -186,6 +194,8 @@ def test_winograd_f4x4_16tile_conv_matches_oracle(eng, knob, case):
     5e-5 of the output's magnitude as for fs_wino4.hip."""
     name, xs, cout, pad, extra, tb = case
     knob("FS_WINO4T_TB", tb)
+    if name.startswith("flat_"):
+        knob("FS_WINO4T_FLAT", 2)
     if extra == "grid5" or name == "tb2_mask_multi_item":
         knob("FS_WINO4T_WGS", 5)
     if extra == "ksplit":
@@ -256,14 +266,18 @@ def test_winograd_f4x4_16tile_residual_block_form(eng, knob, tb):
     assert rel(y, want) < 1e-4
 
 
-@pytest.mark.parametrize("form", ["raw_relu", "raw_linear", "add_relu", "add_linear_grid3"])
+@pytest.mark.parametrize("form", ["raw_relu", "raw_linear", "add_relu", "add_linear_grid3", "flat_raw_relu", "flat_add_relu_grid3"])
 def test_winograd_f4x4_16tile_input_gradient_leaves_the_instance_norm_backward_partial_sums(eng, knob, form):
     """Round 5: the residual input-gradient launches of fs_tnet_backward (3x3 'full' convs of dz on fs_wino4t.hip, EPI 5 raw / EPI 6 + the residual
     gradient) also leave, per 16 x 16-pixel item, the instance-norm-backward partial sums of the unit whose OUTPUT gradient they write:
     {sum g', sum g' xhat}, g' = g where the unit's ReLU passed (im_transf_net.py:218-247 adjoint; what in_bwd_partial4_kernel computed in a pass of
     its own over g and z).  Ragged 35 x 39 outputs: partial items, a last tile row / column of 3 pixels; 'grid3': several items per workgroup
     (the deferred-load item loop).  g itself must equal the launch without the records bit for bit."""
-    relu = form.endswith("relu")
+    flat = form.startswith("flat_")
+    knob("FS_WINO4T_FLAT", 2 if flat else 0)      # 2: records per 16 consecutive tiles of the flattened tile list instead of per 16 x 16-pixel block
+    if flat:                                       # (0: never -- left to itself the planner takes the flattened form where it saves a round of the grid)
+        form = form[5:]
+    relu = "relu" in form
     with_add = form.startswith("add")
     if form.endswith("grid3"):
         knob("FS_WINO4T_WGS", 3)
@@ -288,12 +302,25 @@ def test_winograd_f4x4_16tile_input_gradient_leaves_the_instance_norm_backward_p
     g, rec = down(eng, g_dev), down(eng, rec_dev)
     assert np.array_equal(g, plain)
     ty, tx = -(-Ho // 16), -(-Wo // 16)
-    assert rec.shape == (N, ty * tx, C, 2)
     g64, z64 = g.astype(np.float64), z.astype(np.float64)
     keep = (z64 * a[:, None, None, :] + b[:, None, None, :] > 0) if relu else np.ones_like(z64, bool)
     gq = np.where(keep, g64, 0.0)
     xhat = (z64 - mean[:, None, None, :]) * rstd[:, None, None, :]
     scale1, scale2 = np.abs(gq).sum(axis=(1, 2)).max() / (ty * tx), np.abs(gq * xhat).sum(axis=(1, 2)).max() / (ty * tx)
+    if flat:      # item i = tiles 16 i .. 16 i + 15 of the row-major grid of 4 x 4-pixel tiles
+        Ty, Tx = -(-Ho // 4), -(-Wo // 4)
+        assert rec.shape == (N, -(-(Ty * Tx) // 16), C, 2)
+        for i in range(rec.shape[1]):
+            want1, want2 = np.zeros((N, C)), np.zeros((N, C))
+            for t in range(16 * i, min(16 * i + 16, Ty * Tx)):
+                blk = (slice(None), slice(4 * (t // Tx), 4 * (t // Tx) + 4), slice(4 * (t % Tx), 4 * (t % Tx) + 4))
+                want1 += gq[blk].sum(axis=(1, 2))
+                want2 += (gq * xhat)[blk].sum(axis=(1, 2))
+            assert np.abs(rec[:, i, :, 0] - want1).max() < 2e-5 * scale1 * 16, i
+            assert np.abs(rec[:, i, :, 1] - want2).max() < 2e-5 * scale2 * 16, i
+        ty = tx = 0
+    else:
+        assert rec.shape == (N, ty * tx, C, 2)
     for by in range(ty):
         for bx in range(tx):
             blk = (slice(None), slice(16 * by, 16 * by + 16), slice(16 * bx, 16 * bx + 16))
@@ -303,6 +330,41 @@ def test_winograd_f4x4_16tile_input_gradient_leaves_the_instance_norm_backward_p
     # the whole-sample sums (what the apply kernel's prologue forms) against the float64 sums
     assert np.abs(rec[..., 0].sum(axis=1) - gq.sum(axis=(1, 2))).max() < 2e-5 * np.abs(gq).sum(axis=(1, 2)).max()
     assert np.abs(rec[..., 1].sum(axis=1) - (gq * xhat).sum(axis=(1, 2))).max() < 2e-5 * np.abs(gq * xhat).sum(axis=(1, 2)).max()
+
+
+def test_winograd_f4x4_flattened_residual_block_form(eng, knob):
+    """The residual-block form on the FLATTENED 16-tile F(4x4) items (round 5, FS_WINO4T_FLAT): VALID padding, per-item statistics records
+    {mean, M2, count} over 16 consecutive tiles (count = the item's valid pixels, ragged tiles and the grid's tail included), merged by
+    instnorm_finalize; the next conv applies the instance norm + ReLU on load, again on flattened items."""
+    knob("FS_WINO4T_FLAT", 2)
+    knob("FS_WINO4T_WGS", 7)
+    rng = np.random.default_rng(29)
+    x = rng.standard_normal((2, 37, 41, 64)).astype(np.float32) + 0.5        # 35 x 39 outputs: 9 x 10 tiles = 5.6 items per sample
+    w1 = (rng.standard_normal((3, 3, 64, 64)) * 0.1).astype(np.float32)
+    w2 = (rng.standard_normal((3, 3, 64, 64)) * 0.1).astype(np.float32)
+    gamma = (1 + 0.3 * rng.standard_normal(64)).astype(np.float32)
+    beta = (0.2 * rng.standard_normal(64)).astype(np.float32)
+    z, stats, tiles = eng.conv2d(up(eng, x), up(eng, w1), 1, "VALID", want_stats=True, winograd="4t")
+    assert tiles == 6
+    st = down(eng, stats).astype(np.float64)
+    z64 = nnops.conv2d(x.astype(np.float64), w1.astype(np.float64), 1, "VALID")
+    assert st[..., 2].sum(axis=1).min() == st[..., 2].sum(axis=1).max() == 35 * 39
+    for i in (0, 3, 5):          # records of the first, a middle and the last (partial) item
+        px = np.zeros((35, 39), bool)
+        for t in range(16 * i, min(16 * i + 16, 90)):
+            px[4 * (t // 10):4 * (t // 10) + 4, 4 * (t % 10):4 * (t % 10) + 4] = True
+        blk = z64[1][px]
+        assert np.all(st[1, i, :, 2] == px.sum())
+        assert np.abs(st[1, i, :, 0] - blk.mean(axis=0)).max() < 1e-4 * np.abs(z64).max()
+        assert np.abs(st[1, i, :, 1] - ((blk - blk.mean(axis=0)) ** 2).sum(axis=0)).max() < 1e-4 * ((blk - blk.mean(axis=0)) ** 2).sum(axis=0).max()
+    mean, rstd, a, b = eng.instnorm_finalize(stats, tiles, 64, 1, up(eng, gamma), up(eng, beta))
+    y = down(eng, eng.conv2d(z, up(eng, w2), 1, "VALID", in_a=a, in_b=b, in_per_sample=1, in_relu=1, winograd="4t"))
+    n64, (xhat, rs, _) = nnops.inst_norm(z64, gamma.astype(np.float64), beta.astype(np.float64))
+    assert rel(down(eng, z), z64) < 5e-5
+    assert rel(down(eng, mean), z64.mean(axis=(1, 2))) < 5e-5
+    assert rel(down(eng, rstd), rs[:, 0, 0, :]) < 5e-5
+    want = nnops.conv2d(nnops.relu(n64), w2.astype(np.float64), 1, "VALID")
+    assert rel(y, want) < 1e-4
 
 
 def test_winograd_accuracy_is_that_of_the_direct_kernel(eng):

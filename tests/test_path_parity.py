@@ -162,7 +162,7 @@ def test_tnet_residual_convs_through_the_winograd_kernel(eng, shape, wgs, knob):
     assert grads_close(eng, g, want, 2e-4) == []
 
 
-@pytest.mark.parametrize("shape,wgs", [((1, 45, 67), 0), ((3, 52, 44), 3)])
+@pytest.mark.parametrize("shape,wgs", [((1, 45, 67), 0), ((3, 52, 44), 3), ((2, 56, 44), -5)])   # (wgs < 0: the flattened form, grid of -wgs)
 def test_tnet_residual_convs_through_the_16tile_f4x4_kernel(eng, shape, wgs, knob):
     """fs_wino4t.hip: what 720p frames and the training batches select by themselves (>= 64 items of 16x16 pixels) -- the ten
     residual convs and their ten input gradients through the 16-tile Winograd F(4x4,3x3) kernel (instance norm + ReLU on load,
@@ -170,6 +170,9 @@ def test_tnet_residual_convs_through_the_16tile_f4x4_kernel(eng, shape, wgs, kno
     FS_WINO4T_WGS=3 makes workgroups walk several items.  Same oracle, same tolerances as every other path (measured: 2.5e-6 .. 4.4e-6
     of the pixel range with the shipped weights -- 64-channel reductions keep F(4x4)'s larger transform constants harmless)."""
     knob("FS_TNET_WINO4", 2)
+    if wgs < 0:      # round 5: items over the flattened per-sample tile lists (what a batch of 32 selects by itself: a round of the persistent grid less)
+        knob("FS_WINO4T_FLAT", 2)
+        wgs = -wgs
     if wgs:
         knob("FS_WINO4T_WGS", wgs)
     rng = np.random.default_rng(9)
@@ -646,7 +649,12 @@ def test_hip_train_step_b32_256_kernel_paths_and_data_parallel_identity(knob_hip
     def cos_l2(a, b):
         return float(torch.dot(a, b) / (a.norm() * b.norm())), float((a - b).norm() / b.norm())
     assert bool(torch.isfinite(g_new).all()) and float(g_new.norm()) > 0
-    assert float((y_new - y_dir).abs().max()) < 2e-5 * 255
+    # two float32 paths against each other: each is held to the float64 oracle at 2e-5 of the range (above, and test_tnet_forward_...), so their
+    # difference has a budget of 4e-5; measured 1.2e-5 .. 1.6e-5 with 16 x 16-pixel items, 2.03e-5 since the residual convs of this shape take
+    # the flattened tile lists (round 5: the statistics records partition the pixels differently)
+    dy_paths = float((y_new - y_dir).abs().max())
+    print("b32 256x256: forward pixels, default vs direct kernels: %.2e of the range" % (dy_paths / 255))
+    assert dy_paths < 3e-5 * 255
     assert float(((l_new - l_dir).abs() / l_dir.abs().clamp_min(1e-30))[:3].max()) < 2e-5, (l_new, l_dir)
     c1, e1 = cos_l2(g_new, g_dir)
     # (b): losses are batch sums (losses.py:32,63), instance norm / Grams are per sample

@@ -187,6 +187,7 @@ def main():
             n, h, w = int(rng.integers(1, 3)), int(rng.integers(3 - pad, 40)), int(rng.integers(3 - pad, 70))
             os.environ["FS_WINO4T_WGS"] = str(int(rng.choice([1, 3, 256])))
             os.environ["FS_WINO4T_TB"] = str(int(rng.choice([1, 2])))
+            os.environ["FS_WINO4T_FLAT"] = str(int(rng.choice([0, 2])))    # (2: the flattened 16-tile form wherever its epilogue forms allow)
             e.lib.fs_debug_reload_env()
             x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
             wt = (rng.standard_normal((3, 3, cin, cout)) * 0.1).astype(np.float32)
@@ -235,8 +236,8 @@ def main():
             if stats:
                 mean, var = merge_stats(down(out[1]))
                 r = max(r, rel(mean, want.mean(axis=(1, 2))), rel(var, want.var(axis=(1, 2))))
-            print("case %3d wino4t %s -> %d pad %d epilogue %d tb %s wgs %s  rel %.2e" % (it, x.shape, cout, pad, epi, os.environ["FS_WINO4T_TB"],
-                                                                                       os.environ["FS_WINO4T_WGS"], r), flush=True)
+            print("case %3d wino4t %s -> %d pad %d epilogue %d tb %s flat %s wgs %s  rel %.2e" % (it, x.shape, cout, pad, epi, os.environ["FS_WINO4T_TB"],
+                                                                                               os.environ["FS_WINO4T_FLAT"], os.environ["FS_WINO4T_WGS"], r), flush=True)
             assert r < 5e-5
         elif kind == 14:      # the VGG16 section through the big-item forms of fs_wino4t.hip (32 tiles x 64 channels, 16 tiles x 128 channels)
             from faststyle_amd import engine as fs_engine
