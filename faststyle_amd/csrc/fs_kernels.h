@@ -174,6 +174,7 @@ struct Wg2Plan {
     int waves_k;          // waves tiling the k dimension; the other 4/waves_k split the tile's pixel rows
     int patch_floats, stage_floats, lds_bytes;
     int xn, dn;           // 16-byte loads per thread and tile: patch / dY
+    int combine;          // the pixel-row groups of a workgroup are summed through LDS before the store: ONE slab per workgroup
 };
 struct Wg2Prob {
     const float* x;       // [N,H,W,Cin] (virtual via src_mode)
@@ -182,7 +183,7 @@ struct Wg2Prob {
     const float* in_b;
     const float* dy_a;    // optional on-load affine of dy (conv2d_transpose units)
     const float* dy_b;
-    float* slabs;         // [wg_count * 4/waves_k][K][Cout]
+    float* slabs;         // [wg_count * (combine ? 1 : 4/waves_k)][K][Cout]
     size_t slab_off;      // offset of `slabs` inside the launch's scratch (floats)
     int N, H, W, Ho, Wo, tiles_y, tiles_x;
     int wg_begin, wg_count;

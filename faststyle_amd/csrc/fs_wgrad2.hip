@@ -453,8 +453,35 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wg2Args a) {
         __syncthreads();
     }
 
-    // ---- this wave's part of the workgroup's partial slab(s): [K][Cout], one slab per pixel-row group wp
-    float* slab = P.slabs + ((size_t)wl * waves_p + wp) * (size_t)p.K * a.Cout;
+    // ---- the pixel-row groups of the workgroup summed through LDS (round 5; both stages are free, the loop ended on a barrier): group w = 1,
+    // 2, .. hands its accumulators to group 0 lane for lane -- the groups of one wk hold the same elements in the same (register, lane) places --
+    // in that fixed order.  One slab per workgroup instead of 4 / waves_k: a quarter / half of the slab bytes written here and read by the reduction.
+    if (p.combine) {
+        float* cb = smem + (size_t)wk * (KM * KN * 4 * 64) + lane;
+        for (int w = 1; w < waves_p; ++w) {
+            if (wp == w) {
+#pragma unroll
+                for (int q = 0; q < KM; ++q)
+#pragma unroll
+                    for (int j = 0; j < KN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) cb[((q * KN + j) * 4 + r) * 64] = acc[q][j][r];
+            }
+            __syncthreads();
+            if (wp == 0) {
+#pragma unroll
+                for (int q = 0; q < KM; ++q)
+#pragma unroll
+                    for (int j = 0; j < KN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[q][j][r] += cb[((q * KN + j) * 4 + r) * 64];
+            }
+            __syncthreads();
+        }
+        if (wp != 0) return;
+    }
+    // ---- this wave's part of the workgroup's partial slab(s): [K][Cout]; !combine: one slab per pixel-row group wp
+    float* slab = P.slabs + (p.combine ? (size_t)wl : (size_t)wl * waves_p + wp) * (size_t)p.K * a.Cout;
 #pragma unroll
     for (int q = 0; q < KM; ++q) {
         if (kb0 + q >= p.KB) continue;
@@ -670,6 +697,8 @@ size_t wgrad2_plan(const WgradArgs* probs, int n, Wg2Args* out) {
         }
     if (best < 0) return 0;
     p.lds_bytes = 2 * p.stage_floats * 4;
+    p.combine = waves_p > 1 && tune_int("FS_WGRAD2_COMBINE", 1) != 0;
+    if (p.combine && p.lds_bytes < p.waves_k * p.KM * p.KN * 4 * 64 * 4) p.lds_bytes = p.waves_k * p.KM * p.KN * 4 * 64 * 4;   // the hand-over buffer of one group
     // deal workgroups to problems in proportion to their tile counts (same geometry: same cost per tile)
     long tiles_total = 0;
     long tiles[kW2MaxProb];
@@ -710,7 +739,7 @@ size_t wgrad2_plan(const WgradArgs* probs, int n, Wg2Args* out) {
         wg_begin += cnt;
         wg_left -= cnt;
         tiles_left -= tiles[i];
-        slab_floats += (size_t)cnt * waves_p * p.K * g.Cout;
+        slab_floats += (size_t)cnt * (p.combine ? 1 : waves_p) * p.K * g.Cout;
     }
     A.n_wg = wg_begin;
     *out = A;
@@ -748,7 +777,7 @@ int wgrad2_run(const Wg2Args& planned, float* slabs, float* const* dw, float sca
     for (int i = 0; i < a.nprob; ++i) {
         a.prob[i].slabs = slabs + a.prob[i].slab_off;
         r.job[i].slabs = a.prob[i].slabs;
-        r.job[i].n_slabs = a.prob[i].wg_count * waves_p;
+        r.job[i].n_slabs = a.prob[i].wg_count * (a.p.combine ? 1 : waves_p);
         r.job[i].count = (size_t)a.p.K * a.Cout;
         r.job[i].out = dw[i];
         if (r.job[i].count / 4 > max4) max4 = r.job[i].count / 4;
