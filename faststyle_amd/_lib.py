@@ -56,7 +56,7 @@ class fs_conv_desc(Structure):
                 ("w_wino4", c_void_p), ("mask_src", c_void_p), ("pool_out", c_void_p),
                 ("w_wino4t", c_void_p),
                 ("inb_z", c_void_p), ("inb_mean", c_void_p), ("inb_rstd", c_void_p), ("inb_a", c_void_p), ("inb_b", c_void_p),
-                ("inb_relu", c_int), ("inb_rec", c_void_p)]
+                ("inb_relu", c_int), ("inb_rec", c_void_p), ("route_src", c_void_p)]
 
 
 class fs_wgrad_desc(Structure):

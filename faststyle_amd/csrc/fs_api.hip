@@ -525,6 +525,8 @@ static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
     a->add_pad = d->add_pad;
     a->w_nstride = d->w_nstride;
     a->mask_src = d->mask_src;
+    a->route_src = d->route_src;
+    if (a->route_src && (!a->mask_src || a->add_pad)) return fail(-2, "fs_conv_desc: route_src needs mask_src and add_pad = 0");
     a->w_wino4 = d->w_wino4;
     if (a->w_wino4 && !fs::wino4_eligible(*a)) a->w_wino4 = nullptr;   // (not a 3x3 stride-1 SAME conv of the supported shapes)
     a->w_wino4t = d->w_wino4t;
@@ -574,6 +576,14 @@ int fs_conv2d_fwd(fs_ctx* ctx, fs_conv_desc* d) {
         const int rc0 = fs::gram_bwd2_launch(a.x, a.w, a.add_src, a.y, a.N, a.H * a.W, a.Cin, ctx->stream);
         return rc0 ? fail(rc0, "fs_conv2d_fwd: launch failed (%d)", rc0) : 0;
     }
+    // ... with the max-pool routing and the ReLU mask of x itself in its epilogue (fs_conv_desc.route_src)
+    if (a.route_src && a.mask_src == a.x && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.Cin == a.Cout && a.w_nstride == (long long)a.Cin * a.Cout &&
+        a.src_mode == fs::SRC_PLAIN && !a.in_a && !a.bias && !a.out_relu && !a.shuffle && !a.stats && a.H == a.Ho && a.W == a.Wo &&
+        fs::gram_bwd2_route_eligible(a.N, a.H, a.W, a.Cin)) {
+        const int rc0 = fs::gram_bwd2_launch(a.x, a.w, a.add_src, a.y, a.N, a.H * a.W, a.Cin, ctx->stream, a.route_src, a.W);
+        return rc0 ? fail(rc0, "fs_conv2d_fwd: launch failed (%d)", rc0) : 0;
+    }
+    if (a.route_src && !fs::conv_route_ok(a)) return fail(-2, "fs_conv2d_fwd: this launch cannot take route_src (direct kernel, no add_src / shuffle / split-K)");
     // 3x3 SAME, 64 -> 3 channels (the shape of VGG conv1_1's input gradient): vector-ALU kernel, fs_c3.hip
     const int rc = fs::conv3x3_to3_eligible(a) ? fs::conv3x3_to3_launch(a, ctx->stream) : fs::conv_launch(a, ctx->stream);
     return rc ? fail(rc, "fs_conv2d_fwd: launch failed (%d)", rc) : 0;

@@ -14,6 +14,8 @@
 //   * v_mfma_f32_32x32x2_f32, K = a pair of pixels; partial slabs are summed in a fixed order (deterministic, no atomics).
 #include "fs_kernels.h"
 
+#include <cstdio>
+
 #include <type_traits>
 
 namespace fs {
@@ -359,10 +361,18 @@ struct GramBwdArgs {
     float* dF;          // [N][HW][C]
     int N, HW, C;
     int wpg;            // workgroups per (sample, channel half)
+    const float* above; // RT: [N][H/2][W/2][C], the gradient of max_pool(F)
+    int W;              // RT: map width (H = HW / W)
 };
 }  // namespace
 
-template <int C, int WN, int TPX>
+// RT (round 5): the kernel also does what vgg_bwd_route did in a pass of its own behind it -- the result is
+//     d_pre = (dF + the max-pool gradient `above` routed to the FIRST maximum of each 2x2 window of F) * (F > 0)
+// (TF MaxPoolGrad + ReluGrad; the sums in vgg_bwd_route_kernel's order, so the two paths agree bit for bit).  F is this kernel's own A operand:
+// a tile is two map rows x TPX/2 columns, laid into the LDS stage so that 32-pixel block 2b holds row 0 and block 2b + 1 row 1 of the same 32
+// columns -- the four pixels of a window are then the accumulator registers (m, r), (m, r + 1), (m + 1, r), (m + 1, r + 1) of ONE lane, and their
+// F values four LDS reads of the stage the sweep just used.  Needs an even H and W a multiple of TPX/2 (the VGG maps of 256 x 256 inputs).
+template <int C, int WN, int TPX, bool RT = false>
 __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
     HIP_DYNAMIC_SHARED(float, smem)
     constexpr int NH = C > 128 ? C / 128 : 1;              // channel halves (workgroup groups)
@@ -380,10 +390,18 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
     const int wi = lin % a.wpg;
     lin /= a.wpg;
     const int nh = lin % NH, n = lin / NH;
-    const int tiles = (a.HW + TPX - 1) / TPX;
+    constexpr int TW = TPX / 2, TWSH = TW == 128 ? 7 : 6;  // RT: tile columns
+    static_assert(!RT || ((WM % 2) == 0 && (TW == 128 || TW == 64)), "RT tiles: row pairs");
+    const int tpr = RT ? a.W / TW : 1;                     // RT: tiles per row pair
+    const int tiles = RT ? (a.HW / a.W / 2) * tpr : (a.HW + TPX - 1) / TPX;
     const int t_beg = (int)((long long)tiles * wi / a.wpg), t_end = (int)((long long)tiles * (wi + 1) / a.wpg);
     if (t_beg >= t_end) return;
     const int co0 = nh * CW + nbw * NB * 32;               // first output channel of this wave
+    // RT: first pixel of tile t = rows 2 ty, 2 ty + 1, columns tx TW ..
+    auto tile_p0 = [&](int t) {
+        const int ty = t / tpr, tx = t - ty * tpr;
+        return 2 * ty * a.W + tx * TW;
+    };
 
     // ---- S[n] rows k = 2j + kq, columns co0 + nn*32 + lm: resident for the workgroup's lifetime
     const float* Sn = a.S + (size_t)n * C * C;
@@ -418,6 +436,16 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
     // staging: element e = tid + i*256 = (pixel e / C4, channel quad e % C4): consecutive threads read consecutive 16 bytes
     float4 pv[SX];
     auto issue = [&](int t) {
+        if constexpr (RT) {
+            const unsigned base = (unsigned)tile_p0(t) * (unsigned)(C * 4), row1 = (unsigned)(a.W - TW) * (unsigned)(C * 4);
+#pragma unroll
+            for (int i = 0; i < SX; ++i) {   // element e: tile pixel e / C4 in row-major order (row = pixel / TW), whole tiles only
+                const int e = tid + i * 256;
+                const unsigned off = base + (unsigned)e * 16u + ((e >> C4SH) >> TWSH ? row1 : 0u);
+                pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(fr, off, 0, 0));
+            }
+            return;
+        }
         const unsigned base = (unsigned)(t * TPX) * (unsigned)(C * 4);
 #pragma unroll
         for (int i = 0; i < SX; ++i) {   // (pixels beyond the map: out-of-range offset -> zeros)
@@ -429,7 +457,12 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < SX; ++i) {
             const int e = tid + i * 256;
-            float* d = smem + (e >> C4SH) * S + (e & (C4 - 1)) * 4;
+            int q = e >> C4SH;   // stage row of the element's pixel
+            if constexpr (RT) {
+                const int row = q >> TWSH, col = q & (TW - 1);
+                q = (col >> 5) * 64 + row * 32 + (col & 31);
+            }
+            float* d = smem + q * S + (e & (C4 - 1)) * 4;
             d[0] = pv[i].x;
             d[1] = pv[i].y;
             d[2] = pv[i].z;
@@ -478,6 +511,94 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
     }
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(dFn, 0, f_bytes, 0x00020000);
     const float* addn = a.add ? a.add + (size_t)n * a.HW * C : nullptr;
+    // ---- RT: the pooled gradient of the tile's windows (loaded beside the next tile, before the sweep), the routing pass over the accumulators
+    // (after the sweep, while the stage still holds F), and the store
+    constexpr int NW = RT ? (WM / 2) * NB * 8 : 1;
+    float da[NW];
+    const float* aboven = RT ? a.above + (size_t)n * (a.HW / 4) * C : nullptr;
+    auto issue_above = [&](int t) {
+        const int ty = t / tpr, tx = t - ty * tpr;
+        // window (mp, nn, wd) of this lane: column (tx TW + (mw WM / 2 + mp) 32 + pi) / 2 of pooled row ty, pi = 2 (wd & 1) + 8 (wd >> 1) + 4 kq
+        const float* base = aboven + ((size_t)ty * (a.W >> 1) + ((tx * TW + (mw * WM / 2) * 32 + 4 * kq) >> 1)) * C + co0 + lm;
+#pragma unroll
+        for (int mp = 0; mp < WM / 2; ++mp)
+#pragma unroll
+            for (int nn = 0; nn < NB; ++nn)
+#pragma unroll
+                for (int wd = 0; wd < 8; ++wd) da[(mp * NB + nn) * 8 + wd] = base[(mp * 16 + (wd & 1) + 4 * (wd >> 1)) * C + nn * 32];
+    };
+    auto route = [&](int t) {
+        const int p0 = tile_p0(t);
+        const float* frow = smem + (mw * WM * 32 + 4 * kq) * S + co0 + lm;   // F of this lane's pixels: stage row (mw WM + m) 32 + pi
+        const unsigned lane_off = ((unsigned)(p0 + (mw * WM / 2) * 32 + 4 * kq) * (unsigned)C + (unsigned)(co0 + lm)) * 4u;
+        const unsigned row1 = (unsigned)a.W * (unsigned)(C * 4);
+        if (addn) {   // (sixteen loads at a time, as the plain epilogue's)
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int nn = 0; nn < NB; ++nn) {
+                    float ad[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ad[r] = addn[(lane_off + (m & 1) * row1 + (unsigned)(((m >> 1) * 32 + (r & 3) + 8 * (r >> 2)) * C + nn * 32) * 4u) >> 2];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][nn][r] += ad[r];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        // groups of two windows (eight F values), the reads of group g + 1 in flight behind the arithmetic of group g: with one wave per SIMD
+        // nothing else hides the LDS latency (all 128 reads first: registers; each group waited for on its own: 2.3x the routing time)
+        constexpr int NG = (WM / 2) * NB * 4;
+        float fb[2][8];
+        auto read_f = [&](int g, float (&f)[8]) {
+            const int mp = g / (NB * 4), nn = (g >> 2) % NB;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int wd = 2 * (g & 3) + (k >> 2), e = k & 3, r0 = 2 * wd, pi = (r0 & 3) + 8 * (r0 >> 2);
+                f[k] = frow[((2 * mp + (e >> 1)) * 32 + pi + (e & 1)) * S + nn * 32];
+            }
+        };
+        read_f(0, fb[0]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) read_f(g + 1, fb[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int mp = g / (NB * 4), nn = (g >> 2) % NB;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int wd = 2 * (g & 3) + h, r0 = 2 * wd;
+                const float* f = &fb[g & 1][4 * h];
+                const float dav = da[(mp * NB + nn) * 8 + wd];
+                // the first maximum of the window in the order (0,0) (0,1) (1,0) (1,1)
+                const bool w0 = f[0] >= f[1] && f[0] >= f[2] && f[0] >= f[3];
+                const bool w1 = f[1] > f[0] && f[1] >= f[2] && f[1] >= f[3];
+                const bool w2 = f[2] > f[0] && f[2] > f[1] && f[2] >= f[3];
+                const bool w3 = f[3] > f[0] && f[3] > f[1] && f[3] > f[2];
+                const bool win[4] = {w0, w1, w2, w3};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gv = acc[2 * mp + (e >> 1)][nn][r0 + (e & 1)];
+                    const float v = win[e] ? gv + dav : gv;
+                    acc[2 * mp + (e >> 1)][nn][r0 + (e & 1)] = f[e] > 0.f ? v : 0.f;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto store_rt = [&](int t) {
+        const unsigned lane_off = ((unsigned)(tile_p0(t) + (mw * WM / 2) * 32 + 4 * kq) * (unsigned)C + (unsigned)(co0 + lm)) * 4u;
+        const unsigned row1 = (unsigned)a.W * (unsigned)(C * 4);
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int nn = 0; nn < NB; ++nn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned off = lane_off + (m & 1) * row1 + (unsigned)(((m >> 1) * 32 + (r & 3) + 8 * (r >> 2)) * C + nn * 32) * 4u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][nn][r]), yr, off, 0, 0);
+                }
+        zero_acc();
+    };
     auto epilogue = [&](int t) {
         // accumulator register r of lane (lm, kq): pixel (mw*WM + m)*32 + (r & 3) + 8 (r >> 2) + 4 kq of the tile, channel co0 + nn*32 + lm.
         // Byte offset = lane part + compile-time part; pixels beyond the map get the out-of-range offset and are dropped.
@@ -510,10 +631,13 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
     for (int t = t_beg; t < t_end; ++t) {
         const bool more = t + 1 < t_end;
         if (more) issue(t + 1);
+        if constexpr (RT) issue_above(t);
         sweep();
+        if constexpr (RT) route(t);
         FS_LDS_BARRIER();
         if (more) commit();
-        epilogue(t);
+        if constexpr (RT) store_rt(t);
+        else epilogue(t);
         FS_LDS_BARRIER();   // (LDS only: the tile's stores drain during the next sweep instead of being waited for here)
     }
 }
@@ -641,10 +765,21 @@ int gram_symmetrize(const float* dG, float* S, int N, int C, float scale, hipStr
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-// dF[n] = F[n] S[n] (+ add[n])
-int gram_bwd2_launch(const float* F, const float* S, const float* add, float* dF, int N, int HW, int C, hipStream_t s) {
+// the routed form (gram_bwd_kernel<.., RT = true>): whole tiles of two rows x TPX/2 columns
+bool gram_bwd2_route_eligible(int N, int H, int W, int C) {
+    if (!tune_int("FS_GRAM_ROUTE_FUSED", 1) || H < 2 || W < 2 || !gram_bwd2_eligible(N, H * W, C)) return false;
+    const int TW = C == 64 ? 128 : 64;
+    return !(H & 1) && W % TW == 0;
+}
+
+// dF[n] = F[n] S[n] (+ add[n]);  above != nullptr (gram_bwd2_route_eligible(N, HW / W, W, C)): dF = (that + the max-pool gradient `above`
+// ([N][H/2][W/2][C]) routed through F) * (F > 0)
+int gram_bwd2_launch(const float* F, const float* S, const float* add, float* dF, int N, int HW, int C, hipStream_t s, const float* above, int W) {
     if (!gram_bwd2_eligible(N, HW, C)) return -1;
+    if (above && (W < 1 || HW % W || !gram_bwd2_route_eligible(N, HW / W, W, C))) return -1;
     GramBwdArgs a{};
+    a.above = above;
+    a.W = W;
     a.F = F;
     a.S = S;
     a.add = add;
@@ -652,17 +787,32 @@ int gram_bwd2_launch(const float* F, const float* S, const float* add, float* dF
     a.N = N;
     a.HW = HW;
     a.C = C;
-    const int NH = C > 128 ? C / 128 : 1, TPX = C == 256 ? 128 : 256;
-    const int tiles = cdiv(HW, TPX);
+    const int NH = C > 128 ? C / 128 : 1, TPX = C == 256 || (above && C == 128) ? 128 : 256;   // (routed, C = 128: 128-pixel tiles -- the 256-pixel form spills)
+    const int tiles = above ? (HW / W / 2) * (W / (TPX / 2)) : cdiv(HW, TPX);
     int wpg = tune_int("FS_GRAM_BWD2_WGS", 256) / (N * NH);
     if (wpg < 1) wpg = 1;
     if (wpg > tiles) wpg = tiles;
     a.wpg = wpg;
     const unsigned grid = (unsigned)(N * NH * wpg);
     const size_t lds = (size_t)TPX * (C + 1) * sizeof(float);
+    if (tune_int("FS_CONV_DEBUG", 0))
+        fprintf(stderr, "gram_bwd2: N %d HW %d (W %d) C %d tile %d px%s%s, %d tiles / sample, %u workgroups\n", N, HW, W, C, TPX, above ? " + pool routing + mask" : "",
+                add ? " + addend" : "", tiles, grid);
     Profiler* prof = Profiler::current();
     if (prof) prof->begin(PF_GRAM_BWD, 2.0 * N * (double)HW * C * C, s);
-    if (C == 64) {
+    if (above) {
+        static BigLds l64, l128, l256;
+        if (C == 64) {
+            l64.ensure(reinterpret_cast<const void*>(gram_bwd_kernel<64, 1, 256, true>));
+            hipLaunchKernelGGL((gram_bwd_kernel<64, 1, 256, true>), dim3(grid), dim3(256), lds, s, a);
+        } else if (C == 128) {
+            l128.ensure(reinterpret_cast<const void*>(gram_bwd_kernel<128, 4, 128, true>));
+            hipLaunchKernelGGL((gram_bwd_kernel<128, 4, 128, true>), dim3(grid), dim3(256), lds, s, a);
+        } else {
+            l256.ensure(reinterpret_cast<const void*>(gram_bwd_kernel<256, 4, 128, true>));
+            hipLaunchKernelGGL((gram_bwd_kernel<256, 4, 128, true>), dim3(grid), dim3(256), lds, s, a);
+        }
+    } else if (C == 64) {
         static BigLds lds_attr;
         lds_attr.ensure(reinterpret_cast<const void*>(gram_bwd_kernel<64, 1, 256>));
         hipLaunchKernelGGL((gram_bwd_kernel<64, 1, 256>), dim3(grid), dim3(256), lds, s, a);

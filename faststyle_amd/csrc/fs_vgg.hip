@@ -440,6 +440,16 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
                         return 0;
                     }
                 }
+                // (round 5) ... and the streaming Gram-gradient kernel does the routing and the mask itself where the map tiles into row pairs (the
+                // three pooled style layers of a 256 x 256 step): vgg_bwd_route's 0.63 ms per batch-32 step are gone, the tap tensor is never written
+                int n_style_here = 0;
+                for (int k = 0; k < cfg.n_style; ++k) n_style_here += cfg.style_layer[k] == l;
+                if (fuse_dst && fuse_above && n_style_here == 1 && gram_bwd2_route_eligible(N, H, W, C)) {
+                    FS_TRY(gram_bwd2_launch(a.x, a.w, a.add_src, fuse_dst, N, H * W, C, s, fuse_above, W));
+                    *fused = true;
+                    *out = nullptr;
+                    return 0;
+                }
                 if (gram_bwd2_eligible(N, H * W, C))   // streaming kernel with S[n] in registers (fs_gram.hip)
                     FS_TRY(gram_bwd2_launch(a.x, a.w, a.add_src, dst, N, H * W, C, s));
                 else

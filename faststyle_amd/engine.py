@@ -517,6 +517,7 @@ class Engine(object):
         d.add_pad = int(kw.get("add_pad", 0))
         d.w_nstride = int(kw.get("w_nstride", 0))
         d.mask_src = p(kw.get("mask_src"))
+        d.route_src = p(kw.get("route_src"))
         inb = kw.get("inb")      # (z, mean, rstd, a, b, relu): also leave the instance-norm-backward partial sums of the unit that produced z
         if kw.get("winograd") == "4t":     # F(4x4,3x3), 16-tile items (fs_wino4t.hip)
             U = self.mem.empty((36, Cin, Cout))

@@ -223,6 +223,13 @@ typedef struct {
     const float* inb_b;
     int inb_relu;
     float* inb_rec;
+    /* optional, with mask_src, no add_pad: [N,ceil(Ho/2),ceil(Wo/2),Cout], the gradient of tf.nn.max_pool 2x2/2 SAME over mask_src
+     * (vgg16.py:68,104,154); it is routed to the FIRST maximum of every window (TF MaxPoolGrad) and added before the mask:
+     *   y = mask_src > 0 ? y + (this pixel is its window's arg-max ? route_src : 0) : 0
+     * -- what fs_perceptual_loss has the Gram-gradient launch of relu1_2 / relu2_2 / relu3_3 do (a 1x1 conv with one C x C filter per sample over
+     * x = mask_src): the streaming kernel of fs_gram.hip for C = 64 / 128 / 256, even Ho and Wo a multiple of 128 (C = 64) or 64 (add_src allowed),
+     * else the direct kernel (no add_src); a launch that cannot take it is an error (-2). */
+    const float* route_src;
 } fs_conv_desc;
 /* U = G g G^T for every (ci, co) filter g = w[:, :, ci, co] of a 3x3 HWIO filter (Lavin & Gray F(2x2,3x3)), 16 values per
  * filter, in the order the Winograd kernels stage them; the caller owns U (16*Cin*Cout floats; Cin % 8 == 0).

@@ -623,6 +623,44 @@ def test_gram_gradient_streaming_kernel(eng, shape, with_add):
     assert rel(y, want) < TOL
 
 
+@pytest.mark.parametrize("shape", [(2, 4, 256, 64), (1, 6, 128, 64), (2, 4, 128, 128), (1, 2, 64, 128), (2, 4, 128, 256), (1, 6, 64, 256),
+                                   (1, 4, 96, 64), (1, 5, 128, 128)])
+@pytest.mark.parametrize("with_add", [False, True])
+def test_gram_gradient_with_pool_routing_and_mask(eng, shape, with_add, monkeypatch):
+    """(F S (+ addend) + MaxPoolGrad(above) routed through F) * (F > 0) in ONE launch (fs_conv_desc.route_src; fs_gram.hip gram_bwd_kernel<.., RT>:
+    tiles of two map rows, the four pixels of a pooling window in one lane) -- what fs_perceptual_loss runs at relu1_2 / relu2_2 / relu3_3 instead
+    of the Gram-gradient launch + vgg_bwd_route (the adjoint of vgg16.py:63-67 and :48 behind train.py:203).  Ties inside a window (post-ReLU zeros,
+    repeated values) go to the FIRST maximum.  The last two shapes do not tile into row pairs: the direct kernel takes them (no addend there)."""
+    rng = np.random.default_rng(17)
+    n, h, w, c = shape
+    streaming = h % 2 == 0 and w % (128 if c == 64 else 64) == 0
+    if with_add and not streaming:
+        pytest.skip("the direct kernel's routing epilogue takes no addend")
+    x = np.maximum(rng.standard_normal(shape), 0).astype(np.float32)                 # post-ReLU features: zeros tie
+    x[:, :, ::6, :] = np.round(x[:, :, ::6, :])                                      # ... and repeated positive values
+    s = (rng.standard_normal((n, c, c)) * 0.1).astype(np.float32)
+    above = rng.standard_normal((n, -(-h // 2), -(-w // 2), c)).astype(np.float32)
+    add = rng.standard_normal(shape).astype(np.float32) if with_add else None
+    _, idx = nnops.max_pool_2x2(x.astype(np.float64))
+    want = np.einsum("nhwc,ncd->nhwd", x.astype(np.float64), s.astype(np.float64))
+    if with_add:
+        want = want + add
+    want = (want + nnops.max_pool_2x2_bwd(above.astype(np.float64), idx, (h, w))) * (x > 0)
+    xd = up(eng, x)
+    kw = {"w_nstride": c * c, "mask_src": xd, "route_src": up(eng, above)}
+    if with_add:
+        kw["add_src"] = up(eng, add)
+    y = down(eng, eng.conv2d(xd, up(eng, s.reshape(n, 1, 1, c, c)), 1, "SAME", **kw))
+    assert y.shape == want.shape
+    assert rel(y, want) < TOL
+    assert np.array_equal(y == 0, want == 0)     # the mask and the routing are exact decisions
+    if streaming:   # bit for bit the two-launch form's result: tap = F S (+ addend), then the routing pass's sums in its order
+        tap = down(eng, eng.conv2d(xd, up(eng, s.reshape(n, 1, 1, c, c)), 1, "SAME", w_nstride=c * c, **({"add_src": kw["add_src"]} if with_add else {})))
+        routed = nnops.max_pool_2x2_bwd(above, idx, (h, w))
+        two = np.where(x > 0, np.where(routed != 0, tap + routed, tap), np.float32(0)).astype(np.float32)
+        assert np.array_equal(y, two)
+
+
 # ------------------------------------------------------------------ full-size properties (no CPU oracle at these sizes)
 FULL = [("vgg3_2_b8", (8, 64, 64, 256), 256, 3, 1), ("vgg1_2_b8", (8, 256, 256, 64), 64, 3, 1),
         ("vgg4_2_b4", (4, 32, 32, 512), 512, 3, 1), ("initconv_1_b4", (4, 336, 336, 16), 32, 3, 2),

@@ -402,6 +402,30 @@ def test_pool_gradient_routing_fused_into_the_gram_gradient_conv(eng, knob, hw):
     assert flat_close(dy1, dyo)
 
 
+def test_pool_gradient_routing_in_the_streaming_gram_gradient_kernel(eng, knob):
+    """Round 5: where the three pooled style layers tile into row pairs (every 256-wide input: relu1_2 8 x 256, relu2_2 4 x 128, relu3_3 2 x 64 here;
+    relu3_3 also carries the content term, i.e. the addend) the streaming Gram-gradient kernel itself routes the max-pool gradient and applies the
+    ReLU mask (gram_bwd_kernel<.., RT>) and vgg_bwd_route does not run.  Bit for bit the three-launch result (FS_GRAM_ROUTE_FUSED=0), and the oracle's."""
+    rng = np.random.default_rng(6)
+    Wv = perceptual.synthetic_vgg_weights(seed=3)
+    eng.vgg_load(Wv)
+    cfg = engine.default_loss_cfg()
+    style = rng.uniform(0, 255, (1, 40, 36, 3)).astype(np.float32)
+    tg = eng.style_targets(eng.mem.from_numpy(style), cfg)
+    y = rng.uniform(0, 255, (2, 8, 256, 3)).astype(np.float32)
+    xc = rng.uniform(0, 255, (2, 8, 256, 3)).astype(np.float32)
+    l1, dy1 = eng.perceptual_loss(eng.mem.from_numpy(y), eng.mem.from_numpy(xc), tg, cfg)
+    l1, dy1 = eng.mem.to_numpy(l1).copy(), eng.mem.to_numpy(dy1).copy()
+    knob("FS_GRAM_ROUTE_FUSED", 0)
+    l0, dy0 = eng.perceptual_loss(eng.mem.from_numpy(y), eng.mem.from_numpy(xc), tg, cfg)
+    l0, dy0 = eng.mem.to_numpy(l0), eng.mem.to_numpy(dy0)
+    assert np.array_equal(l0, l1) and np.array_equal(dy0, dy1)
+    tgo = perceptual.target_grams(style.astype(np.float64), f64(Wv), cfg["style_layers"])
+    feats = perceptual.vgg16(xc.astype(np.float64), f64(Wv), upto="conv3_3")
+    _, dyo = perceptual.perceptual_loss(y.astype(np.float64), [feats["conv3_3"]], tgo, f64(Wv), beta=0.0)
+    assert flat_close(dy1, dyo)
+
+
 def test_adam_tf_step_matches_oracle(eng):
     rng = np.random.default_rng(2)
     n = 5000
