@@ -106,6 +106,8 @@ struct ConvArgs {
                             // (the backward of vgg16.py's pool + ReLU behind a tapped layer, fused into the Gram-gradient conv)
     float* pool_out;        // optional [N,Ho/2,Wo/2,Cout] (Winograd kernels, even Ho/Wo, no split-K): max over every 2x2 output tile =
                             // tf.nn.max_pool 2x2/2 of the stored result (vgg16.py:68,104,154) straight from the epilogue's registers
+    int y_keep_n;           // with pool_out (fs_wino4t.hip): > 0 -- samples n >= y_keep_n get the pooled tensor only, their full-resolution y is NOT stored (the content
+                            // half of the perceptual-loss batch at conv1_2 / conv2_2: nothing reads it again)
     long long w_nstride;
     int prof_tag;            // 1: launched by the transform net -- selects the PROFILER ROW only (no effect on the plan or the computation)
     int tnet_plan;           // 1: plan as the transform net's launches are planned -- 16-tile items in fs_wino4t.hip whatever the grid (the layout allocated

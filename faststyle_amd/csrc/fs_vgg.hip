@@ -208,7 +208,7 @@ void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, 
 
 // pool: optional destination of the 2x2/2 max-pool of the result; *pooled tells whether the conv launch produced it
 static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, const float* w_wino, const float* w_wino2, const float* w_wino4, const float* w_wino4t, const float* w_wino4u, const float* bias, const float* ab,
-                    float* y, float* split_ws, size_t split_ws_floats, hipStream_t s, float* pool = nullptr, bool* pooled = nullptr) {
+                    float* y, float* split_ws, size_t split_ws_floats, hipStream_t s, float* pool = nullptr, bool* pooled = nullptr, int y_keep_n = 0) {
     ConvArgs a{};
     a.x = x;
     a.w = w;
@@ -239,6 +239,7 @@ static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, 
     if (pool && (a.p.variant == 5 || a.p.variant == 6 || a.p.variant == 10 || a.p.variant == 11) && a.p.ksplit <= 1 && !(H & 1) && !(W & 1) && tune_int("FS_VGG_POOL_FUSED", 1)) {
         a.pool_out = pool;   // the Winograd epilogues hold whole 2x2 tiles: the pooled tensor comes for one extra store per tile
         if (pooled) *pooled = true;
+        if (a.p.variant == 11 && tune_int("FS_VGG_SKIP_CONTENT_Y", 1)) a.y_keep_n = y_keep_n;
     }
     return conv_launch(a, s);
 }
@@ -258,7 +259,9 @@ static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS],
                         (wl && vgg_use_4t()) ? prepared + wino4t_offset(l, false) : nullptr,
                         (wl && vgg_use_4t() && kCout[l] % 128 == 0) ? prepared + wino4u_offset(l, false) : nullptr, b[l],
                         ws + L.ab, ws + L.act[l], ws + L.splitws, L.splitws_floats, s,
-                        (pool_after(l) && l < L.lmax) ? ws + L.pool[pool_index(l)] : nullptr, &pooled));
+                        (pool_after(l) && l < L.lmax) ? ws + L.pool[pool_index(l)] : nullptr, &pooled,
+                        // (the content half [N, NB) only feeds the next layer: of a pooled layer below the content layer it needs the pooled tensor alone)
+                        (nb > L.N && l < L.cmax) ? L.N : 0));
         src = ws + L.act[l];
         if (pool_after(l) && l < L.lmax) {
             if (!pooled)

@@ -613,6 +613,8 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // (EPI 3 with a.y_keep_n: this sample's full-resolution result is read by nobody -- only its pooled tensor is stored; wave-uniform)
+            const bool keep_y = !(EPI == 3 && pool && a.y_keep_n > 0 && I.n >= a.y_keep_n);
 #pragma unroll
             for (int px = 0; px < 16; ++px) {
                 const float av4[4] = {ad[px].x, ad[px].y, ad[px].z, ad[px].w};
@@ -625,7 +627,8 @@ __global__ __launch_bounds__(256) void wino4t_conv_kernel(ConvArgs a) {
                     if (EPI == 4) v[r] = av4[r] > 0.f ? v[r] : 0.f;
                     if (EPI == 3) o[px][r] = v[r];   // (the pool reads the stored values)
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fs_u32x4, make_float4(v[0], v[1], v[2], v[3])), yr, voff(px), soff(px), 0);
+                if (EPI != 3 || keep_y)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fs_u32x4, make_float4(v[0], v[1], v[2], v[3])), yr, voff(px), soff(px), 0);
             }
             if (pool) {   // 2x2/2 max-pool: the tile's four windows (tiles sit on multiples of four; Ho, Wo even)
                 const float* pb_ = a.pool_out + (size_t)I.n * (a.Ho >> 1) * (a.Wo >> 1) * a.Cout;
