@@ -363,6 +363,9 @@ struct GramBwdArgs {
     int wpg;            // workgroups per (sample, channel half)
     const float* above; // RT: [N][H/2][W/2][C], the gradient of max_pool(F)
     int W;              // RT: map width (H = HW / W)
+    const float* content;   // RT, optional [N][HW][C]: the content features -- the addend is cscale * (F - content) (the content-loss gradient, formed
+    float cscale;           // here instead of read), and cpartial[workgroup] = the workgroup's sum of (F - content)^2 (the loss's partial sums)
+    float* cpartial;
 };
 }  // namespace
 
@@ -390,12 +393,15 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
     const int wi = lin % a.wpg;
     lin /= a.wpg;
     const int nh = lin % NH, n = lin / NH;
-    constexpr int TW = TPX / 2, TWSH = TW == 128 ? 7 : 6;  // RT: tile columns
-    static_assert(!RT || ((WM % 2) == 0 && (TW == 128 || TW == 64)), "RT tiles: row pairs");
+    constexpr int TW = TPX / 2;                            // RT: tile columns
+    static_assert(!RT || ((WM % 2) == 0 && TW % 32 == 0), "RT tiles: row pairs of whole 32-column blocks");
     const int tpr = RT ? a.W / TW : 1;                     // RT: tiles per row pair
     const int tiles = RT ? (a.HW / a.W / 2) * tpr : (a.HW + TPX - 1) / TPX;
     const int t_beg = (int)((long long)tiles * wi / a.wpg), t_end = (int)((long long)tiles * (wi + 1) / a.wpg);
-    if (t_beg >= t_end) return;
+    if (t_beg >= t_end) {
+        if (RT && a.cpartial && tid == 0) a.cpartial[blockIdx.x] = 0.f;
+        return;
+    }
     const int co0 = nh * CW + nbw * NB * 32;               // first output channel of this wave
     // RT: first pixel of tile t = rows 2 ty, 2 ty + 1, columns tx TW ..
     auto tile_p0 = [&](int t) {
@@ -437,12 +443,15 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
     float4 pv[SX];
     auto issue = [&](int t) {
         if constexpr (RT) {
-            const unsigned base = (unsigned)tile_p0(t) * (unsigned)(C * 4), row1 = (unsigned)(a.W - TW) * (unsigned)(C * 4);
+            // pass i fills stage rows i P .. i P + P - 1 (P = 256 / C4 pixels, P divides 32): one map row, 32-column block (i P) >> 6, columns from
+            // (i P) & 31 -- the thread's part of the address is tid * 16 as in the plain form, the pass's part is a scalar; whole tiles only
+            constexpr int P = 256 / C4;
+            const unsigned base = (unsigned)tile_p0(t) * (unsigned)(C * 4), row1 = (unsigned)a.W * (unsigned)(C * 4);
 #pragma unroll
-            for (int i = 0; i < SX; ++i) {   // element e: tile pixel e / C4 in row-major order (row = pixel / TW), whole tiles only
-                const int e = tid + i * 256;
-                const unsigned off = base + (unsigned)e * 16u + ((e >> C4SH) >> TWSH ? row1 : 0u);
-                pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(fr, off, 0, 0));
+            for (int i = 0; i < SX; ++i) {
+                const int qi = i * P;
+                const unsigned soff = base + (((qi >> 5) & 1) ? row1 : 0u) + (unsigned)(((qi >> 6) * 32 + (qi & 31)) * C * 4);
+                pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(fr, (unsigned)tid * 16u, __builtin_amdgcn_readfirstlane(soff), 0));
             }
             return;
         }
@@ -457,12 +466,7 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < SX; ++i) {
             const int e = tid + i * 256;
-            int q = e >> C4SH;   // stage row of the element's pixel
-            if constexpr (RT) {
-                const int row = q >> TWSH, col = q & (TW - 1);
-                q = (col >> 5) * 64 + row * 32 + (col & 31);
-            }
-            float* d = smem + q * S + (e & (C4 - 1)) * 4;
+            float* d = smem + (e >> C4SH) * S + (e & (C4 - 1)) * 4;   // (RT: the same stage rows -- issue() chose the pixels to suit)
             d[0] = pv[i].x;
             d[1] = pv[i].y;
             d[2] = pv[i].z;
@@ -511,28 +515,64 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
     }
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(dFn, 0, f_bytes, 0x00020000);
     const float* addn = a.add ? a.add + (size_t)n * a.HW * C : nullptr;
+    const float* contn = RT && a.content ? a.content + (size_t)n * a.HW * C : nullptr;
+    float csum = 0.f;
+    // (RT: every global access of the routing pass is a buffer operation "lane offset register + SCALAR offset": the per-element parts are
+    // wave-uniform, and as 64-bit lane addresses they were hoisted out of the tile loop into ~100 spilled registers)
+    auto rsrc_of = [&](const float* p, unsigned bytes) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t cr = rsrc_of(RT ? (contn ? contn : (addn ? addn : Fn)) : Fn, f_bytes);                     // content features or addend
+    const __amdgpu_buffer_rsrc_t ar = rsrc_of(RT ? a.above + (size_t)n * (a.HW / 4) * C : Fn, RT ? f_bytes / 4 : f_bytes);   // pooled gradient
+    auto ldf = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, __builtin_amdgcn_readfirstlane(soff), 0));
+    };
     // ---- RT: the pooled gradient of the tile's windows (loaded beside the next tile, before the sweep), the routing pass over the accumulators
     // (after the sweep, while the stage still holds F), and the store
     constexpr int NW = RT ? (WM / 2) * NB * 8 : 1;
     float da[NW];
-    const float* aboven = RT ? a.above + (size_t)n * (a.HW / 4) * C : nullptr;
     auto issue_above = [&](int t) {
         const int ty = t / tpr, tx = t - ty * tpr;
         // window (mp, nn, wd) of this lane: column (tx TW + (mw WM / 2 + mp) 32 + pi) / 2 of pooled row ty, pi = 2 (wd & 1) + 8 (wd >> 1) + 4 kq
-        const float* base = aboven + ((size_t)ty * (a.W >> 1) + ((tx * TW + (mw * WM / 2) * 32 + 4 * kq) >> 1)) * C + co0 + lm;
+        const unsigned base = ((unsigned)(ty * (a.W >> 1) + ((tx * TW + (mw * WM / 2) * 32 + 4 * kq) >> 1)) * (unsigned)C + (unsigned)(co0 + lm)) * 4u;
 #pragma unroll
         for (int mp = 0; mp < WM / 2; ++mp)
 #pragma unroll
             for (int nn = 0; nn < NB; ++nn)
 #pragma unroll
-                for (int wd = 0; wd < 8; ++wd) da[(mp * NB + nn) * 8 + wd] = base[(mp * 16 + (wd & 1) + 4 * (wd >> 1)) * C + nn * 32];
+                for (int wd = 0; wd < 8; ++wd) da[(mp * NB + nn) * 8 + wd] = ldf(ar, base, (unsigned)((mp * 16 + (wd & 1) + 4 * (wd >> 1)) * C + nn * 32) * 4u);
     };
     auto route = [&](int t) {
         const int p0 = tile_p0(t);
         const float* frow = smem + (mw * WM * 32 + 4 * kq) * S + co0 + lm;   // F of this lane's pixels: stage row (mw WM + m) 32 + pi
         const unsigned lane_off = ((unsigned)(p0 + (mw * WM / 2) * 32 + 4 * kq) * (unsigned)C + (unsigned)(co0 + lm)) * 4u;
         const unsigned row1 = (unsigned)a.W * (unsigned)(C * 4);
-        if (addn) {   // (sixteen loads at a time, as the plain epilogue's)
+        constexpr int CH = 16;
+        if (contn) {   // the content term formed here: cscale * (F - content) added, (F - content)^2 summed -- sqdiff_kernel's products, rounded as there
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int nn = 0; nn < NB; ++nn)
+#pragma unroll
+                    for (int h = 0; h < 16; h += CH) {   // (C = 256: eight at a time -- registers)
+                        float fc[CH], ff[CH];
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) {
+                            const int r = h + k;
+                            fc[k] = ldf(cr, lane_off, (m & 1) * row1 + (unsigned)(((m >> 1) * 32 + (r & 3) + 8 * (r >> 2)) * C + nn * 32) * 4u);
+                            ff[k] = frow[(m * 32 + (r & 3) + 8 * (r >> 2)) * S + nn * 32];
+                        }
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) {
+                            const float d = ff[k] - fc[k];
+                            csum = fmaf(d, d, csum);
+                            acc[m][nn][h + k] += __fmul_rn(a.cscale, d);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+        } else if (addn) {   // (sixteen loads at a time, as the plain epilogue's)
 #pragma unroll
             for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -540,7 +580,7 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
                     float ad[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        ad[r] = addn[(lane_off + (m & 1) * row1 + (unsigned)(((m >> 1) * 32 + (r & 3) + 8 * (r >> 2)) * C + nn * 32) * 4u) >> 2];
+                        ad[r] = ldf(cr, lane_off, (m & 1) * row1 + (unsigned)(((m >> 1) * 32 + (r & 3) + 8 * (r >> 2)) * C + nn * 32) * 4u);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[m][nn][r] += ad[r];
                     __builtin_amdgcn_sched_barrier(0);
@@ -594,8 +634,8 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
             for (int nn = 0; nn < NB; ++nn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const unsigned off = lane_off + (m & 1) * row1 + (unsigned)(((m >> 1) * 32 + (r & 3) + 8 * (r >> 2)) * C + nn * 32) * 4u;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][nn][r]), yr, off, 0, 0);
+                    const unsigned soff = (m & 1) * row1 + (unsigned)(((m >> 1) * 32 + (r & 3) + 8 * (r >> 2)) * C + nn * 32) * 4u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][nn][r]), yr, lane_off, __builtin_amdgcn_readfirstlane(soff), 0);
                 }
         zero_acc();
     };
@@ -639,6 +679,13 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(GramBwdArgs a) {
         if constexpr (RT) store_rt(t);
         else epilogue(t);
         FS_LDS_BARRIER();   // (LDS only: the tile's stores drain during the next sweep instead of being waited for here)
+    }
+    if (RT && a.cpartial) {   // the workgroup's partial sum of the content loss: waves in a fixed order (the stage is free: the loop ended on a barrier)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) csum += __shfl_xor(csum, o);
+        if (lane == 0) smem[wave] = csum;
+        __syncthreads();
+        if (tid == 0) a.cpartial[blockIdx.x] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
     }
 }
 
@@ -768,18 +815,33 @@ int gram_symmetrize(const float* dG, float* S, int N, int C, float scale, hipStr
 // the routed form (gram_bwd_kernel<.., RT = true>): whole tiles of two rows x TPX/2 columns
 bool gram_bwd2_route_eligible(int N, int H, int W, int C) {
     if (!tune_int("FS_GRAM_ROUTE_FUSED", 1) || H < 2 || W < 2 || !gram_bwd2_eligible(N, H * W, C)) return false;
-    const int TW = C == 64 ? 128 : 64;
+    const int TW = C == 64 ? 128 : C == 128 ? 64 : 32;
     return !(H & 1) && W % TW == 0;
+}
+
+// workgroups of the routed launch (= the partial sums a content term leaves)
+int gram_bwd2_route_grid(int N, int H, int W, int C) {
+    const int NH = C > 128 ? C / 128 : 1, TPX = C == 64 ? 256 : C == 128 ? 128 : 64;
+    const int tiles = (H / 2) * (W / (TPX / 2));
+    int wpg = tune_int("FS_GRAM_BWD2_WGS", 256) / (N * NH);
+    if (wpg < 1) wpg = 1;
+    if (wpg > tiles) wpg = tiles;
+    return N * NH * wpg;
 }
 
 // dF[n] = F[n] S[n] (+ add[n]);  above != nullptr (gram_bwd2_route_eligible(N, HW / W, W, C)): dF = (that + the max-pool gradient `above`
 // ([N][H/2][W/2][C]) routed through F) * (F > 0)
-int gram_bwd2_launch(const float* F, const float* S, const float* add, float* dF, int N, int HW, int C, hipStream_t s, const float* above, int W) {
+int gram_bwd2_launch(const float* F, const float* S, const float* add, float* dF, int N, int HW, int C, hipStream_t s, const float* above, int W,
+                     const float* content, float cscale, float* cpartial) {
     if (!gram_bwd2_eligible(N, HW, C)) return -1;
     if (above && (W < 1 || HW % W || !gram_bwd2_route_eligible(N, HW / W, W, C))) return -1;
+    if (content && (!above || add || !cpartial)) return -1;
     GramBwdArgs a{};
     a.above = above;
     a.W = W;
+    a.content = content;
+    a.cscale = cscale;
+    a.cpartial = cpartial;
     a.F = F;
     a.S = S;
     a.add = add;
@@ -787,7 +849,7 @@ int gram_bwd2_launch(const float* F, const float* S, const float* add, float* dF
     a.N = N;
     a.HW = HW;
     a.C = C;
-    const int NH = C > 128 ? C / 128 : 1, TPX = C == 256 || (above && C == 128) ? 128 : 256;   // (routed, C = 128: 128-pixel tiles -- the 256-pixel form spills)
+    const int NH = C > 128 ? C / 128 : 1, TPX = above ? (C == 64 ? 256 : C == 128 ? 128 : 64) : (C == 256 ? 128 : 256);   // (routed: half the pixels for C >= 128 -- the plain tile sizes spill with the routing pass's registers)
     const int tiles = above ? (HW / W / 2) * (W / (TPX / 2)) : cdiv(HW, TPX);
     int wpg = tune_int("FS_GRAM_BWD2_WGS", 256) / (N * NH);
     if (wpg < 1) wpg = 1;
@@ -797,7 +859,7 @@ int gram_bwd2_launch(const float* F, const float* S, const float* add, float* dF
     const size_t lds = (size_t)TPX * (C + 1) * sizeof(float);
     if (tune_int("FS_CONV_DEBUG", 0))
         fprintf(stderr, "gram_bwd2: N %d HW %d (W %d) C %d tile %d px%s%s, %d tiles / sample, %u workgroups\n", N, HW, W, C, TPX, above ? " + pool routing + mask" : "",
-                add ? " + addend" : "", tiles, grid);
+                content ? " + content term" : (add ? " + addend" : ""), tiles, grid);
     Profiler* prof = Profiler::current();
     if (prof) prof->begin(PF_GRAM_BWD, 2.0 * N * (double)HW * C * C, s);
     if (above) {
@@ -809,8 +871,8 @@ int gram_bwd2_launch(const float* F, const float* S, const float* add, float* dF
             l128.ensure(reinterpret_cast<const void*>(gram_bwd_kernel<128, 4, 128, true>));
             hipLaunchKernelGGL((gram_bwd_kernel<128, 4, 128, true>), dim3(grid), dim3(256), lds, s, a);
         } else {
-            l256.ensure(reinterpret_cast<const void*>(gram_bwd_kernel<256, 4, 128, true>));
-            hipLaunchKernelGGL((gram_bwd_kernel<256, 4, 128, true>), dim3(grid), dim3(256), lds, s, a);
+            l256.ensure(reinterpret_cast<const void*>(gram_bwd_kernel<256, 4, 64, true>));
+            hipLaunchKernelGGL((gram_bwd_kernel<256, 4, 64, true>), dim3(grid), dim3(256), lds, s, a);
         }
     } else if (C == 64) {
         static BigLds lds_attr;

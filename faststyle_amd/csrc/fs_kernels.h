@@ -515,8 +515,9 @@ int gram2_launch(const float* F, float* G, float* slabs, int N, int HW, int C, f
 // ... and the gradient through them: dF[n] = F[n] S[n] (+ add[n]), S [N][C][C], C = 64, 128 or 256
 bool gram_bwd2_eligible(int N, int HW, int C);
 bool gram_bwd2_route_eligible(int N, int H, int W, int C);
+int gram_bwd2_route_grid(int N, int H, int W, int C);
 int gram_bwd2_launch(const float* F, const float* S, const float* add, float* dF, int N, int HW, int C, hipStream_t s, const float* above = nullptr,
-                     int W = 0);
+                     int W = 0, const float* content = nullptr, float cscale = 0.f, float* cpartial = nullptr);
 int gram_symmetrize(const float* dG, float* S, int N, int C, float scale, hipStream_t s);   // S[n] = scale * (dG[n] + dG[n]^T)
 // streaming conv of the narrow full-resolution layers (fs_cstream.hip): plan variant 7
 bool cstream_eligible(const ConvArgs& a);

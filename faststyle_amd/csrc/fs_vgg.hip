@@ -399,10 +399,27 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         int n_terms = 0;
         for (int i = 0; i < cfg.n_content; ++i) n_terms += cfg.content_layer[i] == l;
         for (int i = 0; i < cfg.n_style; ++i) n_terms += cfg.style_layer[i] == l;
+        int n_style_here = 0, n_content_here = 0;
+        for (int k = 0; k < cfg.n_style; ++k) n_style_here += cfg.style_layer[k] == l;
+        for (int k = 0; k < cfg.n_content; ++k) n_content_here += cfg.content_layer[k] == l;
+        const bool route_in_gram = fuse_dst && fuse_above && n_style_here == 1 && gram_bwd2_route_eligible(N, H, W, C);
+        // (round 5) a layer that carries one content and one style term and takes the routed Gram-gradient launch below forms the content term THERE
+        // (F is that kernel's operand): no sqdiff pass, no content-gradient tensor
+        const bool content_in_gram = route_in_gram && n_content_here == 1 && tune_int("FS_GRAM_CONTENT_FUSED", 1) && gram_bwd2_route_grid(N, H, W, C) <= 1024;
+        const float* fused_content = nullptr;
+        float fused_cscale = 0.f;
+        float* fused_cpartial = nullptr;
         for (int i = 0; i < cfg.n_content; ++i)
             if (cfg.content_layer[i] == l) {
                 const float hwc = (float)H * W * C;
                 const float wgt = cfg.content_weight[i];
+                if (content_in_gram) {
+                    fused_content = ws + L.act[l] + act_n;
+                    fused_cscale = 2.0f * wgt / hwc;
+                    fused_cpartial = term(1, gram_bwd2_route_grid(N, H, W, C), wgt / hwc);
+                    if (!fused_cpartial) return -12;
+                    continue;
+                }
                 // reference losses.py:32-37: w * sum_{b,h,w,c} (phi(Y)-phi_t)^2 / (h*w*c)
                 float* pp = term(1, 1024, wgt / hwc);
                 if (!pp) return -12;
@@ -445,10 +462,8 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
                 }
                 // (round 5) ... and the streaming Gram-gradient kernel does the routing and the mask itself where the map tiles into row pairs (the
                 // three pooled style layers of a 256 x 256 step): vgg_bwd_route's 0.63 ms per batch-32 step are gone, the tap tensor is never written
-                int n_style_here = 0;
-                for (int k = 0; k < cfg.n_style; ++k) n_style_here += cfg.style_layer[k] == l;
-                if (fuse_dst && fuse_above && n_style_here == 1 && gram_bwd2_route_eligible(N, H, W, C)) {
-                    FS_TRY(gram_bwd2_launch(a.x, a.w, a.add_src, fuse_dst, N, H * W, C, s, fuse_above, W));
+                if (route_in_gram) {
+                    FS_TRY(gram_bwd2_launch(a.x, a.w, a.add_src, fuse_dst, N, H * W, C, s, fuse_above, W, fused_content, fused_cscale, fused_cpartial));
                     *fused = true;
                     *out = nullptr;
                     return 0;

@@ -227,7 +227,7 @@ typedef struct {
      * (vgg16.py:68,104,154); it is routed to the FIRST maximum of every window (TF MaxPoolGrad) and added before the mask:
      *   y = mask_src > 0 ? y + (this pixel is its window's arg-max ? route_src : 0) : 0
      * -- what fs_perceptual_loss has the Gram-gradient launch of relu1_2 / relu2_2 / relu3_3 do (a 1x1 conv with one C x C filter per sample over
-     * x = mask_src): the streaming kernel of fs_gram.hip for C = 64 / 128 / 256, even Ho and Wo a multiple of 128 (C = 64) or 64 (add_src allowed),
+     * x = mask_src): the streaming kernel of fs_gram.hip for C = 64 / 128 / 256, even Ho and Wo a multiple of 128 (C = 64), 64 (C = 128) or 32 (add_src allowed),
      * else the direct kernel (no add_src); a launch that cannot take it is an error (-2). */
     const float* route_src;
 } fs_conv_desc;

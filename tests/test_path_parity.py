@@ -404,8 +404,9 @@ def test_pool_gradient_routing_fused_into_the_gram_gradient_conv(eng, knob, hw):
 
 def test_pool_gradient_routing_in_the_streaming_gram_gradient_kernel(eng, knob):
     """Round 5: where the three pooled style layers tile into row pairs (every 256-wide input: relu1_2 8 x 256, relu2_2 4 x 128, relu3_3 2 x 64 here;
-    relu3_3 also carries the content term, i.e. the addend) the streaming Gram-gradient kernel itself routes the max-pool gradient and applies the
-    ReLU mask (gram_bwd_kernel<.., RT>) and vgg_bwd_route does not run.  Bit for bit the three-launch result (FS_GRAM_ROUTE_FUSED=0), and the oracle's."""
+    relu3_3 also carries the content term) the streaming Gram-gradient kernel itself routes the max-pool gradient, applies the ReLU mask
+    (gram_bwd_kernel<.., RT>) and forms the content-loss gradient and partial sums from its own operand; vgg_bwd_route and the sqdiff pass do not run.
+    Against the three-launch result (FS_GRAM_ROUTE_FUSED=0) and the oracle."""
     rng = np.random.default_rng(6)
     Wv = perceptual.synthetic_vgg_weights(seed=3)
     eng.vgg_load(Wv)
@@ -418,11 +419,17 @@ def test_pool_gradient_routing_in_the_streaming_gram_gradient_kernel(eng, knob):
     l1, dy1 = eng.mem.to_numpy(l1).copy(), eng.mem.to_numpy(dy1).copy()
     knob("FS_GRAM_ROUTE_FUSED", 0)
     l0, dy0 = eng.perceptual_loss(eng.mem.from_numpy(y), eng.mem.from_numpy(xc), tg, cfg)
-    l0, dy0 = eng.mem.to_numpy(l0), eng.mem.to_numpy(dy0)
-    assert np.array_equal(l0, l1) and np.array_equal(dy0, dy1)
+    l0, dy0 = eng.mem.to_numpy(l0).copy(), eng.mem.to_numpy(dy0).copy()
+    # the gradient bit for bit; the content loss is summed per workgroup of the Gram-gradient launch instead of per block of the sqdiff pass
+    assert np.array_equal(dy0, dy1) and np.array_equal(l0[2:], l1[2:]) and abs(l0[1] - l1[1]) <= 2e-6 * abs(l0[1])
+    knob("FS_GRAM_ROUTE_FUSED", 1)
+    knob("FS_GRAM_CONTENT_FUSED", 0)      # routing in the kernel, content term from the sqdiff pass: every loss bit for bit too
+    l2, dy2 = eng.perceptual_loss(eng.mem.from_numpy(y), eng.mem.from_numpy(xc), tg, cfg)
+    assert np.array_equal(eng.mem.to_numpy(l2), l0) and np.array_equal(eng.mem.to_numpy(dy2), dy0)
     tgo = perceptual.target_grams(style.astype(np.float64), f64(Wv), cfg["style_layers"])
     feats = perceptual.vgg16(xc.astype(np.float64), f64(Wv), upto="conv3_3")
-    _, dyo = perceptual.perceptual_loss(y.astype(np.float64), [feats["conv3_3"]], tgo, f64(Wv), beta=0.0)
+    lo, dyo = perceptual.perceptual_loss(y.astype(np.float64), [feats["conv3_3"]], tgo, f64(Wv), beta=0.0)
+    np.testing.assert_allclose(l1[:3], [lo[k] for k in ("loss", "content_loss", "style_loss")], rtol=2e-5)
     assert flat_close(dy1, dyo)
 
 
