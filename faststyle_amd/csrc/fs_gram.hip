@@ -278,6 +278,7 @@ struct GramFinishArgs {
 }  // namespace
 __global__ __launch_bounds__(256) void gram_finish_kernel(GramFinishArgs f) {
     __shared__ float sh[4];
+    __shared__ float tile[32][33];
     int q = 0;
 #pragma unroll
     for (int k = 1; k < 4; ++k)
@@ -285,18 +286,22 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(GramFinishArgs f) {
     const GramFinishArgs::J& J_ = f.j[q];
     const GramArgs& a = J_.a;
     const int CG = a.CG;
-    const int bx = (CG * CG / 4 + 255) / 256;
+    const int bx = (CG * CG / 4 + 255) / 256;   // 32 x 32 sub-blocks of the CG x CG tile, one per workgroup
     if ((int)blockIdx.x >= bx) return;   // (uniform per block)
     const int pair_id = (int)blockIdx.y - J_.pair0;
-    const int e4 = (int)blockIdx.x * 256 + (int)threadIdx.x;   // float4 index inside the tile
-    const int r = (e4 * 4) / CG, c = (e4 * 4) - r * CG;
+    // (round 5) a workgroup owns a 32 x 32 sub-block: rows of 128 contiguous bytes for the direct half, and -- through a transposing LDS tile --
+    // rows of 128 contiguous bytes of the MIRRORED half too (the element-wise mirror wrote and read single floats C apart: 110 us per batch-32 step)
+    const int sbn = CG >> 5, sr = (int)blockIdx.x / sbn, sc = (int)blockIdx.x - sr * sbn;
+    const int tr = (int)threadIdx.x >> 3, tc = ((int)threadIdx.x & 7) * 4;
+    const int r = sr * 32 + tr, c = sc * 32 + tc;
     int pair = pair_id, I = 0;
     while (pair >= a.groups - I) {
         pair -= a.groups - I;
         ++I;
     }
     const int J = I + pair, n = (int)blockIdx.z;
-    const bool active = e4 * 4 < CG * CG && !(I == J && CG == 128 && (r >> 5) > (c >> 5));
+    const bool active = !(I == J && CG == 128 && sr > sc);                 // (block-uniform; diagonal 128-tiles hold their upper sub-blocks only)
+    const bool mirror = I != J || (CG == 128 && sr < sc);                  // (blocks ON the diagonal hold both halves already)
     float acc = 0.f;
     if (active) {
         const float* p = a.slabs + (((size_t)n * a.pairs + pair_id) * a.splits) * CG * CG + (size_t)r * CG + c;
@@ -313,28 +318,33 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(GramFinishArgs f) {
         s.z *= J_.scale;
         s.w *= J_.scale;
         const size_t cc = (size_t)a.C * a.C;
-        float* Gn = J_.G + (size_t)n * cc;
+        float* Gn = J_.G ? J_.G + (size_t)n * cc : nullptr;   // (G itself is optional: the training step reads S only)
         float* Sn = J_.S + (size_t)n * cc;
         const int gr = I * CG + r, gc = J * CG + c;
         const float4 t = *reinterpret_cast<const float4*>(J_.Gt + (size_t)gr * a.C + gc);
         const float d[4] = {s.x - t.x, s.y - t.y, s.z - t.z, s.w - t.w};
         const float g = J_.gscale;
-        *reinterpret_cast<float4*>(Gn + (size_t)gr * a.C + gc) = s;
+        if (Gn) *reinterpret_cast<float4*>(Gn + (size_t)gr * a.C + gc) = s;
         *reinterpret_cast<float4*>(Sn + (size_t)gr * a.C + gc) = make_float4(g * d[0], g * d[1], g * d[2], g * d[3]);
-        const bool mirror = I != J || (CG == 128 && (r >> 5) < (c >> 5));   // (blocks ON the diagonal hold both halves already)
-        if (mirror) {
-            const float sv[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                Gn[(size_t)(gc + e) * a.C + gr] = sv[e];
-                // (the target is symmetric up to rounding, the product of another kernel: the mirrored element takes ITS target)
-                const float dm = sv[e] - J_.Gt[(size_t)(gc + e) * a.C + gr];
-                Sn[(size_t)(gc + e) * a.C + gr] = g * dm;
-                acc = fmaf(dm, dm, acc);
-            }
-        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = fmaf(d[e], d[e], acc);
+        if (mirror) {
+            tile[tr][tc + 0] = s.x;
+            tile[tr][tc + 1] = s.y;
+            tile[tr][tc + 2] = s.z;
+            tile[tr][tc + 3] = s.w;
+            __syncthreads();   // (block-uniform branch)
+            // mirrored row = a column of the sub-block: element (J CG + sc 32 + tr, I CG + sr 32 + tc ..) = sub-block elements (tc .. tc + 3, tr)
+            const float sv[4] = {tile[tc + 0][tr], tile[tc + 1][tr], tile[tc + 2][tr], tile[tc + 3][tr]};
+            const size_t mo = (size_t)(J * CG + sc * 32 + tr) * a.C + (size_t)(I * CG + sr * 32 + tc);
+            // (the target is symmetric up to rounding, the product of another kernel: the mirrored element takes ITS target)
+            const float4 tm = *reinterpret_cast<const float4*>(J_.Gt + mo);
+            const float dm[4] = {sv[0] - tm.x, sv[1] - tm.y, sv[2] - tm.z, sv[3] - tm.w};
+            if (Gn) *reinterpret_cast<float4*>(Gn + mo) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+            *reinterpret_cast<float4*>(Sn + mo) = make_float4(g * dm[0], g * dm[1], g * dm[2], g * dm[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = fmaf(dm[e], dm[e], acc);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);

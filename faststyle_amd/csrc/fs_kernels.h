@@ -614,7 +614,7 @@ int gram2_stream(const float* F, float* slabs, int N, int HW, int C, hipStream_t
 struct GramFinishJob {
     const float* slabs;
     const float* Gt;      // [C][C] target
-    float* G;             // [N][C][C]
+    float* G;             // [N][C][C], optional (nullptr: not written)
     float* S;             // [N][C][C]
     float* partial;       // gram2_finish_partials(N, C) floats
     int HW, C;

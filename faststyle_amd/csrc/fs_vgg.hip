@@ -363,7 +363,7 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
                 GramFinishJob& j = jobs[i];
                 j.slabs = ws + L.gslab[i];
                 j.Gt = cfg.target_gram[i];
-                j.G = ws + L.gram[i];
+                j.G = tune_int("FS_GRAM_FINISH_KEEP_G", 0) ? ws + L.gram[i] : nullptr;   // (nothing reads G after the finish: S and the loss's partial sums are its products)
                 j.S = ws + L.sm[i];
                 j.HW = HW;
                 j.C = C;
