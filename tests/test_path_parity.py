@@ -413,8 +413,8 @@ def test_pool_gradient_routing_in_the_streaming_gram_gradient_kernel(eng, knob):
     cfg = engine.default_loss_cfg()
     style = rng.uniform(0, 255, (1, 40, 36, 3)).astype(np.float32)
     tg = eng.style_targets(eng.mem.from_numpy(style), cfg)
-    y = rng.uniform(0, 255, (2, 8, 256, 3)).astype(np.float32)
-    xc = rng.uniform(0, 255, (2, 8, 256, 3)).astype(np.float32)
+    y = rng.uniform(0, 255, (1, 8, 256, 3)).astype(np.float32)
+    xc = rng.uniform(0, 255, (1, 8, 256, 3)).astype(np.float32)
     l1, dy1 = eng.perceptual_loss(eng.mem.from_numpy(y), eng.mem.from_numpy(xc), tg, cfg)
     l1, dy1 = eng.mem.to_numpy(l1).copy(), eng.mem.to_numpy(dy1).copy()
     knob("FS_GRAM_ROUTE_FUSED", 0)
