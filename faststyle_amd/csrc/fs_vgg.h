@@ -11,6 +11,7 @@ struct VggLayout {
     int H, W;
     int lmax;     // last conv layer evaluated
     int cmax;     // last layer the content half is needed for (-1: none)
+    unsigned content_mask;   // bit l: a content term reads the content half of act[l] (its full-resolution store must not be skipped)
     int Hl[FS_VGG_NLAYERS], Wl[FS_VGG_NLAYERS];
     size_t xin, ab, act[FS_VGG_NLAYERS], pool[3];
     size_t gram[4], sm[4], slabs;

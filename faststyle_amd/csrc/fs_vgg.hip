@@ -129,6 +129,7 @@ void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, 
     for (int i = 0; i < cfg.n_content; ++i) {
         if (cfg.content_layer[i] > lmax) lmax = cfg.content_layer[i];
         if (cfg.content_layer[i] > cmax) cmax = cfg.content_layer[i];
+        if (with_content) L->content_mask |= 1u << cfg.content_layer[i];
     }
     if (!with_content) cmax = -1;
     L->lmax = lmax;
@@ -260,8 +261,9 @@ static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS],
                         (wl && vgg_use_4t() && kCout[l] % 128 == 0) ? prepared + wino4u_offset(l, false) : nullptr, b[l],
                         ws + L.ab, ws + L.act[l], ws + L.splitws, L.splitws_floats, s,
                         (pool_after(l) && l < L.lmax) ? ws + L.pool[pool_index(l)] : nullptr, &pooled,
-                        // (the content half [N, NB) only feeds the next layer: of a pooled layer below the content layer it needs the pooled tensor alone)
-                        (nb > L.N && l < L.cmax) ? L.N : 0));
+                        // (the content half [N, NB) only feeds the next layer: of a pooled layer below the LAST content layer it needs the pooled tensor
+                        // alone -- unless a content term of its own reads the full-resolution half, --loss_content_layers takes several)
+                        (nb > L.N && l < L.cmax && !((L.content_mask >> l) & 1u)) ? L.N : 0));
         src = ws + L.act[l];
         if (pool_after(l) && l < L.lmax) {
             if (!pooled)
