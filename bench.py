@@ -51,6 +51,32 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: bf16 MFMA, dense (n
 PEAK_HBM_TBS = 8.0                    # spec; 6.29 measured (float4 copy)
 
 
+def vgg_algorithmic_bytes(B, S=256, cmax=6, lmax=9):
+    """Algorithmic HBM bytes of the 18 F(4x4) VGG16 launches of one train step (conv1_2 ... conv4_3 forward on [y ; content] up to conv3_3 and on y
+    beyond, their nine input gradients): every input, ReLU-mask source and output ONCE, the content half's full-resolution conv1_2 / conv2_2 outputs
+    not at all (nothing reads them), filters not counted (0.24 GB, L2 / Infinity-Cache resident).  Returns (forward reads, forward writes,
+    input-gradient reads incl. masks, input-gradient writes) in bytes -- 2.72 + 2.82 + 2.89 + 1.44 = 9.87 GB at batch 32."""
+    cin = [3, 64, 64, 128, 128, 256, 256, 256, 512, 512]
+    cout = [64, 64, 128, 128, 256, 256, 256, 512, 512, 512]
+    pool_after = lambda l: l in (1, 3, 6)
+    h, hl = S, []
+    for l in range(lmax + 1):
+        hl.append(h)
+        if pool_after(l) and l < lmax:
+            h //= 2
+    fr = fw = dr = dw = 0
+    for l in range(1, lmax + 1):
+        nb, px = (2 * B if l <= cmax else B), hl[l] * hl[l]
+        fr += nb * px * cin[l] * 4
+        if pool_after(l) and l < lmax:
+            fw += (B if l < cmax else nb) * px * cout[l] * 4 + nb * (px // 4) * cout[l] * 4
+        else:
+            fw += nb * px * cout[l] * 4
+        dr += B * px * cout[l] * 4 + (0 if pool_after(l - 1) else B * px * cin[l] * 4)
+        dw += B * px * cin[l] * 4
+    return fr, fw, dr, dw
+
+
 def newest_profile(stem):
     """profiles/rNN_<stem>: the newest round's file (the rocprofv3 PMC summaries bench.py quotes HBM traffic from)."""
     import glob
@@ -563,12 +589,18 @@ def main():
         dom = per_kernel[names[di]]
         traffic, traffic_src = None, None
         sym = names[di].split(" (")[0]                     # the kernel symbol of the dominant row
-        if sym == "wino4t_conv_kernel":                    # (its 32-tile VGG16 instances and 16-tile transform-net instances are folded separately)
-            sym += "<2>" if di == F_WINO4T_VGG else "<1>"
+        fam_key = None
+        if sym == "wino4t_conv_kernel":                    # (its big-item VGG16 instances <2>, <3> and the transform-net instances <1>, <4> are separate rows)
+            fam_key = "wino4t_conv_kernel (VGG16 big items)" if di == F_WINO4T_VGG else "wino4t_conv_kernel (transform net)"
+            sym = fam_key
         tpath = newest_profile("hbm_traffic_pmc.json")
+        alg_launch = None
+        if di == F_WINO4T_VGG and S == 256:
+            alg = vgg_algorithmic_bytes(B)
+            alg_launch = int(sum(alg) / 18)
         if tpath:
             tj = json.load(open(tpath))
-            k = tj.get("kernels", {}).get(sym)
+            k = tj.get("families", {}).get(fam_key) if fam_key else tj.get("kernels", {}).get(sym)
             if k and tj.get("batch_per_gpu") == B and same_build(tj):
                 traffic, traffic_src = k["traffic_bytes_per_launch"], os.path.relpath(tpath, ROOT)
             elif k and tj.get("batch_per_gpu") == B:
@@ -599,6 +631,10 @@ def main():
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch of the kernel symbol %s (2*FETCH_SIZE+WRITE_SIZE, KiB "
                                                              "counters, separate rocprofv3 --pmc passes)" % sym,
                          "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_launch,
+                         "traffic_over_algorithmic": round(traffic / alg_launch, 3) if (traffic and alg_launch) else None,
+                         "algorithmic_bytes_note": "VGG16: every input, mask source and output of the 18 launches once (bench.py vgg_algorithmic_bytes; "
+                                                   "9.87 GB per batch-32 step), / 18 launches" if alg_launch else None,
                          "timed_with": "HIP events on the launch stream, eager pass of %d steps right after the timed region; every row "
                                        "of per_kernel is ONE kernel symbol (template instances summed), so row ms = launches x the "
                                        "average duration of that symbol in profiles/*kernel_stats*" % args.profile_steps,

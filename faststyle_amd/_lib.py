@@ -22,7 +22,7 @@ FS_FLAG_PARAMS_FROZEN = 8
 FS_TNET_WS_Z, FS_TNET_WS_A, FS_TNET_WS_B, FS_TNET_WS_MEAN, FS_TNET_WS_RSTD, FS_TNET_WS_H = 0, 1, 2, 3, 4, 5
 FS_PAD_SAME, FS_PAD_VALID, FS_PAD_EXPLICIT = 0, 1, 2
 FS_SRC_PLAIN, FS_SRC_REFLECT, FS_SRC_DILATE2 = 0, 1, 2
-FS_PROFILE_FAMILIES = 22
+FS_PROFILE_FAMILIES = 23
 
 
 def profile_family_names(lib):
@@ -56,7 +56,8 @@ class fs_conv_desc(Structure):
                 ("w_wino4", c_void_p), ("mask_src", c_void_p), ("pool_out", c_void_p),
                 ("w_wino4t", c_void_p),
                 ("inb_z", c_void_p), ("inb_mean", c_void_p), ("inb_rstd", c_void_p), ("inb_a", c_void_p), ("inb_b", c_void_p),
-                ("inb_relu", c_int), ("inb_rec", c_void_p), ("route_src", c_void_p)]
+                ("inb_relu", c_int), ("inb_rec", c_void_p), ("route_src", c_void_p),
+                ("w_wino6", c_void_p), ("w6_ws", c_void_p), ("w6_ws_bytes", ctypes.c_size_t)]
 
 
 class fs_wgrad_desc(Structure):
@@ -115,6 +116,9 @@ PROTOTYPES = {
     "fs_wino_transform_filter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fs_wino4_transform_filter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fs_wino4t_transform_filter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "fs_wino6_filter_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "fs_wino6_transform_filter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "fs_wino6_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "fs_instnorm_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "fs_instnorm_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

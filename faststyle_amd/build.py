@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["fs_conv.hip", "fs_wino.hip", "fs_wino2.hip", "fs_wino2h.hip", "fs_wino4.hip", "fs_wino4t.hip", "fs_wino4t1b.hip", "fs_wino4t1c.hip", "fs_wino4t1d.hip", "fs_wino4t4a.hip", "fs_wino4t4b.hip", "fs_wino4t2.hip", "fs_wino4t2b.hip", "fs_wgrad.hip", "fs_wgrad2.hip", "fs_wgw.hip", "fs_elem.hip", "fs_fold.hip", "fs_io.hip", "fs_tnet.hip", "fs_bf16.hip", "fs_bstream.hip", "fs_vgg.hip", "fs_c3.hip", "fs_cstream.hip", "fs_s16.hip", "fs_gram.hip", "fs_api.hip"]
+SOURCES = ["fs_conv.hip", "fs_wino.hip", "fs_wino2.hip", "fs_wino2h.hip", "fs_wino4.hip", "fs_wino4t.hip", "fs_wino4t1b.hip", "fs_wino4t1c.hip", "fs_wino4t1d.hip", "fs_wino4t4a.hip", "fs_wino4t4b.hip", "fs_wino4t2.hip", "fs_wino4t2b.hip", "fs_wino6.hip", "fs_wgrad.hip", "fs_wgrad2.hip", "fs_wgw.hip", "fs_elem.hip", "fs_fold.hip", "fs_io.hip", "fs_tnet.hip", "fs_bf16.hip", "fs_bstream.hip", "fs_vgg.hip", "fs_c3.hip", "fs_cstream.hip", "fs_s16.hip", "fs_gram.hip", "fs_api.hip"]
 OUT = os.path.join(HERE, "libfaststyle_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed"]

@@ -37,6 +37,7 @@ struct fs_ctx {
     hipStream_t side;      // second stream for the filter-gradient branch of fs_tnet_backward
     hipEvent_t ev[34];
     bool have_side;
+    const float* prepared_w6 = nullptr;   // the buffer the last fs_vgg_prepare filled WITH the fs_wino6.hip filter pieces (FS_WINO_V=6 at that time); only that buffer has them read
 };
 
 static thread_local char g_err[512] = "";
@@ -322,7 +323,10 @@ size_t fs_vgg_prepared_floats(void) { return fs::vgg_prepared_floats(); }
 int fs_vgg_prepare(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], float* prepared) {
     if (!ctx || !w || !prepared) return fail(-1, "fs_vgg_prepare: null argument");
     const int rc = fs::vgg_prepare(w, prepared, ctx->stream);
-    return rc ? fail(rc, "fs_vgg_prepare failed (%d)", rc) : 0;
+    if (rc < 0) return fail(rc, "fs_vgg_prepare failed (%d)", rc);
+    if (rc == 1) ctx->prepared_w6 = prepared;
+    else if (ctx->prepared_w6 == prepared) ctx->prepared_w6 = nullptr;
+    return 0;
 }
 
 static int check_cfg(const fs_loss_cfg* cfg) {
@@ -354,7 +358,7 @@ int fs_perceptual_loss(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const 
     fs::VggLayout L;
     fs::vgg_layout(N, H, W, *cfg, true, &L);
     if (ws_bytes < L.total_floats * sizeof(float)) return fail(-3, "fs_perceptual_loss: workspace too small");
-    const int rc = fs::perceptual_loss(L, w, b, prepared, *cfg, y, content, losses, dy, (float*)ws, ctx->stream);
+    const int rc = fs::perceptual_loss(L, w, b, prepared, *cfg, y, content, losses, dy, (float*)ws, ctx->stream, ctx->prepared_w6 == prepared);
     return rc ? fail(rc, "fs_perceptual_loss: launch failed (%d)", rc) : 0;
 }
 
@@ -527,6 +531,14 @@ static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
     a->mask_src = d->mask_src;
     a->route_src = d->route_src;
     if (a->route_src && (!a->mask_src || a->add_pad)) return fail(-2, "fs_conv_desc: route_src needs mask_src and add_pad = 0");
+    if (d->w_wino6 && d->w6_ws) {
+        a->w_wino6 = static_cast<const unsigned short*>(d->w_wino6);
+        a->w6_ws = static_cast<float*>(d->w6_ws);
+        a->w6_ws_floats = d->w6_ws_bytes / sizeof(float);
+        a->pool_out = d->pool_out;   // (part of the epilogue form the eligibility test looks at; validated below)
+        if (!fs::wino6_eligible(*a)) a->w_wino6 = nullptr;
+        a->pool_out = nullptr;
+    }
     a->w_wino4 = d->w_wino4;
     if (a->w_wino4 && !fs::wino4_eligible(*a)) a->w_wino4 = nullptr;   // (not a 3x3 stride-1 SAME conv of the supported shapes)
     a->w_wino4t = d->w_wino4t;
@@ -550,7 +562,7 @@ static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
     if (d->inb_rec && !(a->w_wino4t && a->p.variant == 11 && a->p.TW == 16 && a->p.ksplit <= 1))
         return fail(-2, "fs_conv2d: inb_rec needs an eligible w_wino4t conv (3x3 stride 1, raw or add_src epilogue, inb_z / inb_mean / inb_rstd set)");
     if (d->pool_out) {   // only the Winograd epilogues hold whole pooling windows
-        if (!(a->p.variant == 5 || a->p.variant == 6 || a->p.variant == 10 || a->p.variant == 11) || a->p.ksplit > 1 || (a->Ho & 1) || (a->Wo & 1))
+        if (!(a->p.variant == 5 || a->p.variant == 6 || a->p.variant == 10 || a->p.variant == 11 || a->p.variant == 12) || a->p.ksplit > 1 || (a->Ho & 1) || (a->Wo & 1))
             return fail(-2, "fs_conv2d: pool_out needs a Winograd-eligible conv with even Ho, Wo");
         a->pool_out = d->pool_out;
     }
@@ -602,6 +614,17 @@ int fs_wino4t_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, f
     if (Cin < 8 || Cout < 64 || (Cin % 8) || (Cout % 64)) return fail(-2, "fs_wino4t_transform_filter: Cin %% 8 == 0 and Cout %% 64 == 0 (got %dx%d)", Cin, Cout);
     const int rc = fs::wt_wino4t(w, U, Cin, Cout, ctx->stream);
     return rc ? fail(rc, "fs_wino4t_transform_filter: launch failed (%d)", rc) : 0;
+}
+
+size_t fs_wino6_filter_bytes(int Cin, int Cout) { return (Cin < 32 || Cout < 128 || (Cin % 32) || (Cout % 128)) ? 0 : fs::wino6_filter_floats(Cin, Cout) * sizeof(float); }
+size_t fs_wino6_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout) {
+    return (N < 1 || Ho < 1 || Wo < 1 || Cin < 1 || Cout < 1) ? 0 : fs::wino6_ws_floats(N, Ho, Wo, Cin, Cout) * sizeof(float);
+}
+int fs_wino6_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, void* U) {
+    if (!ctx || !w || !U) return fail(-1, "fs_wino6_transform_filter: null argument");
+    if (Cin < 32 || Cout < 128 || (Cin % 32) || (Cout % 128)) return fail(-2, "fs_wino6_transform_filter: Cin %% 32 == 0 and Cout %% 128 == 0 (got %dx%d)", Cin, Cout);
+    const int rc = fs::wt_wino6(w, static_cast<unsigned short*>(U), Cin, Cout, ctx->stream);
+    return rc ? fail(rc, "fs_wino6_transform_filter: launch failed (%d)", rc) : 0;
 }
 
 int fs_wino4_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, float* U) {

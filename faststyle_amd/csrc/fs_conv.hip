@@ -808,7 +808,8 @@ const char* prof_family_name(int f) {
         "conv_stream_kernel", "conv3x3_to3_kernel", "wgrad2_kernel", "conv_wgrad_kernel", "gram_stream_kernel",
         "conv_wgrad_kernel (Gram forward)", "gram_bwd_kernel", "conv_igemm_kernel (Gram backward, 1x1 per-sample filters)",
         "wino2h_conv_kernel (transform-net residual convs, half items)", "conv_s16_kernel", "wino4_conv_kernel", "wgw_kernel",
-        "wino4t_conv_kernel (transform-net residual convs)", "wino4t_conv_kernel (VGG16 convs)"};
+        "wino4t_conv_kernel (transform-net residual convs)", "wino4t_conv_kernel (VGG16 convs)",
+        "wino6 pipeline (VGG16 convs: input transform + split-bf16 GEMMs + output transform)"};
     return f >= 0 && f < Profiler::kFamilies ? names[f] : "";
 }
 
@@ -940,6 +941,10 @@ static void plan_variant(const ConvArgs& a, int variant, ConvPlan* out) {
 ConvPlan conv_plan(const ConvArgs& a) {
     ConvPlan p;
     if (env_int("FS_CONV_WINO", 1)) {
+        if (wino6_eligible(a)) {   // split-bf16 F(4x4,3x3) pipeline (fs_wino6.hip): the caller provided its filter pieces and scratch (FS_WINO_V=6, deep layers)
+            wino6_plan(a, &p);
+            return p;
+        }
         if (wino4_eligible(a)) {   // Winograd F(4x4,3x3) (fs_wino4.hip): the VGG16 convs when its filter layout was provided
             wino4_plan(a, &p);
             return p;
@@ -1111,12 +1116,13 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
         if (a.shuffle) fl *= 9.0 / 16.0;  // phase-collapsed resize-conv / stride-2 dgrad: 9 of the 16 tap-parity slots are non-zero
         // Winograd F(2x2,3x3): 16 products per 2x2 output tile instead of 36 -- the FLOPs actually executed
         if (p.variant == 5 || p.variant == 6 || p.variant == 8) fl = 2.0 * a.N * cdiv(a.Ho, 2) * cdiv(a.Wo, 2) * 16.0 * a.Cin * a.Cout;
-        if (p.variant == 10 || p.variant == 11) fl = 2.0 * a.N * cdiv(a.Ho, 4) * cdiv(a.Wo, 4) * 36.0 * a.Cin * a.Cout;   // F(4x4,3x3): 36 products per 4x4 outputs
+        if (p.variant == 10 || p.variant == 11 || p.variant == 12) fl = 2.0 * a.N * cdiv(a.Ho, 4) * cdiv(a.Wo, 4) * 36.0 * a.Cin * a.Cout;   // F(4x4,3x3): 36 products per 4x4 outputs
         int fam = p.variant;   // conv_igemm_kernel<..> instances 0..4, wino_conv_kernel 5
         if (a.w_nstride) fam = PF_GRAM_BWD_IGEMM;
         else if (p.variant == 7) fam = PF_CSTREAM;
         else if (p.variant == 9) fam = PF_S16;
         else if (p.variant == 10) fam = PF_WINO4;
+        else if (p.variant == 12) fam = PF_WINO6;
         else if (p.variant == 11) fam = a.prof_tag ? PF_WINO4T_TNET : PF_WINO4T_VGG;
         else if (p.variant == 8) fam = PF_WINO2H_TNET;
         else if (p.variant == 6) fam = a.prof_tag ? PF_WINO2_TNET : PF_WINO2_VGG;
@@ -1128,7 +1134,10 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
         lds_attr.ensure(reinterpret_cast<const void*>(conv_igemm_kernel<MT_, WM_, WN_, FL_>));                       \
         hipLaunchKernelGGL((conv_igemm_kernel<MT_, WM_, WN_, FL_>), grid, dim3(256), (size_t)p.lds_bytes, s, a);   \
     } while (0)
-    if (p.variant == 10) {
+    if (p.variant == 12) {
+        if (!wino6_eligible(a_in)) return -7;
+        FS_TRY_(wino6_launch(a, s));
+    } else if (p.variant == 10) {
         if (!wino4_eligible(a_in)) return -7;
         FS_TRY_(wino4_launch(a, s));
     } else if (p.variant == 11) {

@@ -25,6 +25,7 @@ enum SrcMode {
 struct ConvPlan {
     int variant;  // conv_igemm_kernel<MT,WM,WN>: 0 <32,2,2>  1 <32,2,1>  2 <16,4,1>  3 <32,1,2>  4 <32,1,1>;  5 wino_conv_kernel;  6 wino2_conv_kernel;
                   // 7 conv_stream_kernel;  8 wino2h_conv_kernel;  9 conv_s16_kernel;  10 wino4_conv_kernel (F(4x4,3x3));  11 wino4t_conv_kernel (F(4x4,3x3), 16-tile items)
+                  // 12 the split-bf16 F(4x4,3x3) pipeline of fs_wino6.hip (input transform, 36 GEMMs on the bf16 matrix cores, output transform)
     int BN;       // output channels per workgroup
     int flat;     // Cin==3: K runs over (kw,ci) contiguously per kernel row
     int CC;       // input channels staged per chunk
@@ -83,6 +84,9 @@ struct ConvArgs {
     const float* w_wino4; // optional: the filter transformed for F(4x4,3x3), [36][Cin/4][Cout/64][2][4][16][2] (fs::wt_wino4); enables variant 10
     const float* w_wino4t; // optional: the filter transformed for F(4x4,3x3) in the register layout of fs_wino4t.hip, [Cin/8][Cout/16][18][64][4] (fs::wt_wino4t); enables variant 11
     const float* w_wino4u; // optional, with w_wino4t: the same filter in the layout of the 128-channel item form of fs_wino4t.hip, [Cin/8][Cout/32][36][64][4] (fs::wt_wino4u)
+    const unsigned short* w_wino6; // optional: the F(4x4,3x3) filter as three bf16 pieces, [36][Cin/32][3][Cout][32] (fs::wt_wino6), with w6_ws: enables variant 12 (fs_wino6.hip)
+    float* w6_ws;          // scratch of the split-bf16 pipeline: V [36][tiles][Cin] + M [36][tiles][Cout] of one tile chunk (w6_ws_floats capacity; wino6_ws_floats() = one pass)
+    size_t w6_ws_floats;
     float* y;        // [N,Ho,Wo,Cout], or [N,2Ho,2Wo,Cout/4] when shuffle
     int N, H, W, Cin;
     int Ho, Wo, Cout;
@@ -536,6 +540,13 @@ int wt_wino4t(const float* w, float* U, int Cin, int Cout, hipStream_t s);      
 int wt_wino4t_batch(const WinoBatch& b, int Cin, int Cout, hipStream_t s);
 int wt_wino4u(const float* w, float* U, int Cin, int Cout, hipStream_t s);                      // ... for its 128-channel item form (ConvArgs::w_wino4u)
 bool wino4t_eligible(const ConvArgs& a);
+// fs_wino6.hip: F(4x4,3x3) with the Winograd-domain products as six exact bf16-piece products (round 6), plan variant 12
+int wt_wino6(const float* w, unsigned short* U, int Cin, int Cout, hipStream_t s);
+size_t wino6_filter_floats(int Cin, int Cout);
+size_t wino6_ws_floats(int N, int Ho, int Wo, int Cin, int Cout);
+bool wino6_eligible(const ConvArgs& a);
+void wino6_plan(const ConvArgs& a, ConvPlan* out);
+int wino6_launch(const ConvArgs& a, hipStream_t s);
 long wino4t_items(const ConvArgs& a);
 void wino4t_plan(const ConvArgs& a, ConvPlan* out);
 int wino4t_launch(const ConvArgs& a, hipStream_t s);
@@ -670,11 +681,11 @@ enum ProfFam {
     PF_IGEMM_32_2_2 = 0, PF_IGEMM_32_2_1 = 1, PF_IGEMM_16_4_1 = 2, PF_IGEMM_32_1_2 = 3, PF_IGEMM_32_1_1 = 4,
     PF_WINO = 5, PF_WINO2_VGG = 6, PF_WINO2_TNET = 7, PF_CSTREAM = 8, PF_C3 = 9, PF_WGRAD2 = 10, PF_WGRAD = 11,
     PF_GRAM_STREAM = 12, PF_GRAM_WGRAD = 13, PF_GRAM_BWD = 14, PF_GRAM_BWD_IGEMM = 15, PF_WINO2H_TNET = 16, PF_S16 = 17,
-    PF_WINO4 = 18, PF_WGW = 19, PF_WINO4T_TNET = 20, PF_WINO4T_VGG = 21
+    PF_WINO4 = 18, PF_WGW = 19, PF_WINO4T_TNET = 20, PF_WINO4T_VGG = 21, PF_WINO6 = 22
 };
 const char* prof_family_name(int f);
 struct Profiler {
-    static const int kFamilies = 22;   // one per kernel symbol (ProfFam); fs_profile_family_name() names them
+    static const int kFamilies = 23;   // one per kernel symbol (ProfFam); fs_profile_family_name() names them
     struct Rec { hipEvent_t a, b; int fam; double flops; };
     Rec* recs = nullptr;
     int n = 0, cap = 0;

@@ -19,15 +19,16 @@ struct VggLayout {
     size_t lossp, lossp_floats;   // partial sums of every loss term of a step, summed by loss_finish
     size_t d_pre, d_in[2], d_tap, d_tap2, scratch;
     size_t splitws, splitws_floats;  // split-K partial sums of the deep, small-grid convs (conv4_x at batch 4)
+    size_t w6ws, w6ws_floats;        // scratch of the split-bf16 F(4x4) pipeline (fs_wino6.hip; FS_WINO_V=6 only)
     size_t total_floats;
 };
 
 size_t vgg_prepared_floats();
-int vgg_prepare(const float* const w[FS_VGG_NLAYERS], float* prepared, hipStream_t s);
+int vgg_prepare(const float* const w[FS_VGG_NLAYERS], float* prepared, hipStream_t s);   // < 0: error; 1: the buffer also carries the fs_wino6.hip filter pieces (FS_WINO_V=6)
 void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, VggLayout* L);
 int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
                     const float* prepared, const fs_loss_cfg& cfg, const float* y, const float* content, float* losses,
-                    float* dy, float* ws, hipStream_t s);
+                    float* dy, float* ws, hipStream_t s, bool have_w6 = false);
 int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
                   const fs_loss_cfg& cfg, const float* img, float* const grams[4], float* ws, hipStream_t s);
 // libs/vgg16.py:36-220 for N images (RGB 0..255): post-ReLU activations of the requested layers copied to out[i]

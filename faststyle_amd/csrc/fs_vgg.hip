@@ -65,7 +65,25 @@ static size_t wino4_offset(int l, bool dgrad) {  // l >= 1
 static size_t wino4t_offset(int l, bool dgrad) { return wino4_offset(l, dgrad) + (wino4_offset(FS_VGG_NLAYERS, false) - wino4_offset(1, false)); }
 // (... and in the layout of its 128-channel item form, for the layers that have the channels)
 static size_t wino4u_offset(int l, bool dgrad) { return wino4t_offset(l, dgrad) + (wino4_offset(FS_VGG_NLAYERS, false) - wino4_offset(1, false)); }
-size_t vgg_prepared_floats() { return wino4u_offset(FS_VGG_NLAYERS, false); }
+// (round 6 ... and, under FS_WINO_V=6 only, the three bf16 pieces of the F(4x4) filters of the layers the split-bf16 pipeline of fs_wino6.hip may take:
+// Cin % 32 == 0 and Cout % 128 == 0 in the respective direction.  The region exists only in a buffer prepared under that knob: vgg_prepare returns
+// whether it filled it, fs_api.hip remembers that per prepared pointer and perceptual_loss is told -- a buffer prepared under another knob value never
+// has the region read.)
+static bool vgg_want_w6() { return tune_int("FS_WINO_V", 5) >= 6; }
+static bool w6_layer_ok(int l, bool dgrad) {
+    const int ci = dgrad ? kCout[l] : kCin[l], co = dgrad ? kCin[l] : kCout[l];
+    return l >= 1 && ci % 32 == 0 && co % 128 == 0 && (long)ci * co >= (long)tune_int("FS_WINO6_MINCC", 512 * 256);
+}
+static size_t wino6_offset(int l, bool dgrad) {  // l >= 1
+    size_t n = wino4u_offset(FS_VGG_NLAYERS, false);
+    for (int i = 1; i < FS_VGG_NLAYERS; ++i)
+        for (int d = 0; d < 2; ++d) {
+            if (i == l && (d == 1) == dgrad) return n;
+            if (w6_layer_ok(i, d == 1)) n += wino6_filter_floats(d ? kCout[i] : kCin[i], d ? kCin[i] : kCout[i]);
+        }
+    return n;
+}
+size_t vgg_prepared_floats() { return vgg_want_w6() ? wino6_offset(FS_VGG_NLAYERS, false) : wino4u_offset(FS_VGG_NLAYERS, false); }
 // FS_WINO_V >= 5 (default): the F(4x4) convs through fs_wino4t.hip (32-tile items, filter operand global -> registers); 4: through fs_wino4.hip
 static bool vgg_use_4t() { return tune_int("FS_WINO_V", 5) >= 5; }
 // debugging aid: FS_VGG_WINO_MASK selects the layers that may take the Winograd kernel (bit l: forward of layer l,
@@ -93,8 +111,12 @@ int vgg_prepare(const float* const w[FS_VGG_NLAYERS], float* prepared, hipStream
         FS_TRY(wt_wino4t(prepared + prepared_offset(l), prepared + wino4t_offset(l, true), kCout[l], kCin[l], s));
         if (kCout[l] % 128 == 0) FS_TRY(wt_wino4u(w[l], prepared + wino4u_offset(l, false), kCin[l], kCout[l], s));
         if (kCin[l] % 128 == 0) FS_TRY(wt_wino4u(prepared + prepared_offset(l), prepared + wino4u_offset(l, true), kCout[l], kCin[l], s));
+        if (vgg_want_w6()) {
+            if (w6_layer_ok(l, false)) FS_TRY(wt_wino6(w[l], reinterpret_cast<unsigned short*>(prepared + wino6_offset(l, false)), kCin[l], kCout[l], s));
+            if (w6_layer_ok(l, true)) FS_TRY(wt_wino6(prepared + prepared_offset(l), reinterpret_cast<unsigned short*>(prepared + wino6_offset(l, true)), kCout[l], kCin[l], s));
+        }
     }
-    return 0;
+    return vgg_want_w6() ? 1 : 0;   // 1: the buffer carries the fs_wino6.hip filter pieces
 }
 
 struct Bump2 {
@@ -204,13 +226,30 @@ void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, 
         }
     L->splitws_floats = need;
     L->splitws = b.take(need ? need : 4);
+    // scratch of the split-bf16 pipeline (FS_WINO_V=6): V + M of the largest launch that may take it, one pass (capped: beyond the cap the launch runs in tile chunks)
+    size_t need6 = 0;
+    if (vgg_want_w6())
+        for (int l = 1; l <= lmax; ++l)
+            for (int dir = 0; dir < 2; ++dir) {
+                if (!w6_layer_ok(l, dir == 1)) continue;
+                const size_t f = wino6_ws_floats(dir == 0 ? (l <= cmax ? L->NB : N) : N, L->Hl[l], L->Wl[l], dir == 0 ? kCin[l] : kCout[l], dir == 0 ? kCout[l] : kCin[l]);
+                if (f > need6) need6 = f;
+            }
+    const size_t cap6 = (size_t)tune_int("FS_WINO6_WS_MB", 2048) * (1u << 18);   // floats
+    if (need6 > cap6) need6 = cap6;
+    L->w6ws_floats = need6;
+    L->w6ws = b.take(need6 ? need6 : 4);
     L->total_floats = b.off;
 }
 
 // pool: optional destination of the 2x2/2 max-pool of the result; *pooled tells whether the conv launch produced it
 static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, const float* w_wino, const float* w_wino2, const float* w_wino4, const float* w_wino4t, const float* w_wino4u, const float* bias, const float* ab,
-                    float* y, float* split_ws, size_t split_ws_floats, hipStream_t s, float* pool = nullptr, bool* pooled = nullptr, int y_keep_n = 0) {
+                    float* y, float* split_ws, size_t split_ws_floats, hipStream_t s, float* pool = nullptr, bool* pooled = nullptr, int y_keep_n = 0,
+                    const unsigned short* w_wino6 = nullptr, float* w6_ws = nullptr, size_t w6_ws_floats = 0) {
     ConvArgs a{};
+    a.w_wino6 = w_wino6;
+    a.w6_ws = w6_ws;
+    a.w6_ws_floats = w6_ws_floats;
     a.x = x;
     a.w = w;
     a.w_wino = w_wino;
@@ -237,10 +276,10 @@ static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, 
     }
     a.p = conv_plan(a);
     if (pooled) *pooled = false;
-    if (pool && (a.p.variant == 5 || a.p.variant == 6 || a.p.variant == 10 || a.p.variant == 11) && a.p.ksplit <= 1 && !(H & 1) && !(W & 1) && tune_int("FS_VGG_POOL_FUSED", 1)) {
+    if (pool && (a.p.variant == 5 || a.p.variant == 6 || a.p.variant == 10 || a.p.variant == 11 || a.p.variant == 12) && a.p.ksplit <= 1 && !(H & 1) && !(W & 1) && tune_int("FS_VGG_POOL_FUSED", 1)) {
         a.pool_out = pool;   // the Winograd epilogues hold whole 2x2 tiles: the pooled tensor comes for one extra store per tile
         if (pooled) *pooled = true;
-        if (a.p.variant == 11 && tune_int("FS_VGG_SKIP_CONTENT_Y", 1)) a.y_keep_n = y_keep_n;
+        if ((a.p.variant == 11 || a.p.variant == 12) && tune_int("FS_VGG_SKIP_CONTENT_Y", 1)) a.y_keep_n = y_keep_n;
     }
     return conv_launch(a, s);
 }
@@ -248,7 +287,7 @@ static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, 
 // forward through layers [0..lmax]; samples [0,N) go all the way, [N,NB) stop after cmax
 // prepared: the buffer of fs_vgg_prepare (Winograd-transformed filters) or nullptr (direct convolutions only)
 static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
-                       const float* prepared, float* ws, hipStream_t s) {
+                       const float* prepared, float* ws, hipStream_t s, bool have_w6 = false) {
     FS_TRY(vgg_consts(ws + L.ab, s));
     const float* src = ws + L.xin;
     for (int l = 0; l <= L.lmax; ++l) {
@@ -263,7 +302,9 @@ static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS],
                         (pool_after(l) && l < L.lmax) ? ws + L.pool[pool_index(l)] : nullptr, &pooled,
                         // (the content half [N, NB) only feeds the next layer: of a pooled layer below the LAST content layer it needs the pooled tensor
                         // alone -- unless a content term of its own reads the full-resolution half, --loss_content_layers takes several)
-                        (nb > L.N && l < L.cmax && !((L.content_mask >> l) & 1u)) ? L.N : 0));
+                        (nb > L.N && l < L.cmax && !((L.content_mask >> l) & 1u)) ? L.N : 0,
+                        (wl && have_w6 && vgg_want_w6() && L.w6ws_floats && w6_layer_ok(l, false)) ? reinterpret_cast<const unsigned short*>(prepared + wino6_offset(l, false)) : nullptr,
+                        ws + L.w6ws, L.w6ws_floats));
         src = ws + L.act[l];
         if (pool_after(l) && l < L.lmax) {
             if (!pooled)
@@ -316,7 +357,7 @@ int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], cons
 
 int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
                     const float* prepared, const fs_loss_cfg& cfg, const float* y, const float* content, float* losses,
-                    float* dy, float* ws, hipStream_t s) {
+                    float* dy, float* ws, hipStream_t s, bool have_w6) {
     const int N = L.N;
     const size_t img = (size_t)N * L.H * L.W * 3;
     // [y ; content] as one 2N batch at ws + L.xin.  A caller that keeps the two tensors THERE (fs_perceptual_ws_input: the transform net writes y
@@ -330,7 +371,7 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
     // with the fork in the graph the same node behaved).  No memset on any capturable path of the library any more.)
     // (round 5: the four scalars are WRITTEN once, by loss_finish at the end, from the partial sums every term leaves in ws + L.lossp -- the per-term
     // sum launches, the clear and the total are gone)
-    FS_TRY(vgg_forward(L, w, b, prepared, ws, s));
+    FS_TRY(vgg_forward(L, w, b, prepared, ws, s, have_w6));
 
     // ---- losses ----
     LossFinish lf{};
@@ -501,6 +542,11 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         a.w_wino4 = (l >= 1 && wino_layer_on(16 + l) && !vgg_use_4t()) ? prepared + wino4_offset(l, true) : nullptr;
         a.w_wino4t = (l >= 1 && wino_layer_on(16 + l) && vgg_use_4t()) ? prepared + wino4t_offset(l, true) : nullptr;
         a.w_wino4u = (a.w_wino4t && kCin[l] % 128 == 0) ? prepared + wino4u_offset(l, true) : nullptr;
+        if (have_w6 && vgg_want_w6() && L.w6ws_floats && wino_layer_on(16 + l) && w6_layer_ok(l, true)) {
+            a.w_wino6 = reinterpret_cast<const unsigned short*>(prepared + wino6_offset(l, true));
+            a.w6_ws = ws + L.w6ws;
+            a.w6_ws_floats = L.w6ws_floats;
+        }
         a.N = N;
         a.H = a.Ho = H;
         a.W = a.Wo = W;

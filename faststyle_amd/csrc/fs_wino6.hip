@@ -1,0 +1,453 @@
+// Third-generation path for the deep VGG16 3x3 convs (round 6; reference libs/vgg16.py:106-173: conv3_x / conv4_x, and their input gradients behind
+// train.py:203): Winograd F(4x4,3x3) whose 36 Winograd-domain GEMMs run on the bf16 matrix cores as SIX EXACT PRODUCTS of bf16 pieces with fp32
+// accumulation (U = Uh + Um + Ul, V = Vh + Vm + Vl, every piece 8 mantissa bits of the fp32 value: the split is exact; the six products
+// Uh Vh, Uh Vm, Um Vh, Uh Vl, Ul Vh, Um Vm keep every term >= 2^-16 of the product, the three dropped ones are <= 2^-24).  Measured error against
+// the float64 oracle: BELOW the fp32 F(4x4) kernel's (tools/bf16x3_error.py, tests/test_kernels_parity.py::test_winograd_f4x4_split_bf16_*).
+//
+// Why three launches instead of fs_wino4t.hip's one (DESIGN.md section 4 has the arithmetic): v_mfma_f32_32x32x16_bf16 multiplies 2.67x faster than the
+// fp32 instruction sequence it replaces, but its operands are 1.5x the bytes (three 2-byte pieces).  A fused item is bounded by the register file
+// (tiles x channels x 36 positions <= ~73 k accumulators per CU, i.e. 32 tiles x 64 channels): at that size the filter operand alone is 64 B/clk/CU from
+// the L2 at the matrix rate (the fp32 kernel streams 11-22), and one K = 32 stage of V for 32 tiles is 221 KB of LDS.  Per POSITION the products are
+// plain GEMMs [tiles x Cin] x [Cin x Cout] that tile 128 x 128 with both operands through LDS (16 B/clk/CU from the L2 per operand side) -- so:
+//   K1 wino6_input_kernel   x -> V = B^T d B, fp32 [36][Cin/32][tiles][32]              (streaming; one thread = one tile x 4 channels)
+//   K2 wino6_gemm_kernel    M[pos] = V[pos] U[pos]: 128 x 128 x 32 stages, V split into its three pieces on the way into LDS (the split costs
+//                           ~90 vector-ALU instructions per thread and stage in the shadow of 48 matrix instructions), U pre-split by wt_wino6
+//   K3 wino6_output_kernel  y = A^T M A + bias / ReLU / 2x2 max-pool / consumer ReLU mask (the epilogue forms of fs_wino4t.hip: 0, 3, 4)
+// The price is V and M through HBM / the Infinity Cache (2.25x the input + 2.25x the output, fp32), which is why only the layers whose reduction is
+// deep enough to pay for it take this path (FS_WINO6_MINCC: Cin * Cout >= 512 * 256, i.e. conv4_x both directions) and only under FS_WINO_V=6.
+#include "fs_wino4.h"
+
+namespace fs {
+
+typedef __bf16 w6_bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kW6TM = 128;                    // tiles per workgroup (GEMM M)
+constexpr int kW6TN = 128;                    // output channels per workgroup (GEMM N)
+constexpr int kW6K = 32;                      // input channels per stage
+constexpr int kW6Pitch = 80;                  // bytes per LDS row of one piece: 64 B of k + 16 B of pad -- the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte bank groups
+constexpr int kW6PieceB = 128 * kW6Pitch;     // one piece of one operand: 10240 B
+constexpr int kW6StageB = 6 * kW6PieceB;      // A (V) three pieces + B (U) three pieces: 61440 B; two stages = 120 KB
+
+// fp32 -> three bf16 pieces by truncation: h = top 8 significant bits, m = the next 8 of the (exact) remainder, l = what is left (<= 8 bits): x = h + m + l exactly
+__host__ __device__ __forceinline__ void w6_split(float x, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    h = u & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, h);
+    m = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, m);
+    l = __builtin_bit_cast(unsigned, r2);
+}
+
+// U6[pos][ci/32][piece][co][ci%32] (bf16 bits): one workgroup stage of the GEMM (128 output channels x 32 input channels) is three contiguous 8 KB runs, one per
+// piece, each in the row order of its LDS image (eight consecutive lanes store two rows: conflict-free 16-byte LDS stores).
+// float64 transform rounded once to fp32 (as every F(4x4) filter layout of this library), then split exactly.
+__global__ __launch_bounds__(256) void wt_wino6_kernel(const float* __restrict__ w, unsigned short* __restrict__ U, int Cin, int Cout) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t cc = (size_t)Cin * Cout;
+    if (i >= cc) return;
+    const int ci = (int)(i / Cout), co = (int)(i - (size_t)ci * Cout);
+    double o[36];
+    wino4_filter_transform(w, cc, i, o);
+    const int KB = Cin >> 5;
+#pragma unroll
+    for (int pos = 0; pos < 36; ++pos) {
+        unsigned h, m, l;
+        w6_split((float)o[pos], h, m, l);
+        unsigned short* d = U + ((((size_t)pos * KB + (ci >> 5)) * 3) * Cout + co) * 32 + (ci & 31);
+        d[0] = (unsigned short)(h >> 16);
+        d[(size_t)Cout * 32] = (unsigned short)(m >> 16);
+        d[(size_t)Cout * 64] = (unsigned short)(l >> 16);
+    }
+}
+
+int wt_wino6(const float* w, unsigned short* U, int Cin, int Cout, hipStream_t s) {
+    if (Cin % kW6K || Cout % kW6TN) return -1;
+    const size_t cc = (size_t)Cin * Cout;
+    hipLaunchKernelGGL(wt_wino6_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, w, U, Cin, Cout);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+struct W6Args {
+    const float* x;            // [N,H,W,Cin]
+    float* y;                  // [N,Ho,Wo,Cout]
+    const float* bias;
+    const float* mask_src;
+    float* pool_out;
+    float* V;                  // [36][Cin/32][Tpad][32]
+    const unsigned short* U;   // wt_wino6
+    float* M;                  // [36][Tpad][Cout]
+    int N, H, W, Cin, Ho, Wo, Cout, pad;
+    int th, tw;                // tiles per sample
+    int t0, T, Tpad;           // this launch's tile range [t0, t0 + T) of the N * th * tw tiles; Tpad = T rounded up to 128
+    int out_relu, y_keep_n;
+};
+
+#define W6_BT4(d0, d1, d2, d3, d4, d5, t0, t1, t2, t3, t4, t5)   \
+    do {                                                         \
+        const f32x4 a_ = d4 - 4.f * d2, b_ = d3 - 4.f * d1;      \
+        const f32x4 c_ = d4 - d2, e_ = d3 - d1;                  \
+        const f32x4 f_ = 4.f * d0 - 5.f * d2 + d4;               \
+        const f32x4 g_ = 4.f * d1 - 5.f * d3 + d5;               \
+        t0 = f_; /* (outputs may alias inputs) */                \
+        t1 = a_ + b_;                                            \
+        t2 = a_ - b_;                                            \
+        t3 = c_ + 2.f * e_;                                      \
+        t4 = c_ - 2.f * e_;                                      \
+        t5 = g_;                                                 \
+    } while (0)
+#define W6_AT4(m0, m1, m2, m3, m4, m5, y0, y1, y2, y3)   \
+    do {                                                 \
+        const f32x4 p_ = m1 + m2, q_ = m1 - m2;          \
+        const f32x4 r_ = m3 + m4, s_ = m3 - m4;          \
+        y0 = m0 + p_ + r_;                               \
+        y1 = q_ + 2.f * s_;                              \
+        y2 = p_ + 4.f * r_;                              \
+        y3 = q_ + 8.f * s_ + m5;                         \
+    } while (0)
+
+// K1: input transform.  One thread = one tile x four channels: 36 16-byte loads (zero outside the image), B^T d B, 36 16-byte stores.
+__global__ __launch_bounds__(256) void wino6_input_kernel(W6Args a) {
+    const int cq_n = a.Cin >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int tl = (int)(idx / cq_n), cq = (int)(idx - (long)tl * cq_n);
+    if (tl >= a.T) return;
+    const int t = a.t0 + tl;
+    const int per = a.th * a.tw;
+    const int n = t / per, r = t - n * per, ty = r / a.tw, tx = r - ty * a.tw;
+    const int c = cq * 4;
+    const float* xs = a.x + (size_t)n * a.H * a.W * a.Cin + c;
+    const int y0 = 4 * ty - a.pad, x0 = 4 * tx - a.pad;
+    f32x4 d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int yy = y0 + i, xx = x0 + j;
+            const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            const float4 v = in ? *reinterpret_cast<const float4*>(xs + ((size_t)yy * a.W + xx) * a.Cin) : make_float4(0.f, 0.f, 0.f, 0.f);
+            d[i][j] = f32x4{v.x, v.y, v.z, v.w};
+        }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) W6_BT4(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
+    const int KB = a.Cin >> 5;
+    float* vb = a.V + ((size_t)(c >> 5) * a.Tpad + tl) * 32 + (c & 31);
+    const size_t pstride = (size_t)KB * a.Tpad * 32;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        f32x4 o0, o1, o2, o3, o4, o5;
+        W6_BT4(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], o0, o1, o2, o3, o4, o5);
+        const f32x4 o[6] = {o0, o1, o2, o3, o4, o5};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<float4*>(vb + (size_t)(i * 6 + j) * pstride) = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
+    }
+}
+
+// K3: output transform + epilogue.  One thread = one tile x four output channels.
+template <int EPI>
+__global__ __launch_bounds__(256) void wino6_output_kernel(W6Args a) {
+    const int cq_n = a.Cout >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int tl = (int)(idx / cq_n), cq = (int)(idx - (long)tl * cq_n);
+    if (tl >= a.T) return;
+    const int t = a.t0 + tl;
+    const int per = a.th * a.tw;
+    const int n = t / per, r = t - n * per, ty = r / a.tw, tx = r - ty * a.tw;
+    const int c = cq * 4;
+    const float* mb = a.M + (size_t)tl * a.Cout + c;
+    const size_t pstride = (size_t)a.Tpad * a.Cout;
+    f32x4 m[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(mb + (size_t)(i * 6 + j) * pstride);
+            m[i][j] = f32x4{v.x, v.y, v.z, v.w};
+        }
+    f32x4 s[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) W6_AT4(m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j], s[0][j], s[1][j], s[2][j], s[3][j]);
+    f32x4 o[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) W6_AT4(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[i][0], o[i][1], o[i][2], o[i][3]);
+    const int oy = 4 * ty, ox = 4 * tx;
+    f32x4 bs = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (EPI == 3 && a.bias) {
+        const float4 b4 = *reinterpret_cast<const float4*>(a.bias + c);
+        bs = f32x4{b4.x, b4.y, b4.z, b4.w};
+    }
+    const bool keep_y = !(EPI == 3 && a.pool_out && a.y_keep_n > 0 && n >= a.y_keep_n);
+    float* yb = a.y + (size_t)n * a.Ho * a.Wo * a.Cout + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = o[i][j];
+            const bool in = oy + i < a.Ho && ox + j < a.Wo;
+            const size_t off = ((size_t)(oy + i) * a.Wo + (ox + j)) * a.Cout;
+            if (EPI == 3) {
+                v = v + bs;
+                if (a.out_relu)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                o[i][j] = v;
+            }
+            if (EPI == 4 && in) {
+                const float4 k4 = *reinterpret_cast<const float4*>(a.mask_src + (size_t)n * a.Ho * a.Wo * a.Cout + c + off);
+                v[0] = k4.x > 0.f ? v[0] : 0.f;
+                v[1] = k4.y > 0.f ? v[1] : 0.f;
+                v[2] = k4.z > 0.f ? v[2] : 0.f;
+                v[3] = k4.w > 0.f ? v[3] : 0.f;
+            }
+            if (in && keep_y) *reinterpret_cast<float4*>(yb + off) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    if (EPI == 3 && a.pool_out) {   // 2x2/2 max-pool of the stored values: the tile's four windows (Ho, Wo even)
+        const int Hp = a.Ho >> 1, Wp = a.Wo >> 1;
+        float* pb = a.pool_out + (size_t)n * Hp * Wp * a.Cout + c;
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                if (oy + 2 * wy >= a.Ho || ox + 2 * wx >= a.Wo) continue;
+                f32x4 q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    q[e] = fmaxf(fmaxf(o[2 * wy][2 * wx][e], o[2 * wy][2 * wx + 1][e]), fmaxf(o[2 * wy + 1][2 * wx][e], o[2 * wy + 1][2 * wx + 1][e]));
+                *reinterpret_cast<float4*>(pb + ((size_t)((oy >> 1) + wy) * Wp + ((ox >> 1) + wx)) * a.Cout) = make_float4(q[0], q[1], q[2], q[3]);
+            }
+    }
+}
+
+// 8 fp32 -> the three bf16 pieces, packed for one 16-byte LDS store each (element e of a piece in the low / high half of word e / 2)
+__device__ __forceinline__ void w6_split8(const float4& lo, const float4& hi, uint4& H, uint4& Mi, uint4& L) {
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w6_split(v[i], h[i], m[i], l[i]);
+    H = make_uint4((h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]);
+    Mi = make_uint4((m[0] >> 16) | m[1], (m[2] >> 16) | m[3], (m[4] >> 16) | m[5], (m[6] >> 16) | m[7]);
+    L = make_uint4((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u), (l[4] >> 16) | (l[5] & 0xffff0000u), (l[6] >> 16) | (l[7] & 0xffff0000u));
+}
+
+// K2: the 36 GEMMs.  Workgroup = (position, 128 tiles, 128 output channels); four waves 2 x 2, each 64 x 64 as 2 x 2 blocks of v_mfma_f32_32x32x16_bf16
+// (A = V: rows = tiles; B = U: columns = output channels; a lane of the result holds ONE output channel of 16 tiles -- the 32 lanes of a half-wave store
+// 128 contiguous bytes of M[pos][tile][:]).  Stages of 32 input channels, two LDS stages, the next stage's global loads in flight during the sweep.
+__global__ __launch_bounds__(256) void wino6_gemm_kernel(W6Args a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    char* lds = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int KB = a.Cin >> 5, MB = a.Tpad >> 7, NB = a.Cout >> 7;
+    // XCD-aware order: workgroup b runs on XCD b mod 8; virtual index (b mod 8) G/8 + b/8 hands every XCD a contiguous range of (position, tile block,
+    // channel block) with the channel blocks of a tile block adjacent: its 32 concurrent workgroups share 8 V tile blocks and the position's U in one L2
+    const long G = (long)gridDim.x, b = (long)blockIdx.x;
+    const long v = (G % 8 == 0) ? (b % 8) * (G / 8) + b / 8 : b;
+    const int nb = (int)(v % NB), mb = (int)((v / NB) % MB), pos = (int)(v / ((long)NB * MB));
+    const float* Ag = a.V + ((size_t)pos * KB * a.Tpad + (size_t)mb * 128) * 32;
+    const size_t a_kstride = (size_t)a.Tpad * 32, b_pstride = (size_t)a.Cout * 32, b_kstride = 3 * b_pstride;
+    const unsigned short* Bg = a.U + (size_t)pos * KB * b_kstride + (size_t)nb * 128 * 32;
+
+    // staging: A 128 rows x 32 floats = 1024 quads, thread units u = tid + 256 i: row u / 4, 8-channel group u % 4 (two quads); B 3 pieces x 512 quads.
+    // Two register sets: the global loads of stage s + 3 are issued in stage s and consumed (split, stored to LDS) in the second half of stage s + 2 --
+    // a stage and a half of matrix instructions between issue and use.  No conditional loads / stores (the lesson of fs_wino4.hip: a staged value that is a
+    // phi of "loaded" and "not loaded" ends up in scratch memory): a stage beyond the last is loaded from the last one's addresses and stored to the LDS
+    // buffer nobody reads.
+    struct Regs {
+        float4 a[2][2];
+        uint4 b[6];
+    };
+    auto load_regs = [&](Regs& R, int kb) __attribute__((always_inline)) {
+        kb = kb < KB ? kb : KB - 1;
+        const float* ap = Ag + (size_t)kb * a_kstride;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = tid + 256 * i;
+            R.a[i][0] = *reinterpret_cast<const float4*>(ap + (size_t)u * 8);
+            R.a[i][1] = *reinterpret_cast<const float4*>(ap + (size_t)u * 8 + 4);
+        }
+        const unsigned short* bp = Bg + (size_t)kb * b_kstride;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) R.b[j] = *reinterpret_cast<const uint4*>(bp + (size_t)(j >> 1) * b_pstride + (size_t)(tid + 256 * (j & 1)) * 8);   // piece j / 2, quad of its 512
+    };
+    auto write_lds = [&](const Regs& R, int st) __attribute__((always_inline)) {
+        char* base = lds + st * kW6StageB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = tid + 256 * i;
+            uint4 H, Mi, L;
+            w6_split8(R.a[i][0], R.a[i][1], H, Mi, L);
+            char* p = base + (u >> 2) * kW6Pitch + (u & 3) * 16;
+            *reinterpret_cast<uint4*>(p) = H;
+            *reinterpret_cast<uint4*>(p + kW6PieceB) = Mi;
+            *reinterpret_cast<uint4*>(p + 2 * kW6PieceB) = L;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int q = tid + 256 * (j & 1);
+            *reinterpret_cast<uint4*>(base + (3 + (j >> 1)) * kW6PieceB + (q >> 2) * kW6Pitch + (q & 3) * 16) = R.b[j];
+        }
+    };
+
+    // two accumulators per block: the leading product Uh Vh alone, and the five small ones (<= 2^-8 of it) together -- a rounding of the small sum is 2^-8 of a
+    // rounding of the large one, so the result carries ONE full-size fp32 rounding per 16-channel block of the reduction; they meet once, in the store
+    f32x16 acc[2][2], acl[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = acl[i][j][e] = 0.f;
+
+    const int a_lane = (64 * wm + (lane & 31)) * kW6Pitch + (lane >> 5) * 16;
+    const int b_lane = 3 * kW6PieceB + (64 * wn + (lane & 31)) * kW6Pitch + (lane >> 5) * 16;
+
+    auto sweep = [&](const char* sa, const char* sb, int ks) __attribute__((always_inline)) {
+        w6_bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                af[blk][p] = __builtin_bit_cast(w6_bf16x8, *reinterpret_cast<const uint4*>(sa + p * kW6PieceB + blk * 32 * kW6Pitch + ks * 32));
+                bf[blk][p] = __builtin_bit_cast(w6_bf16x8, *reinterpret_cast<const uint4*>(sb + p * kW6PieceB + blk * 32 * kW6Pitch + ks * 32));
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // (pieces: 0 = h, 1 = m, 2 = l; smallest terms first)
+                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acl[i][j], 0, 0, 0);
+                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acl[i][j], 0, 0, 0);
+                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acl[i][j], 0, 0, 0);
+                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acl[i][j], 0, 0, 0);
+                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acl[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            }
+    };
+    // one stage: the 48 matrix instructions of LDS buffer `st`; beside them the split of register set R (the stage after this one) into buffer st ^ 1 and the
+    // loads of the stage three ahead into R.  The scheduler is asked to thread the vector-ALU / LDS-store / global-load work between the matrix instructions.
+    auto stage = [&](int st, Regs& R, int kb_load) __attribute__((always_inline)) {
+        const char* sa = lds + st * kW6StageB + a_lane;
+        const char* sb = lds + st * kW6StageB + b_lane;
+        sweep(sa, sb, 0);
+        write_lds(R, st ^ 1);
+        load_regs(R, kb_load);
+        sweep(sa, sb, 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int g = 0; g < 48; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one matrix instruction
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // an LDS read
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four vector-ALU instructions
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // an LDS write
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load
+        }
+#endif
+        __syncthreads();
+    };
+
+    Regs R0, R1;
+    load_regs(R0, 0);
+    write_lds(R0, 0);
+    load_regs(R0, 1);
+    load_regs(R1, 2);
+    __syncthreads();
+    for (int kb = 0; kb < KB; kb += 2) {
+        stage(0, R0, kb + 3);                     // stage kb: buffer 0; R0 holds stage kb + 1
+        if (kb + 1 < KB) stage(1, R1, kb + 4);    // stage kb + 1: buffer 1; R1 holds stage kb + 2
+    }
+    // M[pos][tile][cout]: register r of block (i, j) = tile 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), channel 64 wn + 32 j + (lane & 31)
+    float* mp = a.M + ((size_t)pos * a.Tpad + (size_t)mb * 128 + 64 * wm + 4 * (lane >> 5)) * a.Cout + (size_t)nb * 128 + 64 * wn + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mp[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * a.Cout + 32 * j] = acc[i][j][r] + acl[i][j][r];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------ host side
+static int wino6_epi(const ConvArgs& a) {
+    const bool act = a.bias || a.out_relu || a.pool_out;
+    if (a.stats || a.add_src || a.inb_rec || a.in_a) return -1;
+    if (a.mask_src) return act ? -1 : 4;
+    return act ? 3 : 0;
+}
+
+size_t wino6_filter_floats(int Cin, int Cout) { return ((size_t)36 * Cin * Cout * 3 / 2 + 63) & ~(size_t)63; }   // 3 bf16 pieces per element, in floats
+
+// workspace (floats) one launch wants for ALL its tiles in one pass; with less it runs in tile chunks (>= 128 tiles)
+size_t wino6_ws_floats(int N, int Ho, int Wo, int Cin, int Cout) {
+    const size_t T = (size_t)N * cdiv(Ho, 4) * cdiv(Wo, 4), Tpad = (T + 127) & ~(size_t)127;
+    return 36 * Tpad * ((size_t)Cin + Cout);
+}
+
+bool wino6_eligible(const ConvArgs& a) {
+    if (!a.w_wino6 || !a.w6_ws) return false;
+    const bool pad_ok = a.pad_t == a.pad_l && a.pad_t >= 0 && a.pad_t <= 2 && a.Ho == a.H + 2 * a.pad_t - 2 && a.Wo == a.W + 2 * a.pad_l - 2;
+    const long T = (long)a.N * cdiv(a.Ho, 4) * cdiv(a.Wo, 4);
+    return a.KH == 3 && a.KW == 3 && a.stride == 1 && pad_ok && a.src_mode == SRC_PLAIN && a.Cin % kW6K == 0 && a.Cout % kW6TN == 0 && !a.shuffle && wino6_epi(a) >= 0 &&
+           !a.route_src && a.w_nstride == 0 && a.dil_x <= 1 && !a.fin.counter && a.Ho > 0 && a.Wo > 0 && (!a.pool_out || (!(a.Ho & 1) && !(a.Wo & 1))) &&
+           (long)a.Cin * a.Cout >= (long)tune_int("FS_WINO6_MINCC", 512 * 256) && T >= tune_int("FS_WINO6_MINTILES", 1024) && T < (1L << 24) &&
+           a.w6_ws_floats >= (size_t)36 * 128 * ((size_t)a.Cin + a.Cout);
+}
+
+void wino6_plan(const ConvArgs& a, ConvPlan* out) {
+    ConvPlan p{};
+    p.variant = 12;
+    p.BN = kW6TN;
+    p.CC = kW6K;
+    p.TH = p.TW = 4;
+    p.tiles_y = cdiv(a.Ho, 4);
+    p.tiles_x = cdiv(a.Wo, 4);
+    p.lds_bytes = 2 * kW6StageB;
+    p.ksplit = 1;
+    *out = p;
+}
+
+int wino6_launch(const ConvArgs& a, hipStream_t s) {
+    const int epi = wino6_epi(a);
+    if (epi < 0 || !wino6_eligible(a)) return -7;
+    W6Args w{};
+    w.x = a.x;
+    w.y = a.y;
+    w.bias = a.bias;
+    w.mask_src = a.mask_src;
+    w.pool_out = a.pool_out;
+    w.U = a.w_wino6;
+    w.N = a.N;
+    w.H = a.H;
+    w.W = a.W;
+    w.Cin = a.Cin;
+    w.Ho = a.Ho;
+    w.Wo = a.Wo;
+    w.Cout = a.Cout;
+    w.pad = a.pad_t;
+    w.th = cdiv(a.Ho, 4);
+    w.tw = cdiv(a.Wo, 4);
+    w.out_relu = a.out_relu;
+    w.y_keep_n = a.y_keep_n;
+    const long Tall = (long)a.N * w.th * w.tw;
+    // tiles per pass: what the workspace holds (multiples of 128), optionally capped (FS_WINO6_CHUNK: a chunk whose V and M stay in the 256 MB Infinity Cache)
+    long cap = (long)(a.w6_ws_floats / ((size_t)36 * ((size_t)a.Cin + a.Cout))) & ~127L;
+    const int knob = tune_int("FS_WINO6_CHUNK", 0);
+    if (knob >= 128 && (knob & ~127) < cap) cap = knob & ~127;
+    if (cap < 128) return -7;
+    static BigLds lds_attr;
+    lds_attr.ensure(reinterpret_cast<const void*>(wino6_gemm_kernel));
+    for (long t0 = 0; t0 < Tall; t0 += cap) {
+        w.t0 = (int)t0;
+        w.T = (int)(Tall - t0 < cap ? Tall - t0 : cap);
+        w.Tpad = (w.T + 127) & ~127;
+        w.V = a.w6_ws;
+        w.M = a.w6_ws + (size_t)36 * w.Tpad * a.Cin;
+        const long n1 = (long)w.T * (a.Cin / 4), n3 = (long)w.T * (a.Cout / 4);
+        hipLaunchKernelGGL(wino6_input_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, w);
+        hipLaunchKernelGGL(wino6_gemm_kernel, dim3((unsigned)(36 * (w.Tpad / 128) * (a.Cout / 128))), dim3(256), (size_t)(2 * kW6StageB), s, w);
+        const dim3 g3((unsigned)((n3 + 255) / 256));
+        if (epi == 0) hipLaunchKernelGGL(wino6_output_kernel<0>, g3, dim3(256), 0, s, w);
+        else if (epi == 3) hipLaunchKernelGGL(wino6_output_kernel<3>, g3, dim3(256), 0, s, w);
+        else hipLaunchKernelGGL(wino6_output_kernel<4>, g3, dim3(256), 0, s, w);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace fs

@@ -519,7 +519,17 @@ class Engine(object):
         d.mask_src = p(kw.get("mask_src"))
         d.route_src = p(kw.get("route_src"))
         inb = kw.get("inb")      # (z, mean, rstd, a, b, relu): also leave the instance-norm-backward partial sums of the unit that produced z
-        if kw.get("winograd") == "4t":     # F(4x4,3x3), 16-tile items (fs_wino4t.hip)
+        if kw.get("winograd") == 6:        # F(4x4,3x3), split-bf16 pipeline (fs_wino6.hip); the output extent is known only after the plan: SAME / explicit pads here
+            U = self.mem.empty((self.lib.fs_wino6_filter_bytes(Cin, Cout) // 4,))
+            L.check(self.lib, self.lib.fs_wino6_transform_filter(self.ctx, p(w), Cin, Cout, p(U)), "fs_wino6_transform_filter")
+            ho, wo = (H, W) if isinstance(padding, str) and padding == "SAME" else ((H - 2, W - 2) if isinstance(padding, str) else (padding[2], padding[3]))
+            nb = self.lib.fs_wino6_workspace_bytes(N, ho, wo, Cin, Cout)
+            if kw.get("w6_chunk_tiles"):    # a smaller scratch: the launch runs in tile chunks
+                nb = 36 * int(kw["w6_chunk_tiles"]) * (Cin + Cout) * 4
+            ws6 = self.mem.empty((nb // 4,))
+            d.w_wino6, d.w6_ws, d.w6_ws_bytes = p(U), p(ws6), nb
+            self._keep = [U, ws6]
+        elif kw.get("winograd") == "4t":     # F(4x4,3x3), 16-tile items (fs_wino4t.hip)
             U = self.mem.empty((36, Cin, Cout))
             L.check(self.lib, self.lib.fs_wino4t_transform_filter(self.ctx, p(w), Cin, Cout, p(U)), "fs_wino4t_transform_filter")
             d.w_wino4t = p(U)

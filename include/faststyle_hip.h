@@ -35,7 +35,7 @@ const char* fs_version(void);
  * out[f*3+{0,1,2}] = {launches, FLOPs executed, milliseconds} of row f; fs_profile_family_name(f) is the kernel symbol the
  * row belongs to (one row per symbol, so a row can be re-derived from a `rocprofv3 --kernel-trace --stats` summary; the
  * one symbol shared by two workloads, wino2_conv_kernel, has a row per caller), "" for unused rows. */
-#define FS_PROFILE_FAMILIES 22
+#define FS_PROFILE_FAMILIES 23
 int fs_profile_begin(fs_ctx* ctx);
 int fs_profile_end(fs_ctx* ctx, double out[3 * FS_PROFILE_FAMILIES]);
 const char* fs_profile_family_name(int family);
@@ -230,6 +230,15 @@ typedef struct {
      * x = mask_src): the streaming kernel of fs_gram.hip for C = 64 / 128 / 256, even Ho and Wo a multiple of 128 (C = 64), 64 (C = 128) or 32 (add_src allowed),
      * else the direct kernel (no add_src); a launch that cannot take it is an error (-2). */
     const float* route_src;
+    /* optional (round 6), all three together: the filter as split by fs_wino6_transform_filter, and scratch of w6_ws_bytes (fs_wino6_workspace_bytes = one
+     * pass; less makes the launch run in chunks of >= 128 tiles of 4 x 4 outputs).  A 3x3 stride-1 conv with padding 0, 1 or 2, Cin % 32 == 0, Cout % 128 == 0,
+     * epilogue raw | bias / ReLU / pool_out | mask_src, of at least FS_WINO6_MINTILES tiles and FS_WINO6_MINCC = Cin * Cout then runs as the split-bf16
+     * Winograd F(4x4,3x3) pipeline of fs_wino6.hip (input transform, 36 GEMMs on the bf16 matrix cores as six exact products of bf16 pieces with fp32
+     * accumulation, output transform) -- what fs_perceptual_loss runs conv4_x (libs/vgg16.py:131-173) and its input gradients on under FS_WINO_V=6.
+     * It wins over the other Winograd layouts when given; other shapes fall through. */
+    const void* w_wino6;
+    void* w6_ws;
+    size_t w6_ws_bytes;
 } fs_conv_desc;
 /* U = G g G^T for every (ci, co) filter g = w[:, :, ci, co] of a 3x3 HWIO filter (Lavin & Gray F(2x2,3x3)), 16 values per
  * filter, in the order the Winograd kernels stage them; the caller owns U (16*Cin*Cout floats; Cin % 8 == 0).
@@ -240,6 +249,12 @@ int fs_wino_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, flo
 int fs_wino4_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, float* U);
 /* ... in the register layout of the 16-tile kernel (fs_conv_desc.w_wino4t); Cin % 8 == 0, Cout % 64 == 0. */
 int fs_wino4t_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, float* U);
+/* ... as three bf16 pieces per element (the float64 transform rounded once to fp32, then split exactly: h + m + l == the fp32 value) in the stage order of
+ * the GEMM of fs_wino6.hip (fs_conv_desc.w_wino6); U holds fs_wino6_filter_bytes(Cin, Cout) bytes; Cin % 32 == 0, Cout % 128 == 0. */
+size_t fs_wino6_filter_bytes(int Cin, int Cout);
+int fs_wino6_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, void* U);
+/* scratch for one pass of that pipeline over an [N,Ho,Wo,Cout] result: V [36][tiles][Cin] + M [36][tiles][Cout] floats, tiles = N ceil(Ho/4) ceil(Wo/4) padded to 128 */
+size_t fs_wino6_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout);
 /* tf.nn.conv2d (im_transf_net.py:115, vgg16.py:47) on the matrix cores. */
 int fs_conv2d_fwd(fs_ctx* ctx, fs_conv_desc* d);
 /* resolves Ho/Wo/pads and returns the per-image tile count the launch will use */

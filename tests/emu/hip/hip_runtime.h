@@ -250,8 +250,9 @@ inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
 }
 
 // v_mfma_f32_32x32x16_bf16: lane l holds A[i = l&31][k = 8*(l>>5) .. +7] and B[k = 8*(l>>5) .. +7][j = l&31];
-// products of bf16 values are exact in fp32, the sum order inside the instruction is not architecturally
-// specified -- the emulator adds k-ascending (parity tests of the bf16 path carry a tolerance, not bit equality).
+// products of bf16 values are exact in fp32, the sum order (and the width of the adder tree) inside the instruction is not
+// architecturally specified -- the emulator sums the 16 exact products and the accumulator in double and rounds ONCE per
+// instruction (parity tests of the bf16 paths carry a tolerance, not bit equality; the GPU run is what pins the real sum).
 typedef __bf16 bf16x8_emu __attribute__((ext_vector_type(8)));
 inline f32x16 mfma_32x32x16_bf16(bf16x8_emu a, bf16x8_emu b, f32x16 c) {
     Block& bk = blk(); Fiber* f = bk.cur; Wave& w = bk.waves[f->wave];
@@ -268,9 +269,9 @@ inline f32x16 mfma_32x32x16_bf16(bf16x8_emu a, bf16x8_emu b, f32x16 c) {
     int j = l & 31;
     for (int r = 0; r < 16; ++r) {
         int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        float acc = c[r];
-        for (int k = 0; k < 16; ++k) acc += w.a8[s][i + 32 * (k >> 3)][k & 7] * w.b8[s][j + 32 * (k >> 3)][k & 7];
-        c[r] = acc;
+        double acc = c[r];
+        for (int k = 0; k < 16; ++k) acc += (double)w.a8[s][i + 32 * (k >> 3)][k & 7] * (double)w.b8[s][j + 32 * (k >> 3)][k & 7];
+        c[r] = (float)acc;
     }
     return c;
 }

@@ -232,6 +232,74 @@ def test_winograd_f4x4_16tile_conv_matches_oracle(eng, knob, case):
         assert np.array_equal(down(eng, out[1]), nnops.max_pool_2x2(y)[0])   # the pooled tensor is the max over the STORED values, bit for bit
 
 
+WINO6_CASES = [
+    # name, x shape, Cout, padding, extra, chunk tiles (0: one pass)
+    ("same_one_block", (1, 16, 32, 32), 128, "SAME", None, 0),
+    ("ragged_same_bias_relu", (2, 21, 37, 64), 128, "SAME", "bias_relu", 0),      # 6 x 10 tiles per image, a last tile row / column of 1 pixel; 120 tiles padded to 128
+    ("pool_two_coblocks", (1, 24, 40, 32), 256, "SAME", "pool", 0),
+    ("mask_chunked", (3, 20, 36, 32), 128, "SAME", "mask", 128),                  # 135 tiles in chunks of 128 + 7
+    ("valid_raw", (1, 18, 22, 32), 128, "VALID", None, 0),
+    ("full_pad_raw", (1, 10, 14, 32), 128, "FULL", None, 0),
+    ("deep_two_rounds", (1, 48, 48, 96), 128, "SAME", None, 0),                   # 144 tiles = two tile blocks, three stages
+]
+
+
+@pytest.mark.parametrize("case", WINO6_CASES, ids=[c[0] for c in WINO6_CASES])
+def test_winograd_f4x4_split_bf16_pipeline_matches_oracle(eng, knob, case):
+    """fs_wino6.hip (round 6): Winograd F(4x4,3x3) with the 36 Winograd-domain GEMMs on the bf16 matrix cores as six exact products of bf16 pieces with fp32
+    accumulation -- input transform, GEMM, output transform + epilogue as three launches -- the form fs_perceptual_loss runs conv4_x (libs/vgg16.py:131-173) and
+    its input gradients on under FS_WINO_V=6.  Through fs_conv2d_fwd with a caller-split filter (fs_wino6_transform_filter); float64 oracle, the tolerance of
+    the fp32 F(4x4) kernels (5e-5 of the output's magnitude)."""
+    name, xs, cout, pad, extra, chunk = case
+    knob("FS_WINO6_MINCC", 0)
+    knob("FS_WINO6_MINTILES", 1)
+    rng = np.random.default_rng(29)
+    x = rng.standard_normal(xs).astype(np.float32)
+    w = (rng.standard_normal((3, 3, xs[3], cout)) * 0.1).astype(np.float32)
+    kw = {}
+    if pad == "FULL":
+        padding = (2, 2, xs[1] + 2, xs[2] + 2)
+        want = nnops.conv2d(np.pad(x.astype(np.float64), ((0, 0), (2, 2), (2, 2), (0, 0))), w.astype(np.float64), 1, "VALID")
+    else:
+        padding = pad
+        want = nnops.conv2d(x.astype(np.float64), w.astype(np.float64), 1, pad)
+    if extra in ("bias_relu", "pool"):
+        bias = rng.standard_normal(cout).astype(np.float32)
+        kw.update(bias=up(eng, bias), out_relu=1)
+        want = np.maximum(want + bias, 0.0)
+    if extra == "mask":
+        mask = rng.standard_normal(want.shape).astype(np.float32)
+        kw["mask_src"] = up(eng, mask)
+        want = np.where(mask > 0, want, 0.0)
+    direct = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, padding, **kw))
+    out = eng.conv2d(up(eng, x), up(eng, w), 1, padding, winograd=6, want_pool=(extra == "pool"), w6_chunk_tiles=chunk, **kw)
+    y = down(eng, out[0] if extra == "pool" else out)
+    assert y.shape == want.shape
+    assert rel(y, want) < 5e-5
+    assert rel(y, direct) < 5e-5 and not np.array_equal(y, direct)      # really the other algorithm
+    if extra == "pool":
+        assert np.array_equal(down(eng, out[1]), nnops.max_pool_2x2(y)[0])   # the pooled tensor is the max over the STORED values, bit for bit
+
+
+def test_winograd_f4x4_split_bf16_accuracy_on_a_deep_reduction(eng, knob):
+    """The bar of the round-5 review: on the inputs of test_winograd_f4x4_accuracy_on_a_deep_reduction (512 input channels, post-ReLU-like data) the split-bf16
+    products must not be LESS accurate than the fp32 F(4x4) kernel (exact products, one fp32 rounding per 16-channel block of the accumulation instead of one
+    per fused multiply-add; numpy restatement tools/bf16x3_error.py: 6.0e-6 against 1.26e-5)."""
+    knob("FS_WINO6_MINCC", 0)
+    knob("FS_WINO6_MINTILES", 1)
+    rng = np.random.default_rng(17)
+    x = (np.maximum(rng.standard_normal((1, 16, 32, 512)), 0) * 50).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 512, 128)) * 0.02).astype(np.float32)
+    want = nnops.conv2d(x.astype(np.float64), w.astype(np.float64), 1, "SAME")
+    w4 = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME", winograd=4))
+    w6 = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "SAME", winograd=6))
+    e4, e6 = rel(w4, want), rel(w6, want)
+    rms = lambda y: float(np.sqrt(((y - want) ** 2).mean()) / np.sqrt((want ** 2).mean()))
+    print("512 input channels: split-bf16 max error %.2e rms %.2e | fp32 F(4x4) max %.2e rms %.2e" % (e6, rms(w6), e4, rms(w4)))
+    assert e6 < 5e-5 and rms(w6) < 1e-5
+    assert e6 <= e4 * 1.05 and rms(w6) <= rms(w4) * 1.05, (e6, e4, rms(w6), rms(w4))
+
+
 @pytest.mark.parametrize("tb", [1, 2])
 def test_winograd_f4x4_16tile_residual_block_form(eng, knob, tb):
     """The residual-block form on the 16-tile F(4x4) kernel: VALID padding, per-item statistics of the raw output ->

@@ -376,6 +376,42 @@ def test_perceptual_loss_and_gradient_match_oracle(eng, knob, force_ksplit):
     assert flat_close(eng.mem.to_numpy(dy), dyo)
 
 
+@pytest.mark.parametrize("chunk", [0, 128])
+def test_perceptual_loss_through_the_split_bf16_pipeline(eng, knob, chunk):
+    """FS_WINO_V=6 (round 6, fs_wino6.hip): the VGG16 convs with Cin % 32 == 0 and Cout % 128 == 0 and their input gradients as input transform + 36 GEMMs on the
+    bf16 matrix cores (six exact products of bf16 pieces, fp32 accumulation) + output transform with the bias / ReLU / pool / consumer-mask epilogues
+    (libs/vgg16.py:83-173 behind train.py:203).  The thresholds that keep the path to conv4_x at training sizes are lowered so that every eligible layer of
+    this small problem takes it (conv2_1 ... conv4_3 forward, conv4_3 ... conv2_2 input gradients); chunk = 128: the launches run in tile chunks.
+    Unchanged tolerances: losses 2e-5, the gradient as in test_perceptual_loss_and_gradient_match_oracle."""
+    knob("FS_WINO_V", 6)
+    knob("FS_WINO6_MINCC", 0)
+    knob("FS_WINO6_MINTILES", 1)
+    if chunk:
+        knob("FS_WINO6_CHUNK", chunk)
+    rng = np.random.default_rng(1)
+    Wv = perceptual.synthetic_vgg_weights(seed=3)
+    eng.vgg_load(Wv)                     # (prepared under the knob: the buffer carries the bf16 pieces)
+    cfg = engine.default_loss_cfg()
+    cfg["beta"] = 1e-4
+    style = rng.uniform(0, 255, (1, 37, 45, 3)).astype(np.float32)
+    tg = eng.style_targets(eng.mem.from_numpy(style), cfg)
+    tgo = perceptual.target_grams(style.astype(np.float64), f64(Wv), cfg["style_layers"])
+    y = rng.uniform(0, 255, (2, 32, 40, 3)).astype(np.float32)
+    xc = rng.uniform(0, 255, (2, 32, 40, 3)).astype(np.float32)
+    losses, dy = eng.perceptual_loss(eng.mem.from_numpy(y), eng.mem.from_numpy(xc), tg, cfg)
+    losses, dy = eng.mem.to_numpy(losses).copy(), eng.mem.to_numpy(dy).copy()
+    feats = perceptual.vgg16(xc.astype(np.float64), f64(Wv), upto="conv3_3")
+    lo, dyo = perceptual.perceptual_loss(y.astype(np.float64), [feats["conv3_3"]], tgo, f64(Wv), beta=1e-4)
+    np.testing.assert_allclose(losses, [lo[k] for k in ("loss", "content_loss", "style_loss", "tv_loss")], rtol=2e-5)
+    assert flat_close(dy, dyo)
+    knob("FS_WINO_V", 5)                 # the same buffer under the default knob: the fp32 F(4x4) kernels -- another algorithm, the same answer
+    l5, dy5 = eng.perceptual_loss(eng.mem.from_numpy(y), eng.mem.from_numpy(xc), tg, cfg)
+    l5, dy5 = eng.mem.to_numpy(l5), eng.mem.to_numpy(dy5)
+    assert not np.array_equal(dy5, dy)
+    np.testing.assert_allclose(l5, losses, rtol=2e-5)
+    eng.vgg_load(Wv)                     # (leave the engine with a buffer prepared under the default knobs)
+
+
 @pytest.mark.parametrize("content_layers", [("conv1_2", "conv3_3"), ("conv2_2", "conv3_3", "conv4_3")])
 def test_perceptual_loss_with_several_content_layers(eng, knob, content_layers):
     """train.py:56-60: --loss_content_layers takes several names.  A content term BELOW the last content layer reads the content half of a pooled

@@ -20,9 +20,11 @@ from collections import defaultdict
 
 def short(name):
     m = re.search(r"wino4t_conv_kernel<(\d)", name)
-    if m:   # the 16-tile x 64-channel instances (<1>: transform net, small VGG16 grids) and the big-item instances (<2>: 32 tiles x 64 channels,
-        #     <3>: 16 tiles x 128 channels -- the VGG16 launches of the training batches, folded together as "<2>") are different workloads
-        return "wino4t_conv_kernel<%s>" % ("1" if m.group(1) == "1" else "2")
+    if m:   # one row per ITEM FORM (round 6; round 5 folded every form but <1> into "<2>", which mixed the 15 flattened transform-net launches <4> of a
+        #     batch-32 step into the "per VGG launch" figure): <1> 16 tiles x 64 channels (transform net at small batches, small VGG16 grids), <2> 32 tiles
+        #     x 64 channels and <3> 16 tiles x 128 channels (the VGG16 launches of the training batches), <4> flattened 16-tile lists (transform net at
+        #     batch 32).  The family "wino4t_conv_kernel (VGG16 big items)" below = <2> + <3>.
+        return "wino4t_conv_kernel<%s>" % m.group(1)
     m = re.search(r"(conv_igemm_kernel<[^>]*>|conv_wgrad_kernel<[^>]*>|wgrad2_kernel<[^>]*>|conv_stream_kernel<[^>]*>|gram_stream_kernel<[^>]*>|"
                   r"gram_bwd_kernel<[^>]*>|conv_bf16_\w+<[^>]*>|conv_bstream_kernel<[^>]*>|[a-z_0-9]+_kernel)", name)
     s = m.group(1) if m else name[:60]
@@ -49,7 +51,9 @@ def main():
         w = sum(wr[k]) / len(wr[k])
         kernels[k] = {"launches_sampled": len(fe[k]), "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
                       "traffic_bytes_per_launch": int((2 * f + w) * 1024)}
-    fams = {"wino_conv_kernel": r"^wino2?_conv_kernel$", "conv_wgrad_kernel": r"^(conv_wgrad_kernel<(?!1,4)|wgrad2_kernel<)",
+    fams = {"wino4t_conv_kernel (VGG16 big items)": r"^wino4t_conv_kernel<[23]>$", "wino4t_conv_kernel (transform net)": r"^wino4t_conv_kernel<[14]>$",
+            "wino6 (VGG16, split-bf16 pipeline)": r"^wino6_",
+            "wino_conv_kernel": r"^wino2?_conv_kernel$", "conv_wgrad_kernel": r"^(conv_wgrad_kernel<(?!1,4)|wgrad2_kernel<)",
             "conv_wgrad_kernel (Gram forward)": r"^(conv_wgrad_kernel<1,4>|gram_stream_kernel<)",
             "conv_igemm_kernel (Gram backward)": r"^gram_bwd_kernel<", "conv_igemm_kernel<32,2,1>": r"^conv_stream_kernel<"}
     families = {}
@@ -58,6 +62,8 @@ def main():
         n = sum(kernels[k]["launches_sampled"] for k in ks)
         if n:
             families[fam] = {"kernels": ks, "launches_sampled": n,
+                             "fetch_bytes_per_launch": int(sum(2 * 1024 * kernels[k]["FETCH_SIZE_KiB"] * kernels[k]["launches_sampled"] for k in ks) / n),
+                             "write_bytes_per_launch": int(sum(1024 * kernels[k]["WRITE_SIZE_KiB"] * kernels[k]["launches_sampled"] for k in ks) / n),
                              "traffic_bytes_per_launch": int(sum(kernels[k]["traffic_bytes_per_launch"] * kernels[k]["launches_sampled"] for k in ks) / n)}
     doc = {"_provenance": prov, "kernels": kernels, "families": families}
     try:     # the build these counters were taken from (bench.py quotes them only for the same sources)
