@@ -37,7 +37,13 @@ struct fs_ctx {
     hipStream_t side;      // second stream for the filter-gradient branch of fs_tnet_backward
     hipEvent_t ev[34];
     bool have_side;
-    const float* prepared_w6 = nullptr;   // the buffer the last fs_vgg_prepare filled WITH the fs_wino6.hip filter pieces (FS_WINO_V=6 at that time); only that buffer has them read
+    // the last buffers fs_vgg_prepare filled and the kernel generations each carries (fs_vgg.hip: PrepLayout); a buffer this ctx did not prepare is taken to have
+    // been prepared under the knobs of the moment
+    struct PrepRec {
+        const float* p = nullptr;
+        unsigned mask = 0;
+    } prep_recs[4];
+    int prep_next = 0;
 };
 
 static thread_local char g_err[512] = "";
@@ -324,9 +330,19 @@ int fs_vgg_prepare(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], float* pre
     if (!ctx || !w || !prepared) return fail(-1, "fs_vgg_prepare: null argument");
     const int rc = fs::vgg_prepare(w, prepared, ctx->stream);
     if (rc < 0) return fail(rc, "fs_vgg_prepare failed (%d)", rc);
-    if (rc == 1) ctx->prepared_w6 = prepared;
-    else if (ctx->prepared_w6 == prepared) ctx->prepared_w6 = nullptr;
+    int slot = -1;
+    for (int i = 0; i < 4; ++i)
+        if (ctx->prep_recs[i].p == prepared) slot = i;
+    if (slot < 0) slot = ctx->prep_next++ & 3;
+    ctx->prep_recs[slot].p = prepared;
+    ctx->prep_recs[slot].mask = (unsigned)rc;
     return 0;
+}
+
+static unsigned prep_mask_of(const fs_ctx* ctx, const float* prepared) {
+    for (int i = 0; i < 4; ++i)
+        if (ctx->prep_recs[i].p == prepared) return ctx->prep_recs[i].mask;
+    return fs::vgg_prep_mask();
 }
 
 static int check_cfg(const fs_loss_cfg* cfg) {
@@ -358,7 +374,7 @@ int fs_perceptual_loss(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const 
     fs::VggLayout L;
     fs::vgg_layout(N, H, W, *cfg, true, &L);
     if (ws_bytes < L.total_floats * sizeof(float)) return fail(-3, "fs_perceptual_loss: workspace too small");
-    const int rc = fs::perceptual_loss(L, w, b, prepared, *cfg, y, content, losses, dy, (float*)ws, ctx->stream, ctx->prepared_w6 == prepared);
+    const int rc = fs::perceptual_loss(L, w, b, prepared, *cfg, y, content, losses, dy, (float*)ws, ctx->stream, prep_mask_of(ctx, prepared));
     return rc ? fail(rc, "fs_perceptual_loss: launch failed (%d)", rc) : 0;
 }
 

@@ -24,11 +24,12 @@ struct VggLayout {
 };
 
 size_t vgg_prepared_floats();
-int vgg_prepare(const float* const w[FS_VGG_NLAYERS], float* prepared, hipStream_t s);   // < 0: error; 1: the buffer also carries the fs_wino6.hip filter pieces (FS_WINO_V=6)
+int vgg_prepare(const float* const w[FS_VGG_NLAYERS], float* prepared, hipStream_t s);   // < 0: error; >= 0: mask of the kernel generations whose filter layouts the buffer carries
+unsigned vgg_prep_mask();   // the mask a prepare under the knobs of the moment builds
 void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, VggLayout* L);
 int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
                     const float* prepared, const fs_loss_cfg& cfg, const float* y, const float* content, float* losses,
-                    float* dy, float* ws, hipStream_t s, bool have_w6 = false);
+                    float* dy, float* ws, hipStream_t s, unsigned prep_mask);
 int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
                   const fs_loss_cfg& cfg, const float* img, float* const grams[4], float* ws, hipStream_t s);
 // libs/vgg16.py:36-220 for N images (RGB 0..255): post-ReLU activations of the requested layers copied to out[i]

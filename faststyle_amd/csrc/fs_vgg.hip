@@ -28,95 +28,89 @@ static inline int pool_index(int l) { return l == 1 ? 0 : (l == 3 ? 1 : 2); }
         if (rc_) return rc_; \
     } while (0)
 
-// prepared buffer: [flip-transposed filters of every layer (dgrad)] [Winograd-transformed forward filters, layers 1..]
-// [Winograd-transformed flip-transposed filters, layers 1..]; the frozen weights are transformed once (fs_vgg_prepare)
-static size_t flipt_floats() {
-    size_t n = 0;
-    for (int l = 0; l < FS_VGG_NLAYERS; ++l) n += ((size_t)9 * kCin[l] * kCout[l] + 63) & ~(size_t)63;
-    return n;
+// The prepared buffer (fs_vgg_prepare, once per frozen weight set): [flip-transposed filters of every layer (input-gradient convs)] followed by the
+// Winograd-transformed filters, forward and flip-transposed, of layers 1.., in the layouts of the kernel GENERATIONS the current knobs select -- round 6:
+// only those (rounds 2-5 built every generation's layout, 490 MB, although a run reads one):
+//   PREP_F2   F(2x2,3x3): U[16][Cin][Cout] (fs_wino.hip) and its K-contiguous form (fs_wino2.hip)     FS_WINO_V <= 3
+//   PREP_W4   F(4x4,3x3), filter through LDS (fs_wino4.hip)                                             FS_WINO_V = 4
+//   PREP_W4T  F(4x4,3x3), filter global -> registers (fs_wino4t.hip) + its 128-channel item form        FS_WINO_V >= 5
+//   PREP_W6   three bf16 pieces for the split-bf16 pipeline (fs_wino6.hip), eligible layers only        FS_WINO_V >= 6 (default)
+// FS_VGG_PREPARE_ALL=1 builds all of them (generation cross-checks inside one process).  vgg_prepare returns the mask it built; fs_api.hip remembers it
+// for that buffer and hands it to every consumer, which reads a generation only if the buffer has it AND the knobs of the moment want it -- a buffer
+// prepared under other knobs degrades to the direct kernels, never to a read of bytes that were not written.
+enum { PREP_F2 = 1, PREP_W4 = 2, PREP_W4T = 4, PREP_W6 = 8 };
+unsigned vgg_prep_mask() {
+    if (tune_int("FS_VGG_PREPARE_ALL", 0)) return PREP_F2 | PREP_W4 | PREP_W4T | PREP_W6;
+    const int v = tune_int("FS_WINO_V", 6);
+    return v >= 6 ? (PREP_W4T | PREP_W6) : v == 5 ? PREP_W4T : v == 4 ? PREP_W4 : PREP_F2;
 }
-static size_t wino_offset(int l, bool dgrad) {  // l >= 1
-    size_t n = flipt_floats();
-    for (int i = 1; i < FS_VGG_NLAYERS; ++i) {
-        const size_t sz = ((size_t)16 * kCin[i] * kCout[i] + 63) & ~(size_t)63;
-        if (i == l && !dgrad) return n;
-        n += sz;
-        if (i == l && dgrad) return n;
-        n += sz;
-    }
-    return n;
-}
-static size_t wino_region_floats() { return wino_offset(FS_VGG_NLAYERS, false) - flipt_floats(); }
-// (the same transformed filters once more in the K-contiguous order of the second-generation kernel, fs_wino2.hip)
-static size_t wino2_offset(int l, bool dgrad) { return wino_offset(l, dgrad) + wino_region_floats(); }
-// (... and the F(4x4,3x3) filters of fs_wino4.hip, 36 positions each, both orientations)
-static size_t wino4_offset(int l, bool dgrad) {  // l >= 1
-    size_t n = wino_offset(FS_VGG_NLAYERS, false) + wino_region_floats();
-    for (int i = 1; i < FS_VGG_NLAYERS; ++i) {
-        const size_t sz = ((size_t)36 * kCin[i] * kCout[i] + 63) & ~(size_t)63;
-        if (i == l && !dgrad) return n;
-        n += sz;
-        if (i == l && dgrad) return n;
-        n += sz;
-    }
-    return n;
-}
-// (... and once more in the register layout of fs_wino4t.hip, the kernel the training step runs them on since the second half of round 4)
-static size_t wino4t_offset(int l, bool dgrad) { return wino4_offset(l, dgrad) + (wino4_offset(FS_VGG_NLAYERS, false) - wino4_offset(1, false)); }
-// (... and in the layout of its 128-channel item form, for the layers that have the channels)
-static size_t wino4u_offset(int l, bool dgrad) { return wino4t_offset(l, dgrad) + (wino4_offset(FS_VGG_NLAYERS, false) - wino4_offset(1, false)); }
-// (round 6 ... and, under FS_WINO_V=6 only, the three bf16 pieces of the F(4x4) filters of the layers the split-bf16 pipeline of fs_wino6.hip may take:
-// Cin % 32 == 0 and Cout % 128 == 0 in the respective direction.  The region exists only in a buffer prepared under that knob: vgg_prepare returns
-// whether it filled it, fs_api.hip remembers that per prepared pointer and perceptual_loss is told -- a buffer prepared under another knob value never
-// has the region read.)
-static bool vgg_want_w6() { return tune_int("FS_WINO_V", 5) >= 6; }
 static bool w6_layer_ok(int l, bool dgrad) {
     const int ci = dgrad ? kCout[l] : kCin[l], co = dgrad ? kCin[l] : kCout[l];
     return l >= 1 && ci % 32 == 0 && co % 128 == 0 && (long)ci * co >= (long)tune_int("FS_WINO6_MINCC", 512 * 256);
 }
-static size_t wino6_offset(int l, bool dgrad) {  // l >= 1
-    size_t n = wino4u_offset(FS_VGG_NLAYERS, false);
-    for (int i = 1; i < FS_VGG_NLAYERS; ++i)
+struct PrepLayout {
+    unsigned mask;
+    size_t flipt[FS_VGG_NLAYERS];
+    size_t wino[FS_VGG_NLAYERS][2], wino2[FS_VGG_NLAYERS][2], wino4[FS_VGG_NLAYERS][2], wino4t[FS_VGG_NLAYERS][2], wino4u[FS_VGG_NLAYERS][2], wino6[FS_VGG_NLAYERS][2];   // [layer][dgrad]
+    size_t total;
+};
+static PrepLayout prep_layout(unsigned mask) {
+    PrepLayout P{};
+    P.mask = mask;
+    size_t n = 0;
+    auto take = [&](size_t floats) {
+        const size_t o = n;
+        n += (floats + 63) & ~(size_t)63;
+        return o;
+    };
+    for (int l = 0; l < FS_VGG_NLAYERS; ++l) P.flipt[l] = take((size_t)9 * kCin[l] * kCout[l]);
+    for (int l = 1; l < FS_VGG_NLAYERS; ++l)
         for (int d = 0; d < 2; ++d) {
-            if (i == l && (d == 1) == dgrad) return n;
-            if (w6_layer_ok(i, d == 1)) n += wino6_filter_floats(d ? kCout[i] : kCin[i], d ? kCin[i] : kCout[i]);
+            const size_t cc = (size_t)kCin[l] * kCout[l];
+            if (mask & PREP_F2) {
+                P.wino[l][d] = take(16 * cc);
+                P.wino2[l][d] = take(16 * cc);
+            }
+            if (mask & PREP_W4) P.wino4[l][d] = take(36 * cc);
+            if (mask & PREP_W4T) {
+                P.wino4t[l][d] = take(36 * cc);
+                if ((d ? kCin[l] : kCout[l]) % 128 == 0) P.wino4u[l][d] = take(36 * cc);
+            }
+            if ((mask & PREP_W6) && w6_layer_ok(l, d == 1)) P.wino6[l][d] = take(wino6_filter_floats(d ? kCout[l] : kCin[l], d ? kCin[l] : kCout[l]));
         }
-    return n;
+    P.total = n;
+    return P;
 }
-size_t vgg_prepared_floats() { return vgg_want_w6() ? wino6_offset(FS_VGG_NLAYERS, false) : wino4u_offset(FS_VGG_NLAYERS, false); }
-// FS_WINO_V >= 5 (default): the F(4x4) convs through fs_wino4t.hip (32-tile items, filter operand global -> registers); 4: through fs_wino4.hip
-static bool vgg_use_4t() { return tune_int("FS_WINO_V", 5) >= 5; }
+size_t vgg_prepared_floats() { return prep_layout(vgg_prep_mask()).total; }
+// which generation the knobs of the moment want for the F(4x4) convs (FS_WINO_V >= 5: fs_wino4t.hip; 4: fs_wino4.hip) and whether the deep layers may take fs_wino6.hip
+static bool vgg_use_4t() { return tune_int("FS_WINO_V", 6) >= 5; }
+static bool vgg_want_w6() { return tune_int("FS_WINO_V", 6) >= 6; }
 // debugging aid: FS_VGG_WINO_MASK selects the layers that may take the Winograd kernel (bit l: forward of layer l,
 // bit 16+l: its input gradient); default all
 static bool wino_layer_on(int bit) {
     return ((unsigned)tune_int("FS_VGG_WINO_MASK", -1) >> bit) & 1u;
 }
-static size_t prepared_offset(int l) {
-    size_t n = 0;
-    for (int i = 0; i < l; ++i) n += ((size_t)9 * kCin[i] * kCout[i] + 63) & ~(size_t)63;
-    return n;
-}
 
 int vgg_prepare(const float* const w[FS_VGG_NLAYERS], float* prepared, hipStream_t s) {
-    for (int l = 0; l < FS_VGG_NLAYERS; ++l)
-        FS_TRY(wt_flip_transpose(w[l], prepared + prepared_offset(l), 3, 3, kCin[l], kCout[l], s));
-    for (int l = 1; l < FS_VGG_NLAYERS; ++l) {
-        FS_TRY(wt_wino(w[l], prepared + wino_offset(l, false), kCin[l], kCout[l], s));
-        FS_TRY(wt_wino(prepared + prepared_offset(l), prepared + wino_offset(l, true), kCout[l], kCin[l], s));  // [3][3][Cout][Cin]
-        FS_TRY(wt_wino2(w[l], prepared + wino2_offset(l, false), kCin[l], kCout[l], s));
-        FS_TRY(wt_wino2(prepared + prepared_offset(l), prepared + wino2_offset(l, true), kCout[l], kCin[l], s));
-        FS_TRY(wt_wino4(w[l], prepared + wino4_offset(l, false), kCin[l], kCout[l], s));
-        FS_TRY(wt_wino4(prepared + prepared_offset(l), prepared + wino4_offset(l, true), kCout[l], kCin[l], s));
-        FS_TRY(wt_wino4t(w[l], prepared + wino4t_offset(l, false), kCin[l], kCout[l], s));
-        FS_TRY(wt_wino4t(prepared + prepared_offset(l), prepared + wino4t_offset(l, true), kCout[l], kCin[l], s));
-        if (kCout[l] % 128 == 0) FS_TRY(wt_wino4u(w[l], prepared + wino4u_offset(l, false), kCin[l], kCout[l], s));
-        if (kCin[l] % 128 == 0) FS_TRY(wt_wino4u(prepared + prepared_offset(l), prepared + wino4u_offset(l, true), kCout[l], kCin[l], s));
-        if (vgg_want_w6()) {
-            if (w6_layer_ok(l, false)) FS_TRY(wt_wino6(w[l], reinterpret_cast<unsigned short*>(prepared + wino6_offset(l, false)), kCin[l], kCout[l], s));
-            if (w6_layer_ok(l, true)) FS_TRY(wt_wino6(prepared + prepared_offset(l), reinterpret_cast<unsigned short*>(prepared + wino6_offset(l, true)), kCout[l], kCin[l], s));
+    const PrepLayout P = prep_layout(vgg_prep_mask());
+    for (int l = 0; l < FS_VGG_NLAYERS; ++l) FS_TRY(wt_flip_transpose(w[l], prepared + P.flipt[l], 3, 3, kCin[l], kCout[l], s));
+    for (int l = 1; l < FS_VGG_NLAYERS; ++l)
+        for (int d = 0; d < 2; ++d) {
+            // forward: the stored HWIO filter; input gradient: its flip-transposed copy [3][3][Cout][Cin] with the channel roles swapped
+            const float* src = d ? prepared + P.flipt[l] : w[l];
+            const int ci = d ? kCout[l] : kCin[l], co = d ? kCin[l] : kCout[l];
+            if (P.mask & PREP_F2) {
+                FS_TRY(wt_wino(src, prepared + P.wino[l][d], ci, co, s));
+                FS_TRY(wt_wino2(src, prepared + P.wino2[l][d], ci, co, s));
+            }
+            if (P.mask & PREP_W4) FS_TRY(wt_wino4(src, prepared + P.wino4[l][d], ci, co, s));
+            if (P.mask & PREP_W4T) {
+                FS_TRY(wt_wino4t(src, prepared + P.wino4t[l][d], ci, co, s));
+                if (co % 128 == 0) FS_TRY(wt_wino4u(src, prepared + P.wino4u[l][d], ci, co, s));
+            }
+            if ((P.mask & PREP_W6) && w6_layer_ok(l, d == 1)) FS_TRY(wt_wino6(src, reinterpret_cast<unsigned short*>(prepared + P.wino6[l][d]), ci, co, s));
         }
-    }
-    return vgg_want_w6() ? 1 : 0;   // 1: the buffer carries the fs_wino6.hip filter pieces
+    return (int)P.mask;   // >= 0: the generations the buffer carries
 }
 
 struct Bump2 {
@@ -287,24 +281,25 @@ static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, 
 // forward through layers [0..lmax]; samples [0,N) go all the way, [N,NB) stop after cmax
 // prepared: the buffer of fs_vgg_prepare (Winograd-transformed filters) or nullptr (direct convolutions only)
 static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
-                       const float* prepared, float* ws, hipStream_t s, bool have_w6 = false) {
+                       const float* prepared, float* ws, hipStream_t s, unsigned prep_mask = 0) {
     FS_TRY(vgg_consts(ws + L.ab, s));
+    const PrepLayout P = prep_layout(prepared ? prep_mask : 0);
     const float* src = ws + L.xin;
     for (int l = 0; l <= L.lmax; ++l) {
         bool pooled = false;
         const int nb = l <= L.cmax ? L.NB : L.N;
         const bool wl = prepared && l >= 1 && wino_layer_on(l);
-        FS_TRY(vgg_conv(src, nb, L.Hl[l], L.Wl[l], l, w[l], wl ? prepared + wino_offset(l, false) : nullptr,
-                        wl ? prepared + wino2_offset(l, false) : nullptr, (wl && !vgg_use_4t()) ? prepared + wino4_offset(l, false) : nullptr,
-                        (wl && vgg_use_4t()) ? prepared + wino4t_offset(l, false) : nullptr,
-                        (wl && vgg_use_4t() && kCout[l] % 128 == 0) ? prepared + wino4u_offset(l, false) : nullptr, b[l],
+        const bool f2 = wl && (P.mask & PREP_F2), w4 = wl && (P.mask & PREP_W4) && !vgg_use_4t(), w4t = wl && (P.mask & PREP_W4T) && vgg_use_4t();
+        const bool w6 = wl && (P.mask & PREP_W6) && vgg_want_w6() && L.w6ws_floats && w6_layer_ok(l, false);
+        FS_TRY(vgg_conv(src, nb, L.Hl[l], L.Wl[l], l, w[l], f2 ? prepared + P.wino[l][0] : nullptr, f2 ? prepared + P.wino2[l][0] : nullptr,
+                        w4 ? prepared + P.wino4[l][0] : nullptr, w4t ? prepared + P.wino4t[l][0] : nullptr,
+                        (w4t && kCout[l] % 128 == 0) ? prepared + P.wino4u[l][0] : nullptr, b[l],
                         ws + L.ab, ws + L.act[l], ws + L.splitws, L.splitws_floats, s,
                         (pool_after(l) && l < L.lmax) ? ws + L.pool[pool_index(l)] : nullptr, &pooled,
                         // (the content half [N, NB) only feeds the next layer: of a pooled layer below the LAST content layer it needs the pooled tensor
                         // alone -- unless a content term of its own reads the full-resolution half, --loss_content_layers takes several)
                         (nb > L.N && l < L.cmax && !((L.content_mask >> l) & 1u)) ? L.N : 0,
-                        (wl && have_w6 && vgg_want_w6() && L.w6ws_floats && w6_layer_ok(l, false)) ? reinterpret_cast<const unsigned short*>(prepared + wino6_offset(l, false)) : nullptr,
-                        ws + L.w6ws, L.w6ws_floats));
+                        w6 ? reinterpret_cast<const unsigned short*>(prepared + P.wino6[l][0]) : nullptr, ws + L.w6ws, L.w6ws_floats));
         src = ws + L.act[l];
         if (pool_after(l) && l < L.lmax) {
             if (!pooled)
@@ -357,7 +352,7 @@ int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], cons
 
 int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
                     const float* prepared, const fs_loss_cfg& cfg, const float* y, const float* content, float* losses,
-                    float* dy, float* ws, hipStream_t s, bool have_w6) {
+                    float* dy, float* ws, hipStream_t s, unsigned prep_mask) {
     const int N = L.N;
     const size_t img = (size_t)N * L.H * L.W * 3;
     // [y ; content] as one 2N batch at ws + L.xin.  A caller that keeps the two tensors THERE (fs_perceptual_ws_input: the transform net writes y
@@ -371,7 +366,8 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
     // with the fork in the graph the same node behaved).  No memset on any capturable path of the library any more.)
     // (round 5: the four scalars are WRITTEN once, by loss_finish at the end, from the partial sums every term leaves in ws + L.lossp -- the per-term
     // sum launches, the clear and the total are gone)
-    FS_TRY(vgg_forward(L, w, b, prepared, ws, s, have_w6));
+    FS_TRY(vgg_forward(L, w, b, prepared, ws, s, prep_mask));
+    const PrepLayout P = prep_layout(prep_mask);
 
     // ---- losses ----
     LossFinish lf{};
@@ -536,14 +532,15 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         const int C = kCout[l], H = L.Hl[l], W = L.Wl[l];
         ConvArgs a{};
         a.x = pre_cur;
-        a.w = prepared + prepared_offset(l);
-        a.w_wino = (l >= 1 && wino_layer_on(16 + l)) ? prepared + wino_offset(l, true) : nullptr;
-        a.w_wino2 = (l >= 1 && wino_layer_on(16 + l)) ? prepared + wino2_offset(l, true) : nullptr;
-        a.w_wino4 = (l >= 1 && wino_layer_on(16 + l) && !vgg_use_4t()) ? prepared + wino4_offset(l, true) : nullptr;
-        a.w_wino4t = (l >= 1 && wino_layer_on(16 + l) && vgg_use_4t()) ? prepared + wino4t_offset(l, true) : nullptr;
-        a.w_wino4u = (a.w_wino4t && kCin[l] % 128 == 0) ? prepared + wino4u_offset(l, true) : nullptr;
-        if (have_w6 && vgg_want_w6() && L.w6ws_floats && wino_layer_on(16 + l) && w6_layer_ok(l, true)) {
-            a.w_wino6 = reinterpret_cast<const unsigned short*>(prepared + wino6_offset(l, true));
+        a.w = prepared + P.flipt[l];
+        const bool wl = l >= 1 && wino_layer_on(16 + l);
+        a.w_wino = (wl && (P.mask & PREP_F2)) ? prepared + P.wino[l][1] : nullptr;
+        a.w_wino2 = (wl && (P.mask & PREP_F2)) ? prepared + P.wino2[l][1] : nullptr;
+        a.w_wino4 = (wl && (P.mask & PREP_W4) && !vgg_use_4t()) ? prepared + P.wino4[l][1] : nullptr;
+        a.w_wino4t = (wl && (P.mask & PREP_W4T) && vgg_use_4t()) ? prepared + P.wino4t[l][1] : nullptr;
+        a.w_wino4u = (a.w_wino4t && kCin[l] % 128 == 0) ? prepared + P.wino4u[l][1] : nullptr;
+        if (wl && (P.mask & PREP_W6) && vgg_want_w6() && L.w6ws_floats && w6_layer_ok(l, true)) {
+            a.w_wino6 = reinterpret_cast<const unsigned short*>(prepared + P.wino6[l][1]);
             a.w6_ws = ws + L.w6ws;
             a.w6_ws_floats = L.w6ws_floats;
         }

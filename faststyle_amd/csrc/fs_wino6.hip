@@ -27,6 +27,9 @@ constexpr int kW6K = 32;                      // input channels per stage
 constexpr int kW6Pitch = 80;                  // bytes per LDS row of one piece: 64 B of k + 16 B of pad -- the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte bank groups
 constexpr int kW6PieceB = 128 * kW6Pitch;     // one piece of one operand: 10240 B
 constexpr int kW6StageB = 6 * kW6PieceB;      // A (V) three pieces + B (U) three pieces: 61440 B; two stages = 120 KB
+#ifndef FS_W6_ABL
+#define FS_W6_ABL 0   // timing builds (results wrong): 1 no split arithmetic, 2 no global loads in the loop, 4 no LDS stores, 8 no barrier, 16 no matrix instructions, 32 no operand reads
+#endif
 
 // fp32 -> three bf16 pieces by truncation: h = top 8 significant bits, m = the next 8 of the (exact) remainder, l = what is left (<= 8 bits): x = h + m + l exactly
 __host__ __device__ __forceinline__ void w6_split(float x, unsigned& h, unsigned& m, unsigned& l) {
@@ -274,7 +277,13 @@ __global__ __launch_bounds__(256) void wino6_gemm_kernel(W6Args a) {
         for (int i = 0; i < 2; ++i) {
             const int u = tid + 256 * i;
             uint4 H, Mi, L;
-            w6_split8(R.a[i][0], R.a[i][1], H, Mi, L);
+            if (FS_W6_ABL & 1) {
+                H = __builtin_bit_cast(uint4, R.a[i][0]);
+                Mi = __builtin_bit_cast(uint4, R.a[i][1]);
+                L = H;
+            } else
+                w6_split8(R.a[i][0], R.a[i][1], H, Mi, L);
+            if ((FS_W6_ABL & 4) && (H.x ^ Mi.y ^ L.z ^ H.w ^ Mi.x ^ L.y ^ H.z ^ Mi.w ^ L.x ^ H.y ^ Mi.z ^ L.w) != 0x9e3779b9u) continue;
             char* p = base + (u >> 2) * kW6Pitch + (u & 3) * 16;
             *reinterpret_cast<uint4*>(p) = H;
             *reinterpret_cast<uint4*>(p + kW6PieceB) = Mi;
@@ -283,6 +292,7 @@ __global__ __launch_bounds__(256) void wino6_gemm_kernel(W6Args a) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int q = tid + 256 * (j & 1);
+            if ((FS_W6_ABL & 4) && (R.b[j].x ^ R.b[j].y ^ R.b[j].z ^ R.b[j].w) != 0x9e3779b9u) continue;
             *reinterpret_cast<uint4*>(base + (3 + (j >> 1)) * kW6PieceB + (q >> 2) * kW6Pitch + (q & 3) * 16) = R.b[j];
         }
     };
@@ -300,48 +310,80 @@ __global__ __launch_bounds__(256) void wino6_gemm_kernel(W6Args a) {
     const int a_lane = (64 * wm + (lane & 31)) * kW6Pitch + (lane >> 5) * 16;
     const int b_lane = 3 * kW6PieceB + (64 * wn + (lane & 31)) * kW6Pitch + (lane >> 5) * 16;
 
-    auto sweep = [&](const char* sa, const char* sb, int ks) __attribute__((always_inline)) {
-        w6_bf16x8 af[2][3], bf[2][3];
+    // operand fragments of one half stage (16 of the 32 input channels): 2 tile blocks x 3 pieces of V, 2 channel blocks x 3 pieces of U
+    struct Frag {
+        w6_bf16x8 a[2][3], b[2][3];
+    };
+    auto read_frag = [&](Frag& F, int st, int ks) __attribute__((always_inline)) {
+        const char* sa = lds + st * kW6StageB + a_lane + ks * 32;
+        const char* sb = lds + st * kW6StageB + b_lane + ks * 32;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                af[blk][p] = __builtin_bit_cast(w6_bf16x8, *reinterpret_cast<const uint4*>(sa + p * kW6PieceB + blk * 32 * kW6Pitch + ks * 32));
-                bf[blk][p] = __builtin_bit_cast(w6_bf16x8, *reinterpret_cast<const uint4*>(sb + p * kW6PieceB + blk * 32 * kW6Pitch + ks * 32));
-            }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                // (pieces: 0 = h, 1 = m, 2 = l; smallest terms first)
-                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acl[i][j], 0, 0, 0);
-                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acl[i][j], 0, 0, 0);
-                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acl[i][j], 0, 0, 0);
-                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acl[i][j], 0, 0, 0);
-                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acl[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                if (FS_W6_ABL & 32) {
+                    F.a[blk][p] = __builtin_bit_cast(w6_bf16x8, make_uint4(lane + p, blk, ks, 1));
+                    F.b[blk][p] = __builtin_bit_cast(w6_bf16x8, make_uint4(lane, blk + p, ks, 2));
+                    continue;
+                }
+                F.a[blk][p] = __builtin_bit_cast(w6_bf16x8, *reinterpret_cast<const uint4*>(sa + p * kW6PieceB + blk * 32 * kW6Pitch));
+                F.b[blk][p] = __builtin_bit_cast(w6_bf16x8, *reinterpret_cast<const uint4*>(sb + p * kW6PieceB + blk * 32 * kW6Pitch));
             }
     };
-    // one stage: the 48 matrix instructions of LDS buffer `st`; beside them the split of register set R (the stage after this one) into buffer st ^ 1 and the
-    // loads of the stage three ahead into R.  The scheduler is asked to thread the vector-ALU / LDS-store / global-load work between the matrix instructions.
+    // the 24 matrix instructions of a half stage, product by product over the four blocks (a block's accumulator is touched every fourth instruction;
+    // pieces: 0 = h, 1 = m, 2 = l; smallest terms first)
+    auto mfma_half = [&](const Frag& F) __attribute__((always_inline)) {
+        if (FS_W6_ABL & 16) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) asm volatile("" ::"v"(F.a[blk][p]), "v"(F.b[blk][p]));
+            return;
+        }
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (t < 5) acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA[t]], F.b[j][PB[t]], acl[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA[t]], F.b[j][PB[t]], acc[i][j], 0, 0, 0);
+                }
+    };
+    // One stage = two halves of 24 matrix instructions, each with its operands read from LDS during the half BEFORE it (a wave issues in order: an operand
+    // read waited for in front of its matrix instruction stalls the matrix pipe -- measured 100 of 245 us on conv4_2):
+    //   first half : products of (stage s, channels 0..15) | reads of (s, 16..31) | split of register set R (= stage s + 1) into the other LDS buffer
+    //   barrier    : buffer st ^ 1 complete; every wave has its reads of buffer st behind it (so the next stage may overwrite st)
+    //   second half: products of (s, 16..31) | reads of (s + 1, 0..15) from the other buffer | global loads of stage s + 3 into R
+    // The scheduler is asked to thread the reads / vector-ALU / LDS-store / global-load work between the matrix instructions.
+    Frag F0, F1;
     auto stage = [&](int st, Regs& R, int kb_load) __attribute__((always_inline)) {
-        const char* sa = lds + st * kW6StageB + a_lane;
-        const char* sb = lds + st * kW6StageB + b_lane;
-        sweep(sa, sb, 0);
+        mfma_half(F0);
+        read_frag(F1, st, 1);
         write_lds(R, st ^ 1);
-        load_regs(R, kb_load);
-        sweep(sa, sb, 1);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-        for (int g = 0; g < 48; ++g) {
+        for (int g = 0; g < 24; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one matrix instruction
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // an LDS read
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four vector-ALU instructions
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);   // vector-ALU instructions of the split
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // an LDS write
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load
         }
 #endif
-        __syncthreads();
+        if (!(FS_W6_ABL & 8)) __syncthreads();
+        mfma_half(F1);
+        read_frag(F0, st ^ 1, 0);
+        if (!(FS_W6_ABL & 2)) load_regs(R, kb_load);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int g = 0; g < 24; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+#endif
     };
 
     Regs R0, R1;
@@ -350,6 +392,7 @@ __global__ __launch_bounds__(256) void wino6_gemm_kernel(W6Args a) {
     load_regs(R0, 1);
     load_regs(R1, 2);
     __syncthreads();
+    read_frag(F0, 0, 0);
     for (int kb = 0; kb < KB; kb += 2) {
         stage(0, R0, kb + 3);                     // stage kb: buffer 0; R0 holds stage kb + 1
         if (kb + 1 < KB) stage(1, R1, kb + 4);    // stage kb + 1: buffer 1; R1 holds stage kb + 2

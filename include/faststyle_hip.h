@@ -80,8 +80,11 @@ int fs_tnet_backward(fs_ctx* ctx, const float* params, const float* x, const flo
 
 /* ---- VGG16 + Gram + losses: reference libs/vgg16.py:36-220, utils.py:66-83, losses.py ------ */
 #define FS_VGG_NLAYERS 10 /* conv1_1 .. conv4_3 (conv5_x is never fetched: train.py:55-59) */
-/* floats needed for the derived forms of the 10 frozen filters: flip-transposed (input-gradient convs) and, for
- * conv1_2 .. conv4_3, Winograd F(2x2,3x3)-transformed [16][Cin][Cout] in both orientations (about 35 M floats) */
+/* floats needed for the derived forms of the 10 frozen filters: flip-transposed (input-gradient convs) and, for conv1_2 .. conv4_3 in both
+ * orientations, the Winograd-transformed filters in the layout(s) of the kernel generation the tuning knobs select AT THE TIME OF THE CALL (round 6; the
+ * default, FS_WINO_V=6: the F(4x4,3x3) register layouts of fs_wino4t.hip + the bf16 pieces of fs_wino6.hip for conv4_x: about 110 M floats).  Call it
+ * immediately before fs_vgg_prepare.  A buffer prepared under other knobs than a later fs_perceptual_loss runs with stays valid: generations it lacks fall
+ * back to the direct kernels. */
 size_t fs_vgg_prepared_floats(void);
 /* w[i], b[i]: conv1_1,conv1_2,conv2_1,...,conv4_3 in the npz convention of vgg16.load_weights
  * (vgg16.py:257-266: HWIO [3,3,Cin,Cout] kernels, [Cout] biases).  Fills `prepared` with the
