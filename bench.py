@@ -51,11 +51,13 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: bf16 MFMA, dense (n
 PEAK_HBM_TBS = 8.0                    # spec; 6.29 measured (float4 copy)
 
 
-def vgg_algorithmic_bytes(B, S=256, cmax=6, lmax=9):
-    """Algorithmic HBM bytes of the 18 F(4x4) VGG16 launches of one train step (conv1_2 ... conv4_3 forward on [y ; content] up to conv3_3 and on y
+def vgg_algorithmic_bytes(B, S=256, cmax=6, lmax=9, layers=None):
+    """Algorithmic HBM bytes of the F(4x4) VGG16 launches of one train step (conv1_2 ... conv4_3 forward on [y ; content] up to conv3_3 and on y
     beyond, their nine input gradients): every input, ReLU-mask source and output ONCE, the content half's full-resolution conv1_2 / conv2_2 outputs
     not at all (nothing reads them), filters not counted (0.24 GB, L2 / Infinity-Cache resident).  Returns (forward reads, forward writes,
-    input-gradient reads incl. masks, input-gradient writes) in bytes -- 2.72 + 2.82 + 2.89 + 1.44 = 9.87 GB at batch 32."""
+    input-gradient reads incl. masks, input-gradient writes) in bytes -- 2.72 + 2.82 + 2.89 + 1.44 = 9.87 GB at batch 32 over the 18 launches (DESIGN.md
+    section 4); `layers`: restrict to those conv layers (1 = conv1_2 ... 9 = conv4_3), e.g. range(1, 7) = the 12 launches that stay on the fp32 kernel
+    when conv4_x runs on the split-bf16 pipeline."""
     cin = [3, 64, 64, 128, 128, 256, 256, 256, 512, 512]
     cout = [64, 64, 128, 128, 256, 256, 256, 512, 512, 512]
     pool_after = lambda l: l in (1, 3, 6)
@@ -65,7 +67,7 @@ def vgg_algorithmic_bytes(B, S=256, cmax=6, lmax=9):
         if pool_after(l) and l < lmax:
             h //= 2
     fr = fw = dr = dw = 0
-    for l in range(1, lmax + 1):
+    for l in (range(1, lmax + 1) if layers is None else layers):
         nb, px = (2 * B if l <= cmax else B), hl[l] * hl[l]
         fr += nb * px * cin[l] * 4
         if pool_after(l) and l < lmax:
@@ -259,6 +261,10 @@ def fam_table(prof, steps, names):
             tab[nm] = {"launches_per_step": round(n / steps, 1), "gflop_per_step": round(fl / steps / 1e9, 2),
                        "ms_per_step": round(ms / steps, 3), "avg_launch_us": round(1e3 * ms / n, 1),
                        "tflops": round(tf, 2), "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+            if nm.startswith("wino6"):   # the split-bf16 pipeline: its FLOP count is the fp32-equivalent F(4x4) products; six bf16 products are issued for each
+                tab[nm]["frac_note"] = "fp32-EQUIVALENT products executed / the fp32 MFMA peak (157.3); the launch issues 6 bf16 products per fp32 one"
+                tab[nm]["bf16_tflops_issued"] = round(6 * tf, 1)
+                tab[nm]["frac_of_bf16_mfma_peak_issued"] = round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4)
     return tab
 
 
@@ -317,6 +323,7 @@ def main():
     F_GRAM_FWD = (fam["gram_stream_kernel"], fam["conv_wgrad_kernel (Gram forward)"])
     F_GRAM_BWD = (fam["gram_bwd_kernel"], fam["conv_igemm_kernel (Gram backward, 1x1 per-sample filters)"])
     WINO_F2 = (F_WINO, F_WINO2_VGG, F_WINO2_TNET)
+    F_WINO6 = next((f for f, n in enumerate(names) if n.startswith("wino6")), None)
 
     B, S = args.batch_per_gpu, args.size
     params = eng.flatten_params(im_transf_net.initial_variables(seed=0), scope="")
@@ -577,6 +584,14 @@ def main():
                                              "time of the section by HIP events in an eager pass (every kernel of it, not only MFMA ones)"},
                 "per_kernel": per_kernel,
             }
+            # all 3x3 VGG16 conv launches of the step (conv1_2 .. conv4_3 forward + input gradients), whichever kernels they took: the fp32 F(4x4) kernel and,
+            # since round 6, the split-bf16 pipeline for conv4_x -- FLOPs = fp32-equivalent products executed
+            vf = [f for f in (F_WINO4T_VGG, F_WINO6, F_WINO4, F_WINO, F_WINO2_VGG) if f is not None and tot[3 * f + 2] > 0]
+            v_fl, v_ms, v_n = (sum(tot[3 * f + k] for f in vf) for k in (1, 2, 0))
+            if v_ms:
+                rep["vgg16_3x3_convs"] = {"kernels": [names[f] for f in vf], "launches_per_step": round(v_n / P, 1), "gflop_per_step": round(v_fl / P / 1e9, 1),
+                                          "ms_per_step": round(v_ms / P, 3), "tflops": round(v_fl / (v_ms * 1e-3) / 1e12, 2),
+                                          "frac": round(v_fl / (v_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
             wf = [F_WINO4T_VGG, F_WINO4T_TNET, F_WINO4, F_WINO, F_WINO2_VGG, F_WINO2_TNET]
             w_fl, w_ms, w_n = (sum(tot[3 * f + k] for f in wf) for k in (1, 2, 0))
             if w_ms:
@@ -596,8 +611,9 @@ def main():
         tpath = newest_profile("hbm_traffic_pmc.json")
         alg_launch = None
         if di == F_WINO4T_VGG and S == 256:
-            alg = vgg_algorithmic_bytes(B)
-            alg_launch = int(sum(alg) / 18)
+            # (18 launches: all of conv1_2 .. conv4_3; 12: conv4_x -- layers 7..9 -- runs on the split-bf16 pipeline and the row holds conv1_2 .. conv3_3)
+            on_row = None if dom["launches_per_step"] > 17.5 else range(1, 7)
+            alg_launch = int(sum(vgg_algorithmic_bytes(B, layers=on_row)) / max(dom["launches_per_step"], 1))
         if tpath:
             tj = json.load(open(tpath))
             k = tj.get("families", {}).get(fam_key) if fam_key else tj.get("kernels", {}).get(sym)
@@ -633,14 +649,15 @@ def main():
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_launch,
                          "traffic_over_algorithmic": round(traffic / alg_launch, 3) if (traffic and alg_launch) else None,
-                         "algorithmic_bytes_note": "VGG16: every input, mask source and output of the 18 launches once (bench.py vgg_algorithmic_bytes; "
-                                                   "9.87 GB per batch-32 step), / 18 launches" if alg_launch else None,
+                         "algorithmic_bytes_note": "VGG16: every input, mask source and output of the row's launches once (bench.py vgg_algorithmic_bytes: "
+                                                   "9.87 GB per batch-32 step over all 18 launches, 8.99 GB over the 12 of conv1_2 .. conv3_3), / launches of the row" if alg_launch else None,
                          "timed_with": "HIP events on the launch stream, eager pass of %d steps right after the timed region; every row "
                                        "of per_kernel is ONE kernel symbol (template instances summed), so row ms = launches x the "
                                        "average duration of that symbol in profiles/*kernel_stats*" % args.profile_steps,
                          "direct_form_equivalent_tflops": round(dom["tflops"] * (4.0 if di in WINO_F4 else 2.25), 2) if di in WINO_F2 + WINO_F4 else None,
                          "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
                          "winograd_family": rep.get("winograd_family"),
+                         "vgg16_3x3_convs": rep.get("vgg16_3x3_convs"),
                          "per_kernel": per_kernel},
             "gram": rep["gram"], "vgg_gram_substep": rep["vgg_gram_substep"],
             "step_tflops_as_written": rep["step_tflops_as_written"], "step_frac_of_f32_mfma_peak": rep["step_frac_as_written"],

@@ -116,6 +116,18 @@ PROTOTYPES = {
     "fs_wino_transform_filter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fs_wino4_transform_filter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fs_wino4t_transform_filter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "fs_loss_sqdiff_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_float, c_void_p, c_void_p, c_void_p]),
+    "fs_loss_tv_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
+    "fs_vgg_dgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "fs_vgg_dgrad": (c_int, [c_void_p, POINTER(_vp10), POINTER(_vp10), c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int), c_void_p, c_void_p,
+                             c_void_p, c_size_t]),
+    "fs_conv2d_dgrad_workspace_bytes": (c_size_t, [POINTER(fs_conv_desc)]),
+    "fs_conv2d_dgrad": (c_int, [c_void_p, POINTER(fs_conv_desc), c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fs_resizeconv_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "fs_resizeconv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t]),
+    "fs_resizeconv_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t]),
+    "fs_resizeconv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t]),
+    "fs_instnorm_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fs_wino6_filter_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "fs_wino6_transform_filter": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "fs_wino6_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int]),

@@ -478,6 +478,50 @@ int fs_loss_tv(fs_ctx* ctx, const float* x, int N, int H, int W, int C, float* o
     return fs::tv_loss(x, N, H, W, C, 1.0f, 0.f, nullptr, out, (float*)scratch, ctx->stream);
 }
 
+// ---- value + gradient forms of the loss terms, and the adjoint of fs_vgg_features (round 6: the pieces a script differentiates through when it composes
+// its own objective as train.py:171-204 / slow_style.py:140-176 do; faststyle_amd/autograd.py wraps them as torch.autograd.Functions) -----------------------
+int fs_loss_sqdiff_grad(fs_ctx* ctx, const float* x, const float* t, size_t t_period, size_t n, float scale, float* out, float* grad, void* scratch) {
+    if (!ctx || !x || !t || !out || !grad || !scratch || !t_period) return fail(-1, "fs_loss_sqdiff_grad: null argument");
+    if (n % t_period || n / t_period > 1024) return fail(-2, "fs_loss_sqdiff_grad: n = %zu must be 1 .. 1024 whole periods of %zu", n, t_period);
+    const int rc = fs::sqdiff_loss(x, t, t_period, n, scale, 2.0f * scale, grad, out, 0, (float*)scratch, ctx->stream);
+    return rc ? fail(rc, "fs_loss_sqdiff_grad: launch failed (%d)", rc) : 0;
+}
+int fs_loss_tv_grad(fs_ctx* ctx, const float* x, int N, int H, int W, int C, float scale, float* out, float* grad, int accumulate, void* scratch) {
+    if (!ctx || !x || !out || !grad || !scratch) return fail(-1, "fs_loss_tv_grad: null argument");
+    if (N < 1 || H < 1 || W < 1 || C < 1) return fail(-2, "fs_loss_tv_grad: empty tensor");
+    if (!accumulate)
+        if (int rc = fs::zero_fill(grad, (size_t)N * H * W * C, ctx->stream)) return fail(rc, "fs_loss_tv_grad: launch failed (%d)", rc);
+    const int rc = fs::tv_loss(x, N, H, W, C, scale, scale, grad, out, (float*)scratch, ctx->stream);
+    return rc ? fail(rc, "fs_loss_tv_grad: launch failed (%d)", rc) : 0;
+}
+
+static const size_t kFliptScratch = (size_t)9 * 512 * 512;   // the largest flip-transposed VGG16 filter (floats)
+size_t fs_vgg_dgrad_workspace_bytes(int N, int H, int W, int max_layer) {
+    if (N < 1 || H < 1 || W < 1 || max_layer < 0 || max_layer >= FS_VGG_NLAYERS) return 0;
+    fs::VggLayout L;
+    features_layout(N, H, W, max_layer, &L);
+    return (L.total_floats + kFliptScratch) * sizeof(float);
+}
+int fs_vgg_dgrad(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS], const float* prepared, const float* x, int N,
+                 int H, int W, int n_layers, const int* layers, const float* const* dfeat, float* dx, void* ws, size_t ws_bytes) {
+    if (!ctx || !w || !b || !x || !layers || !dfeat || !dx || !ws) return fail(-1, "fs_vgg_dgrad: null argument");
+    if (N < 1 || n_layers < 1 || n_layers > FS_VGG_NLAYERS) return fail(-2, "fs_vgg_dgrad: bad N / layer count");
+    int lmax = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        if (layers[i] < 0 || layers[i] >= FS_VGG_NLAYERS) return fail(-2, "fs_vgg_dgrad: layer %d out of range", layers[i]);
+        if (!dfeat[i]) return fail(-1, "fs_vgg_dgrad: null gradient %d", i);
+        for (int j = 0; j < i; ++j)
+            if (layers[j] == layers[i]) return fail(-2, "fs_vgg_dgrad: layer %d listed twice (sum its gradients first)", layers[i]);
+        if (layers[i] > lmax) lmax = layers[i];
+    }
+    fs::VggLayout L;
+    features_layout(N, H, W, lmax, &L);
+    if (ws_bytes < (L.total_floats + kFliptScratch) * sizeof(float)) return fail(-3, "fs_vgg_dgrad: workspace too small");
+    const int rc = fs::vgg_dgrad(L, w, b, prepared, prepared ? prep_mask_of(ctx, prepared) : 0, x, n_layers, layers, dfeat, dx, (float*)ws,
+                                 (float*)ws + L.total_floats, ctx->stream);
+    return rc ? fail(rc, "fs_vgg_dgrad: launch failed (%d)", rc) : 0;
+}
+
 int fs_adam_tf_step(fs_ctx* ctx, float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
                     float beta2, float eps, long long t) {
     if (!ctx || !p || !g || !m || !v) return fail(-1, "fs_adam_tf_step: null argument");
@@ -684,6 +728,153 @@ int fs_instnorm_bwd(fs_ctx* ctx, const float* gin, const float* z, const float* 
         rc = fs::in_bwd(gin, z, mean, rstd, a, b, mode, dz, dgamma, dbeta, (float*)ws, N, HW, C, ctx->stream);
     }
     return rc ? fail(rc, "fs_instnorm_bwd: launch failed (%d)", rc) : 0;
+}
+
+// ---- input gradient of a conv described by its FORWARD descriptor (im_transf_net.py:115 / vgg16.py:47 adjoint) ------------------------------------------
+// dx [N,H,W,Cin] = conv2d_backprop_input(dy [N,Ho,Wo,Cout], w): the forward kernels on the flip-transposed filter (built into ws: KH*KW*Cin*Cout floats) --
+// stride 1: a conv with padding K - 1 - pad over dy; stride 2: the same over the zero-dilated dy (the library's own backward takes the phase-decomposed
+// form for its two stride-2 units; this entry point is the general one).  Square kernels, plain source, no on-load / epilogue options.
+size_t fs_conv2d_dgrad_workspace_bytes(const fs_conv_desc* d) {
+    return (!d || d->KH < 1 || d->KW < 1 || d->Cin < 1 || d->Cout < 1) ? 0 : (size_t)d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
+}
+int fs_conv2d_dgrad(fs_ctx* ctx, fs_conv_desc* d, const float* dy, float* dx, void* ws, size_t ws_bytes) {
+    if (!ctx || !d || !dy || !dx || !ws || !d->w) return fail(-1, "fs_conv2d_dgrad: null argument");
+    if (d->KH != d->KW || (d->stride != 1 && d->stride != 2) || d->src_mode != FS_SRC_PLAIN || d->shuffle || d->w_nstride)
+        return fail(-2, "fs_conv2d_dgrad: square kernel, stride 1 or 2, plain source");
+    if (d->Cout % 4 || d->Cin % 4) return fail(-2, "fs_conv2d_dgrad: Cin and Cout must be multiples of 4 (got %d -> %d)", d->Cin, d->Cout);
+    if (d->pad_mode != FS_PAD_EXPLICIT) resolve_pads(d->H, d->W, d->KH, d->KW, d->stride, d->pad_mode, d->refl, d->src_mode, &d->Ho, &d->Wo, &d->pad_t, &d->pad_l);
+    if (d->Ho < 1 || d->Wo < 1) return fail(-2, "fs_conv2d_dgrad: empty output");
+    if (ws_bytes < fs_conv2d_dgrad_workspace_bytes(d)) return fail(-3, "fs_conv2d_dgrad: workspace too small");
+    const int K = d->KH;
+    if (int rc = fs::wt_flip_transpose(d->w, (float*)ws, K, K, d->Cin, d->Cout, ctx->stream)) return fail(rc, "fs_conv2d_dgrad: launch failed (%d)", rc);
+    fs::ConvArgs a{};
+    a.x = dy;
+    a.w = (const float*)ws;
+    a.y = dx;
+    a.N = d->N;
+    a.H = d->Ho;
+    a.W = d->Wo;
+    a.Cin = d->Cout;
+    a.Ho = d->H;
+    a.Wo = d->W;
+    a.Cout = d->Cin;
+    a.KH = a.KW = K;
+    a.stride = 1;
+    a.pad_t = K - 1 - d->pad_t;
+    a.pad_l = K - 1 - d->pad_l;
+    a.src_mode = d->stride == 2 ? fs::SRC_DILATE2 : fs::SRC_PLAIN;
+    a.p = fs::conv_plan(a);
+    const int rc = fs::conv_launch(a, ctx->stream);
+    return rc ? fail(rc, "fs_conv2d_dgrad: launch failed (%d)", rc) : 0;
+}
+
+// ---- upconv2d (im_transf_net.py:122-155: NEAREST x4, then 3x3 stride-2 SAME conv) as the transform net runs it: phase-collapsed ------------------------------
+// forward: a 2x2-tap conv on the low-resolution input with the pre-summed filters of the four output parities + pixel-shuffle store (9 instead of 36 taps per
+// output quad, no 16x intermediate); input gradient: a 3x3 stride-2 conv over dy with the collapsed flip-transposed filter; filter gradient: a 2x2-tap filter
+// gradient on the pixel-unshuffled dy folded back to 3x3.  x [N,H,W,Cin], w / dw [3,3,Cin,Cout], y / dy [N,2H,2W,Cout]; Cin % 4 == 0, Cout % 4 == 0.
+size_t fs_resizeconv_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+    if (N < 1 || H < 1 || W < 1 || Cin < 4 || Cout < 4 || (Cin % 4) || (Cout % 4)) return 0;
+    fs::WgradArgs a{};
+    a.N = N;
+    a.H = a.Ho = H;
+    a.W = a.Wo = W;
+    a.Cin = Cin;
+    a.Cout = 4 * Cout;
+    a.KH = a.KW = 2;
+    a.stride = 1;
+    a.dy_unshuffle = 1;
+    a.p = fs::wgrad_plan(a);
+    const size_t slabs = (size_t)a.p.n_slabs * a.p.K * a.Cout;
+    return ((size_t)16 * Cin * Cout * 2 + slabs) * sizeof(float);   // [collapsed filter (16 Cin Cout)] [reduced collapsed gradient (16 Cin Cout)] [partial slabs]
+}
+static int resizeconv_check(const char* fn, fs_ctx* ctx, const void* p0, const void* p1, const void* p2, const void* ws, size_t ws_bytes, int N, int H, int W, int Cin,
+                            int Cout) {
+    if (!ctx || !p0 || !p1 || !p2 || !ws) return fail(-1, "%s: null argument", fn);
+    const size_t need = fs_resizeconv_workspace_bytes(N, H, W, Cin, Cout);
+    if (!need) return fail(-2, "%s: N, H, W >= 1 and Cin, Cout multiples of 4 (got %d x %d x %d, %d -> %d)", fn, N, H, W, Cin, Cout);
+    if (ws_bytes < need) return fail(-3, "%s: workspace too small", fn);
+    return 0;
+}
+int fs_resizeconv_fwd(fs_ctx* ctx, const float* x, const float* w, int N, int H, int W, int Cin, int Cout, float* y, void* ws, size_t ws_bytes) {
+    if (int rc = resizeconv_check("fs_resizeconv_fwd", ctx, x, w, y, ws, ws_bytes, N, H, W, Cin, Cout)) return rc;
+    float* weff = (float*)ws;
+    if (int rc = fs::wt_upconv_fwd(w, weff, Cin, Cout, ctx->stream)) return fail(rc, "fs_resizeconv_fwd: launch failed (%d)", rc);
+    fs::ConvArgs a{};
+    a.x = x;
+    a.w = weff;
+    a.y = y;
+    a.N = N;
+    a.H = a.Ho = H;
+    a.W = a.Wo = W;
+    a.Cin = Cin;
+    a.Cout = 4 * Cout;
+    a.KH = a.KW = 2;
+    a.stride = 1;
+    a.shuffle = 1;
+    a.p = fs::conv_plan(a);
+    const int rc = fs::conv_launch(a, ctx->stream);
+    return rc ? fail(rc, "fs_resizeconv_fwd: launch failed (%d)", rc) : 0;
+}
+int fs_resizeconv_dgrad(fs_ctx* ctx, const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, float* dx, void* ws, size_t ws_bytes) {
+    if (int rc = resizeconv_check("fs_resizeconv_dgrad", ctx, dy, w, dx, ws, ws_bytes, N, H, W, Cin, Cout)) return rc;
+    float* v = (float*)ws;
+    if (int rc = fs::wt_upconv_dgrad(w, v, Cin, Cout, ctx->stream)) return fail(rc, "fs_resizeconv_dgrad: launch failed (%d)", rc);
+    fs::ConvArgs a{};
+    a.x = dy;
+    a.w = v;
+    a.y = dx;
+    a.N = N;
+    a.H = 2 * H;
+    a.W = 2 * W;
+    a.Cin = Cout;
+    a.Ho = H;
+    a.Wo = W;
+    a.Cout = Cin;
+    a.KH = a.KW = 3;
+    a.stride = 2;
+    a.pad_t = a.pad_l = 1;
+    a.p = fs::conv_plan(a);
+    const int rc = fs::conv_launch(a, ctx->stream);
+    return rc ? fail(rc, "fs_resizeconv_dgrad: launch failed (%d)", rc) : 0;
+}
+int fs_resizeconv_wgrad(fs_ctx* ctx, const float* x, const float* dy, int N, int H, int W, int Cin, int Cout, float* dw, void* ws, size_t ws_bytes) {
+    if (int rc = resizeconv_check("fs_resizeconv_wgrad", ctx, x, dy, dw, ws, ws_bytes, N, H, W, Cin, Cout)) return rc;
+    fs::WgradArgs a{};
+    a.x = x;
+    a.dy = dy;
+    a.N = N;
+    a.H = a.Ho = H;
+    a.W = a.Wo = W;
+    a.Cin = Cin;
+    a.Cout = 4 * Cout;
+    a.KH = a.KW = 2;
+    a.stride = 1;
+    a.dy_unshuffle = 1;
+    a.p = fs::wgrad_plan(a);
+    float* dweff = (float*)ws + (size_t)16 * Cin * Cout;
+    a.slabs = dweff + (size_t)16 * Cin * Cout;
+    if (int rc = fs::wgrad_launch(a, ctx->stream)) return fail(rc, "fs_resizeconv_wgrad: launch failed (%d)", rc);
+    if (int rc = fs::reduce_slabs(a.slabs, 1, a.p.n_slabs, (size_t)a.p.K * a.Cout, 1.0f, dweff, ctx->stream)) return fail(rc, "fs_resizeconv_wgrad: launch failed (%d)", rc);
+    const int rc = fs::wt_upconv_wgrad_fold(dweff, dw, Cin, Cout, ctx->stream);
+    return rc ? fail(rc, "fs_resizeconv_wgrad: launch failed (%d)", rc) : 0;
+}
+
+// ---- the instance-norm output MATERIALISED (im_transf_net.py:246 with the activation behind it): out = act(a[n,c] z + b[n,c]) with a, b of
+// fs_instnorm_finalize.  mode 0: none, 1: ReLU (:98, :150), 2: scaled tanh (:202-215); skip != NULL (mode 0 only; C % 4 == 0): the residual block's sum
+// (:268-274) out = a z + b + T(skip[n, y + 2, x + 2, c]), skip [N,H+4,W+4,C], T = identity or ReLU(skip_a s + skip_b) when skip_a is given.
+int fs_instnorm_apply(fs_ctx* ctx, const float* z, const float* a, const float* b, int N, int H, int W, int C, int mode, const float* skip,
+                      const float* skip_a, const float* skip_b, float* out) {
+    if (!ctx || !z || !a || !b || !out) return fail(-1, "fs_instnorm_apply: null argument");
+    if (N < 1 || H < 1 || W < 1 || C < 1 || mode < 0 || mode > 2) return fail(-2, "fs_instnorm_apply: bad shape / mode");
+    int rc;
+    if (skip) {
+        if (mode != 0 || (C % 4) || (!skip_a != !skip_b)) return fail(-2, "fs_instnorm_apply: the residual sum takes mode 0, C %% 4 == 0, skip_a and skip_b together");
+        rc = fs::apply_res(z, a, b, skip, skip_a, skip_b, skip_a ? 1 : 0, out, N, H, W, C, ctx->stream);
+    } else if (mode == 2)
+        rc = fs::apply_tanh(z, a, b, out, N, H * W, C, ctx->stream);
+    else
+        rc = fs::apply_affine(z, a, b, out, N, H * W, C, mode == 1, ctx->stream);
+    return rc ? fail(rc, "fs_instnorm_apply: launch failed (%d)", rc) : 0;
 }
 
 static int fill_wgrad(fs_wgrad_desc* d, fs::WgradArgs* a) {

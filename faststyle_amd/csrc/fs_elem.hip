@@ -253,6 +253,30 @@ int apply_tanh(const float* z, const float* a, const float* b, float* y, int N, 
     return launch_status();
 }
 
+// out = act(a[n,c] z + b[n,c]), act = identity | ReLU: the instance-norm output MATERIALISED (im_transf_net.py:246 + :98 / :150) -- the fused paths never
+// form it (the consumer conv applies the affine while staging); the named export fs_instnorm_apply does, for callers that compose units themselves
+__global__ __launch_bounds__(256) void apply_affine_kernel(const float* __restrict__ z, const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ y, int HW, int C, int relu, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int n = (int)(i / ((size_t)HW * C));
+        const float v = fmaf(z[i], a[n * C + c], b[n * C + c]);
+        y[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+int apply_affine(const float* z, const float* a, const float* b, float* y, int N, int HW, int C, int relu, hipStream_t s) {
+    const size_t total = (size_t)N * HW * C;
+    hipLaunchKernelGGL(apply_affine_kernel, dim3((unsigned)min((size_t)8192, (total + 255) / 256)), dim3(256), 0, s, z, a, b, y, HW, C, relu, total);
+    return launch_status();
+}
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.f;
+}
+int zero_fill(float* p, size_t n, hipStream_t s) {   // (a kernel, not hipMemsetAsync: memset nodes misbehave in single-stream graph replays, see zero_words)
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)min((size_t)4096, (n + 255) / 256)), dim3(256), 0, s, p, n);
+    return launch_status();
+}
+
 // ---------------------------------------------------------------- slab reduction
 // out[g][i] = scale * sum_w slabs[g][w][i].  The partial-slab sets are small (<= a few MB) but deep (up to ~500
 // slabs), so the reduction is latency-bound: a workgroup covers EL consecutive elements x SG slab groups

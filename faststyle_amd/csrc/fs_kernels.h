@@ -491,6 +491,8 @@ int in_finalize(const float* stats, int N, int T, int C, int groups, const float
 int apply_res(const float* z, const float* a, const float* b, const float* skip, const float* sa, const float* sb,
               int skip_relu, float* out, int N, int H, int W, int C, hipStream_t s);
 int apply_tanh(const float* z, const float* a, const float* b, float* y, int N, int HW, int C, hipStream_t s);
+int apply_affine(const float* z, const float* a, const float* b, float* y, int N, int HW, int C, int relu, hipStream_t s);
+int zero_fill(float* p, size_t n, hipStream_t s);
 int reduce_slabs(const float* slabs, int groups, int n_wg, size_t count, float scale, float* out, hipStream_t s);
 int zero_words(void* p, int n, hipStream_t s);   // n <= 64 32-bit words = 0 -- a kernel instead of hipMemsetAsync (memset nodes misbehave in single-stream graph replays: fs_perceptual_loss)
 // output-pixel tile (TH x TW <= max_px) with the best fill / halo trade-off for an Ho x Wo image (fs_conv.hip)

@@ -36,5 +36,8 @@ int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], cons
 int vgg_features(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS], const float* x,
                  int n_layers, const int* layers, float* const* out, float* ws, hipStream_t s);
 int vgg_consts(float* ab, hipStream_t s);
+// adjoint of vgg_features: upstream gradients of any subset of layers -> dL/d(images); the forward is recomputed into ws
+int vgg_dgrad(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS], const float* prepared, unsigned prep_mask,
+              const float* x, int n_layers, const int* layers, const float* const* dfeat, float* dx, float* ws, float* flipt_scratch, hipStream_t s);
 
 }  // namespace fs

@@ -336,6 +336,79 @@ int vgg_features(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const
     return 0;
 }
 
+// Adjoint of vgg_features (round 6; the pieces train.py:198-204 / slow_style.py:140-176 differentiate through when a script composes its own objective):
+// dfeat[i] = dL/d(post-ReLU activation of layers[i]) [N,Hl,Wl,C] for any subset of layers -> dx = dL/d(images) [N,H,W,3].  The forward is recomputed
+// into the workspace (VGG is frozen; with `prepared` on the Winograd kernels of fs_perceptual_loss, without on the direct ones), then the backward of
+// perceptual_loss with the given tensors as tap gradients: per layer the 3x3 input-gradient conv with the flip-transposed filter, the tap added and the ReLU
+// mask applied in its epilogue, the 2x2 max-pool gradient routed to the first maximum (TF MaxPoolGrad) by vgg_bwd_route.
+int vgg_dgrad(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS], const float* prepared, unsigned prep_mask,
+              const float* x, int n_layers, const int* layers, const float* const* dfeat, float* dx, float* ws, float* flipt_scratch, hipStream_t s) {
+    const int N = L.N;
+    if (x != ws + L.xin && hipMemcpyAsync(ws + L.xin, x, (size_t)N * L.H * L.W * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return -10;
+    FS_TRY(vgg_forward(L, w, b, prepared, ws, s, prep_mask));
+    const PrepLayout P = prep_layout(prepared ? prep_mask : 0);
+    auto tap_of = [&](int l) -> const float* {
+        for (int i = 0; i < n_layers; ++i)
+            if (layers[i] == l) return dfeat[i];
+        return nullptr;
+    };
+    float* pre_cur = ws + L.d_pre;
+    float* pre_nxt = ws + L.d_in[0];
+    FS_TRY(vgg_bwd_route(ws + L.act[L.lmax], nullptr, tap_of(L.lmax), 0, pre_cur, N, L.Hl[L.lmax], L.Wl[L.lmax], kCout[L.lmax], s));
+    for (int l = L.lmax; l >= 0; --l) {
+        ConvArgs a{};
+        a.x = pre_cur;
+        a.N = N;
+        a.H = a.Ho = L.Hl[l];
+        a.W = a.Wo = L.Wl[l];
+        a.Cin = kCout[l];
+        a.Cout = kCin[l];
+        a.KH = a.KW = 3;
+        a.stride = 1;
+        a.pad_t = a.pad_l = 1;
+        float* flipt = nullptr;
+        if (prepared) {
+            a.w = prepared + P.flipt[l];
+            const bool wl = l >= 1 && wino_layer_on(16 + l);
+            a.w_wino = (wl && (P.mask & PREP_F2)) ? prepared + P.wino[l][1] : nullptr;
+            a.w_wino2 = (wl && (P.mask & PREP_F2)) ? prepared + P.wino2[l][1] : nullptr;
+            a.w_wino4 = (wl && (P.mask & PREP_W4) && !vgg_use_4t()) ? prepared + P.wino4[l][1] : nullptr;
+            a.w_wino4t = (wl && (P.mask & PREP_W4T) && vgg_use_4t()) ? prepared + P.wino4t[l][1] : nullptr;
+            a.w_wino4u = (a.w_wino4t && kCin[l] % 128 == 0) ? prepared + P.wino4u[l][1] : nullptr;
+        } else {   // no prepared buffer: flip-transpose this layer's filter into the caller's scratch (9 * 512 * 512 floats)
+            flipt = flipt_scratch;
+            FS_TRY(wt_flip_transpose(w[l], flipt, 3, 3, kCin[l], kCout[l], s));
+            a.w = flipt;
+        }
+        a.split_ws = ws + L.splitws;
+        a.split_ws_floats = L.splitws_floats;
+        if (l == 0) {
+            a.y = dx;
+            if (conv3x3_to3_eligible(a)) return conv3x3_to3_launch(a, s);
+            a.p = conv_plan(a);
+            return conv_launch(a, s);
+        }
+        const float* tap = tap_of(l - 1);
+        if (!pool_after(l - 1)) {
+            a.y = pre_nxt;
+            a.add_src = tap;
+            a.add_pad = 0;
+            a.mask_src = ws + L.act[l - 1];
+            a.p = conv_plan(a);
+            FS_TRY(conv_launch(a, s));
+        } else {
+            a.y = ws + L.d_in[1];
+            a.p = conv_plan(a);
+            FS_TRY(conv_launch(a, s));
+            FS_TRY(vgg_bwd_route(ws + L.act[l - 1], ws + L.d_in[1], tap, 1, pre_nxt, N, L.Hl[l - 1], L.Wl[l - 1], kCout[l - 1], s));
+        }
+        float* t = pre_cur;
+        pre_cur = pre_nxt;
+        pre_nxt = t;
+    }
+    return 0;
+}
+
 int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
                   const fs_loss_cfg& cfg, const float* img, float* const grams[4], float* ws, hipStream_t s) {
     if (hipMemcpyAsync(ws + L.xin, img, (size_t)L.H * L.W * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)

@@ -458,6 +458,98 @@ class Engine(object):
         L.check(self.lib, self.lib.fs_loss_tv(self.ctx, p(x), N, H, W, C, p(out), p(scratch)), "fs_loss_tv")
         return out
 
+    # ------------------------------------------------------------------ value + gradient forms (round 6; faststyle_amd/autograd.py builds on these)
+    def loss_sqdiff_grad(self, x, t, scale):
+        """(scale * sum((x - t)^2) as a device scalar [1], d/dx = 2 * scale * (x - t)) -- losses.py:32-37 / :61-64 with their derivative."""
+        self._sync_stream()
+        n, period = int(np.prod(x.shape)), int(np.prod(t.shape))
+        assert n % period == 0
+        out, scratch, grad = self.mem.empty((1,)), self.mem.empty((1024,)), self.mem.empty(tuple(x.shape))
+        p = self.mem.ptr
+        L.check(self.lib, self.lib.fs_loss_sqdiff_grad(self.ctx, p(x), p(t), period, n, float(scale), p(out), p(grad), p(scratch)), "fs_loss_sqdiff_grad")
+        return out, grad
+
+    def loss_tv_grad(self, x, scale=1.0, grad=None):
+        """(scale * TV(x) [1], scale * dTV/dx); grad given: the gradient is ADDED to it (train.py:184's beta * tv on top of the perceptual gradient)."""
+        self._sync_stream()
+        N, H, W, C = (int(s) for s in x.shape)
+        out, scratch = self.mem.empty((1,)), self.mem.empty((1024,))
+        acc = grad is not None
+        if grad is None:
+            grad = self.mem.empty((N, H, W, C))
+        p = self.mem.ptr
+        L.check(self.lib, self.lib.fs_loss_tv_grad(self.ctx, p(x), N, H, W, C, float(scale), p(out), p(grad), int(acc), p(scratch)), "fs_loss_tv_grad")
+        return out, grad
+
+    def vgg_dgrad(self, x, layer_names, dfeats, use_prepared=True):
+        """Adjoint of vgg_features: dfeats[i] = dL/d(activation layer_names[i]) -> dL/dx [N,H,W,3] (fs_vgg_dgrad; the forward is recomputed)."""
+        self._sync_stream()
+        N, H, W, _ = (int(s) for s in x.shape)
+        ids = [L.VGG_LAYER_NAMES.index(n) for n in layer_names]
+        dx = self.mem.empty((N, H, W, 3))
+        nbytes = self.lib.fs_vgg_dgrad_workspace_bytes(N, H, W, max(ids))
+        ws = self.mem.empty((nbytes // 4,))
+        lay = (ctypes.c_int * len(ids))(*ids)
+        gp = (ctypes.c_void_p * len(ids))(*[self.mem.ptr(t) for t in dfeats])
+        L.check(self.lib, self.lib.fs_vgg_dgrad(self.ctx, ctypes.byref(self._wp), ctypes.byref(self._bp),
+                                                self.mem.ptr(self.vgg_prepared) if use_prepared else None, self.mem.ptr(x), N, H, W,
+                                                len(ids), lay, gp, self.mem.ptr(dx), self.mem.ptr(ws), nbytes), "fs_vgg_dgrad")
+        return dx
+
+    def conv2d_dgrad(self, dy, w, in_hw, stride=1, padding="SAME"):
+        """tf.nn.conv2d_backprop_input: dy [N,Ho,Wo,Cout], w HWIO [K,K,Cin,Cout] -> dx [N,H,W,Cin] (fs_conv2d_dgrad)."""
+        self._sync_stream()
+        N = int(dy.shape[0])
+        K, _, Cin, Cout = (int(s) for s in w.shape)
+        H, W = in_hw
+        d = L.fs_conv_desc()
+        d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride = N, H, W, Cin, Cout, K, K, stride
+        if isinstance(padding, str):
+            d.pad_mode = L.FS_PAD_SAME if padding == "SAME" else L.FS_PAD_VALID
+        else:
+            d.pad_mode = L.FS_PAD_EXPLICIT
+            d.pad_t, d.pad_l, d.Ho, d.Wo = padding
+        d.w = self.mem.ptr(w)
+        nbytes = self.lib.fs_conv2d_dgrad_workspace_bytes(ctypes.byref(d))
+        ws, dx = self.mem.empty((nbytes // 4,)), self.mem.empty((N, H, W, Cin))
+        L.check(self.lib, self.lib.fs_conv2d_dgrad(self.ctx, ctypes.byref(d), self.mem.ptr(dy), self.mem.ptr(dx), self.mem.ptr(ws), nbytes), "fs_conv2d_dgrad")
+        return dx
+
+    def _resizeconv(self, fn, name, a, b, N, H, W, Cin, Cout, out_shape):
+        self._sync_stream()
+        nbytes = self.lib.fs_resizeconv_workspace_bytes(N, H, W, Cin, Cout)
+        if not nbytes:
+            raise L.FaststyleError("%s: Cin and Cout must be multiples of 4 (got %d -> %d)" % (name, Cin, Cout))
+        ws, out = self.mem.empty((nbytes // 4,)), self.mem.empty(out_shape)
+        p = self.mem.ptr
+        L.check(self.lib, fn(self.ctx, p(a), p(b), N, H, W, Cin, Cout, p(out), p(ws), nbytes), name)
+        return out
+
+    def resizeconv_fwd(self, x, w):
+        """upconv2d's conv (im_transf_net.py:122-155: NEAREST x4 + 3x3 stride-2 SAME), phase-collapsed: x [N,H,W,Cin] -> [N,2H,2W,Cout]."""
+        N, H, W, Cin = (int(s) for s in x.shape)
+        Cout = int(w.shape[3])
+        return self._resizeconv(self.lib.fs_resizeconv_fwd, "fs_resizeconv_fwd", x, w, N, H, W, Cin, Cout, (N, 2 * H, 2 * W, Cout))
+
+    def resizeconv_dgrad(self, dy, w):
+        N, H2, W2, Cout = (int(s) for s in dy.shape)
+        Cin = int(w.shape[2])
+        return self._resizeconv(self.lib.fs_resizeconv_dgrad, "fs_resizeconv_dgrad", dy, w, N, H2 // 2, W2 // 2, Cin, Cout, (N, H2 // 2, W2 // 2, Cin))
+
+    def resizeconv_wgrad(self, x, dy):
+        N, H, W, Cin = (int(s) for s in x.shape)
+        Cout = int(dy.shape[3])
+        return self._resizeconv(self.lib.fs_resizeconv_wgrad, "fs_resizeconv_wgrad", x, dy, N, H, W, Cin, Cout, (3, 3, Cin, Cout))
+
+    def instnorm_apply(self, z, a, b, mode=0, skip=None, skip_a=None, skip_b=None):
+        """act(a z + b) materialised (mode 0 none / 1 ReLU / 2 scaled tanh), or the residual block's sum with `skip` [N,H+4,W+4,C] (fs_instnorm_apply)."""
+        self._sync_stream()
+        N, H, W, C = (int(s) for s in z.shape)
+        out = self.mem.empty((N, H, W, C))
+        p = self.mem.ptr
+        L.check(self.lib, self.lib.fs_instnorm_apply(self.ctx, p(z), p(a), p(b), N, H, W, C, int(mode), p(skip), p(skip_a), p(skip_b), p(out)), "fs_instnorm_apply")
+        return out
+
     def resize_bicubic_u8(self, img_u8, out):
         """tf.image.resize_images(img, out.shape[:2], method=2) of TF 1.0 (datapipe.py:24) on the device:
         img_u8 host uint8 [H,W,3] -> ``out`` (device float32 [Ho,Wo,3], written in place)."""

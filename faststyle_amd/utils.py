@@ -47,4 +47,8 @@ def get_layers(layer_names, vgg):
 
 def get_grams(layer_names, vgg):
     """utils.get_grams (utils.py:66-83): per-sample Gram matrices [b,c,c] = F^T F / (h*w*c) of the named layers."""
-    return [vgg.engine.gram(f) for f in get_layers(layer_names, vgg)]
+    feats = get_layers(layer_names, vgg)
+    if any(getattr(f, "requires_grad", False) for f in feats):     # differentiable (round 6): utils.get_grams inside a graph that is .backward()-ed
+        from . import autograd
+        return [autograd.gram(f, vgg.engine) for f in feats]
+    return [vgg.engine.gram(f) for f in feats]

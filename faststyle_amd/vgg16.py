@@ -55,7 +55,12 @@ class vgg16(object):
     def layers(self, names):
         need = [n for n in names if n not in self._feats]
         if need:
-            for n, t in zip(need, self.engine.vgg_features(self.imgs, need)):
+            if getattr(self.imgs, "requires_grad", False):     # differentiable (round 6): the activations carry their graph back to imgs (fs_vgg_dgrad)
+                from . import autograd
+                outs = autograd.vgg_features(self.imgs, self.engine, need)
+            else:
+                outs = self.engine.vgg_features(self.imgs, need)
+            for n, t in zip(need, outs):
                 self._feats[n] = t
         return [self._feats[n] for n in names]
 

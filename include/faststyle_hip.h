@@ -138,6 +138,22 @@ int fs_gram_bwd(fs_ctx* ctx, const float* F, const float* dG, int N, int HW, int
 int fs_loss_sqdiff(fs_ctx* ctx, const float* x, const float* t, size_t t_period, size_t n, float scale, float* out,
                    void* scratch);
 int fs_loss_tv(fs_ctx* ctx, const float* x, int N, int H, int W, int C, float* out, void* scratch);
+/* ---- round 6: value + gradient forms and the adjoint of fs_vgg_features -- the pieces a script differentiates through when it composes its own objective the
+ * way train.py:171-204 and slow_style.py:140-176 do (faststyle_amd/autograd.py wraps each as a torch.autograd.Function; fs_perceptual_loss remains the fused
+ * fixed-form path the training step runs). */
+/* out[0] = scale * sum((x - t)^2) as fs_loss_sqdiff, and grad = 2 * scale * (x - t[i % t_period]) WRITTEN (n floats): losses.py:32-37 / :61-64 with their
+ * derivative.  scratch: 1024 floats. */
+int fs_loss_sqdiff_grad(fs_ctx* ctx, const float* x, const float* t, size_t t_period, size_t n, float scale, float* out, float* grad, void* scratch);
+/* out[0] = scale * TV(x) (losses.py:70-97) and grad (+)= scale * dTV/dx: written when accumulate == 0, added to otherwise (train.py:184's beta * tv term on
+ * top of a gradient that already sits in `grad`).  scratch: 1024 floats. */
+int fs_loss_tv_grad(fs_ctx* ctx, const float* x, int N, int H, int W, int C, float scale, float* out, float* grad, int accumulate, void* scratch);
+/* Adjoint of fs_vgg_features (libs/vgg16.py:36-173 behind tf.gradients, train.py:203): dfeat[i] = dL/d(post-ReLU activation of layers[i]), [N,Hl,Wl,Cl], for
+ * any subset of conv1_1 .. conv4_3 (each layer at most once) -> dx = dL/d(x) [N,H,W,3].  The forward is recomputed into the workspace (the weights are frozen);
+ * `prepared` (fs_vgg_prepare) selects the Winograd kernels fs_perceptual_loss runs, NULL the direct ones.  ReLU gradient by the sign of the activation, max-pool
+ * gradient to the first maximum of each window (TF MaxPoolGrad), SAME padding -- the same launches as the backward half of fs_perceptual_loss. */
+size_t fs_vgg_dgrad_workspace_bytes(int N, int H, int W, int max_layer);
+int fs_vgg_dgrad(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS], const float* prepared, const float* x, int N,
+                 int H, int W, int n_layers, const int* layers, const float* const* dfeat, float* dx, void* ws, size_t ws_bytes);
 
 /* ---- optimiser: tf.train.AdamOptimizer (train.py:203), TF1 form -- lr_t = lr*sqrt(1-b2^t)/(1-b1^t), epsilon OUTSIDE the
  * bias correction: theta -= lr_t * m / (sqrt(v) + eps) ------------------------------------------------------------------ */
@@ -260,6 +276,23 @@ int fs_wino6_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, vo
 size_t fs_wino6_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout);
 /* tf.nn.conv2d (im_transf_net.py:115, vgg16.py:47) on the matrix cores. */
 int fs_conv2d_fwd(fs_ctx* ctx, fs_conv_desc* d);
+/* tf.nn.conv2d_backprop_input for the conv a FORWARD descriptor describes (im_transf_net.py:115 / vgg16.py:47 adjoint): dx [N,H,W,Cin] from dy [N,Ho,Wo,Cout]
+ * and d->w (HWIO).  Square kernels, stride 1 or 2, plain source, Cin % 4 == 0 and Cout % 4 == 0; x / y / on-load / epilogue fields of the descriptor are
+ * ignored.  ws holds the flip-transposed filter (fs_conv2d_dgrad_workspace_bytes). */
+size_t fs_conv2d_dgrad_workspace_bytes(const fs_conv_desc* d);
+int fs_conv2d_dgrad(fs_ctx* ctx, fs_conv_desc* d, const float* dy, float* dx, void* ws, size_t ws_bytes);
+/* upconv2d (im_transf_net.py:122-155: tf.image.resize_images NEAREST x4 then conv2d 3x3 stride 2 SAME), phase-collapsed as fs_tnet_forward / _backward run
+ * it: x [N,H,W,Cin], w / dw [3,3,Cin,Cout] (HWIO), y / dy [N,2H,2W,Cout]; Cin % 4 == 0, Cout % 4 == 0.  One workspace size serves the three. */
+size_t fs_resizeconv_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int fs_resizeconv_fwd(fs_ctx* ctx, const float* x, const float* w, int N, int H, int W, int Cin, int Cout, float* y, void* ws, size_t ws_bytes);
+int fs_resizeconv_dgrad(fs_ctx* ctx, const float* dy, const float* w, int N, int H, int W, int Cin, int Cout, float* dx, void* ws, size_t ws_bytes);
+int fs_resizeconv_wgrad(fs_ctx* ctx, const float* x, const float* dy, int N, int H, int W, int Cin, int Cout, float* dw, void* ws, size_t ws_bytes);
+/* The instance-norm output materialised: out = act(a[n,c] z + b[n,c]) with a, b from fs_instnorm_finalize (im_transf_net.py:238-246).  mode 0: no activation,
+ * 1: ReLU (:98, :150), 2: scaled tanh (:202-215).  skip != NULL (mode 0, C % 4 == 0): the residual block's sum (:268-274),
+ * out = a z + b + T(skip[n, y + 2, x + 2, c]) with skip [N,H+4,W+4,C] and T = identity, or ReLU(skip_a s + skip_b) when skip_a / skip_b [N,C] are given.
+ * (The fused paths never form these tensors: the consumer conv applies the affine while staging its input.) */
+int fs_instnorm_apply(fs_ctx* ctx, const float* z, const float* a, const float* b, int N, int H, int W, int C, int mode, const float* skip,
+                      const float* skip_a, const float* skip_b, float* out);
 /* resolves Ho/Wo/pads and returns the per-image tile count the launch will use */
 int fs_conv2d_plan(fs_conv_desc* d, int* tiles_per_image);
 /* tf.nn.moments + normalisation constants (im_transf_net.py:238-245) from the conv epilogue's

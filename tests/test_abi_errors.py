@@ -166,3 +166,59 @@ def test_single_op_entry_points_reject_bad_arguments(eng):
     # u8 <-> f32 helpers: alignment contract
     assert lib.fs_u8_to_f32(ctx, P(p + 1), 16, p) == -1 and "aligned" in err(e)
     assert lib.fs_resize_bicubic_u8(ctx, p, 0, 4, p, 4, 4) == -1
+
+
+def test_round6_named_exports_reject_bad_arguments(eng):
+    """The entry points added in round 6 (value + gradient losses, fs_vgg_dgrad, fs_conv2d_dgrad, fs_resizeconv_*, fs_instnorm_apply, fs_wino6_*)."""
+    e, lib, ctx = eng, eng.lib, eng.ctx
+    buf = e.mem.zeros((4096,))
+    p = e.mem.ptr(buf)
+    # losses
+    assert lib.fs_loss_sqdiff_grad(ctx, p, p, 0, 16, 1.0, p, p, p) == -1
+    assert lib.fs_loss_sqdiff_grad(ctx, p, p, 5, 16, 1.0, p, p, p) == -2 and "16" in err(e)            # not whole periods
+    assert lib.fs_loss_sqdiff_grad(ctx, p, p, 4, 16, 1.0, p, None, p) == -1
+    assert lib.fs_loss_tv_grad(ctx, p, 1, 0, 4, 3, 1.0, p, p, 0, p) == -2
+    assert lib.fs_loss_tv_grad(ctx, p, 1, 4, 4, 3, 1.0, p, None, 0, p) == -1
+    # VGG input gradient
+    vp = (ctypes.c_void_p * L.FS_VGG_NLAYERS)(*([p] * L.FS_VGG_NLAYERS))
+    lay = (ctypes.c_int * 2)(6, 6)
+    g2 = (ctypes.c_void_p * 2)(p, p)
+    need = lib.fs_vgg_dgrad_workspace_bytes(1, 32, 32, 6)
+    assert need > 0 and lib.fs_vgg_dgrad_workspace_bytes(1, 32, 32, 10) == 0
+    assert lib.fs_vgg_dgrad(ctx, ctypes.byref(vp), ctypes.byref(vp), None, p, 1, 32, 32, 2, lay, g2, p, p, need) == -2 and "twice" in err(e)
+    lay = (ctypes.c_int * 2)(6, 11)
+    assert lib.fs_vgg_dgrad(ctx, ctypes.byref(vp), ctypes.byref(vp), None, p, 1, 32, 32, 2, lay, g2, p, p, need) == -2 and "11" in err(e)
+    lay = (ctypes.c_int * 2)(3, 6)
+    assert lib.fs_vgg_dgrad(ctx, ctypes.byref(vp), ctypes.byref(vp), None, p, 1, 32, 32, 2, lay, g2, p, p, need - 4) == -3
+    g2 = (ctypes.c_void_p * 2)(p, None)
+    assert lib.fs_vgg_dgrad(ctx, ctypes.byref(vp), ctypes.byref(vp), None, p, 1, 32, 32, 2, lay, g2, p, p, need) == -1
+    # conv input gradient
+    d = L.fs_conv_desc()
+    d.w = p
+    d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride = 1, 16, 16, 8, 64, 3, 3, 1
+    d.pad_mode = L.FS_PAD_SAME
+    need = lib.fs_conv2d_dgrad_workspace_bytes(ctypes.byref(d))
+    assert need == 9 * 8 * 64 * 4
+    assert lib.fs_conv2d_dgrad(ctx, ctypes.byref(d), p, p, p, need - 4) == -3
+    d.stride = 3
+    assert lib.fs_conv2d_dgrad(ctx, ctypes.byref(d), p, p, p, need) == -2 and "stride" in err(e)
+    d.stride, d.Cin = 1, 6
+    assert lib.fs_conv2d_dgrad(ctx, ctypes.byref(d), p, p, p, need) == -2 and "multiples of 4" in err(e)
+    d.Cin = 8
+    assert lib.fs_conv2d_dgrad(ctx, ctypes.byref(d), None, p, p, need) == -1
+    # resize-conv
+    assert lib.fs_resizeconv_workspace_bytes(1, 8, 8, 6, 16) == 0
+    need = lib.fs_resizeconv_workspace_bytes(1, 8, 8, 32, 16)
+    assert need > 0
+    assert lib.fs_resizeconv_fwd(ctx, p, p, 1, 8, 8, 6, 16, p, p, 1 << 20) == -2 and "multiples of 4" in err(e)
+    assert lib.fs_resizeconv_dgrad(ctx, p, p, 1, 8, 8, 32, 16, p, p, need - 4) == -3
+    assert lib.fs_resizeconv_wgrad(ctx, p, None, 1, 8, 8, 32, 16, p, p, need) == -1
+    # instance-norm apply
+    assert lib.fs_instnorm_apply(ctx, p, p, p, 1, 4, 4, 64, 3, None, None, None, p) == -2
+    assert lib.fs_instnorm_apply(ctx, p, p, p, 1, 4, 4, 64, 1, p, None, None, p) == -2 and "residual" in err(e)     # the skip sum takes mode 0
+    assert lib.fs_instnorm_apply(ctx, p, p, p, 1, 4, 4, 64, 0, p, p, None, p) == -2                                # skip_a and skip_b together
+    assert lib.fs_instnorm_apply(ctx, p, None, p, 1, 4, 4, 64, 0, None, None, None, p) == -1
+    # split-bf16 filter pieces
+    assert lib.fs_wino6_filter_bytes(16, 128) == 0 and lib.fs_wino6_filter_bytes(32, 64) == 0 and lib.fs_wino6_filter_bytes(32, 128) == 36 * 32 * 128 * 6
+    assert lib.fs_wino6_transform_filter(ctx, p, 48, 128, p) == -2 and "48" in err(e)
+    assert lib.fs_wino6_workspace_bytes(0, 8, 8, 32, 128) == 0

@@ -772,3 +772,83 @@ def test_full_size_adjoint_linearity_and_shift(case):
     ys = eng.conv2d(xs_, w, stride, "SAME")
     a, b = ys[:, 3:-3, 3:-3], y[:, 2:-4, 2:-4]
     assert float((a - b).abs().max()) / float(y.abs().max()) < 1e-5
+
+
+# ----------------------------------------------------------------------------- round 6: the named exports of SURVEY section 8b-iii that were missing
+@pytest.mark.parametrize("case", [("s1_same_3x3", 3, 1, "SAME", (2, 10, 12), 32, 64), ("s1_valid_3x3", 3, 1, "VALID", (1, 12, 14), 64, 64),
+                                  ("s2_same_odd", 3, 2, "SAME", (2, 11, 14), 16, 32), ("s2_same_even", 3, 2, "SAME", (1, 12, 16), 32, 64),
+                                  ("s1_same_9x9", 9, 1, "SAME", (1, 20, 24), 16, 4)], ids=lambda c: c[0])
+def test_conv2d_dgrad_named_export(eng, case):
+    """fs_conv2d_dgrad: tf.nn.conv2d_backprop_input of the conv a forward descriptor describes (im_transf_net.py:115 adjoint), incl. the asymmetric SAME
+    padding of stride 2 on even / odd sizes -- the library flip-transposes the filter itself."""
+    _, k, stride, pad, (n, h, w_), ci, co = case
+    rng = np.random.default_rng(41)
+    w = (rng.standard_normal((k, k, ci, co)) * 0.1).astype(np.float32)
+    ho = nnops.conv2d(np.zeros((1, h, w_, 1)), np.zeros((k, k, 1, 1)), stride, pad).shape[1:3]
+    dy = rng.standard_normal((n,) + tuple(ho) + (co,)).astype(np.float32)
+    dx = down(eng, eng.conv2d_dgrad(up(eng, dy), up(eng, w), (h, w_), stride, pad))
+    want = nnops.conv2d_bwd_input(dy.astype(np.float64), w.astype(np.float64), (h, w_), stride, pad)
+    assert dx.shape == want.shape and rel(dx, want) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 64, 32), (1, 9, 6, 32, 16), (1, 12, 12, 128, 64)], ids=lambda s: "x".join(map(str, s)))
+def test_resizeconv_named_exports(eng, shape):
+    """fs_resizeconv_fwd / _dgrad / _wgrad: upconv2d's NEAREST x4 + conv3x3 stride 2 SAME (im_transf_net.py:122-155) in the phase-collapsed form the transform
+    net runs, against the AS-WRITTEN float64 oracle (materialised x4 upsample) and its adjoints."""
+    n, h, w_, ci, co = shape
+    rng = np.random.default_rng(43)
+    x = rng.standard_normal((n, h, w_, ci)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, ci, co)) * 0.1).astype(np.float32)
+    dy = rng.standard_normal((n, 2 * h, 2 * w_, co)).astype(np.float32)
+    x4 = nnops.resize_nearest(x.astype(np.float64), 4)
+    y = down(eng, eng.resizeconv_fwd(up(eng, x), up(eng, w)))
+    assert rel(y, nnops.conv2d(x4, w.astype(np.float64), 2, "SAME")) < TOL
+    dx = down(eng, eng.resizeconv_dgrad(up(eng, dy), up(eng, w)))
+    want_dx = nnops.resize_nearest_bwd(nnops.conv2d_bwd_input(dy.astype(np.float64), w.astype(np.float64), x4.shape[1:3], 2, "SAME"), 4)
+    assert dx.shape == want_dx.shape and rel(dx, want_dx) < TOL
+    dw = down(eng, eng.resizeconv_wgrad(up(eng, x), up(eng, dy)))
+    want_dw = nnops.conv2d_bwd_filter(x4, dy.astype(np.float64), 3, 2, "SAME")
+    assert dw.shape == want_dw.shape and rel(dw, want_dw) < TOL
+
+
+def test_instnorm_apply_named_export(eng):
+    """fs_instnorm_apply: the instance-norm output materialised -- linear, ReLU (im_transf_net.py:98), scaled tanh (:202-215), and the residual block's sum with
+    the centre crop of the skip tensor (:268-274), raw or behind its own affine + ReLU."""
+    rng = np.random.default_rng(47)
+    n, h, w_, c = 2, 9, 11, 64
+    z = rng.standard_normal((n, h, w_, c)).astype(np.float32)
+    a = (1 + 0.3 * rng.standard_normal((n, c))).astype(np.float32)
+    b = (0.2 * rng.standard_normal((n, c))).astype(np.float32)
+    lin = z.astype(np.float64) * a[:, None, None, :] + b[:, None, None, :]
+    for mode, want in ((0, lin), (1, np.maximum(lin, 0)), (2, nnops.scaled_tanh(lin))):
+        got = down(eng, eng.instnorm_apply(up(eng, z), up(eng, a), up(eng, b), mode))
+        assert np.abs(got - want).max() < 1e-5 * max(1.0, np.abs(want).max())
+    skip = rng.standard_normal((n, h + 4, w_ + 4, c)).astype(np.float32)
+    got = down(eng, eng.instnorm_apply(up(eng, z), up(eng, a), up(eng, b), 0, skip=up(eng, skip)))
+    assert np.abs(got - (lin + skip[:, 2:-2, 2:-2, :])).max() < 1e-5
+    sa = (1 + 0.3 * rng.standard_normal((n, c))).astype(np.float32)
+    sb = (0.2 * rng.standard_normal((n, c))).astype(np.float32)
+    got = down(eng, eng.instnorm_apply(up(eng, z), up(eng, a), up(eng, b), 0, skip=up(eng, skip), skip_a=up(eng, sa), skip_b=up(eng, sb)))
+    want = lin + np.maximum(skip[:, 2:-2, 2:-2, :].astype(np.float64) * sa[:, None, None, :] + sb[:, None, None, :], 0)
+    assert np.abs(got - want).max() < 1e-5
+
+
+def test_loss_value_and_gradient_named_exports(eng):
+    """fs_loss_sqdiff_grad (one term of losses.content_loss / style_loss, losses.py:32-37 / :61-64, target broadcast over the batch) and fs_loss_tv_grad
+    (losses.py:70-97), value + derivative, written and accumulated."""
+    from oracle import perceptual
+    rng = np.random.default_rng(53)
+    x = rng.standard_normal((3, 6, 7, 16)).astype(np.float32)
+    t = rng.standard_normal((1, 6, 7, 16)).astype(np.float32)
+    out, g = eng.loss_sqdiff_grad(up(eng, x), up(eng, t), 0.37)
+    d = x.astype(np.float64) - t
+    np.testing.assert_allclose(down(eng, out)[0], 0.37 * (d ** 2).sum(), rtol=1e-5)
+    assert np.abs(down(eng, g) - 2 * 0.37 * d).max() < 1e-5
+    img = rng.uniform(0, 255, (2, 9, 8, 3)).astype(np.float32)
+    tv, dtv = perceptual.tv_loss(img.astype(np.float64))
+    out, g = eng.loss_tv_grad(up(eng, img), 1e-4)
+    np.testing.assert_allclose(down(eng, out)[0], 1e-4 * tv, rtol=1e-5)
+    assert np.abs(down(eng, g) - 1e-4 * dtv).max() < 1e-5 * np.abs(1e-4 * dtv).max() + 1e-7
+    base = rng.standard_normal(img.shape).astype(np.float32)
+    _, g2 = eng.loss_tv_grad(up(eng, img), 1e-4, grad=up(eng, base))          # accumulate: train.py:184's beta * tv on top of an existing gradient
+    assert np.abs(down(eng, g2) - (base + 1e-4 * dtv)).max() < 1e-5

@@ -502,6 +502,27 @@ def test_pool_gradient_routing_in_the_streaming_gram_gradient_kernel(eng, knob):
     assert flat_close(dy1, dyo)
 
 
+@pytest.mark.parametrize("layers,prepared", [(("conv1_2", "conv2_2", "conv3_3", "conv4_3"), True), (("conv2_1", "conv3_2"), True), (("conv3_3",), False)])
+def test_vgg_dgrad_named_export_matches_oracle(eng, layers, prepared):
+    """fs_vgg_dgrad (round 6): upstream gradients of ANY subset of VGG16 layers -> dL/d(images) (libs/vgg16.py:36-173 behind tf.gradients, train.py:203): the
+    adjoint of fs_vgg_features as a named entry point -- pooled and unpooled tap layers, the last layer tapped or not, with the prepared Winograd filters and
+    with the direct kernels.  Oracle: perceptual.vgg16_bwd in float64 with random upstream gradients."""
+    rng = np.random.default_rng(4)      # (seed 3 has a ReLU / pooling tie that flips between float32 and float64: 2e-3 instead of 4e-6)
+    Wv = perceptual.synthetic_vgg_weights(seed=3)
+    eng.vgg_load(Wv)
+    x = rng.uniform(0, 255, (2, 24, 40, 3)).astype(np.float32)
+    upto = max(layers)
+    feats, cache = perceptual.vgg16(x.astype(np.float64), f64(Wv), upto=upto, keep=True)
+    dfe = {n: (rng.standard_normal(feats[n].shape) / np.sqrt(feats[n][0].size)).astype(np.float32) for n in layers}
+    got_feats = eng.vgg_features(eng.mem.from_numpy(x), list(layers))
+    for n, t in zip(layers, got_feats):
+        assert np.abs(eng.mem.to_numpy(t) - feats[n]).max() < 2e-5 * np.abs(feats[n]).max()
+    dx = eng.mem.to_numpy(eng.vgg_dgrad(eng.mem.from_numpy(x), list(layers), [eng.mem.from_numpy(dfe[n]) for n in layers], use_prepared=prepared))
+    want = perceptual.vgg16_bwd({n: dfe[n].astype(np.float64) for n in layers}, feats, f64(Wv), cache, upto=upto)
+    assert dx.shape == want.shape == x.shape
+    assert flat_close(dx, want)
+
+
 def test_adam_tf_step_matches_oracle(eng):
     rng = np.random.default_rng(2)
     n = 5000
@@ -517,6 +538,55 @@ def test_adam_tf_step_matches_oracle(eng):
     np.testing.assert_allclose(eng.mem.to_numpy(pd), po["a"], rtol=0, atol=2e-6)
     # float32(0.999) != 0.999: (1-beta2) carries a 1.3e-5 relative rounding, exactly as in TF's float32 ApplyAdam
     np.testing.assert_allclose(eng.mem.to_numpy(vd), vo["a"], rtol=1e-4, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------- GPU-only: the differentiable builder-level API (torch tensors)
+@pytest.mark.gpu
+def test_loss_composed_from_the_differentiable_pieces_matches_the_fused_call_and_the_oracle():
+    """Round 6: a script composes the objective from the reference's own helper names -- vgg16(...).layers / utils.get_layers, utils.get_grams,
+    losses.content_loss / style_loss / tv_loss -- on a tensor that requires grad and calls .backward(), as train.py:157-204 and slow_style.py:140-176 do
+    with tf.gradients.  Every node is one C-ABI call behind a torch.autograd.Function (fs_vgg_features / fs_vgg_dgrad, fs_gram_fwd / fs_gram_bwd,
+    fs_loss_sqdiff_grad, fs_loss_tv_grad).  Against fs_perceptual_loss (the fused fixed-form path) and the float64 oracle: losses 2e-5, dL/dY as tight as the
+    fused path is held."""
+    import torch
+    from faststyle_amd import losses, utils, vgg16
+    e = get_engine("hip")
+    rng = np.random.default_rng(1)
+    Wv = perceptual.synthetic_vgg_weights(seed=3)
+    e.vgg_load(Wv)
+    cfg = engine.default_loss_cfg()
+    cfg["beta"] = 1e-4
+    style = rng.uniform(0, 255, (1, 37, 45, 3)).astype(np.float32)
+    tg = e.style_targets(e.mem.from_numpy(style), cfg)
+    y = rng.uniform(0, 255, (2, 32, 40, 3)).astype(np.float32)
+    xc = rng.uniform(0, 255, (2, 32, 40, 3)).astype(np.float32)
+    lf, dyf = e.perceptual_loss(e.mem.from_numpy(y), e.mem.from_numpy(xc), tg, cfg)
+    lf, dyf = e.mem.to_numpy(lf).copy(), e.mem.to_numpy(dyf).copy()
+    # the same objective, node by node
+    Y = e.mem.from_numpy(y).requires_grad_(True)
+    net = vgg16.vgg16(Y, engine=e)                                             # (the weights are loaded: vgg_load above)
+    tnet = vgg16.vgg16(e.mem.from_numpy(xc), engine=e)
+    content = utils.get_layers(["vgg/conv3_3:0"], net)                         # (the reference's tensor names, utils.py:55-63)
+    targets = utils.get_layers(["vgg/conv3_3:0"], tnet)
+    grams = utils.get_grams(["vgg/%s:0" % n for n in cfg["style_layers"]], net)
+    closs = losses.content_loss(content, targets, cfg["content_weights"], engine=e)
+    sloss = losses.style_loss(grams, tg, cfg["style_weights"], engine=e)
+    tv = losses.tv_loss(Y, engine=e)
+    loss = closs + sloss + cfg["beta"] * tv                                     # train.py:184
+    assert loss.requires_grad
+    loss.backward()
+    got = np.array([loss.item(), closs.item(), sloss.item(), cfg["beta"] * tv.item()])
+    np.testing.assert_allclose(got, lf, rtol=2e-5)
+    dy = Y.grad.detach().cpu().numpy()
+    assert flat_close(dy, dyf, tight=2e-5)                                      # two launch sequences of the same library: rounding apart
+    tgo = perceptual.target_grams(style.astype(np.float64), f64(Wv), cfg["style_layers"])
+    feats = perceptual.vgg16(xc.astype(np.float64), f64(Wv), upto="conv3_3")
+    lo, dyo = perceptual.perceptual_loss(y.astype(np.float64), [feats["conv3_3"]], tgo, f64(Wv), beta=1e-4)
+    np.testing.assert_allclose(got, [lo[k] for k in ("loss", "content_loss", "style_loss", "tv_loss")], rtol=2e-5)
+    assert flat_close(dy, dyo)
+    # value-only use (no grad required) keeps returning plain device scalars
+    v = losses.tv_loss(e.mem.from_numpy(y), engine=e)
+    assert not getattr(v, "requires_grad", False) and abs(float(e.mem.to_numpy(v)[0]) - tv.item()) <= 1e-6 * abs(tv.item())
 
 
 # ----------------------------------------------------------------------------- GPU-only, full sizes
