@@ -1,9 +1,10 @@
 """Image I/O wrappers with the reference's conventions (reference utils.py:14-52), on PIL.
 
 The reference uses OpenCV 3.1: imread -> BGR->RGB uint8; imwrite of float32 rounds + saturates
-to uint8 and writes JPEG quality 95, 4:2:0 chroma.  imresize: INTER_CUBIC up / INTER_AREA down;
-PIL's BICUBIC / BOX are the closest filters (exact OpenCV resampling parity is unpinned:
-SURVEY.md §2 row 9).
+to uint8 and writes JPEG quality 95, 4:2:0 chroma.  imresize: INTER_CUBIC up / INTER_AREA down --
+since round 6 OpenCV's own resampling restated on the host (faststyle_amd/cvresize.py: A = -0.75
+cubic in 11-bit fixed point, coverage-weighted area means, cvRound output sizes; pinned by
+hand-derived known answers, tests/test_cvresize.py -- OpenCV itself cannot be installed here).
 """
 import os
 
@@ -20,10 +21,13 @@ def imresize(img, scale):
     """utils.imresize (utils.py:25-40): cubic for scale>1, area for scale<1, identity at 1."""
     if scale == 1.0:
         return img
-    h, w = img.shape[:2]
-    size = (int(round(w * scale)), int(round(h * scale)))
-    resample = Image.BICUBIC if scale > 1.0 else Image.BOX
-    return np.asarray(Image.fromarray(np.asarray(img, np.uint8)).resize(size, resample))
+    from . import cvresize
+    a = np.asarray(img)
+    if a.dtype != np.uint8:      # (the reference only ever resizes what imread returned: uint8)
+        a = np.clip(np.rint(a), 0, 255).astype(np.uint8)
+    if a.ndim == 2:
+        return cvresize.resize(a[:, :, None], scale)[:, :, 0]
+    return cvresize.resize(a, scale)
 
 
 def imwrite(path, img):
