@@ -374,7 +374,8 @@ int fs_perceptual_loss(fs_ctx* ctx, const float* const w[FS_VGG_NLAYERS], const 
     fs::VggLayout L;
     fs::vgg_layout(N, H, W, *cfg, true, &L);
     if (ws_bytes < L.total_floats * sizeof(float)) return fail(-3, "fs_perceptual_loss: workspace too small");
-    const int rc = fs::perceptual_loss(L, w, b, prepared, *cfg, y, content, losses, dy, (float*)ws, ctx->stream, prep_mask_of(ctx, prepared));
+    fs::StreamAux aux{ctx->side, ctx->ev, 34};
+    const int rc = fs::perceptual_loss(L, w, b, prepared, *cfg, y, content, losses, dy, (float*)ws, ctx->stream, prep_mask_of(ctx, prepared), ctx->have_side ? &aux : nullptr);
     return rc ? fail(rc, "fs_perceptual_loss: launch failed (%d)", rc) : 0;
 }
 

@@ -87,6 +87,8 @@ struct ConvArgs {
     const unsigned short* w_wino6; // optional: the F(4x4,3x3) filter as three bf16 pieces, [36][Cin/32][3][Cout][32] (fs::wt_wino6), with w6_ws: enables variant 12 (fs_wino6.hip)
     float* w6_ws;          // scratch of the split-bf16 pipeline: V [36][tiles][Cin] + M [36][tiles][Cout] of one tile chunk (w6_ws_floats capacity; wino6_ws_floats() = one pass)
     size_t w6_ws_floats;
+    hipStream_t w6_side;   // optional second stream + three events (fs_wino6.hip, round 6): the launch runs as two tile chunks software-pipelined over the two streams --
+    hipEvent_t* w6_ev;     // input transform of chunk b beside the GEMM of chunk a, output transform of chunk a beside the GEMM of chunk b; joined before it returns
     float* y;        // [N,Ho,Wo,Cout], or [N,2Ho,2Wo,Cout/4] when shuffle
     int N, H, W, Cin;
     int Ho, Wo, Cout;

@@ -29,7 +29,7 @@ unsigned vgg_prep_mask();   // the mask a prepare under the knobs of the moment 
 void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, VggLayout* L);
 int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
                     const float* prepared, const fs_loss_cfg& cfg, const float* y, const float* content, float* losses,
-                    float* dy, float* ws, hipStream_t s, unsigned prep_mask);
+                    float* dy, float* ws, hipStream_t s, unsigned prep_mask, const struct StreamAux* aux = nullptr);
 int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
                   const fs_loss_cfg& cfg, const float* img, float* const grams[4], float* ws, hipStream_t s);
 // libs/vgg16.py:36-220 for N images (RGB 0..255): post-ReLU activations of the requested layers copied to out[i]

@@ -10,6 +10,7 @@
 //   backward lmax..0: route (pool argmax, ReLU mask, + tap gradients incl. dF = F*S as a 1x1 conv
 //   with per-sample filters) -> 3x3 dgrad conv with the pre-flipped filters -> ... -> dy (+ beta*dTV)
 #include "fs_vgg.h"
+#include "fs_tnet.h"   // StreamAux
 
 #include <cstdlib>
 
@@ -236,11 +237,75 @@ void vgg_layout(int N, int H, int W, const fs_loss_cfg& cfg, bool with_content, 
     L->total_floats = b.off;
 }
 
+
+// Two half-batch chains on two streams (round 6, the split-bf16 pipeline only).  A run of consecutive layers that all take fs_wino6.hip is launched as chain A
+// (samples [0, N/2)) on the caller's stream and chain B (the other half) on the side stream: the layers of a chain depend on each other, the chains do not, so
+// the memory-bound input / output transforms of one chain run beside the GEMM of the other (their waves are held to <= 168 registers: they fit on a SIMD
+// next to a resident GEMM wave).  Measured on three conv4_2-shaped layers at batch 32: 355 -> 284 us per layer (tools/micro_wino6_overlap.py).  Off while the
+// per-kernel profiler runs (its event pairs would time overlapping launches), for odd N, and under FS_WINO6_CHAINS=0.
+static bool w6_chains_on(const StreamAux* aux, int N) {
+    return aux && aux->side && aux->nev >= 2 && !(N & 1) && !Profiler::current() && tune_int("FS_WINO6_OVERLAP", 1) == 1;
+}
+// ... or every launch on its own as two tile chunks pipelined over the two streams (fs_wino6.hip; FS_WINO6_OVERLAP = 2; measured SLOWER than no overlap in the step -- two GEMM launches of 4.5 grid rounds each and three more graph edges per launch --, kept as a recorded experiment; 0: neither; 1, the default: the chains above)
+static void w6_pipe_args(ConvArgs* a, const StreamAux* aux) {
+    if (aux && aux->side && aux->nev >= 3 && !Profiler::current() && tune_int("FS_WINO6_OVERLAP", 1) == 2) {
+        a->w6_side = aux->side;
+        a->w6_ev = aux->ev;
+    }
+}
+static bool w6_chain_launch_ok(const ConvArgs& a) { return a.p.variant == 12 && !(a.N & 1) && !a.y_keep_n && a.w6_ws_floats >= 2 * wino6_ws_floats(a.N / 2, a.Ho, a.Wo, a.Cin, a.Cout); }
+struct W6Chains {   // fork / join bookkeeping of one run
+    const StreamAux* aux;
+    hipStream_t s;
+    bool open = false;
+    int begin() {
+        if (open) return 0;
+        if (hipEventRecord(aux->ev[0], s) != hipSuccess || hipStreamWaitEvent(aux->side, aux->ev[0], 0) != hipSuccess) return -20;
+        open = true;
+        return 0;
+    }
+    int end() {
+        if (!open) return 0;
+        open = false;
+        return (hipEventRecord(aux->ev[1], aux->side) != hipSuccess || hipStreamWaitEvent(s, aux->ev[1], 0) != hipSuccess) ? -20 : 0;
+    }
+    int launch(const ConvArgs& a);
+};
+static ConvArgs w6_half(const ConvArgs& a, int h) {   // samples [h N/2, (h + 1) N/2) of a launch whose tensors are all batch-major
+    ConvArgs b = a;
+    const int n2 = a.N / 2;
+    b.N = n2;
+    const size_t xin = (size_t)n2 * a.H * a.W * a.Cin, yout = (size_t)n2 * a.Ho * a.Wo * a.Cout;
+    if (h) {
+        b.x = a.x + xin;
+        b.y = a.y + yout;
+        if (a.mask_src) b.mask_src = a.mask_src + yout;
+        if (a.add_src) b.add_src = a.add_src + yout;
+        if (a.pool_out) b.pool_out = a.pool_out + (size_t)n2 * (a.Ho >> 1) * (a.Wo >> 1) * a.Cout;
+    }
+    const size_t half_ws = (a.w6_ws_floats / 2) & ~(size_t)63;
+    b.w6_ws = a.w6_ws + (h ? half_ws : 0);
+    b.w6_ws_floats = half_ws;
+    return b;
+}
+
+int W6Chains::launch(const ConvArgs& a) {
+    FS_TRY(begin());
+    for (int h = 0; h < 2; ++h) {
+        ConvArgs b = w6_half(a, h);
+        b.p = conv_plan(b);
+        if (b.p.variant != 12) return -7;
+        FS_TRY(conv_launch(b, h ? aux->side : s));
+    }
+    return 0;
+}
+
 // pool: optional destination of the 2x2/2 max-pool of the result; *pooled tells whether the conv launch produced it
 static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, const float* w_wino, const float* w_wino2, const float* w_wino4, const float* w_wino4t, const float* w_wino4u, const float* bias, const float* ab,
                     float* y, float* split_ws, size_t split_ws_floats, hipStream_t s, float* pool = nullptr, bool* pooled = nullptr, int y_keep_n = 0,
-                    const unsigned short* w_wino6 = nullptr, float* w6_ws = nullptr, size_t w6_ws_floats = 0) {
+                    const unsigned short* w_wino6 = nullptr, float* w6_ws = nullptr, size_t w6_ws_floats = 0, W6Chains* chains = nullptr, const StreamAux* aux = nullptr) {
     ConvArgs a{};
+    if (w_wino6) w6_pipe_args(&a, aux);
     a.w_wino6 = w_wino6;
     a.w6_ws = w6_ws;
     a.w6_ws_floats = w6_ws_floats;
@@ -275,15 +340,21 @@ static int vgg_conv(const float* x, int N, int H, int W, int l, const float* w, 
         if (pooled) *pooled = true;
         if ((a.p.variant == 11 || a.p.variant == 12) && tune_int("FS_VGG_SKIP_CONTENT_Y", 1)) a.y_keep_n = y_keep_n;
     }
+    if (chains) {   // (a run of split-bf16 launches goes out as two half-batch chains; anything else closes the run first)
+        if (w6_chain_launch_ok(a)) return chains->launch(a);
+        FS_TRY(chains->end());
+    }
     return conv_launch(a, s);
 }
 
 // forward through layers [0..lmax]; samples [0,N) go all the way, [N,NB) stop after cmax
 // prepared: the buffer of fs_vgg_prepare (Winograd-transformed filters) or nullptr (direct convolutions only)
 static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
-                       const float* prepared, float* ws, hipStream_t s, unsigned prep_mask = 0) {
+                       const float* prepared, float* ws, hipStream_t s, unsigned prep_mask = 0, const StreamAux* aux = nullptr) {
     FS_TRY(vgg_consts(ws + L.ab, s));
     const PrepLayout P = prep_layout(prepared ? prep_mask : 0);
+    W6Chains chains{aux, s};
+    const bool use_chains = w6_chains_on(aux, L.N);
     const float* src = ws + L.xin;
     for (int l = 0; l <= L.lmax; ++l) {
         bool pooled = false;
@@ -299,15 +370,17 @@ static int vgg_forward(const VggLayout& L, const float* const w[FS_VGG_NLAYERS],
                         // (the content half [N, NB) only feeds the next layer: of a pooled layer below the LAST content layer it needs the pooled tensor
                         // alone -- unless a content term of its own reads the full-resolution half, --loss_content_layers takes several)
                         (nb > L.N && l < L.cmax && !((L.content_mask >> l) & 1u)) ? L.N : 0,
-                        w6 ? reinterpret_cast<const unsigned short*>(prepared + P.wino6[l][0]) : nullptr, ws + L.w6ws, L.w6ws_floats));
+                        w6 ? reinterpret_cast<const unsigned short*>(prepared + P.wino6[l][0]) : nullptr, ws + L.w6ws, L.w6ws_floats,
+                        (use_chains && nb == L.N) ? &chains : nullptr, aux));
         src = ws + L.act[l];
         if (pool_after(l) && l < L.lmax) {
+            FS_TRY(chains.end());
             if (!pooled)
                 FS_TRY(maxpool(ws + L.act[l], ws + L.pool[pool_index(l)], nb, L.Hl[l], L.Wl[l], kCout[l], s));
             src = ws + L.pool[pool_index(l)];
         }
     }
-    return 0;
+    return chains.end();
 }
 
 static int gram_forward(const VggLayout& L, int l, const float* F, float* G, float* ws, hipStream_t s) {
@@ -425,7 +498,7 @@ int style_targets(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], cons
 
 int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], const float* const b[FS_VGG_NLAYERS],
                     const float* prepared, const fs_loss_cfg& cfg, const float* y, const float* content, float* losses,
-                    float* dy, float* ws, hipStream_t s, unsigned prep_mask) {
+                    float* dy, float* ws, hipStream_t s, unsigned prep_mask, const StreamAux* aux) {
     const int N = L.N;
     const size_t img = (size_t)N * L.H * L.W * 3;
     // [y ; content] as one 2N batch at ws + L.xin.  A caller that keeps the two tensors THERE (fs_perceptual_ws_input: the transform net writes y
@@ -439,7 +512,7 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
     // with the fork in the graph the same node behaved).  No memset on any capturable path of the library any more.)
     // (round 5: the four scalars are WRITTEN once, by loss_finish at the end, from the partial sums every term leaves in ws + L.lossp -- the per-term
     // sum launches, the clear and the total are gone)
-    FS_TRY(vgg_forward(L, w, b, prepared, ws, s, prep_mask));
+    FS_TRY(vgg_forward(L, w, b, prepared, ws, s, prep_mask, aux));
     const PrepLayout P = prep_layout(prep_mask);
 
     // ---- losses ----
@@ -601,6 +674,14 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         if (!fused)
             FS_TRY(vgg_bwd_route(ws + L.act[L.lmax], nullptr, tap, 0, pre_cur, N, L.Hl[L.lmax], L.Wl[L.lmax], kCout[L.lmax], s));
     }
+    // (runs of split-bf16 input-gradient launches -- conv4_3, conv4_2, conv4_1 at the training shapes -- go out as two half-batch chains, see W6Chains)
+    W6Chains bchains{aux, s};
+    const bool use_chains = w6_chains_on(aux, N);
+    auto launch_bwd = [&](const ConvArgs& a) -> int {
+        if (use_chains && w6_chain_launch_ok(a)) return bchains.launch(a);
+        FS_TRY(bchains.end());
+        return conv_launch(a, s);
+    };
     for (int l = L.lmax; l >= 0; --l) {
         const int C = kCout[l], H = L.Hl[l], W = L.Wl[l];
         ConvArgs a{};
@@ -616,6 +697,7 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
             a.w_wino6 = reinterpret_cast<const unsigned short*>(prepared + P.wino6[l][1]);
             a.w6_ws = ws + L.w6ws;
             a.w6_ws_floats = L.w6ws_floats;
+            w6_pipe_args(&a, aux);
         }
         a.N = N;
         a.H = a.Ho = H;
@@ -628,6 +710,7 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         a.split_ws = ws + L.splitws;
         a.split_ws_floats = L.splitws_floats;
         if (l == 0) {
+            FS_TRY(bchains.end());
             a.y = dy;
             if (conv3x3_to3_eligible(a)) {   // 64 -> 3 channels: vector-ALU kernel (fs_c3.hip), no padded MFMA columns
                 FS_TRY(conv3x3_to3_launch(a, s));
@@ -639,17 +722,22 @@ int perceptual_loss(const VggLayout& L, const float* const w[FS_VGG_NLAYERS], co
         }
         const float* tap = nullptr;
         if (!pool_after(l - 1)) {
+            bool has_tap = false;   // (a tap gradient is computed on the caller's stream from tensors both chains write: join first)
+            for (int i = 0; i < cfg.n_content; ++i) has_tap = has_tap || cfg.content_layer[i] == l - 1;
+            for (int i = 0; i < cfg.n_style; ++i) has_tap = has_tap || cfg.style_layer[i] == l - 1;
+            if (has_tap) FS_TRY(bchains.end());
             FS_TRY(compute_tap(l - 1, &tap, nullptr, nullptr, nullptr));
             a.y = pre_nxt;
             a.add_src = tap;
             a.add_pad = 0;
             a.mask_src = ws + L.act[l - 1];
             a.p = conv_plan(a);
-            FS_TRY(conv_launch(a, s));
+            FS_TRY(launch_bwd(a));
         } else {
             a.y = ws + L.d_in[1];
             a.p = conv_plan(a);
-            FS_TRY(conv_launch(a, s));
+            FS_TRY(launch_bwd(a));
+            FS_TRY(bchains.end());
             bool fused = false;
             FS_TRY(compute_tap(l - 1, &tap, ws + L.d_in[1], pre_nxt, &fused));
             if (!fused)

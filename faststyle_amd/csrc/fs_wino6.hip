@@ -87,10 +87,10 @@ struct W6Args {
 
 #define W6_BT4(d0, d1, d2, d3, d4, d5, t0, t1, t2, t3, t4, t5)   \
     do {                                                         \
-        const f32x4 a_ = d4 - 4.f * d2, b_ = d3 - 4.f * d1;      \
-        const f32x4 c_ = d4 - d2, e_ = d3 - d1;                  \
-        const f32x4 f_ = 4.f * d0 - 5.f * d2 + d4;               \
-        const f32x4 g_ = 4.f * d1 - 5.f * d3 + d5;               \
+        const auto a_ = d4 - 4.f * d2, b_ = d3 - 4.f * d1;       \
+        const auto c_ = d4 - d2, e_ = d3 - d1;                   \
+        const auto f_ = 4.f * d0 - 5.f * d2 + d4;                \
+        const auto g_ = 4.f * d1 - 5.f * d3 + d5;                \
         t0 = f_; /* (outputs may alias inputs) */                \
         t1 = a_ + b_;                                            \
         t2 = a_ - b_;                                            \
@@ -100,8 +100,8 @@ struct W6Args {
     } while (0)
 #define W6_AT4(m0, m1, m2, m3, m4, m5, y0, y1, y2, y3)   \
     do {                                                 \
-        const f32x4 p_ = m1 + m2, q_ = m1 - m2;          \
-        const f32x4 r_ = m3 + m4, s_ = m3 - m4;          \
+        const auto p_ = m1 + m2, q_ = m1 - m2;           \
+        const auto r_ = m3 + m4, s_ = m3 - m4;           \
         y0 = m0 + p_ + r_;                               \
         y1 = q_ + 2.f * s_;                              \
         y2 = p_ + 4.f * r_;                              \
@@ -109,7 +109,7 @@ struct W6Args {
     } while (0)
 
 // K1: input transform.  One thread = one tile x four channels: 36 16-byte loads (zero outside the image), B^T d B, 36 16-byte stores.
-__global__ __launch_bounds__(256) void wino6_input_kernel(W6Args a) {
+__global__ __launch_bounds__(256, 3) void wino6_input_kernel(W6Args a) {   // (<= 168 registers: a wave fits on a SIMD beside a resident GEMM wave of an independent launch)
     const int cq_n = a.Cin >> 2;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int tl = (int)(idx / cq_n), cq = (int)(idx - (long)tl * cq_n);
@@ -145,38 +145,40 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(W6Args a) {
     }
 }
 
-// K3: output transform + epilogue.  One thread = one tile x four output channels.
+// K3: output transform + epilogue.  One thread = one tile x TWO output channels (8-byte accesses: 36 + 16 + 16 two-float values are ~110 registers, a wave
+// fits on a SIMD beside a resident GEMM wave of an independent launch; with four channels per thread the kernel needs 200+ or spills).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int EPI>
-__global__ __launch_bounds__(256) void wino6_output_kernel(W6Args a) {
-    const int cq_n = a.Cout >> 2;
+__global__ __launch_bounds__(256, 3) void wino6_output_kernel(W6Args a) {
+    const int cq_n = a.Cout >> 1;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int tl = (int)(idx / cq_n), cq = (int)(idx - (long)tl * cq_n);
     if (tl >= a.T) return;
     const int t = a.t0 + tl;
     const int per = a.th * a.tw;
     const int n = t / per, r = t - n * per, ty = r / a.tw, tx = r - ty * a.tw;
-    const int c = cq * 4;
+    const int c = cq * 2;
     const float* mb = a.M + (size_t)tl * a.Cout + c;
     const size_t pstride = (size_t)a.Tpad * a.Cout;
-    f32x4 m[6][6];
+    f32x2 s[4][6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+        f32x2 m[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(mb + (size_t)(i * 6 + j) * pstride);
-            m[i][j] = f32x4{v.x, v.y, v.z, v.w};
+        for (int i = 0; i < 6; ++i) {
+            const float2 v = *reinterpret_cast<const float2*>(mb + (size_t)(i * 6 + j) * pstride);
+            m[i] = f32x2{v.x, v.y};
         }
-    f32x4 s[4][6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) W6_AT4(m[0][j], m[1][j], m[2][j], m[3][j], m[4][j], m[5][j], s[0][j], s[1][j], s[2][j], s[3][j]);
-    f32x4 o[4][4];
+        W6_AT4(m[0], m[1], m[2], m[3], m[4], m[5], s[0][j], s[1][j], s[2][j], s[3][j]);
+    }
+    f32x2 o[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) W6_AT4(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[i][0], o[i][1], o[i][2], o[i][3]);
     const int oy = 4 * ty, ox = 4 * tx;
-    f32x4 bs = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x2 bs = f32x2{0.f, 0.f};
     if (EPI == 3 && a.bias) {
-        const float4 b4 = *reinterpret_cast<const float4*>(a.bias + c);
-        bs = f32x4{b4.x, b4.y, b4.z, b4.w};
+        const float2 b2 = *reinterpret_cast<const float2*>(a.bias + c);
+        bs = f32x2{b2.x, b2.y};
     }
     const bool keep_y = !(EPI == 3 && a.pool_out && a.y_keep_n > 0 && n >= a.y_keep_n);
     float* yb = a.y + (size_t)n * a.Ho * a.Wo * a.Cout + c;
@@ -184,24 +186,23 @@ __global__ __launch_bounds__(256) void wino6_output_kernel(W6Args a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            f32x4 v = o[i][j];
+            f32x2 v = o[i][j];
             const bool in = oy + i < a.Ho && ox + j < a.Wo;
             const size_t off = ((size_t)(oy + i) * a.Wo + (ox + j)) * a.Cout;
             if (EPI == 3) {
                 v = v + bs;
-                if (a.out_relu)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                if (a.out_relu) {
+                    v[0] = fmaxf(v[0], 0.f);
+                    v[1] = fmaxf(v[1], 0.f);
+                }
                 o[i][j] = v;
             }
             if (EPI == 4 && in) {
-                const float4 k4 = *reinterpret_cast<const float4*>(a.mask_src + (size_t)n * a.Ho * a.Wo * a.Cout + c + off);
-                v[0] = k4.x > 0.f ? v[0] : 0.f;
-                v[1] = k4.y > 0.f ? v[1] : 0.f;
-                v[2] = k4.z > 0.f ? v[2] : 0.f;
-                v[3] = k4.w > 0.f ? v[3] : 0.f;
+                const float2 k2 = *reinterpret_cast<const float2*>(a.mask_src + (size_t)n * a.Ho * a.Wo * a.Cout + c + off);
+                v[0] = k2.x > 0.f ? v[0] : 0.f;
+                v[1] = k2.y > 0.f ? v[1] : 0.f;
             }
-            if (in && keep_y) *reinterpret_cast<float4*>(yb + off) = make_float4(v[0], v[1], v[2], v[3]);
+            if (in && keep_y) *reinterpret_cast<float2*>(yb + off) = make_float2(v[0], v[1]);
         }
     if (EPI == 3 && a.pool_out) {   // 2x2/2 max-pool of the stored values: the tile's four windows (Ho, Wo even)
         const int Hp = a.Ho >> 1, Wp = a.Wo >> 1;
@@ -211,11 +212,11 @@ __global__ __launch_bounds__(256) void wino6_output_kernel(W6Args a) {
 #pragma unroll
             for (int wx = 0; wx < 2; ++wx) {
                 if (oy + 2 * wy >= a.Ho || ox + 2 * wx >= a.Wo) continue;
-                f32x4 q;
+                f32x2 q;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 2; ++e)
                     q[e] = fmaxf(fmaxf(o[2 * wy][2 * wx][e], o[2 * wy][2 * wx + 1][e]), fmaxf(o[2 * wy + 1][2 * wx][e], o[2 * wy + 1][2 * wx + 1][e]));
-                *reinterpret_cast<float4*>(pb + ((size_t)((oy >> 1) + wy) * Wp + ((ox >> 1) + wx)) * a.Cout) = make_float4(q[0], q[1], q[2], q[3]);
+                *reinterpret_cast<float2*>(pb + ((size_t)((oy >> 1) + wy) * Wp + ((ox >> 1) + wx)) * a.Cout) = make_float2(q[0], q[1]);
             }
     }
 }
@@ -429,7 +430,7 @@ bool wino6_eligible(const ConvArgs& a) {
     const long T = (long)a.N * cdiv(a.Ho, 4) * cdiv(a.Wo, 4);
     return a.KH == 3 && a.KW == 3 && a.stride == 1 && pad_ok && a.src_mode == SRC_PLAIN && a.Cin % kW6K == 0 && a.Cout % kW6TN == 0 && !a.shuffle && wino6_epi(a) >= 0 &&
            !a.route_src && a.w_nstride == 0 && a.dil_x <= 1 && !a.fin.counter && a.Ho > 0 && a.Wo > 0 && (!a.pool_out || (!(a.Ho & 1) && !(a.Wo & 1))) &&
-           (long)a.Cin * a.Cout >= (long)tune_int("FS_WINO6_MINCC", 512 * 256) && T >= tune_int("FS_WINO6_MINTILES", 1024) && T < (1L << 24) &&
+           (long)a.Cin * a.Cout >= (long)tune_int("FS_WINO6_MINCC", 512 * 256) && T >= tune_int("FS_WINO6_MINTILES", 1024) && T < (1L << 24) && 36.0 * (double)((T + 127) & ~127L) * (a.Cin > a.Cout ? a.Cin : a.Cout) * 4.0 < 4294967296.0 &&
            a.w6_ws_floats >= (size_t)36 * 128 * ((size_t)a.Cin + a.Cout);
 }
 
@@ -476,19 +477,56 @@ int wino6_launch(const ConvArgs& a, hipStream_t s) {
     if (cap < 128) return -7;
     static BigLds lds_attr;
     lds_attr.ensure(reinterpret_cast<const void*>(wino6_gemm_kernel));
-    for (long t0 = 0; t0 < Tall; t0 += cap) {
-        w.t0 = (int)t0;
-        w.T = (int)(Tall - t0 < cap ? Tall - t0 : cap);
-        w.Tpad = (w.T + 127) & ~127;
-        w.V = a.w6_ws;
-        w.M = a.w6_ws + (size_t)36 * w.Tpad * a.Cin;
-        const long n1 = (long)w.T * (a.Cin / 4), n3 = (long)w.T * (a.Cout / 4);
-        hipLaunchKernelGGL(wino6_input_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, w);
-        hipLaunchKernelGGL(wino6_gemm_kernel, dim3((unsigned)(36 * (w.Tpad / 128) * (a.Cout / 128))), dim3(256), (size_t)(2 * kW6StageB), s, w);
+    auto k1 = [&](const W6Args& c, hipStream_t st) {
+        const long n1 = (long)c.T * (a.Cin / 4);
+        hipLaunchKernelGGL(wino6_input_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, c);
+    };
+    auto k2 = [&](const W6Args& c, hipStream_t st) {
+        hipLaunchKernelGGL(wino6_gemm_kernel, dim3((unsigned)(36 * (c.Tpad / 128) * (a.Cout / 128))), dim3(256), (size_t)(2 * kW6StageB), st, c);
+    };
+    auto k3 = [&](const W6Args& c, hipStream_t st) {
+        const long n3 = (long)c.T * (a.Cout / 2);
         const dim3 g3((unsigned)((n3 + 255) / 256));
-        if (epi == 0) hipLaunchKernelGGL(wino6_output_kernel<0>, g3, dim3(256), 0, s, w);
-        else if (epi == 3) hipLaunchKernelGGL(wino6_output_kernel<3>, g3, dim3(256), 0, s, w);
-        else hipLaunchKernelGGL(wino6_output_kernel<4>, g3, dim3(256), 0, s, w);
+        if (epi == 0) hipLaunchKernelGGL(wino6_output_kernel<0>, g3, dim3(256), 0, st, c);
+        else if (epi == 3) hipLaunchKernelGGL(wino6_output_kernel<3>, g3, dim3(256), 0, st, c);
+        else hipLaunchKernelGGL(wino6_output_kernel<4>, g3, dim3(256), 0, st, c);
+    };
+    auto chunk = [&](long t0, long T, float* base) {
+        W6Args c = w;
+        c.t0 = (int)t0;
+        c.T = (int)T;
+        c.Tpad = (c.T + 127) & ~127;
+        c.V = base;
+        c.M = base + (size_t)36 * c.Tpad * a.Cin;
+        return c;
+    };
+    // Two chunks software-pipelined over two streams (a.w6_side + three events; FS_WINO6_PIPE=0 disables): the transforms are HBM-bound, the GEMM is not, and
+    // their waves fit on a SIMD beside a GEMM wave --   s:    K1a | K2a        | K2b        | K3b
+    //                                                   side:      | K1b        | K3a        |          (joined before returning)
+    const long Ta = ((Tall / 2) + 127) & ~127L;
+    if (a.w6_side && a.w6_ev && !Profiler::current() && tune_int("FS_WINO6_PIPE", 1) && Tall - Ta >= 128 && cap >= Ta + (((Tall - Ta) + 127) & ~127L)) {
+        const W6Args ca = chunk(0, Ta, a.w6_ws);
+        const W6Args cb = chunk(Ta, Tall - Ta, a.w6_ws + (size_t)36 * ca.Tpad * ((size_t)a.Cin + a.Cout));
+        hipStream_t t = a.w6_side;
+        k1(ca, s);
+        if (hipEventRecord(a.w6_ev[0], s) != hipSuccess || hipStreamWaitEvent(t, a.w6_ev[0], 0) != hipSuccess) return -20;
+        k1(cb, t);
+        if (hipEventRecord(a.w6_ev[1], t) != hipSuccess) return -20;
+        k2(ca, s);
+        if (hipEventRecord(a.w6_ev[0], s) != hipSuccess || hipStreamWaitEvent(t, a.w6_ev[0], 0) != hipSuccess) return -20;
+        k3(ca, t);
+        if (hipEventRecord(a.w6_ev[2], t) != hipSuccess) return -20;
+        if (hipStreamWaitEvent(s, a.w6_ev[1], 0) != hipSuccess) return -20;
+        k2(cb, s);
+        k3(cb, s);
+        if (hipStreamWaitEvent(s, a.w6_ev[2], 0) != hipSuccess) return -20;
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
+    for (long t0 = 0; t0 < Tall; t0 += cap) {
+        const W6Args c = chunk(t0, Tall - t0 < cap ? Tall - t0 : cap, a.w6_ws);
+        k1(c, s);
+        k2(c, s);
+        k3(c, s);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
