@@ -232,14 +232,21 @@ __device__ __forceinline__ void w6_split8(const float4& lo, const float4& hi, ui
     L = make_uint4((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u), (l[4] >> 16) | (l[5] & 0xffff0000u), (l[6] >> 16) | (l[7] & 0xffff0000u));
 }
 
-// K2: the 36 GEMMs.  Workgroup = (position, 128 tiles, 128 output channels); four waves 2 x 2, each 64 x 64 as 2 x 2 blocks of v_mfma_f32_32x32x16_bf16
-// (A = V: rows = tiles; B = U: columns = output channels; a lane of the result holds ONE output channel of 16 tiles -- the 32 lanes of a half-wave store
-// 128 contiguous bytes of M[pos][tile][:]).  Stages of 32 input channels, two LDS stages, the next stage's global loads in flight during the sweep.
-__global__ __launch_bounds__(256) void wino6_gemm_kernel(W6Args a) {
+// K2: the 36 GEMMs.  Workgroup = (position, 128 tiles, 128 output channels), blocks of v_mfma_f32_32x32x16_bf16 (A = V: rows = tiles; B = U: columns = output
+// channels; a lane of the result holds ONE output channel of 16 tiles -- the 32 lanes of a half-wave store 128 contiguous bytes of M[pos][tile][:]).  Stages of
+// 32 input channels, two LDS stages, global loads three stages ahead.  NW = 4 (default): four waves 2 x 2, each 64 x 64 (one wave per SIMD); NW = 8 (FS_WINO6_WAVES=8, measured level or slower: its operand reads per matrix instruction are 1.5x): eight
+// waves 2 x 4, each 64 x 32 -- TWO waves per SIMD, so that one wave's staging instructions (split arithmetic, LDS stores, operand reads, global loads: more
+// issue cycles per stage than the matrix instructions themselves, profiles/r06_micro_split_bf16_pipeline.txt) issue while the other's matrix instructions run.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void wino6_gemm_kernel(W6Args a) {
     HIP_DYNAMIC_SHARED(float, smem)
     char* lds = reinterpret_cast<char*>(smem);
+    constexpr int NT = 64 * NW;          // threads
+    constexpr int WNB = NW == 4 ? 2 : 1; // 32-channel blocks per wave
+    constexpr int AU = 512 / NT;         // A staging units (8 channels of one tile row: two quads) per thread and stage
+    constexpr int BQ = 1536 / NT;        // B quads per thread and stage
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = NW == 4 ? wave >> 1 : wave >> 2, wn = NW == 4 ? wave & 1 : wave & 3;
     const int KB = a.Cin >> 5, MB = a.Tpad >> 7, NB = a.Cout >> 7;
     // XCD-aware order: workgroup b runs on XCD b mod 8; virtual index (b mod 8) G/8 + b/8 hands every XCD a contiguous range of (position, tile block,
     // channel block) with the channel blocks of a tile block adjacent: its 32 concurrent workgroups share 8 V tile blocks and the position's U in one L2
@@ -250,33 +257,36 @@ __global__ __launch_bounds__(256) void wino6_gemm_kernel(W6Args a) {
     const size_t a_kstride = (size_t)a.Tpad * 32, b_pstride = (size_t)a.Cout * 32, b_kstride = 3 * b_pstride;
     const unsigned short* Bg = a.U + (size_t)pos * KB * b_kstride + (size_t)nb * 128 * 32;
 
-    // staging: A 128 rows x 32 floats = 1024 quads, thread units u = tid + 256 i: row u / 4, 8-channel group u % 4 (two quads); B 3 pieces x 512 quads.
-    // Two register sets: the global loads of stage s + 3 are issued in stage s and consumed (split, stored to LDS) in the second half of stage s + 2 --
-    // a stage and a half of matrix instructions between issue and use.  No conditional loads / stores (the lesson of fs_wino4.hip: a staged value that is a
-    // phi of "loaded" and "not loaded" ends up in scratch memory): a stage beyond the last is loaded from the last one's addresses and stored to the LDS
-    // buffer nobody reads.
+    // staging: A 128 rows x 32 floats = 512 units of two quads, unit u = tid + NT i: row u / 4, 8-channel group u % 4; B 3 pieces x 512 quads, quad index
+    // q = tid + NT j over [piece][512].  Two register sets: the global loads of stage s + 3 are issued in stage s and consumed (split, stored to LDS) in the
+    // first half of stage s + 2 -- a stage and a half of matrix instructions between issue and use.  No conditional loads / stores (the lesson of fs_wino4.hip:
+    // a staged value that is a phi of "loaded" and "not loaded" ends up in scratch memory): a stage beyond the last is loaded from the last one's addresses and
+    // stored to the LDS buffer nobody reads.
     struct Regs {
-        float4 a[2][2];
-        uint4 b[6];
+        float4 a[AU][2];
+        uint4 b[BQ];
     };
     auto load_regs = [&](Regs& R, int kb) __attribute__((always_inline)) {
         kb = kb < KB ? kb : KB - 1;
         const float* ap = Ag + (size_t)kb * a_kstride;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int u = tid + 256 * i;
+        for (int i = 0; i < AU; ++i) {
+            const int u = tid + NT * i;
             R.a[i][0] = *reinterpret_cast<const float4*>(ap + (size_t)u * 8);
             R.a[i][1] = *reinterpret_cast<const float4*>(ap + (size_t)u * 8 + 4);
         }
         const unsigned short* bp = Bg + (size_t)kb * b_kstride;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) R.b[j] = *reinterpret_cast<const uint4*>(bp + (size_t)(j >> 1) * b_pstride + (size_t)(tid + 256 * (j & 1)) * 8);   // piece j / 2, quad of its 512
+        for (int j = 0; j < BQ; ++j) {
+            const int q = tid + NT * j;   // (piece q / 512 is a compile-time constant per j: NT divides 512)
+            R.b[j] = *reinterpret_cast<const uint4*>(bp + (size_t)(q >> 9) * b_pstride + (size_t)(q & 511) * 8);
+        }
     };
     auto write_lds = [&](const Regs& R, int st) __attribute__((always_inline)) {
         char* base = lds + st * kW6StageB;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int u = tid + 256 * i;
+        for (int i = 0; i < AU; ++i) {
+            const int u = tid + NT * i;
             uint4 H, Mi, L;
             if (FS_W6_ABL & 1) {
                 H = __builtin_bit_cast(uint4, R.a[i][0]);
@@ -291,54 +301,54 @@ __global__ __launch_bounds__(256) void wino6_gemm_kernel(W6Args a) {
             *reinterpret_cast<uint4*>(p + 2 * kW6PieceB) = L;
         }
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int q = tid + 256 * (j & 1);
+        for (int j = 0; j < BQ; ++j) {
+            const int q = tid + NT * j, r = q & 511;
             if ((FS_W6_ABL & 4) && (R.b[j].x ^ R.b[j].y ^ R.b[j].z ^ R.b[j].w) != 0x9e3779b9u) continue;
-            *reinterpret_cast<uint4*>(base + (3 + (j >> 1)) * kW6PieceB + (q >> 2) * kW6Pitch + (q & 3) * 16) = R.b[j];
+            *reinterpret_cast<uint4*>(base + (3 + (q >> 9)) * kW6PieceB + (r >> 2) * kW6Pitch + (r & 3) * 16) = R.b[j];
         }
     };
 
     // two accumulators per block: the leading product Uh Vh alone, and the five small ones (<= 2^-8 of it) together -- a rounding of the small sum is 2^-8 of a
     // rounding of the large one, so the result carries ONE full-size fp32 rounding per 16-channel block of the reduction; they meet once, in the store
-    f32x16 acc[2][2], acl[2][2];
+    f32x16 acc[2][WNB], acl[2][WNB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WNB; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = acl[i][j][e] = 0.f;
 
     const int a_lane = (64 * wm + (lane & 31)) * kW6Pitch + (lane >> 5) * 16;
-    const int b_lane = 3 * kW6PieceB + (64 * wn + (lane & 31)) * kW6Pitch + (lane >> 5) * 16;
+    const int b_lane = 3 * kW6PieceB + (32 * WNB * wn + (lane & 31)) * kW6Pitch + (lane >> 5) * 16;
 
-    // operand fragments of one half stage (16 of the 32 input channels): 2 tile blocks x 3 pieces of V, 2 channel blocks x 3 pieces of U
+    // operand fragments of one half stage (16 of the 32 input channels): 2 tile blocks x 3 pieces of V, WNB channel blocks x 3 pieces of U
     struct Frag {
-        w6_bf16x8 a[2][3], b[2][3];
+        w6_bf16x8 a[2][3], b[WNB][3];
     };
     auto read_frag = [&](Frag& F, int st, int ks) __attribute__((always_inline)) {
         const char* sa = lds + st * kW6StageB + a_lane + ks * 32;
         const char* sb = lds + st * kW6StageB + b_lane + ks * 32;
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+        for (int p = 0; p < 3; ++p) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                if (FS_W6_ABL & 32) {
-                    F.a[blk][p] = __builtin_bit_cast(w6_bf16x8, make_uint4(lane + p, blk, ks, 1));
-                    F.b[blk][p] = __builtin_bit_cast(w6_bf16x8, make_uint4(lane, blk + p, ks, 2));
-                    continue;
-                }
-                F.a[blk][p] = __builtin_bit_cast(w6_bf16x8, *reinterpret_cast<const uint4*>(sa + p * kW6PieceB + blk * 32 * kW6Pitch));
-                F.b[blk][p] = __builtin_bit_cast(w6_bf16x8, *reinterpret_cast<const uint4*>(sb + p * kW6PieceB + blk * 32 * kW6Pitch));
-            }
+            for (int blk = 0; blk < 2; ++blk)
+                F.a[blk][p] = (FS_W6_ABL & 32) ? __builtin_bit_cast(w6_bf16x8, make_uint4(lane + p, blk, ks, 1))
+                                               : __builtin_bit_cast(w6_bf16x8, *reinterpret_cast<const uint4*>(sa + p * kW6PieceB + blk * 32 * kW6Pitch));
+#pragma unroll
+            for (int blk = 0; blk < WNB; ++blk)
+                F.b[blk][p] = (FS_W6_ABL & 32) ? __builtin_bit_cast(w6_bf16x8, make_uint4(lane, blk + p, ks, 2))
+                                               : __builtin_bit_cast(w6_bf16x8, *reinterpret_cast<const uint4*>(sb + p * kW6PieceB + blk * 32 * kW6Pitch));
+        }
     };
-    // the 24 matrix instructions of a half stage, product by product over the four blocks (a block's accumulator is touched every fourth instruction;
+    // the matrix instructions of a half stage, product by product over the blocks (a block's accumulator is touched every 2 WNB-th instruction;
     // pieces: 0 = h, 1 = m, 2 = l; smallest terms first)
     auto mfma_half = [&](const Frag& F) __attribute__((always_inline)) {
         if (FS_W6_ABL & 16) {
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) asm volatile("" ::"v"(F.a[blk][p]), "v"(F.b[blk][p]));
+            for (int p = 0; p < 3; ++p) {
+                asm volatile("" ::"v"(F.a[0][p]), "v"(F.a[1][p]), "v"(F.b[0][p]));
+                if (WNB == 2) asm volatile("" ::"v"(F.b[WNB - 1][p]));
+            }
             return;
         }
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -347,17 +357,18 @@ __global__ __launch_bounds__(256) void wino6_gemm_kernel(W6Args a) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < WNB; ++j) {
                     if (t < 5) acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA[t]], F.b[j][PB[t]], acl[i][j], 0, 0, 0);
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA[t]], F.b[j][PB[t]], acc[i][j], 0, 0, 0);
                 }
     };
-    // One stage = two halves of 24 matrix instructions, each with its operands read from LDS during the half BEFORE it (a wave issues in order: an operand
+    // One stage = two halves of matrix instructions, each with its operands read from LDS during the half BEFORE it (a wave issues in order: an operand
     // read waited for in front of its matrix instruction stalls the matrix pipe -- measured 100 of 245 us on conv4_2):
     //   first half : products of (stage s, channels 0..15) | reads of (s, 16..31) | split of register set R (= stage s + 1) into the other LDS buffer
     //   barrier    : buffer st ^ 1 complete; every wave has its reads of buffer st behind it (so the next stage may overwrite st)
     //   second half: products of (s, 16..31) | reads of (s + 1, 0..15) from the other buffer | global loads of stage s + 3 into R
     // The scheduler is asked to thread the reads / vector-ALU / LDS-store / global-load work between the matrix instructions.
+    constexpr int NM = 12 * WNB;   // matrix instructions per half
     Frag F0, F1;
     auto stage = [&](int st, Regs& R, int kb_load) __attribute__((always_inline)) {
         mfma_half(F0);
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(256) void wino6_gemm_kernel(W6Args a) {
         write_lds(R, st ^ 1);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-        for (int g = 0; g < 24; ++g) {
+        for (int g = 0; g < NM; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one matrix instruction
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // an LDS read
             __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);   // vector-ALU instructions of the split
@@ -378,7 +389,7 @@ __global__ __launch_bounds__(256) void wino6_gemm_kernel(W6Args a) {
         if (!(FS_W6_ABL & 2)) load_regs(R, kb_load);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-        for (int g = 0; g < 24; ++g) {
+        for (int g = 0; g < NM; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load
@@ -398,12 +409,12 @@ __global__ __launch_bounds__(256) void wino6_gemm_kernel(W6Args a) {
         stage(0, R0, kb + 3);                     // stage kb: buffer 0; R0 holds stage kb + 1
         if (kb + 1 < KB) stage(1, R1, kb + 4);    // stage kb + 1: buffer 1; R1 holds stage kb + 2
     }
-    // M[pos][tile][cout]: register r of block (i, j) = tile 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), channel 64 wn + 32 j + (lane & 31)
-    float* mp = a.M + ((size_t)pos * a.Tpad + (size_t)mb * 128 + 64 * wm + 4 * (lane >> 5)) * a.Cout + (size_t)nb * 128 + 64 * wn + (lane & 31);
+    // M[pos][tile][cout]: register r of block (i, j) = tile 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), channel 32 WNB wn + 32 j + (lane & 31)
+    float* mp = a.M + ((size_t)pos * a.Tpad + (size_t)mb * 128 + 64 * wm + 4 * (lane >> 5)) * a.Cout + (size_t)nb * 128 + 32 * WNB * wn + (lane & 31);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WNB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mp[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * a.Cout + 32 * j] = acc[i][j][r] + acl[i][j][r];
 }
@@ -475,14 +486,18 @@ int wino6_launch(const ConvArgs& a, hipStream_t s) {
     const int knob = tune_int("FS_WINO6_CHUNK", 0);
     if (knob >= 128 && (knob & ~127) < cap) cap = knob & ~127;
     if (cap < 128) return -7;
-    static BigLds lds_attr;
-    lds_attr.ensure(reinterpret_cast<const void*>(wino6_gemm_kernel));
+    const int nw = tune_int("FS_WINO6_WAVES", 4) == 8 ? 8 : 4;   // 8 measured level or slower (profiles/r06_ab_split_bf16_pipeline.txt): kept as an experiment
+    static BigLds lds_attr4, lds_attr8;
+    if (nw == 4) lds_attr4.ensure(reinterpret_cast<const void*>(wino6_gemm_kernel<4>));
+    else lds_attr8.ensure(reinterpret_cast<const void*>(wino6_gemm_kernel<8>));
     auto k1 = [&](const W6Args& c, hipStream_t st) {
         const long n1 = (long)c.T * (a.Cin / 4);
         hipLaunchKernelGGL(wino6_input_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, c);
     };
     auto k2 = [&](const W6Args& c, hipStream_t st) {
-        hipLaunchKernelGGL(wino6_gemm_kernel, dim3((unsigned)(36 * (c.Tpad / 128) * (a.Cout / 128))), dim3(256), (size_t)(2 * kW6StageB), st, c);
+        const dim3 g2((unsigned)(36 * (c.Tpad / 128) * (a.Cout / 128)));
+        if (nw == 4) hipLaunchKernelGGL(wino6_gemm_kernel<4>, g2, dim3(256), (size_t)(2 * kW6StageB), st, c);
+        else hipLaunchKernelGGL(wino6_gemm_kernel<8>, g2, dim3(512), (size_t)(2 * kW6StageB), st, c);
     };
     auto k3 = [&](const W6Args& c, hipStream_t st) {
         const long n3 = (long)c.T * (a.Cout / 2);
