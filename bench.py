@@ -377,11 +377,14 @@ def main():
         # kind with an event before and after each; gap = end of step i -> start of step i+1 on the device time line
         Gs = 20
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(Gs)]
+        tr.ar_events = []
         for i in range(Gs):
             evs[i][0].record()
             tr.step(pool[i % len(pool)])
             evs[i][1].record()
         sync()
+        res["allreduce_us"] = float(np.median([a.elapsed_time(b) for a, b in tr.ar_events])) * 1e3 if tr.ar_events else None
+        tr.ar_events = None
         busy = [evs[i][0].elapsed_time(evs[i][1]) for i in range(Gs)]
         gaps = [evs[i][1].elapsed_time(evs[i + 1][0]) for i in range(Gs - 1)]
         res["step_device_ms"] = float(np.median(busy))
@@ -558,6 +561,8 @@ def main():
                 # the step as the device sees it (events around graph replay + all-reduce + Adam) and the idle time between two
                 # steps: what keeping the all-reduce and the optimiser outside the captured graph costs
                 "step_device_ms": round(leg["step_device_ms"], 3), "inter_step_gap_us": round(leg["inter_step_gap_us"], 1),
+                # HIP events around the one all-reduce(SUM) of the flat gradient buffer (None without a process group: a plain `python bench.py`)
+                "allreduce_us": round(leg["allreduce_us"], 1) if leg.get("allreduce_us") is not None else None,
                 "host_gap_frac_of_step": round(leg["inter_step_gap_us"] * 1e-3 / (leg["elapsed"] / steps * 1e3), 5),
                 "step_tflops_as_written": round(GF_STEP * value / 1e3, 2),
                 "step_frac_as_written": round(GF_STEP * value / 1e3 / world / PEAK_F32_MFMA_TFLOPS, 4),
@@ -665,7 +670,7 @@ def main():
             "step_frac_executed": rep["step_frac_executed"], "all_mfma_kernels_tflops": rep["all_mfma_kernels_tflops"],
             "mfma_kernel_ms_per_step": rep["mfma_kernel_ms_per_step"], "sections_ms_eager": rep["sections_ms_eager"],
             "final_loss": rep["final_loss"], "hip_graph": rep["hip_graph"],
-            "step_device_ms": rep["step_device_ms"], "inter_step_gap_us": rep["inter_step_gap_us"],
+            "step_device_ms": rep["step_device_ms"], "inter_step_gap_us": rep["inter_step_gap_us"], "allreduce_us": rep["allreduce_us"],
             "host_gap_frac_of_step": rep["host_gap_frac_of_step"],
         }
         if b4_leg is not None:

@@ -199,6 +199,7 @@ static const fs::TnetLayout* get_layout(fs_ctx* ctx, int N, int H, int W, int fl
         ctx->tnet_valid = true;
         ctx->tnet_epoch = fs::tune_epoch();
         ++ctx->tnet_serial;
+        for (auto& q : ctx->fwd_recs) q.bwd_filters = false;   // (filters a forward built under the OLD plan are not what a backward under the new one reads)
     }
     return &ctx->tnet;
 }
@@ -612,7 +613,7 @@ static int fill_conv(fs_conv_desc* d, fs::ConvArgs* a) {
     a->inb_rec = d->inb_rec;
     a->tnet_plan = d->inb_rec ? 1 : 0;   // (the partial sums exist for 16-tile items: plan them whatever the grid)
     if (a->w_wino4t && (a->w_wino4 || !fs::wino4t_eligible(*a))) a->w_wino4t = nullptr;
-    if (fs::tune_int("FS_WINO_V", 2) >= 2) {   // the filter layout fs_wino_transform_filter produced (see there)
+    if (fs::wino_gen().f2_second()) {   // the filter layout fs_wino_transform_filter produced (see there)
         a->w_wino2 = d->w_wino;
         if (a->w_wino2 && !fs::wino2_eligible(*a)) a->w_wino2 = nullptr;   // (not a 3x3 stride-1 conv of the supported shapes: direct kernel)
     } else {
@@ -666,7 +667,7 @@ int fs_wino_transform_filter(fs_ctx* ctx, const float* w, int Cin, int Cout, flo
     if (!ctx || !w || !U) return fail(-1, "fs_wino_transform_filter: null argument");
     if (Cin < 1 || Cout < 1) return fail(-2, "fs_wino_transform_filter: bad shape %dx%d", Cin, Cout);
     if (Cin % 8) return fail(-2, "fs_wino_transform_filter: Cin must be a multiple of 8 (got %d)", Cin);
-    const int rc = fs::tune_int("FS_WINO_V", 2) >= 2 ? fs::wt_wino2(w, U, Cin, Cout, ctx->stream) : fs::wt_wino(w, U, Cin, Cout, ctx->stream);
+    const int rc = fs::wino_gen().f2_second() ? fs::wt_wino2(w, U, Cin, Cout, ctx->stream) : fs::wt_wino(w, U, Cin, Cout, ctx->stream);
     return rc ? fail(rc, "fs_wino_transform_filter: launch failed (%d)", rc) : 0;
 }
 

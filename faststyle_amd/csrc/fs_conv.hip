@@ -938,41 +938,34 @@ static void plan_variant(const ConvArgs& a, int variant, ConvPlan* out) {
     *out = p;
 }
 
+// The specialised conv kernel families in order of preference (each takes a launch only when the caller provided ITS filter layout / scratch and the shape
+// fits; what falls through runs on conv_igemm_kernel below).  Generations of the Winograd kernels: WinoGen in fs_kernels.h.
+const ConvFamily* conv_families(int* n) {
+    static const ConvFamily kFamilies[] = {
+        {"wino6: split-bf16 F(4x4,3x3) pipeline (deep VGG16 layers)", 12, true, wino6_eligible, wino6_plan, wino6_launch},
+        {"wino4: F(4x4,3x3), filter through LDS (FS_WINO_V=4)", 10, true, wino4_eligible, wino4_plan, wino4_launch},
+        {"wino4t: F(4x4,3x3), filter in registers", 11, true, wino4t_eligible, wino4t_plan, wino4t_launch},
+        {"wino2h: F(2x2,3x3), half items (small grids)", 8, true, wino2h_eligible, wino2h_plan, wino2h_launch},
+        {"wino2: F(2x2,3x3), second generation", 6, true, wino2_eligible, wino2_plan, wino2_launch},
+        {"wino: F(2x2,3x3), first kernel", 5, true, wino_eligible, wino_plan, wino_launch},
+        {"cstream: narrow full-resolution layers, persistent streaming", 7, false, cstream_eligible, cstream_plan, cstream_launch},
+        {"s16: 16-output-channel blocks (9x9 image layer, folded output layer)", 9, false, s16_eligible, s16_plan, s16_launch},
+    };
+    *n = (int)(sizeof(kFamilies) / sizeof(kFamilies[0]));
+    return kFamilies;
+}
+
 ConvPlan conv_plan(const ConvArgs& a) {
     ConvPlan p;
-    if (env_int("FS_CONV_WINO", 1)) {
-        if (wino6_eligible(a)) {   // split-bf16 F(4x4,3x3) pipeline (fs_wino6.hip): the caller provided its filter pieces and scratch (FS_WINO_V=6, deep layers)
-            wino6_plan(a, &p);
-            return p;
-        }
-        if (wino4_eligible(a)) {   // Winograd F(4x4,3x3) (fs_wino4.hip): the VGG16 convs when its filter layout was provided
-            wino4_plan(a, &p);
-            return p;
-        }
-        if (wino4t_eligible(a)) {   // Winograd F(4x4,3x3), 16-tile items (fs_wino4t.hip): the caller provided its filter layout
-            wino4t_plan(a, &p);
-            return p;
-        }
-        if (wino2h_eligible(a)) {   // half-item Winograd kernel (fs_wino2h.hip): the caller asked for it (small grids)
-            wino2h_plan(a, &p);
-            return p;
-        }
-        if (wino2_eligible(a)) {   // second-generation Winograd kernel (fs_wino2.hip) when its filter layout was provided
-            wino2_plan(a, &p);
-            return p;
-        }
-        if (wino_eligible(a)) {
-            wino_plan(a, &p);
-            return p;
-        }
-    }
-    if (cstream_eligible(a)) {   // narrow full-resolution layers with enough tiles: persistent streaming kernel (fs_cstream.hip)
-        cstream_plan(a, &p);
-        return p;
-    }
-    if (s16_eligible(a)) {   // 16 output channels (9x9 image layer, input gradient of the output layer, kw-folded output layer): fs_s16.hip
-        s16_plan(a, &p);
-        return p;
+    {   // the specialised families, in the table's order (first taker wins)
+        int nf = 0;
+        const ConvFamily* fam = conv_families(&nf);
+        const bool wino_on = env_int("FS_CONV_WINO", 1) != 0;
+        for (int i = 0; i < nf; ++i)
+            if ((wino_on || !fam[i].winograd) && fam[i].eligible(a)) {
+                fam[i].plan(a, &p);
+                return p;
+            }
     }
     if (a.Cout <= 16 || a.Cin == 3) {  // narrow outputs, and the flat Cin==3 path, have one variant each
         plan_variant(a, a.Cout <= 16 ? 2 : 0, &p);
@@ -1134,30 +1127,16 @@ int conv_launch(const ConvArgs& a_in, hipStream_t s) {
         lds_attr.ensure(reinterpret_cast<const void*>(conv_igemm_kernel<MT_, WM_, WN_, FL_>));                       \
         hipLaunchKernelGGL((conv_igemm_kernel<MT_, WM_, WN_, FL_>), grid, dim3(256), (size_t)p.lds_bytes, s, a);   \
     } while (0)
-    if (p.variant == 12) {
-        if (!wino6_eligible(a_in)) return -7;
-        FS_TRY_(wino6_launch(a, s));
-    } else if (p.variant == 10) {
-        if (!wino4_eligible(a_in)) return -7;
-        FS_TRY_(wino4_launch(a, s));
-    } else if (p.variant == 11) {
-        if (!wino4t_eligible(a_in)) return -7;
-        FS_TRY_(wino4t_launch(a, s));
-    } else if (p.variant == 8) {
-        if (!wino2h_eligible(a_in)) return -7;
-        FS_TRY_(wino2h_launch(a, s));
-    } else if (p.variant == 7) {
-        if (!cstream_eligible(a_in)) return -7;
-        FS_TRY_(cstream_launch(a, s));
-    } else if (p.variant == 9) {
-        if (!s16_eligible(a_in)) return -7;
-        FS_TRY_(s16_launch(a, s));
-    } else if (p.variant == 6) {
-        if (!wino2_eligible(a_in)) return -7;
-        FS_TRY_(wino2_launch(a, s));
-    } else if (p.variant == 5) {
-        if (!wino_eligible(a_in)) return -7;
-        FS_TRY_(wino_launch(a, s));
+    const ConvFamily* special = nullptr;
+    {
+        int nf = 0;
+        const ConvFamily* fam = conv_families(&nf);
+        for (int i = 0; i < nf; ++i)
+            if (fam[i].variant == p.variant) special = &fam[i];
+    }
+    if (special) {
+        if (!special->eligible(a_in)) return -7;
+        FS_TRY_(special->launch(a, s));
     } else if (p.flat) {
         if (p.variant == 0)
             FS_LAUNCH(32, 2, 2, true);

@@ -564,6 +564,31 @@ void plan_tile(int Ho, int Wo, int KH, int KW, int stride, int max_px, int* TH, 
 int tune_int(const char* name, int unset);
 void tune_reload();
 unsigned tune_epoch();   // bumped by tune_reload: cached plans made under older knob values are stale
+// The Winograd generations are selected by ONE knob with ONE default, read through this accessor only (FS_WINO_V):
+//   1  fs_wino.hip    F(2x2), first kernel          2  + fs_wino2.hip / fs_wino2h.hip  F(2x2), second generation (Cin <= 128, half items)
+//   4  + fs_wino4.hip F(4x4), filter through LDS    5  + fs_wino4t.hip F(4x4), filter in registers (the fp32 default of every 3x3 stride-1 launch)
+//   6  + fs_wino6.hip F(4x4) with split-bf16 products for the deep VGG16 layers (the default)
+// A generation is "on" when the knob is >= its number; which one a launch takes is decided by conv_plan's family table (fs_conv.hip) from the
+// filter layouts the caller provides, in the table's order.
+struct WinoGen {
+    int v;
+    bool f2_second() const { return v >= 2; }
+    bool f4_lds() const { return v >= 4; }
+    bool f4_reg() const { return v >= 5; }
+    bool split_bf16() const { return v >= 6; }
+};
+inline WinoGen wino_gen() { return WinoGen{tune_int("FS_WINO_V", 6)}; }
+// One row per specialised conv kernel family: conv_plan takes the first row whose eligible() accepts the launch, conv_launch finds the row of the
+// plan's variant again (and re-checks eligibility: a plan made for other arguments is refused with -7).  fs_conv.hip holds the table.
+struct ConvFamily {
+    const char* name;
+    int variant;       // ConvPlan::variant of its plans
+    bool winograd;     // off under FS_CONV_WINO=0
+    bool (*eligible)(const ConvArgs&);
+    void (*plan)(const ConvArgs&, ConvPlan*);
+    int (*launch)(const ConvArgs&, hipStream_t);
+};
+const ConvFamily* conv_families(int* n);
 // does a launch of this size qualify?  (one workgroup reads N*C*T*groups records: beyond a few 10^4 a launch of its own,
 // spread over the chip, is faster)
 // (GPU-UNVERIFIED when on: its cross-XCD hand-off -- relaxed agent-scope atomics + a manual s_waitcnt -- is exercised by the

@@ -255,7 +255,7 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
             if (mode && u.kind == 0 && i >= 3 && i <= 12 && (wino_eligible(a) || wino2_eligible(a)) && (mode == 2 || blocks >= 200)) u.wino = 1;
             // ... and through the half-item kernel (<= 32 tiles per item: twice the items) when 64-tile items leave most of
             // the chip idle -- batch 4 per GPU: 100..144 items of 16x16 pixels, 180..252 half items
-            if (!u.wino && mode && mode != 2 && u.kind == 0 && i >= 3 && i <= 12 && tune_int("FS_WINO_V", 2) >= 2 && tune_int("FS_TNET_WINO_HALF", 1)) {
+            if (!u.wino && mode && mode != 2 && u.kind == 0 && i >= 3 && i <= 12 && wino_gen().f2_second() && tune_int("FS_TNET_WINO_HALF", 1)) {
                 ConvArgs h = a;
                 h.half_items = 1;
                 if (wino2h_eligible(h) && wino2h_items(h) >= tune_int("FS_WINO2H_MIN_ITEMS", 96)) u.wino = 2;
@@ -317,9 +317,9 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
     for (int i = 3; i <= 12; ++i) {   // residual input gradients (3x3 'full' convs of dz) through the Winograd kernel when its blocks fill the chip
         const Unit& u = L->u[i];
         const long blocks = (long)N * cdiv(u.Hin, 16) * cdiv(u.Win, 16);
-        bool on = L->wino_mode && tune_int("FS_WINO_V", 2) >= 2 && (L->wino_mode == 2 || blocks >= 200);
+        bool on = L->wino_mode && wino_gen().f2_second() && (L->wino_mode == 2 || blocks >= 200);
         L->wino_dh[i - 3] = 0;
-        if (!on && L->wino_mode && L->wino_mode != 2 && tune_int("FS_WINO_V", 2) >= 2 && tune_int("FS_TNET_WINO_HALF", 1)) {
+        if (!on && L->wino_mode && L->wino_mode != 2 && wino_gen().f2_second() && tune_int("FS_TNET_WINO_HALF", 1)) {
             ConvArgs h{};   // the 3x3 'full' conv of dz that unit_dgrad launches
             h.N = N;
             h.H = u.Hout;
@@ -482,7 +482,7 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
         // a training step: the backward's input-gradient filters ride in the same launches (two launches less per step)
         if (with_bwd_filters) bwd_filter_jobs(L, params, ws, &wb, &nbd, &nb4);
         FS_TRY(wt_batch(wb, s));
-        FS_TRY(tune_int("FS_WINO_V", 2) >= 2 ? wt_wino2_batch(nb, 64, 64, s) : wt_wino_batch(nb, 64, 64, s));
+        FS_TRY(wino_gen().f2_second() ? wt_wino2_batch(nb, 64, 64, s) : wt_wino_batch(nb, 64, 64, s));
         if (with_bwd_filters) FS_TRY(wt_wino2_batch(nbd, 64, 64, s));
         FS_TRY(wt_wino4t_batch(nb4, 64, 64, s));
     }
@@ -510,8 +510,8 @@ int tnet_forward(const TnetLayout& L, const float* params, const float* x, float
         a.in_nstride = src_a ? u.Cin : 0;
         a.in_relu = src_a ? 1 : 0;
         a.w = (u.kind == 1 || (u.kind == 3 && i < 15)) ? ws + L.weff[i - 13] : ((u.kind == 2 || u.kind == 3) ? ws + L.wfold : params + u.w_off);
-        a.w_wino = (u.wino && u.wino != 3 && tune_int("FS_WINO_V", 2) < 2) ? ws + u.wino_u : nullptr;
-        a.w_wino2 = (u.wino && u.wino != 3 && tune_int("FS_WINO_V", 2) >= 2) ? ws + u.wino_u : nullptr;
+        a.w_wino = (u.wino && u.wino != 3 && !wino_gen().f2_second()) ? ws + u.wino_u : nullptr;
+        a.w_wino2 = (u.wino && u.wino != 3 && wino_gen().f2_second()) ? ws + u.wino_u : nullptr;
         a.w_wino4t = u.wino == 3 ? ws + u.wino_u : nullptr;
         a.half_items = u.wino == 2;
         a.y = u.kind == 2 ? ws + L.zfold : ws + u.z;

@@ -42,8 +42,8 @@ static inline int pool_index(int l) { return l == 1 ? 0 : (l == 3 ? 1 : 2); }
 enum { PREP_F2 = 1, PREP_W4 = 2, PREP_W4T = 4, PREP_W6 = 8 };
 unsigned vgg_prep_mask() {
     if (tune_int("FS_VGG_PREPARE_ALL", 0)) return PREP_F2 | PREP_W4 | PREP_W4T | PREP_W6;
-    const int v = tune_int("FS_WINO_V", 6);
-    return v >= 6 ? (PREP_W4T | PREP_W6) : v == 5 ? PREP_W4T : v == 4 ? PREP_W4 : PREP_F2;
+    const WinoGen g = wino_gen();
+    return g.split_bf16() ? (PREP_W4T | PREP_W6) : g.f4_reg() ? PREP_W4T : g.f4_lds() ? PREP_W4 : PREP_F2;
 }
 static bool w6_layer_ok(int l, bool dgrad) {
     const int ci = dgrad ? kCout[l] : kCin[l], co = dgrad ? kCin[l] : kCout[l];
@@ -84,8 +84,8 @@ static PrepLayout prep_layout(unsigned mask) {
 }
 size_t vgg_prepared_floats() { return prep_layout(vgg_prep_mask()).total; }
 // which generation the knobs of the moment want for the F(4x4) convs (FS_WINO_V >= 5: fs_wino4t.hip; 4: fs_wino4.hip) and whether the deep layers may take fs_wino6.hip
-static bool vgg_use_4t() { return tune_int("FS_WINO_V", 6) >= 5; }
-static bool vgg_want_w6() { return tune_int("FS_WINO_V", 6) >= 6; }
+static bool vgg_use_4t() { return wino_gen().f4_reg(); }
+static bool vgg_want_w6() { return wino_gen().split_bf16(); }
 // debugging aid: FS_VGG_WINO_MASK selects the layers that may take the Winograd kernel (bit l: forward of layer l,
 // bit 16+l: its input gradient); default all
 static bool wino_layer_on(int bit) {

@@ -799,7 +799,7 @@ bool wino2_eligible(const ConvArgs& a) {
     const bool pad_ok = a.pad_t == a.pad_l && a.pad_t >= 0 && a.pad_t <= 2 && a.Ho == a.H + 2 * a.pad_t - 2 && a.Wo == a.W + 2 * a.pad_l - 2;
     // (measured: ahead of the first-generation kernel on the 64-channel layers -- 8 chunks per block, where the fixed cost of
     // a block weighs most --, level at 128 input channels, behind it beyond: FS_WINO2_MAXCIN)
-    return a.w_wino2 && tune_int("FS_WINO_V", 2) >= 2 && a.Cin <= tune_int("FS_WINO2_MAXCIN", 128) && a.KH == 3 && a.KW == 3 && a.stride == 1 && pad_ok && a.src_mode == SRC_PLAIN && a.Cin % kCC == 0 &&
+    return a.w_wino2 && wino_gen().f2_second() && a.Cin <= tune_int("FS_WINO2_MAXCIN", 128) && a.KH == 3 && a.KW == 3 && a.stride == 1 && pad_ok && a.src_mode == SRC_PLAIN && a.Cin % kCC == 0 &&
            a.Cout % kBN == 0 && !a.shuffle && (!a.in_a || a.pad_t == 0) && a.w_nstride == 0 && (a.dil_x <= 1) &&
            (!a.add_src || !a.stats);
 }

@@ -615,7 +615,7 @@ bool wino4_eligible(const ConvArgs& a) {
     const bool pad_ok = a.pad_t == 1 && a.pad_l == 1 && a.Ho == a.H && a.Wo == a.W;
     // byte offsets inside one sample are 32-bit with the top bit reserved for "out of range"; the filter planes likewise
     const bool fits = (double)a.H * a.W * (a.Cin > a.Cout ? a.Cin : a.Cout) * 4.0 < 2147483648.0 && 36.0 * a.Cin * a.Cout * 4.0 < 2147483648.0;
-    return fits && a.w_wino4 && tune_int("FS_WINO_V", 4) >= 4 && a.KH == 3 && a.KW == 3 && a.stride == 1 && pad_ok && a.src_mode == SRC_PLAIN &&
+    return fits && a.w_wino4 && wino_gen().f4_lds() && a.KH == 3 && a.KW == 3 && a.stride == 1 && pad_ok && a.src_mode == SRC_PLAIN &&
            a.Cin % kCC == 0 && a.Cout % kBN == 0 && !a.shuffle && !a.add_src && !a.in_a && !a.stats && !a.route_src && a.w_nstride == 0 &&
            a.dil_x <= 1 && (!a.pool_out || (!(a.Ho & 1) && !(a.Wo & 1)));
 }

@@ -95,6 +95,7 @@ class Engine(object):
         self._pinned = {}          # id(workspace tensor) -> pin count
         self._tnet_nbytes = {}     # (N, H, W, bf16) -> fs_tnet_workspace_bytes, see _tnet_key
         self._perc_io = {}         # perceptual workspace key -> (y offset, content offset), see perceptual_inputs
+        self._private = []         # [(weakref to a new_tnet_workspace() tensor, nbytes)]: counted in the byte budget while alive
         self._keep = []
 
     def close(self):
@@ -154,7 +155,8 @@ class Engine(object):
     def _evict(self, cache, incoming_bytes):
         """Drop least-recently-used, unpinned entries of `cache` until `incoming_bytes` more fit the budget."""
         def total():
-            return sum(nb for _, nb in self._tnet_ws.values()) + sum(nb for _, nb in self._perc_ws.values())
+            self._private = [(r, nb) for r, nb in self._private if r() is not None]
+            return sum(nb for _, nb in self._tnet_ws.values()) + sum(nb for _, nb in self._perc_ws.values()) + sum(nb for _, nb in self._private)
         dropped = False
         for key in list(cache):
             if len(cache) < self.MAX_CACHED_SHAPES and total() + incoming_bytes <= self.MAX_CACHED_BYTES:
@@ -234,9 +236,19 @@ class Engine(object):
         """A transform-net workspace of the caller's own (not in the shape cache): what a hipGraph capturer with frozen=True replays into --
         the re-laid-out filters inside it belong to ONE parameter set, and no other call of this engine may rewrite them (a shared, per-shape
         workspace would be rewritten by any other same-shape forward: another FrameStylizer with another checkpoint, a Trainer, an eval)."""
+        import weakref
         nbytes = self._tnet_key(N, H, W, bf16)[4]
+        # a private workspace counts in MAX_CACHED_BYTES for as long as its owner keeps it: make room among the cached (unpinned) entries first,
+        # largest cache first -- several stylizers plus a Trainer otherwise add up outside every budget (the caller's workspace itself is never refused)
+        for cache in sorted((self._tnet_ws, self._perc_ws), key=lambda c: -sum(nb for _, nb in c.values())):
+            self._evict(cache, nbytes)
         self.invalidate_frozen()          # (a fresh allocation may re-use an address the library remembers)
-        return (self.mem.empty((nbytes // 4,)), nbytes)
+        t = self.mem.empty((nbytes // 4,))
+        try:
+            self._private.append((weakref.ref(t), nbytes))
+        except TypeError:                 # (a memory backend whose buffers take no weak references: not counted)
+            pass
+        return (t, nbytes)
 
     @staticmethod
     def _method_flag(upsample_method):
@@ -341,10 +353,12 @@ class Engine(object):
             self._perc_ws[key] = self._perc_ws.pop(key)
         return self._perc_ws[key]
 
-    def perceptual_inputs(self, N, H, W, cfg):
+    def perceptual_inputs(self, N, H, W, cfg, with_ws=False):
         """(y, content) views INSIDE the (cached) perceptual workspace of this shape, where fs_perceptual_loss stages its two inputs
         (fs_perceptual_ws_input): a caller that lets tnet_forward(out=y) write there and keeps its batch in `content` saves both
-        staging copies of a step.  content is None when cfg has no content layer.  The views die with the workspace (pin it)."""
+        staging copies of a step.  content is None when cfg has no content layer.  The views die with the workspace: a caller that keeps
+        one across calls (a hipGraph capturer) asks for the workspace tensor too (with_ws=True -> (y, content, ws)) and pins exactly that
+        tensor (pin_workspaces([ws]))."""
         c = self._cfg(cfg)
         ws, _ = self._perceptual_workspace(N, H, W, cfg, c)
         key = (N, H, W, tuple(cfg["content_layers"]), tuple(cfg["style_layers"]))
@@ -353,7 +367,8 @@ class Engine(object):
             L.check(self.lib, self.lib.fs_perceptual_ws_input(N, H, W, ctypes.byref(c), ctypes.byref(yo), ctypes.byref(co)), "fs_perceptual_ws_input")
             self._perc_io[key] = (yo.value, None if co.value == ctypes.c_size_t(-1).value else co.value)
         yo, co = self._perc_io[key]
-        return self.mem.view(ws, yo, (N, H, W, 3)), (None if co is None else self.mem.view(ws, co, (N, H, W, 3)))
+        out = (self.mem.view(ws, yo, (N, H, W, 3)), (None if co is None else self.mem.view(ws, co, (N, H, W, 3))))
+        return out + (ws,) if with_ws else out
 
     def perceptual_loss(self, y, content, target_grams, cfg):
         """loss = content + style + beta*tv (train.py:164-184) and dL/dy.

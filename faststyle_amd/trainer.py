@@ -44,6 +44,7 @@ class Trainer(object):
         self._graph_keepalive = []
         self._static_in = None
         self._static_losses = None
+        self.ar_events = None        # bench.py: a list -> step() appends an (event before, event after) pair around every all-reduce
 
     def _dist_on(self):
         d = self.dist
@@ -70,11 +71,16 @@ class Trainer(object):
         import torch
         self._release_graph()
         N, H, W, _ = (int(v) for v in batch.shape)
-        content_view = self.eng.perceptual_inputs(N, H, W, self.cfg)[1] if self.eng.tnet_out_shape(H, W) == (H, W) and hasattr(self.eng.mem, "view") else None
-        if content_view is not None:          # the step's input lives where the content half of the VGG batch is staged
+        content_view = perc_ws = None
+        if self.eng.tnet_out_shape(H, W) == (H, W) and hasattr(self.eng.mem, "view"):
+            _, content_view, perc_ws = self.eng.perceptual_inputs(N, H, W, self.cfg, with_ws=True)
+        if content_view is not None:          # the step's input lives where the content half of the VGG batch is staged:
+            self.eng.pin_workspaces([perc_ws], True)    # pin exactly the tensor self._static_in views, before anything can evict it
+            self._graph_keepalive = [perc_ws]
             self._static_in = content_view
             self._static_in.copy_(batch)
         else:
+            perc_ws = None
             self._static_in = batch.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -90,7 +96,7 @@ class Trainer(object):
         self.graph = g
         # the graph replays raw pointers into the two workspaces ITS forward/backward used (the most recently used entry of
         # each cache): keep exactly those alive and un-evictable for as long as the graph lives
-        self._graph_keepalive = self.eng.pin_last_used(tnet=True, perceptual=True)
+        self._graph_keepalive = self._graph_keepalive + self.eng.pin_last_used(tnet=True, perceptual=perc_ws is None)
 
     def _release_graph(self):
         self.eng.release_pins(self._graph_keepalive)
@@ -123,7 +129,14 @@ class Trainer(object):
         else:
             losses = self._forward_backward(batch)
         if self._dist_on():       # also at world_size 1 (torchrun --nproc-per-node 1): the RCCL path is then exercised as is
+            if self.ar_events is not None:
+                import torch
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             self.dist.all_reduce(self.grads, op=self.dist.ReduceOp.SUM)   # 1,696,408 B, once per step
+            if self.ar_events is not None:
+                ev[1].record()
+                self.ar_events.append(ev)
         self.global_step += 1
         e.adam_tf_step(self.params, self.grads, self.m, self.v, self.global_step, lr=self.lr)
         return losses

@@ -74,7 +74,11 @@ int fs_tnet_invalidate(fs_ctx* ctx);
 /* grads[FS_TNET_NPARAMS] = d loss / d params given dy = d loss / d y; `ws` must be the workspace a
  * fs_tnet_forward(..., FS_FLAG_SAVE_FOR_BWD) call on the same inputs just filled.  Replaces the
  * transform-net half of AdamOptimizer.minimize's gradient graph (train.py:203).  Error -5: this context filled `ws` with a forward of
- * another shape or another upsample method. */
+ * another shape or another upsample method.
+ * Contract: `params` must hold, bit for bit, the values that forward read -- the FS_FLAG_SAVE_FOR_BWD forward also builds the
+ * re-laid-out input-gradient filters, and the FIRST backward on (`ws`, `params`) uses them as they are (a second one rebuilds them).
+ * A caller that rewrites `params` in place between the two (a finite-difference probe, a delayed optimiser update) calls
+ * fs_tnet_invalidate first; a re-plan (another shape, fs_debug_reload_env) drops them by itself. */
 int fs_tnet_backward(fs_ctx* ctx, const float* params, const float* x, const float* dy, int N, int H, int W, float* grads,
                      void* ws, size_t ws_bytes, int flags);
 

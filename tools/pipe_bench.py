@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Throughput of the TFRecord input pipeline alone (decode threads + GPU resize + HBM shuffle queue) on
-synthetic COCO-like shards (640x480 JPEG quality 90).  usage: pipe_bench.py [n_images] [threads]"""
+synthetic COCO-like shards (640x480 JPEG quality 90).  usage: pipe_bench.py [n_images] [threads] [host]
+"host": the host half only -- record framing, Example parsing and the JPEG decode pool, decoded images dropped (no engine, no GPU): what a rank's
+cores sustain when eight pools run side by side on one box whose single GPU would otherwise be shared by all eight (tools/pipe_bench8.sh)."""
 import io
 import os
 import sys
@@ -35,6 +37,14 @@ def main():
                                                  "image/channels": 3}))
         files.append(p)
     print("shards: %d images, %.1f KB/jpeg" % (n, np.mean([len(j) for j in jpegs]) / 1e3))
+    if len(sys.argv) > 3 and sys.argv[3] == "host":
+        th = threads or 24
+        it = datapipe._prefetch_map(datapipe.decode_jpeg, datapipe._examples(files, 1, np.random.default_rng(0)), th, window=4 * th)
+        t0 = time.time()
+        k = sum(1 for _ in it)
+        dt = time.time() - t0
+        print("pipeline: %.0f images/s host half only (%d images decoded in %.2f s, %d decode threads, %d host cores)" % (k / dt, k, dt, th, os.cpu_count()))
+        return
     eng = engine.Engine()
     import torch
     it = datapipe.batcher(files, 4, (256, 256), num_epochs=1, min_after_dequeue=256, engine=eng, num_threads=threads)
