@@ -146,6 +146,7 @@ PROTOTYPES = {
     "fs_example_bytes": (c_int, [c_void_p, c_size_t, c_char_p, POINTER(c_uint64), POINTER(c_uint64)]),
     "fs_example_int64": (c_int, [c_void_p, c_size_t, c_char_p, POINTER(c_longlong)]),
     "fs_resize_bicubic_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int]),
+    "fs_resize_bicubic_u8x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int]),
     "fs_u8_to_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "fs_f32_to_u8": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
 }

@@ -104,6 +104,13 @@ int fs_resize_bicubic_u8(fs_ctx* ctx, const unsigned char* src, int H, int W, fl
     const int rc = fs::resize_bicubic_u8(src, H, W, dst, Ho, Wo, ctx->stream);
     return rc ? fail(rc, "fs_resize_bicubic_u8: launch failed (%d)", rc) : 0;
 }
+int fs_resize_bicubic_u8x(fs_ctx* ctx, const unsigned char* src, int H, int W, int pixel_bytes, float* dst, int Ho, int Wo) {
+    if (!ctx || !src || !dst) return fail(-1, "fs_resize_bicubic_u8x: null argument");
+    if (H < 1 || W < 1 || Ho < 1 || Wo < 1) return fail(-1, "fs_resize_bicubic_u8x: bad shape %dx%d -> %dx%d", H, W, Ho, Wo);
+    if (pixel_bytes != 3 && pixel_bytes != 4) return fail(-2, "fs_resize_bicubic_u8x: pixel_bytes must be 3 (RGB) or 4 (RGBX), got %d", pixel_bytes);
+    const int rc = fs::resize_bicubic_u8(src, H, W, dst, Ho, Wo, ctx->stream, pixel_bytes);
+    return rc ? fail(rc, "fs_resize_bicubic_u8x: launch failed (%d)", rc) : 0;
+}
 
 int fs_u8_to_f32(fs_ctx* ctx, const unsigned char* src, size_t n, float* dst) {
     if (!ctx || !src || !dst) return fail(-1, "fs_u8_to_f32: null argument");

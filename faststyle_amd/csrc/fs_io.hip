@@ -206,6 +206,9 @@ __device__ __forceinline__ float interp1d(const float w[4], float v0, float v1, 
     return acc + p3;
 }
 
+// PB = bytes per source pixel: 3 (packed RGB) or 4 (RGBX -- PIL's own storage of an RGB image, which the host hands over as it is: no repack
+// under the interpreter lock; the fourth byte is never read)
+template <int PB>
 __global__ __launch_bounds__(256) void resize_bicubic_u8_kernel(const unsigned char* __restrict__ src, int H, int W,
                                                                 float* __restrict__ dst, int Ho, int Wo, float hs, float ws) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -220,8 +223,8 @@ __global__ __launch_bounds__(256) void resize_bicubic_u8_kernel(const unsigned c
         float col[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const unsigned char* row = src + ((size_t)iy[r] * W) * 3 + c;
-            col[r] = interp1d(wx, (float)row[ix[0] * 3], (float)row[ix[1] * 3], (float)row[ix[2] * 3], (float)row[ix[3] * 3]);
+            const unsigned char* row = src + ((size_t)iy[r] * W) * PB + c;
+            col[r] = interp1d(wx, (float)row[ix[0] * PB], (float)row[ix[1] * PB], (float)row[ix[2] * PB], (float)row[ix[3] * PB]);
         }
         dst[(size_t)i * 3 + c] = interp1d(wy, col[0], col[1], col[2], col[3]);
     }
@@ -260,10 +263,12 @@ int f32_to_u8(const float* src, unsigned char* dst, size_t npix, int swap_rb, hi
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int resize_bicubic_u8(const unsigned char* src, int H, int W, float* dst, int Ho, int Wo, hipStream_t s) {
+int resize_bicubic_u8(const unsigned char* src, int H, int W, float* dst, int Ho, int Wo, hipStream_t s, int pixel_bytes) {
     // CalculateResizeScale(in, out, align_corners=false) = in / static_cast<float>(out)
     const float hs = (float)H / (float)Ho, ws = (float)W / (float)Wo;
-    hipLaunchKernelGGL(resize_bicubic_u8_kernel, dim3(cdiv(Ho * Wo, 256)), dim3(256), 0, s, src, H, W, dst, Ho, Wo, hs, ws);
+    if (pixel_bytes == 4) hipLaunchKernelGGL(resize_bicubic_u8_kernel<4>, dim3(cdiv(Ho * Wo, 256)), dim3(256), 0, s, src, H, W, dst, Ho, Wo, hs, ws);
+    else if (pixel_bytes == 3) hipLaunchKernelGGL(resize_bicubic_u8_kernel<3>, dim3(cdiv(Ho * Wo, 256)), dim3(256), 0, s, src, H, W, dst, Ho, Wo, hs, ws);
+    else return -1;
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -605,7 +605,7 @@ inline bool fused_finalize_ok(int N, int C, int T, int groups) {
 // thread-local message behind fs_last_error(); returns `code` (fs_api.hip)
 int set_error(int code, const char* fmt, ...);
 // tf.image.resize_images(method=2) of TF 1.0 on device u8 [H,W,3] -> f32 [Ho,Wo,3] (fs_io.hip)
-int resize_bicubic_u8(const unsigned char* src, int H, int W, float* dst, int Ho, int Wo, hipStream_t s);
+int resize_bicubic_u8(const unsigned char* src, int H, int W, float* dst, int Ho, int Wo, hipStream_t s, int pixel_bytes = 3);
 int u8_to_f32(const unsigned char* src, float* dst, size_t n, hipStream_t s);
 int f32_to_u8(const float* src, unsigned char* dst, size_t npix, int swap_rb, hipStream_t s);
 int in_bwd(const float* gin, const float* z, const float* mean, const float* rstd, const float* a, const float* b, int mode,

@@ -567,14 +567,19 @@ class Engine(object):
 
     def resize_bicubic_u8(self, img_u8, out):
         """tf.image.resize_images(img, out.shape[:2], method=2) of TF 1.0 (datapipe.py:24) on the device:
-        img_u8 host uint8 [H,W,3] -> ``out`` (device float32 [Ho,Wo,3], written in place)."""
+        img_u8 host uint8 [H,W,3] (packed RGB) or [H,W,4] (RGBX as a decoder stores it: datapipe.decode_jpeg; the fourth byte is ignored)
+        -> ``out`` (device float32 [Ho,Wo,3], written in place)."""
         self._sync_stream()
         H, W, C = (int(s) for s in img_u8.shape)
         Ho, Wo, Co = (int(s) for s in out.shape)
-        assert C == 3 and Co == 3
+        assert C in (3, 4) and Co == 3
         src = self.mem.upload_u8(img_u8)
-        L.check(self.lib, self.lib.fs_resize_bicubic_u8(self.ctx, self.mem.ptr_u8(src), H, W, self.mem.ptr(out), Ho, Wo),
-                "fs_resize_bicubic_u8")
+        if C == 3:
+            L.check(self.lib, self.lib.fs_resize_bicubic_u8(self.ctx, self.mem.ptr_u8(src), H, W, self.mem.ptr(out), Ho, Wo),
+                    "fs_resize_bicubic_u8")
+        else:
+            L.check(self.lib, self.lib.fs_resize_bicubic_u8x(self.ctx, self.mem.ptr_u8(src), H, W, 4, self.mem.ptr(out), Ho, Wo),
+                    "fs_resize_bicubic_u8x")
         return out
 
     def u8_to_f32(self, src_u8, dst):

@@ -50,6 +50,11 @@ int fs_example_int64(const void* ex, size_t n, const char* key, long long* value
  * result NOT clipped to [0,255] (tensorflow/core/kernels/resize_bicubic_op.cc @ r1.0).
  * src: device u8 [H,W,3]; dst: device f32 [Ho,Wo,3].  Asynchronous on the ctx stream. */
 int fs_resize_bicubic_u8(fs_ctx* ctx, const unsigned char* src, int H, int W, float* dst, int Ho, int Wo);
+/* The same with pixel_bytes bytes per source pixel: 3 = packed RGB (what fs_resize_bicubic_u8 takes), 4 = RGBX -- the storage a JPEG decoder
+ * such as PIL's keeps an RGB image in, handed over without a host-side repack (faststyle_amd/datapipe.py exports it zero-copy through the Arrow C
+ * data interface; the repack was the largest interpreter-locked piece of a decode thread's work).  The fourth byte is never read; the result is
+ * bit-identical to the packed form's.  Error -2: another pixel size. */
+int fs_resize_bicubic_u8x(fs_ctx* ctx, const unsigned char* src, int H, int W, int pixel_bytes, float* dst, int Ho, int Wo);
 
 /* Frame streaming (stylize_webcam.py:88-95): u8 frame -> float net input (channel order untouched), and
  * net output -> u8 by truncation (numpy .astype(np.uint8)) with an optional R<->B swap

@@ -25,3 +25,8 @@ def get_engine(kind):
         else:
             _cache[kind] = _hip_engine()
     return _cache[kind]
+
+
+def on_emulator(eng):
+    """The CPU fiber emulator (tests/emu): ~10^3 x slower than the GPU, so a few tests take their SMALLER shape there (same code paths)."""
+    return type(eng.mem).__name__ == "NumpyMem"

@@ -166,6 +166,8 @@ def test_single_op_entry_points_reject_bad_arguments(eng):
     # u8 <-> f32 helpers: alignment contract
     assert lib.fs_u8_to_f32(ctx, P(p + 1), 16, p) == -1 and "aligned" in err(e)
     assert lib.fs_resize_bicubic_u8(ctx, p, 0, 4, p, 4, 4) == -1
+    assert lib.fs_resize_bicubic_u8x(ctx, p, 4, 4, 2, p, 4, 4) == -2 and "pixel_bytes" in err(e)
+    assert lib.fs_resize_bicubic_u8x(ctx, p, 4, 0, 4, p, 4, 4) == -1
 
 
 def test_round6_named_exports_reject_bad_arguments(eng):

@@ -152,6 +152,35 @@ def test_resize_kernel_is_bit_exact_against_the_restatement(eng, shape, out):
     assert np.array_equal(got, want)
 
 
+def test_resize_kernel_reads_rgbx_pixels_as_the_decoder_stores_them(eng):
+    """fs_resize_bicubic_u8x(pixel_bytes=4): the decode threads hand over PIL's own RGBX storage (no repack under the interpreter lock); the fourth
+    byte is never read and the result is the packed form's, bit for bit -- hence the restatement's."""
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    rgbx = np.concatenate([img, rng.integers(0, 256, (37, 53, 1), dtype=np.uint8)], axis=2)     # garbage in the fourth byte
+    a, b = eng.mem.empty((24, 40, 3)), eng.mem.empty((24, 40, 3))
+    eng.resize_bicubic_u8(img, a)
+    eng.resize_bicubic_u8(rgbx, b)
+    assert np.array_equal(eng.mem.to_numpy(a), eng.mem.to_numpy(b))
+    assert np.array_equal(eng.mem.to_numpy(b), odp.resize_bicubic_tf1(img, 24, 40))
+
+
+def test_decode_jpeg_zero_copy_view_equals_the_packed_decode():
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    arr = (np.linspace(0, 255, 48)[None, :, None] * np.ones((31, 1, 3)) * rng.uniform(0.4, 1, (1, 1, 3))).astype(np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(arr).save(buf, "JPEG", quality=92)
+    packed = datapipe.decode_jpeg(buf.getvalue())
+    view = datapipe.decode_jpeg(buf.getvalue(), packed=False)
+    assert packed.shape == (31, 48, 3) and view.dtype == np.uint8 and view.shape[:2] == (31, 48)
+    assert view.shape[2] == (4 if datapipe._ARROW_OK else 3)
+    assert np.array_equal(view[:, :, :3], packed)
+    gray = io.BytesIO()
+    Image.fromarray(arr[:, :, 0]).save(gray, "JPEG", quality=92)                       # channels=3 of a grayscale file: converted, as tf.image.decode_jpeg does
+    assert np.array_equal(datapipe.decode_jpeg(gray.getvalue(), packed=False)[:, :, :3], datapipe.decode_jpeg(gray.getvalue()))
+
+
 # ------------------------------------------------------------------ batcher
 def make_shards(tmp_path, counts, seed=0):
     from PIL import Image

@@ -21,7 +21,7 @@ def test_random_shapes_under_address_and_undefined_behaviour_sanitizers():
     env = dict(os.environ, FS_EMU_SANITIZE="1", LD_PRELOAD=emu_lib.ASAN_RT,
                ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1:verify_asan_link_order=0",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_emu.py"), "18", "7"], cwd=ROOT, capture_output=True,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_emu.py"), "10", "7"], cwd=ROOT, capture_output=True,
                          text=True, timeout=2400, env=env)
-    assert out.returncode == 0 and "fuzz_emu: 18 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+    assert out.returncode == 0 and "fuzz_emu: 10 cases ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
     assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error:" not in out.stderr, out.stderr[-3000:]
