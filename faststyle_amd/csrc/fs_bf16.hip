@@ -875,6 +875,15 @@ __global__ __launch_bounds__(256) void apply_res_bf16_kernel(const unsigned shor
     const float4 b0 = *reinterpret_cast<const float4*>(b + k0), b1 = *reinterpret_cast<const float4*>(b + k0 + 4);
     const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
     const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    // the skip's own on-load affine (block 0: skip = IN + ReLU of the third conv's raw output), as two 16-byte loads per vector like a / b -- the sixteen
+    // 4-byte loads per thread it replaces made the first apply of a 1080p batch-8 forward 172 us against 72 us for the other four
+    float sav[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, sbv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (sa) {
+        const float4 s0 = *reinterpret_cast<const float4*>(sa + k0), s1 = *reinterpret_cast<const float4*>(sa + k0 + 4);
+        const float4 t0 = *reinterpret_cast<const float4*>(sb + k0), t1 = *reinterpret_cast<const float4*>(sb + k0 + 4);
+        sav[0] = s0.x, sav[1] = s0.y, sav[2] = s0.z, sav[3] = s0.w, sav[4] = s1.x, sav[5] = s1.y, sav[6] = s1.z, sav[7] = s1.w;
+        sbv[0] = t0.x, sbv[1] = t0.y, sbv[2] = t0.z, sbv[3] = t0.w, sbv[4] = t1.x, sbv[5] = t1.y, sbv[6] = t1.z, sbv[7] = t1.w;
+    }
     uint4 ov;
     unsigned* o32 = reinterpret_cast<unsigned*>(&ov);
 #pragma unroll
@@ -882,9 +891,8 @@ __global__ __launch_bounds__(256) void apply_res_bf16_kernel(const unsigned shor
         float r[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int c = k0 + 2 * k + h;
             float sk = bf2f((unsigned short)(h ? s32[k] >> 16 : s32[k] & 0xFFFFu));
-            if (sa) sk = fmaf(sk, sa[c], sb[c]);
+            if (sa) sk = fmaf(sk, sav[2 * k + h], sbv[2 * k + h]);
             if (skip_relu) sk = fmaxf(sk, 0.f);
             const float zz = bf2f((unsigned short)(h ? z32[k] >> 16 : z32[k] & 0xFFFFu));
             r[h] = fmaf(zz, av[2 * k + h], bv[2 * k + h]) + sk;

@@ -396,6 +396,24 @@ __device__ __forceinline__ f32x2 fs_pk_fma(f32x2 a, f32x2 b, f32x2 c) {   // a *
 #else
 #define FS_WAIT_VMEM() ((void)0)
 #endif
+// The same wait, pinned: the builtin alone is no barrier for the instruction scheduler (round 6, fs_wino6.hip: it sank a prologue's loads BELOW the
+// wait), and an inline-assembly s_waitcnt is invisible to the wait-count insertion pass, which then keeps its pending set.  The builtin between two
+// empty assembly statements with a memory clobber is both: no load or store crosses it, and the pass clears its pending vector-memory set there.
+// Use: at a point of a loop body that EVERY iteration passes after its last staged load has been consumed (the end of the body).  Loads issued and
+// waited for inside conditional blocks (`if (more) issue(..)`, per-element `if (i >= n) break`) otherwise stay "possibly pending" at the loop header,
+// and the pass protects the first re-use of one of their destination registers -- often an address computation in the NEXT tile's issue phase --
+// with s_waitcnt vmcnt(0..1): the tile loads just issued are drained before the matrix instructions they were meant to travel beside
+// (fs_wgrad2.hip before this macro: the whole global -> register latency of a tile exposed in front of every sweep).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FS_WAIT_VMEM_FENCED()            \
+    do {                                 \
+        asm volatile("" ::: "memory");   \
+        FS_WAIT_VMEM();                  \
+        asm volatile("" ::: "memory");   \
+    } while (0)
+#else
+#define FS_WAIT_VMEM_FENCED() ((void)0)
+#endif
 
 // The tail of a persistent kernel with ConvArgs::fin set, called by EVERY thread of EVERY workgroup after its last
 // statistics record is written.  `scratch`: >= 2 KB of LDS nobody else uses any more.  One workgroup -- the last to arrive at

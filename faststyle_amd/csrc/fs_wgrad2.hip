@@ -450,6 +450,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wg2Args a) {
         if (more && !(a.debug & 2 && t >= t_beg)) issue(t + 1);
         if (t >= t_beg && active && nsteps > 0 && !(a.debug & 1)) sweep(cur);
         if (more && !(a.debug & 2 && t >= t_beg)) commit(nxt);
+        FS_WAIT_VMEM_FENCED();   // (free: commit consumed every load of this iteration -- tells the wait-count pass so; fs_kernels.h)
         __syncthreads();
     }
 

@@ -114,14 +114,20 @@ __global__ __launch_bounds__(256) void wgw_kernel(WgwArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool ok = valid && y0 + i < H && x0 + j < W;
-                xv[4 * i + j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? xb : kOOB, (unsigned)((i * W + j) * kC * 4), 0));
+                // (the offset is made opaque: the compiler otherwise turns some of these selects into branches with ONE LOAD PER ARM into the same
+                // registers, and the wait-count pass guards the second arm with s_waitcnt vmcnt(0) -- the loads just issued drained inside the issue phase)
+                unsigned vo = ok ? xb : kOOB;
+                FS_OPAQUE(vo);
+                xv[4 * i + j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, vo, (unsigned)((i * W + j) * kC * 4), 0));
             }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const bool ok = valid && y0 + i < Ho && x0 + j < Wo;
-                dv[2 * i + j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(dr, ok ? db : kOOB, (unsigned)((i * Wo + j) * kC * 4), 0));
+                unsigned vo = ok ? db : kOOB;
+                FS_OPAQUE(vo);
+                dv[2 * i + j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(dr, vo, (unsigned)((i * Wo + j) * kC * 4), 0));
             }
         if (has_ab) {   // the producer's instance norm (+ ReLU) of this sample's channels, applied in `commit`
             av = *reinterpret_cast<const float4*>(P.in_a + (size_t)n * ka->in_nstride + 4 * cq);
@@ -210,6 +216,7 @@ __global__ __launch_bounds__(256) void wgw_kernel(WgwArgs a) {
     if (g_beg < g_end) {
         issue(g_beg);
         commit();
+        FS_WAIT_VMEM_FENCED();
         __syncthreads();
         for (int g = g_beg; g < g_end; ++g) {
             const bool more = g + 1 < g_end;
@@ -217,6 +224,9 @@ __global__ __launch_bounds__(256) void wgw_kernel(WgwArgs a) {
             sweep();
             __syncthreads();
             if (more) commit();
+            // (free: commit consumed every load of this step.  Without it the loads of the conditional `issue` stay "possibly pending" at the loop
+            // header and the next issue phase drains its own first loads -- s_waitcnt vmcnt(0) twice among its 22 loads -- before the sweep; fs_kernels.h)
+            FS_WAIT_VMEM_FENCED();
             __syncthreads();
         }
     }

@@ -382,6 +382,10 @@ __global__ __launch_bounds__(64 * NW) void wino6_gemm_kernel(W6Args a) {
             __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);   // vector-ALU instructions of the split
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // an LDS write
         }
+        // nothing crosses the half's end: the groups above ask for more vector-ALU instructions than a half holds, and with both stages in one basic
+        // block the scheduler otherwise fills them with the NEXT stage's split arithmetic -- which reads the other register set and drags its
+        // s_waitcnt vmcnt up here (the loads issued half a stage ago)
+        __builtin_amdgcn_sched_barrier(0);
 #endif
         if (!(FS_W6_ABL & 8)) __syncthreads();
         mfma_half(F1);
@@ -395,6 +399,7 @@ __global__ __launch_bounds__(64 * NW) void wino6_gemm_kernel(W6Args a) {
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a global load
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #endif
     };
 
@@ -405,10 +410,23 @@ __global__ __launch_bounds__(64 * NW) void wino6_gemm_kernel(W6Args a) {
     load_regs(R1, 2);
     __syncthreads();
     read_frag(F0, 0, 0);
-    for (int kb = 0; kb < KB; kb += 2) {
-        stage(0, R0, kb + 3);                     // stage kb: buffer 0; R0 holds stage kb + 1
-        if (kb + 1 < KB) stage(1, R1, kb + 4);    // stage kb + 1: buffer 1; R1 holds stage kb + 2
+    // The prologue's loads have landed before the loop: the loop header's only pending set is then the back edge's, where set R0 is older than set R1
+    // and stage 0 can wait for R0 alone.  The wait is the BUILTIN (the wait-count insertion pass reads it and clears its pending set; it cannot read an
+    // inline-assembly s_waitcnt) between two empty assembly statements with a memory clobber (the scheduler otherwise sinks the prologue's loads BELOW the
+    // builtin and interleaves the two sets -- after which every iteration's stage 0 ended its first half with s_waitcnt vmcnt(1)).
+    FS_WAIT_VMEM_FENCED();
+    // The loop body is two UNCONDITIONAL stages (an odd last stage runs after the loop) on purpose: with `if (kb + 1 < KB) stage(1, ...)` inside, the loop
+    // header had a predecessor on which stage 0's own global loads were the youngest outstanding ones (the path that skips stage 1 -- never taken before the
+    // exit, but the wait-count insertion merges it), so every iteration's stage 0 began with s_waitcnt vmcnt(6) and ended its first half with vmcnt(0): the
+    // loads issued half a stage earlier (set R1) had to land inside half a stage of matrix instructions.  With one back edge and a drained preheader the
+    // waits are exact -- vmcnt(17) ... vmcnt(10): each set is waited for a stage and a half after its issue, with the other set's ten loads still in
+    // flight (conv4_2 at batch 32: 409 -> 355 us, same lease; profiles/r06_ab_wino6_exact_waits.txt).
+    const int KB2 = KB & ~1;
+    for (int kb = 0; kb < KB2; kb += 2) {
+        stage(0, R0, kb + 3);   // stage kb: buffer 0; R0 holds stage kb + 1
+        stage(1, R1, kb + 4);   // stage kb + 1: buffer 1; R1 holds stage kb + 2
     }
+    if (KB & 1) stage(0, R0, KB + 2);   // (stage KB - 1: buffer 0; its staging half writes a stage nobody reads)
     // M[pos][tile][cout]: register r of block (i, j) = tile 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), channel 32 WNB wn + 32 j + (lane & 31)
     float* mp = a.M + ((size_t)pos * a.Tpad + (size_t)mb * 128 + 64 * wm + 4 * (lane >> 5)) * a.Cout + (size_t)nb * 128 + 32 * WNB * wn + (lane & 31);
 #pragma unroll
