@@ -404,6 +404,16 @@ __device__ __forceinline__ f32x2 fs_pk_fma(f32x2 a, f32x2 b, f32x2 c) {   // a *
 // and the pass protects the first re-use of one of their destination registers -- often an address computation in the NEXT tile's issue phase --
 // with s_waitcnt vmcnt(0..1): the tile loads just issued are drained before the matrix instructions they were meant to travel beside
 // (fs_wgrad2.hip before this macro: the whole global -> register latency of a tile exposed in front of every sweep).
+// A narrower tool for the same disease where a full drain would also wait for stores in flight (a persistent kernel whose epilogue stores are meant to
+// drain during the next sweep): an unconditional READ of a register that a conditional block loads (`if (has_ab) va = load(..)`) and another
+// conditional block consumes.  The pass puts the exact wait for that load in front of the read and knows the register clean from there on; without it
+// the register is "possibly pending" at the loop header and the next issue phase's address arithmetic -- the allocator likes to build the next address
+// in the load's own destination -- is guarded with vmcnt(0..1).  Place it where the consumer's waits are (after the commit).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FS_TOUCH_F4(v) asm volatile("" ::"v"((v).x), "v"((v).y), "v"((v).z), "v"((v).w))
+#else
+#define FS_TOUCH_F4(v) ((void)0)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FS_WAIT_VMEM_FENCED()            \
     do {                                 \

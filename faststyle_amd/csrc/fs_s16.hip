@@ -344,6 +344,8 @@ __global__ __launch_bounds__(256, 2) void conv_s16_kernel(ConvArgs a) {
     Item cur = decode(0), prev = cur;
     issue(cur);
     commit();
+    FS_TOUCH_F4(va);   // (... and on the path into the loop)
+    FS_TOUCH_F4(vb);
     __syncthreads();
     for (int it = 0; it < my_items; ++it) {
         const bool more = it + 1 < my_items;
@@ -356,6 +358,8 @@ __global__ __launch_bounds__(256, 2) void conv_s16_kernel(ConvArgs a) {
         sweep();
         FS_LDS_BARRIER();   // A: every wave is done reading the patch
         if (more) commit();
+        FS_TOUCH_F4(va);   // (the conditional affine loads of `issue` are known complete at the loop header: fs_kernels.h -- the next issue phase waited
+        FS_TOUCH_F4(vb);   //  vmcnt(0) for its own patch loads AND the previous tile's stores before the sweep)
         epilogue(cur, red + (it & 1) * REDF);
         FS_LDS_BARRIER();   // B: next patch and this tile's statistics records (LDS) visible; the stores drain during the next sweep
         prev = cur;
