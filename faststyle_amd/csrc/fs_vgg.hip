@@ -253,7 +253,12 @@ static void w6_pipe_args(ConvArgs* a, const StreamAux* aux) {
         a->w6_ev = aux->ev;
     }
 }
-static bool w6_chain_launch_ok(const ConvArgs& a) { return a.p.variant == 12 && !(a.N & 1) && !a.y_keep_n && a.w6_ws_floats >= 2 * wino6_ws_floats(a.N / 2, a.Ho, a.Wo, a.Cin, a.Cout); }
+// (a half of at least FS_WINO6_CHAIN_MINTILES tiles, default 1024 = conv4_x at batch 32, where the chains were measured; below it -- batch 4 per GPU: 256 tiles
+// per launch -- ONE chain: 3.283 -> 3.239 ms per batch-4 step against the fp32 kernel's split-K launches, profiles/r06_ab_wino6_exact_waits.txt)
+static bool w6_chain_launch_ok(const ConvArgs& a) {
+    return a.p.variant == 12 && !(a.N & 1) && !a.y_keep_n && (long)(a.N / 2) * cdiv(a.Ho, 4) * cdiv(a.Wo, 4) >= (long)tune_int("FS_WINO6_CHAIN_MINTILES", 1024) &&
+           a.w6_ws_floats >= 2 * wino6_ws_floats(a.N / 2, a.Ho, a.Wo, a.Cin, a.Cout);
+}
 struct W6Chains {   // fork / join bookkeeping of one run
     const StreamAux* aux;
     hipStream_t s;

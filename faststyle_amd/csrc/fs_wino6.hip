@@ -459,7 +459,7 @@ bool wino6_eligible(const ConvArgs& a) {
     const long T = (long)a.N * cdiv(a.Ho, 4) * cdiv(a.Wo, 4);
     return a.KH == 3 && a.KW == 3 && a.stride == 1 && pad_ok && a.src_mode == SRC_PLAIN && a.Cin % kW6K == 0 && a.Cout % kW6TN == 0 && !a.shuffle && wino6_epi(a) >= 0 &&
            !a.route_src && a.w_nstride == 0 && a.dil_x <= 1 && !a.fin.counter && a.Ho > 0 && a.Wo > 0 && (!a.pool_out || (!(a.Ho & 1) && !(a.Wo & 1))) &&
-           (long)a.Cin * a.Cout >= (long)tune_int("FS_WINO6_MINCC", 512 * 256) && T >= tune_int("FS_WINO6_MINTILES", 1024) && T < (1L << 24) && 36.0 * (double)((T + 127) & ~127L) * (a.Cin > a.Cout ? a.Cin : a.Cout) * 4.0 < 4294967296.0 &&
+           (long)a.Cin * a.Cout >= (long)tune_int("FS_WINO6_MINCC", 512 * 256) && T >= tune_int("FS_WINO6_MINTILES", 256) && T < (1L << 24) && 36.0 * (double)((T + 127) & ~127L) * (a.Cin > a.Cout ? a.Cin : a.Cout) * 4.0 < 4294967296.0 &&
            a.w6_ws_floats >= (size_t)36 * 128 * ((size_t)a.Cin + a.Cout);
 }
 
