@@ -22,6 +22,9 @@ namespace {
 constexpr unsigned kOOB = 0x80000000u;
 constexpr int kTW = 16;     // output tile width; TH (8 or 16) rows: TH/2 32-pixel blocks
 }  // namespace
+#ifndef FS_CS_ABL
+#define FS_CS_ABL 0   /* timing experiments (results wrong): 1 no sweep, 2 no commit, 4 no epilogue stores, 8 no patch loads, 16 no statistics */
+#endif
 
 // TH x 16 output pixels per tile; the four waves tile it as (4/WN waves over the 32-pixel blocks) x (WN waves over the channel
 // blocks), a wave owns WM = (TH/2)/(4/WN) pixel blocks x NB channel blocks (Cout = WN*NB*32); CIN input channels; KS x KS taps;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     }
     auto epilogue = [&](const Item& I, float* rbuf) __attribute__((always_inline)) {
         const int th_valid = min(TH, a.Ho - I.ty0), tw_valid = min(kTW, a.Wo - I.tx0);
-        if (a.stats) {
+        if (a.stats && !(FS_CS_ABL & 16)) {
             // per-WAVE partial sums of (x - c), (x - c)^2 over the wave's 2*WM tile rows, c = the wave's own first pixel of the
             // channel; the records of the WMW waves that share a channel are merged when the next pipeline step starts
             // (finalize below): no barrier here
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
                     const int row_off = (I.ty0 + pyl) * rowb;
                     float v = acc[m][nn][r];
                     if (a.add_src) v += ad[m][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, ok ? (unsigned)(lane_off + row_off + pxc * colb) : kOOB, 0, 0);
+                    if (!(FS_CS_ABL & 4) || v == 12345.678f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yr, ok ? (unsigned)(lane_off + row_off + pxc * colb) : kOOB, 0, 0);
                 }
         }
         zero_acc();
@@ -355,11 +358,11 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
         Item nxt = cur;
         if (more) {
             nxt = decode(it + 1);
-            issue(nxt);
+            if (!(FS_CS_ABL & 8)) issue(nxt);
         }
-        sweep();
+        if (!(FS_CS_ABL & 1)) sweep();
         FS_LDS_BARRIER();   // A: every wave is done reading the patch
-        if (more) commit();
+        if (more && !(FS_CS_ABL & 2)) commit();
         epilogue(cur, red + (it & 1) * REDF);
         FS_LDS_BARRIER();   // B: next patch and this tile's statistics records (LDS) visible.  LDS-only on purpose: __syncthreads()
                             // waits for vmcnt(0), i.e. for every store of the epilogue to be acknowledged, before the next sweep

@@ -368,7 +368,320 @@ __global__ __launch_bounds__(256, 2) void conv_s16_kernel(ConvArgs a) {
     if (NB == 1 && a.stats && tid < 16) finalize(prev, red + ((my_items - 1) & 1) * REDF);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the kw-folded output layer (16 -> 16 virtual channels, 9 x 2 taps, spacing 5) with its products on the bf16 matrix cores as SIX EXACT
+// products of bf16 pieces (the arithmetic of fs_wino6.hip: x = h + m + l exactly, three bf16 pieces by truncation; hh, hm, mh, hl, lh, mm issued, the
+// three terms below 2^-24 of the leading one dropped; fp32 accumulation, the five small products in an accumulator of their own).
+// v_mfma_f32_16x16x32_bf16 multiplies 16 pixels x 16 channels x 32 k in 16 cycles where eight v_mfma_f32_16x16x4_f32 take 256: six products cost 96.
+// And unlike the fp32 matrix instruction (which shares the fp32 lanes with the vector ALU) it runs beside the other resident workgroup's commit /
+// epilogue arithmetic.  What it costs: the commit splits every staged value (4 + 1.5 vector instructions per element on top of the affine + ReLU),
+// the patch holds three bf16 pieces (6 bytes per element instead of 4) and the filter three pieces in registers (108 instead of 72).
+//   * one k-step = the two taps of a kernel row x 16 channels: lane (pixel m16, k group kg) reads channels 8 (kg & 1) .. + 7 of tap kw = kg >> 1 -- the
+//     tap's column offset is part of the lane's base address, every operand read is lane base + immediate, one ds_read_b128 per piece;
+//   * LDS patch [half = channel / 8][pixel][piece][8 channels] bf16: 48 bytes per pixel and half (an odd number of 16-byte slots: the 16 pixels of a
+//     fragment fall on 16 distinct slots), the second half a multiple of 256 bytes behind the first (the two halves of a ds_read_b128 lane group hit
+//     the same slots a whole bank row apart: conflict-free);
+//   * the pipeline, the statistics records and the stores are conv_s16_kernel's.
+typedef __bf16 s16_bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef FS_S16X_ABL
+#define FS_S16X_ABL 0   /* timing experiments (results wrong): 1 no sweep, 2 no split (h only), 4 no stores */
+#endif
+__host__ __device__ __forceinline__ void s16x_split(float x, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    h = u & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, h);
+    m = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, m);
+    l = __builtin_bit_cast(unsigned, r2);   // (<= 8 significant bits: its low half is zero)
+}
+template <int KH, int DILX>
+__global__ __launch_bounds__(256, 2) void conv_s16x_kernel(ConvArgs a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    char* const lds = reinterpret_cast<char*>(smem);
+    const ConvPlan& p = a.p;
+    constexpr int CIN = 16, COUT = 16, KW = 2;
+    constexpr int PH = kT - 1 + KH, PW = kT - 1 + (KW - 1) * DILX + 1, NPX = PH * PW;
+    constexpr int PXB = 48;                                               // bytes per pixel and half: [piece 3][8 channels bf16]
+    constexpr int HPB = ((NPX + 1) * PXB + 255) & ~255;                   // half plane (+ one pixel: the sink of unowned elements), a multiple of 256 bytes
+    constexpr int KSTEPS = KH;                                            // one kernel row = two taps x 16 channels = 32 k
+    constexpr int NE = NPX * 4, SX = (NE + 255) / 256;
+    constexpr int REDF = 4 * 3 * 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m16 = lane & 15, kg = lane >> 4;
+    float* const red = reinterpret_cast<float*>(lds + 2 * HPB);   // [2][REDF]
+    auto fdiv = [](int x, float inv_d) __attribute__((always_inline)) { return (int)(((float)x + 0.5f) * inv_d); };
+    auto uniform_ptr = [](const float* ptr) __attribute__((always_inline)) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    };
+
+    // ---- the filter, once, into registers as three pieces: lane (channel m16, kg) holds k = 8 kg .. + 7 of k-step j = (tap 2 j + (kg >> 1), ci 8 (kg & 1) ..)
+    s16_bf16x8 breg[KSTEPS][3];
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j) {
+        unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s16x_split(a.w[((2 * j + (kg >> 1)) * CIN + 8 * (kg & 1) + e) * COUT + m16], hh[e], mm[e], ll[e]);
+        const uint4 H = make_uint4((hh[0] >> 16) | hh[1], (hh[2] >> 16) | hh[3], (hh[4] >> 16) | hh[5], (hh[6] >> 16) | hh[7]);
+        const uint4 M = make_uint4((mm[0] >> 16) | mm[1], (mm[2] >> 16) | mm[3], (mm[4] >> 16) | mm[5], (mm[6] >> 16) | mm[7]);
+        const uint4 L = make_uint4((ll[0] >> 16) | (ll[1] & 0xffff0000u), (ll[2] >> 16) | (ll[3] & 0xffff0000u), (ll[4] >> 16) | (ll[5] & 0xffff0000u), (ll[6] >> 16) | (ll[7] & 0xffff0000u));
+        breg[j][0] = __builtin_bit_cast(s16_bf16x8, H);
+        breg[j][1] = __builtin_bit_cast(s16_bf16x8, M);
+        breg[j][2] = __builtin_bit_cast(s16_bf16x8, L);
+    }
+    // ---- A operands: block m of this wave is tile row 4 wave + m; lane (m16, kg) feeds pixel column m16 with tap column kg >> 1, channel half kg & 1
+    const int laneA = (kg & 1) * HPB + ((4 * wave) * PW + m16 + (kg >> 1) * DILX) * PXB;
+    auto aoff = [](int j, int m, int pc) __attribute__((always_inline)) { return (j + m) * PW * PXB + pc * 16; };   // compile-time byte offset
+
+    // ---- staging descriptors (tile-invariant): element e = tid + i*256 is float4 c4 of patch pixel e / 4
+    const int c4 = tid & 3;
+    int pq[SX], pdst[SX];
+    unsigned poffb[SX];
+#pragma unroll
+    for (int i = 0; i < SX; ++i) {
+        const int e = tid + i * 256;
+        pq[i] = -1;
+        pdst[i] = NPX * PXB;   // the sink pixel
+        poffb[i] = kOOB;
+        if (e < NE) {
+            const int pix = e >> 2;
+            const int py = fdiv(pix, 1.0f / (float)PW), px = pix - py * PW;
+            pq[i] = (py << 8) | px;
+            pdst[i] = (c4 >> 1) * HPB + pix * PXB + (c4 & 1) * 8;
+            poffb[i] = (unsigned)((py * a.W + px) * CIN + c4 * 4) * 4u;
+        }
+    }
+    const unsigned x_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * CIN) * 4u);
+    const bool has_ab = a.in_a != nullptr;
+    const bool in_relu = a.in_relu != 0;
+
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int total = a.N * tiles;
+    const int GX = (int)gridDim.x;
+    const int my_items = ((int)blockIdx.x < total) ? (total - 1 - (int)blockIdx.x) / GX + 1 : 0;
+    const float inv_tiles = 1.0f / (float)tiles, inv_tx = 1.0f / (float)p.tiles_x;
+    struct Item {
+        int n, ty0, tx0, lin;
+    };
+    auto decode = [&](int it) __attribute__((always_inline)) {
+        Item r;
+        r.lin = (int)blockIdx.x + it * GX;
+        r.n = fdiv(r.lin, inv_tiles);
+        const int tr = r.lin - r.n * tiles;
+        const int tyi = fdiv(tr, inv_tx);
+        r.ty0 = tyi * kT;
+        r.tx0 = (tr - tyi * p.tiles_x) * kT;
+        r.lin = __builtin_amdgcn_readfirstlane(r.lin);
+        r.n = __builtin_amdgcn_readfirstlane(r.n);
+        r.ty0 = __builtin_amdgcn_readfirstlane(r.ty0);
+        r.tx0 = __builtin_amdgcn_readfirstlane(r.tx0);
+        return r;
+    };
+    float4 pv[SX];
+    unsigned pok = 0;   // bit i: element i came from inside the image; bit 31: the whole patch did (interior tile)
+    float4 va = make_float4(1.f, 1.f, 1.f, 1.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto issue = [&](const Item& I) __attribute__((always_inline)) {
+        const int vy0 = I.ty0 - a.pad_t, vx0 = I.tx0 - a.pad_l;
+        const float* xn = uniform_ptr(a.x + (size_t)I.n * a.H * a.W * CIN);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, x_bytes, 0x00020000);
+        if (vy0 >= 0 && vx0 >= 0 && vy0 + PH <= a.H && vx0 + PW <= a.W) {
+            pok = 0xFFFFFFFFu;
+            const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)((vy0 * a.W + vx0) * CIN) * 4u);
+#pragma unroll
+            for (int i = 0; i < SX; ++i) pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, poffb[i], base, 0));
+        } else {
+            pok = 0;
+#pragma unroll
+            for (int i = 0; i < SX; ++i) {
+                const int sy = vy0 + (pq[i] >> 8), sx = vx0 + (pq[i] & 255);
+                const bool ok = pq[i] >= 0 && (unsigned)sy < (unsigned)a.H && (unsigned)sx < (unsigned)a.W;
+                pok |= ok ? (1u << i) : 0u;
+                pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((sy * a.W + sx) * CIN + c4 * 4) * 4u : kOOB, 0, 0));
+            }
+        }
+        if (has_ab) {
+            va = *reinterpret_cast<const float4*>(a.in_a + (size_t)I.n * a.in_nstride + c4 * 4);
+            vb = *reinterpret_cast<const float4*>(a.in_b + (size_t)I.n * a.in_nstride + c4 * 4);
+        }
+    };
+    auto relu1 = [](float x) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        float r;
+        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+        return r;
+#else
+        return x > 0.f ? x : 0.f;
+#endif
+    };
+    auto commit_as = [&](auto MASKED) __attribute__((always_inline)) {
+        constexpr bool masked = decltype(MASKED)::value;
+#pragma unroll
+        for (int i = 0; i < SX; ++i) {
+            float v[4] = {pv[i].x, pv[i].y, pv[i].z, pv[i].w};
+            if (has_ab) {   // producer instance norm folded into the load; padding arrives as 0 and must stay 0
+                const unsigned okm = (!masked || ((pok >> i) & 1u)) ? 0xFFFFFFFFu : 0u;
+                v[0] = fmaf(v[0], va.x, __uint_as_float(__float_as_uint(vb.x) & okm));
+                v[1] = fmaf(v[1], va.y, __uint_as_float(__float_as_uint(vb.y) & okm));
+                v[2] = fmaf(v[2], va.z, __uint_as_float(__float_as_uint(vb.z) & okm));
+                v[3] = fmaf(v[3], va.w, __uint_as_float(__float_as_uint(vb.w) & okm));
+            }
+            if (in_relu) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = relu1(v[c]);
+            }
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (FS_S16X_ABL & 2) {
+                    h[c] = __float_as_uint(v[c]) & 0xffff0000u;
+                    m[c] = l[c] = 0u;
+                } else {
+                    s16x_split(v[c], h[c], m[c], l[c]);
+                }
+            }
+            char* d = lds + pdst[i];
+            *reinterpret_cast<uint2*>(d) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
+            *reinterpret_cast<uint2*>(d + 16) = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
+            *reinterpret_cast<uint2*>(d + 32) = make_uint2((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u));
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+        if (pok >> 31)
+            commit_as(std::false_type{});
+        else
+            commit_as(std::true_type{});
+    };
+
+    f32x4 acc[4], acs[4];   // the leading product / the five small ones
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = acs[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+    // one straight line: the six matrix instructions of (j, m) with the three operand reads of the next (j, m) in front of them
+    auto sweep = [&]() __attribute__((always_inline)) {
+        s16_bf16x8 av[2][3];
+        auto rd = [&](int u, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) av[buf][pc] = __builtin_bit_cast(s16_bf16x8, *reinterpret_cast<const uint4*>(lds + laneA + aoff(u >> 2, u & 3, pc)));
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int u = 0; u < KSTEPS * 4; ++u) {
+            const int j = u >> 2, m = u & 3, b = u & 1;
+            if (u + 1 < KSTEPS * 4) rd(u + 1, b ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // smallest first: h l, l h, m m, h m, m h into the small accumulator, h h into the leading one
+            acs[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[b][0], breg[j][2], acs[m], 0, 0, 0);
+            acs[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[b][2], breg[j][0], acs[m], 0, 0, 0);
+            acs[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[b][1], breg[j][1], acs[m], 0, 0, 0);
+            acs[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[b][0], breg[j][1], acs[m], 0, 0, 0);
+            acs[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[b][1], breg[j][0], acs[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[b][0], breg[j][0], acc[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] += acs[m];
+    };
+
+    // ---- epilogue of one item: accumulator register r of block m, lane (m16, kg) = pixel (row 4 wave + m, column 4 kg + r), channel m16
+    const unsigned y_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.Ho * a.Wo * COUT) * 4u);
+    auto epilogue = [&](const Item& I, float* rbuf) __attribute__((always_inline)) {
+        const int th_valid = min(kT, a.Ho - I.ty0), tw_valid = min(kT, a.Wo - I.tx0);
+        if (a.stats) {
+            const float cs = __shfl(acc[0][0], m16);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = 4 * wave + m < th_valid && 4 * kg + r < tw_valid;
+                    const float d = ok ? acc[m][r] - cs : 0.f;
+                    s1 += d;
+                    s2 = fmaf(d, d, s2);
+                }
+            s1 += __shfl_xor(s1, 16);
+            s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lane < 16) {
+                rbuf[(wave * 3 + 0) * 16 + lane] = s1;
+                rbuf[(wave * 3 + 1) * 16 + lane] = s2;
+                rbuf[(wave * 3 + 2) * 16 + lane] = cs;
+            }
+        }
+        float* yn = a.y + (size_t)I.n * a.Ho * a.Wo * COUT;
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(yn)), 0, y_bytes, 0x00020000);
+        const int lane_off = ((I.tx0 + 4 * kg) * COUT + m16) * 4;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = 4 * wave + m;
+            const int row_off = (I.ty0 + row) * a.Wo * COUT * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = row < th_valid && 4 * kg + r < tw_valid;
+                if (!(FS_S16X_ABL & 4) || acc[m][r] == 12345.678f)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][r]), yr, ok ? (unsigned)(lane_off + row_off + r * COUT * 4) : kOOB, 0, 0);
+            }
+        }
+        zero_acc();
+    };
+    auto finalize = [&](const Item& I, const float* rbuf) __attribute__((always_inline)) {
+        const int th_valid = min(kT, a.Ho - I.ty0), tw_valid = min(kT, a.Wo - I.tx0);
+        float cnt = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int rows = min(4, max(0, th_valid - 4 * w));
+            const float cb = (float)(rows * tw_valid);
+            if (cb > 0.f) {
+                const float S1 = rbuf[(w * 3 + 0) * 16 + tid], S2 = rbuf[(w * 3 + 1) * 16 + tid], sh = rbuf[(w * 3 + 2) * 16 + tid];
+                const float mb = sh + S1 / cb, qb2 = fmaxf(S2 - S1 * S1 / cb, 0.f);
+                const float nn_ = cnt + cb, d = mb - mean, rr = cb / nn_;
+                mean += d * rr;
+                m2 += qb2 + d * d * cnt * rr;
+                cnt = nn_;
+            }
+        }
+        float* st = a.stats + ((size_t)I.lin * 16 + tid) * 3;
+        st[0] = mean;
+        st[1] = m2;
+        st[2] = cnt;
+    };
+
+    if (my_items == 0) return;
+    Item cur = decode(0), prev = cur;
+    issue(cur);
+    commit();
+    FS_TOUCH_F4(va);
+    FS_TOUCH_F4(vb);
+    __syncthreads();
+    for (int it = 0; it < my_items; ++it) {
+        const bool more = it + 1 < my_items;
+        if (it > 0 && a.stats && tid < 16) finalize(prev, red + ((it - 1) & 1) * REDF);
+        Item nxt = cur;
+        if (more) {
+            nxt = decode(it + 1);
+            issue(nxt);
+        }
+        if (!(FS_S16X_ABL & 1)) sweep();
+        FS_LDS_BARRIER();   // A: every wave is done reading the patch
+        if (more) commit();
+        FS_TOUCH_F4(va);
+        FS_TOUCH_F4(vb);
+        epilogue(cur, red + (it & 1) * REDF);
+        FS_LDS_BARRIER();   // B: next patch and this tile's statistics records (LDS) visible; the stores drain during the next sweep
+        prev = cur;
+        cur = nxt;
+    }
+    if (a.stats && tid < 16) finalize(prev, red + ((my_items - 1) & 1) * REDF);
+}
+
 // ------------------------------------------------------------------------------------------------------------ host
+// FS_S16_SPLIT (default 1): the folded output layer on the bf16 matrix cores as six exact bf16-piece products (conv_s16x_kernel); 0: fp32 matrix instructions
+static bool s16_split_on() { return tune_int("FS_S16_SPLIT", 1) != 0; }
 static int s16_instance(const ConvArgs& a) {
     if (a.stride != 1) return 0;
     if (a.Cout == 64) {   // VGG16 conv1_1: 3 -> 64, 3x3 (mean on load, bias + ReLU)
@@ -406,6 +719,10 @@ void s16_plan(const ConvArgs& a, ConvPlan* out) {
     p.S = inst == 2 ? 17 : 3;
     const int patch_f = (p.PH * p.PW * p.S + 8 + 3) & ~3;
     p.lds_bytes = 4 * (patch_f + 2 * 4 * 3 * 16);
+    if (inst == 2 && s16_split_on()) {   // conv_s16x_kernel: two half planes of (pixels + 1) x 48 bytes, each rounded up to 256 bytes
+        p.S = 48;
+        p.lds_bytes = 2 * (((p.PH * p.PW + 1) * 48 + 255) & ~255) + 4 * (2 * 4 * 3 * 16);
+    }
     p.ksplit = 1;
     *out = p;
 }
@@ -417,7 +734,12 @@ int s16_launch(const ConvArgs& a, hipStream_t s) {
     const unsigned grid = (unsigned)(total < wgs ? total : wgs);
     switch (s16_instance(a)) {
         case 1: hipLaunchKernelGGL((conv_s16_kernel<3, 9, 9, 1>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a); break;
-        case 2: hipLaunchKernelGGL((conv_s16_kernel<16, 9, 2, 5>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a); break;
+        case 2:
+            if (p.S == 48)
+                hipLaunchKernelGGL((conv_s16x_kernel<9, 5>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a);
+            else
+                hipLaunchKernelGGL((conv_s16_kernel<16, 9, 2, 5>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a);
+            break;
         case 3: hipLaunchKernelGGL((conv_s16_kernel<3, 3, 3, 1, 4>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a); break;
         default: return -4;
     }

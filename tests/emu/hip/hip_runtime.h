@@ -276,6 +276,30 @@ inline f32x16 mfma_32x32x16_bf16(bf16x8_emu a, bf16x8_emu b, f32x16 c) {
     return c;
 }
 
+// v_mfma_f32_16x16x32_bf16: lane l holds A[i = l&15][k = 8*(l>>4) .. +7] and B[k = 8*(l>>4) .. +7][j = l&15]; result register r of lane l = D[4*(l>>4) + r][l&15]
+// (summed in double, rounded once per instruction: see mfma_32x32x16_bf16)
+inline f32x4 mfma_16x16x32_bf16(bf16x8_emu a, bf16x8_emu b, f32x4 c) {
+    Block& bk = blk(); Fiber* f = bk.cur; Wave& w = bk.waves[f->wave];
+    int s = f->mfma_seq++ & 1, l = f->lane;
+    unsigned short ra[8], rb[8];
+    __builtin_memcpy(ra, &a, 16);
+    __builtin_memcpy(rb, &b, 16);
+    for (int k = 0; k < 8; ++k) {
+        unsigned ua = (unsigned)ra[k] << 16, ub = (unsigned)rb[k] << 16;
+        __builtin_memcpy(&w.a8[s][l][k], &ua, 4);
+        __builtin_memcpy(&w.b8[s][l][k], &ub, 4);
+    }
+    wave_sync();
+    int j = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int i = 4 * (l >> 4) + r;
+        double acc = c[r];
+        for (int k = 0; k < 32; ++k) acc += (double)w.a8[s][i + 16 * (k >> 3)][k & 7] * (double)w.b8[s][j + 16 * (k >> 3)][k & 7];
+        c[r] = (float)acc;
+    }
+    return c;
+}
+
 inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     Block& bk = blk(); Fiber* f = bk.cur; Wave& w = bk.waves[f->wave];
     int s = f->mfma_seq++ & 1, l = f->lane;
@@ -311,6 +335,7 @@ inline float shfl_idx(float v, int src) {
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) fsemu::mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) fsemu::mfma_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) fsemu::mfma_32x32x16_bf16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) fsemu::mfma_16x16x32_bf16((a), (b), (c))
 #define __builtin_amdgcn_s_getreg(imm) 0u   /* hardware id register: slot 0 everywhere */
 
 /* buffer resources: a (base, size) pair; loads beyond the size return zeros, as the hardware range check does.  The kernels mark a
