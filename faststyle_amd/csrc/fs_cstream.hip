@@ -29,16 +29,51 @@ constexpr int kTW = 16;     // output tile width; TH (8 or 16) rows: TH/2 32-pix
 // TH x 16 output pixels per tile; the four waves tile it as (4/WN waves over the 32-pixel blocks) x (WN waves over the channel
 // blocks), a wave owns WM = (TH/2)/(4/WN) pixel blocks x NB channel blocks (Cout = WN*NB*32); CIN input channels; KS x KS taps;
 // STRIDE 1 or 2.  The register budget of the resident filter decides the split: KS*KS*CIN/2 * NB registers per lane.
-template <int TH, int WN, int NB, int CIN, int KS, int STRIDE>
+// X6 (round 6, FS_CSTREAM_SPLIT): the products on the bf16 matrix cores as SIX EXACT products of bf16 pieces (the arithmetic of fs_wino6.hip / conv_s16x_kernel:
+// x = h + m + l exactly by truncation; hh, hm, mh, hl, lh, mm issued, fp32 accumulation, the five small products in an accumulator of their own).
+// v_mfma_f32_32x32x16_bf16 takes 32 cycles for 16 k where eight v_mfma_f32_32x32x2_f32 take 512: six products cost 192.  What changes against the fp32 form:
+//   * the filter in registers as three bf16 pieces (12 registers per 16 k and channel block: 108-216 of the 512 a lone wave owns);
+//   * the LDS patch holds [piece 3][CIN] bf16 per pixel + one 16-byte slot (an odd number of slots per pixel: the 16 pixels of a tile row fall on 16
+//     distinct slots of a ds_read_b128 lane group), row pitch 32 pixels (stride 1) / 40 (stride 2): the second tile row of a fragment lies a multiple of
+//     256 bytes behind the first -- conflict-free; stride 2 stores a row's even and odd columns apart, so that a tap reads ONE parity at unit stride;
+//   * one k-step = 16 channels of one tap: lane (pixel lm, half kq) reads channels 8 kq .. + 7, one ds_read_b128 per piece, address = lane base + immediate;
+//   * the commit splits every staged value (4 + 1.5 vector instructions on top of the affine + ReLU) and writes three 8-byte pieces.
+typedef __bf16 cs_bf16x8 __attribute__((ext_vector_type(8)));
+__host__ __device__ __forceinline__ void cs_split(float x, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    h = u & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, h);
+    m = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, m);
+    l = __builtin_bit_cast(unsigned, r2);   // (<= 8 significant bits: its low half is zero)
+}
+namespace {
+// geometry of the split form's patch, shared with the host (LDS bytes)
+template <int TH, int CIN, int KS, int STRIDE>
+struct CsxGeo {
+    static constexpr int PH = (TH - 1) * STRIDE + KS, PW = (kTW - 1) * STRIDE + KS;
+    static constexpr int PXB = 3 * CIN * 2 + 16;             // bytes per patch pixel
+    static constexpr int HALF = (PW + 1) / 2;                // stride 2: odd columns start here
+    static constexpr int PWP = STRIDE == 2 ? 40 : 32;        // row pitch in pixels
+    static constexpr int PATCH_B = (PH * PWP + 1) * PXB;     // + one pixel: the sink of elements a thread does not own
+    static_assert(PW <= PWP && 2 * HALF <= PWP, "patch row pitch");
+};
+}  // namespace
+
+template <int TH, int WN, int NB, int CIN, int KS, int STRIDE, bool X6 = false>
 __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     HIP_DYNAMIC_SHARED(float, smem)
+    char* const lds = reinterpret_cast<char*>(smem);
     const ConvPlan& p = a.p;
     constexpr int WMW = 4 / WN, WM = (TH / 2) / WMW, BN = WN * NB * 32, S = CIN + 1, C4 = CIN / 4, G = KS * KS, KSTEPS = G * CIN / 2;
     constexpr int C4SH = C4 == 4 ? 2 : (C4 == 8 ? 3 : 4);
     constexpr int PH = (TH - 1) * STRIDE + KS, PW = (kTW - 1) * STRIDE + KS, NPX = PH * PW;
     constexpr int REDF = WMW * 3 * BN;                    // one statistics buffer: [waves over pixels][s1, s2, shift][BN]
     constexpr int SX = (NPX * C4 + 255) / 256;            // 16-byte patch loads per thread and tile
-    constexpr int PATCH_F = (NPX * S + 4 + 3) & ~3;       // + four slack floats: the LDS sink of elements a thread does not own
+    using XG = CsxGeo<TH, CIN, KS, STRIDE>;
+    constexpr int PXB = XG::PXB, PWP = XG::PWP, HALF = XG::HALF;
+    constexpr int KST = G * CIN / 16, SPT = CIN / 16;     // X6: 16-k steps, steps per tap
+    constexpr int PATCH_F = X6 ? (XG::PATCH_B + 15) / 16 * 4 : ((NPX * S + 4 + 3) & ~3);       // fp32: + four slack floats: the LDS sink of elements a thread does not own
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 31, kq = lane >> 5;
@@ -53,11 +88,27 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
 
     // ---- the filter, once, into REGISTERS: lane (lm, kq) multiplies rows k = 2j + kq of [k = tap*Cin + ci][co] against
     // its columns nn*32 + lm -- KSTEPS x NB values that never change (no filter traffic through LDS at all)
-    float breg[KSTEPS][NB];
+    float breg[X6 ? 1 : KSTEPS][NB];
+    cs_bf16x8 bx[X6 ? KST : 1][NB][3];   // X6: lane (lm, kq) holds rows k = 16 s + 8 kq .. + 7 of step s as three pieces
+    if constexpr (!X6) {
 #pragma unroll
-    for (int j = 0; j < KSTEPS; ++j)
+        for (int j = 0; j < KSTEPS; ++j)
 #pragma unroll
-        for (int nn = 0; nn < NB; ++nn) breg[j][nn] = a.w[(2 * j + kq) * BN + (nbw * NB + nn) * 32 + lm];
+            for (int nn = 0; nn < NB; ++nn) breg[j][nn] = a.w[(2 * j + kq) * BN + (nbw * NB + nn) * 32 + lm];
+    } else {
+#pragma unroll
+        for (int sI = 0; sI < KST; ++sI)
+#pragma unroll
+            for (int nn = 0; nn < NB; ++nn) {
+                unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs_split(a.w[(16 * sI + 8 * kq + e) * BN + (nbw * NB + nn) * 32 + lm], hh[e], mm[e], ll[e]);
+                bx[sI][nn][0] = __builtin_bit_cast(cs_bf16x8, make_uint4((hh[0] >> 16) | hh[1], (hh[2] >> 16) | hh[3], (hh[4] >> 16) | hh[5], (hh[6] >> 16) | hh[7]));
+                bx[sI][nn][1] = __builtin_bit_cast(cs_bf16x8, make_uint4((mm[0] >> 16) | mm[1], (mm[2] >> 16) | mm[3], (mm[4] >> 16) | mm[5], (mm[6] >> 16) | mm[7]));
+                bx[sI][nn][2] = __builtin_bit_cast(cs_bf16x8, make_uint4((ll[0] >> 16) | (ll[1] & 0xffff0000u), (ll[2] >> 16) | (ll[3] & 0xffff0000u),
+                                                                         (ll[4] >> 16) | (ll[5] & 0xffff0000u), (ll[6] >> 16) | (ll[7] & 0xffff0000u)));
+            }
+    }
 
     // ---- this lane's pixels: pixel t of the tile = (mw*WM + m)*32 + rr, rr = (r & 3) + 8 (r >> 2) + 4 kq for accumulator
     // register r; with 16 columns that is row py = 2 (mw*WM + m) + (r >> 3), column px = 4 kq + (r & 3) + 8 ((r >> 2) & 1)
@@ -66,7 +117,8 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
         const int t = (mw * WM + m) * 32 + lm;            // A operand: lane lm feeds pixel t (all 32 rows of the block)
-        laneA[m] = (((t >> 4) * STRIDE) * PW + (t & 15) * STRIDE) * S + kq;
+        laneA[m] = X6 ? (((t >> 4) * STRIDE) * PWP + (t & 15)) * PXB + kq * 16      // (bytes; stride 2: column (t & 15) of the tap's parity half)
+                      : (((t >> 4) * STRIDE) * PW + (t & 15) * STRIDE) * S + kq;
     }
 
     // ---- staging descriptors (tile-invariant): element e = tid + i*256 is channel quad c4 of patch pixel e / C4
@@ -77,13 +129,13 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     for (int i = 0; i < SX; ++i) {
         const int e = tid + i * 256;
         pq[i] = -1;
-        pdst[i] = NPX * S;   // slack
+        pdst[i] = X6 ? PH * PWP * PXB : NPX * S;   // slack
         poffb[i] = kOOB;
         if (e < NPX * C4) {
             const int pix = e >> C4SH;
             const int py = fdiv(pix, 1.0f / (float)PW), px = pix - py * PW;
             pq[i] = (py << 8) | px;
-            pdst[i] = pix * S + c4 * 4;
+            pdst[i] = X6 ? (py * PWP + (STRIDE == 2 ? (px & 1) * HALF + (px >> 1) : px)) * PXB + c4 * 8 : pix * S + c4 * 4;
             poffb[i] = (unsigned)((py * a.W + px) * CIN + c4 * 4) * 4u;
         }
     }
@@ -172,11 +224,22 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
                 v.z = relu1(v.z);
                 v.w = relu1(v.w);
             }
-            float* d = smem + pdst[i];
-            d[0] = v.x;
-            d[1] = v.y;
-            d[2] = v.z;
-            d[3] = v.w;
+            if constexpr (X6) {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cs_split(vv[c], h[c], m[c], l[c]);
+                char* d = lds + pdst[i];
+                *reinterpret_cast<uint2*>(d) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
+                *reinterpret_cast<uint2*>(d + CIN * 2) = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
+                *reinterpret_cast<uint2*>(d + CIN * 4) = make_uint2((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u));
+            } else {
+                float* d = smem + pdst[i];
+                d[0] = v.x;
+                d[1] = v.y;
+                d[2] = v.z;
+                d[3] = v.w;
+            }
         }
     };
     auto commit = [&]() __attribute__((always_inline)) {
@@ -200,7 +263,65 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     // software pipeline pinned with sched_barrier: the A operands of step j + D are read before the matrix instructions of
     // step j (the compiler's own schedule waits for every read right before its MFMA)
     auto aoff = [&](int j) __attribute__((always_inline)) { return (((j / (CIN / 2)) / KS) * PW + ((j / (CIN / 2)) % KS)) * S + 2 * (j % (CIN / 2)); };
+    // X6: the five small products of a block in an accumulator of their own where the register file has room (instance 1: 108 filter + 64 accumulator
+    // registers; the others hold 192-216 filter registers and accumulate all six products of a step, smallest first, in one)
+    constexpr bool SEP = X6 && (2 * WM * NB * 16 + KST * NB * 12 <= 250);
+    f32x16 acs[SEP ? WM : 1][SEP ? NB : 1];
+    auto zero_acs = [&]() __attribute__((always_inline)) {
+        if constexpr (SEP) {
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int nn = 0; nn < NB; ++nn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acs[m][nn][r] = 0.f;
+        }
+    };
+    zero_acs();
+    // X6: units u = (step s, block m); the three operand pieces of unit u + 1 are read in front of the 6 NB matrix instructions of unit u
+    auto xoff = [&](int sI, int pc) __attribute__((always_inline)) {   // compile-time byte offset of step sI, piece pc
+        const int tap = sI / SPT, kh = tap / KS, kw = tap % KS;
+        return (kh * PWP + (STRIDE == 2 ? (kw & 1) * HALF + (kw >> 1) : kw)) * PXB + pc * CIN * 2 + (sI % SPT) * 32;
+    };
+    auto sweep_x6 = [&]() __attribute__((always_inline)) {
+        cs_bf16x8 av[2][3];
+        auto rd = [&](int u, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) av[buf][pc] = __builtin_bit_cast(cs_bf16x8, *reinterpret_cast<const uint4*>(lds + laneA[u % WM] + xoff(u / WM, pc)));
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int u = 0; u < KST * WM; ++u) {
+            const int sI = u / WM, m = u % WM, b = u & 1;
+            if (u + 1 < KST * WM) rd(u + 1, b ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nn = 0; nn < NB; ++nn) {   // smallest first: h l, l h, m m, h m, m h into the small accumulator, h h into the leading one
+                f32x16& sm = SEP ? acs[SEP ? m : 0][SEP ? nn : 0] : acc[m][nn];
+                sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[b][0], bx[sI][nn][2], sm, 0, 0, 0);
+                sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[b][2], bx[sI][nn][0], sm, 0, 0, 0);
+                sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[b][1], bx[sI][nn][1], sm, 0, 0, 0);
+                sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[b][0], bx[sI][nn][1], sm, 0, 0, 0);
+                sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[b][1], bx[sI][nn][0], sm, 0, 0, 0);
+                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[b][0], bx[sI][nn][0], acc[m][nn], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (SEP) {
+#pragma unroll
+            for (int m = 0; m < WM; ++m)
+#pragma unroll
+                for (int nn = 0; nn < NB; ++nn) {
+                    acc[m][nn] += acs[m][nn];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acs[m][nn][r] = 0.f;
+                }
+        }
+    };
     auto sweep = [&]() __attribute__((always_inline)) {
+        if constexpr (X6) {
+            sweep_x6();
+        } else {
         constexpr int D = WM * NB >= 8 ? 1 : (WM * NB >= 4 ? 2 : 3);
         float av[D + 1][WM];
 #pragma unroll
@@ -219,6 +340,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
 #pragma unroll
                 for (int m = 0; m < WM; ++m) acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j % (D + 1)][m], breg[j][nn], acc[m][nn], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
     };
 
@@ -392,6 +514,9 @@ static int cstream_instance(const ConvArgs& a) {
     return 0;
 }
 
+// FS_CSTREAM_SPLIT (default 1): instances 1-4 on the bf16 matrix cores as six exact bf16-piece products (the X6 form of the kernel); 0: fp32 matrix instructions
+static bool cstream_split_on() { return tune_int("FS_CSTREAM_SPLIT", 1) != 0; }
+
 bool cstream_eligible(const ConvArgs& a) {
     const int inst = cstream_instance(a);
     if (!tune_int("FS_CSTREAM", 1) || !inst) return false;
@@ -427,16 +552,22 @@ void cstream_plan(const ConvArgs& a, ConvPlan* out) {
     p.PW = (kTW - 1) * a.stride + a.KW;
     p.S = a.Cin + 1;
     p.ksplit = 1;
-    const int patch_floats = (p.PH * p.PW * p.S + 4 + 3) & ~3;
+    int patch_floats = (p.PH * p.PW * p.S + 4 + 3) & ~3;
+    if (inst >= 1 && inst <= 4 && cstream_split_on()) {   // the split-bf16 form (X6): [piece][Cin] bf16 + 16 bytes per pixel, row pitch 32 / 40 pixels, + the sink pixel
+        p.S = 3 * a.Cin * 2 + 16;
+        const int patch_b = (p.PH * (a.stride == 2 ? 40 : 32) + 1) * p.S;
+        patch_floats = (patch_b + 15) / 16 * 4;
+        p.flat = 1;   // (the launch reads this: the plan was made for the split form)
+    }
     p.lds_bytes = 4 * (patch_floats + 2 * 12 * a.Cout);   // (statistics buffers: at most 4 wave records x 3 x Cout, twice)
     *out = p;
 }
 
-template <int TH, int WN, int NB, int CIN, int KS, int STRIDE>
+template <int TH, int WN, int NB, int CIN, int KS, int STRIDE, bool X6 = false>
 static void cs_launch(const ConvArgs& a, unsigned grid, hipStream_t s) {
     static BigLds lds_attr;
-    lds_attr.ensure(reinterpret_cast<const void*>(conv_stream_kernel<TH, WN, NB, CIN, KS, STRIDE>));
-    hipLaunchKernelGGL((conv_stream_kernel<TH, WN, NB, CIN, KS, STRIDE>), dim3(grid), dim3(256), (size_t)a.p.lds_bytes, s, a);
+    lds_attr.ensure(reinterpret_cast<const void*>(conv_stream_kernel<TH, WN, NB, CIN, KS, STRIDE, X6>));
+    hipLaunchKernelGGL((conv_stream_kernel<TH, WN, NB, CIN, KS, STRIDE, X6>), dim3(grid), dim3(256), (size_t)a.p.lds_bytes, s, a);
 }
 
 int cstream_launch(const ConvArgs& a, hipStream_t s) {
@@ -444,6 +575,16 @@ int cstream_launch(const ConvArgs& a, hipStream_t s) {
     const long total = (long)a.N * p.tiles_y * p.tiles_x;
     const int wgs = tune_int("FS_CSTREAM_WGS", 256);
     const unsigned grid = (unsigned)(total < wgs ? total : wgs);
+    if (p.flat) {   // the split-bf16 form
+        switch (cstream_instance(a)) {
+            case 1: cs_launch<16, 1, 1, 16, 3, 2, true>(a, grid, s); break;
+            case 2: cs_launch<16, 1, 2, 32, 2, 1, true>(a, grid, s); break;
+            case 3: cs_launch<8, 2, 1, 32, 3, 2, true>(a, grid, s); break;
+            case 4: cs_launch<8, 4, 1, 64, 2, 1, true>(a, grid, s); break;
+            default: return -4;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     switch (cstream_instance(a)) {
         case 1: cs_launch<16, 1, 1, 16, 3, 2>(a, grid, s); break;   // 4 waves over the pixels; 72 filter registers
         case 2: cs_launch<16, 1, 2, 32, 2, 1>(a, grid, s); break;   // 4 waves over the pixels; 128
