@@ -679,6 +679,330 @@ __global__ __launch_bounds__(256, 2) void conv_s16x_kernel(ConvArgs a) {
     if (a.stats && tid < 16) finalize(prev, red + ((my_items - 1) & 1) * REDF);
 }
 
+
+// The 9 x 9 layers with THREE input channels (the image layer 3 -> 16 with REFLECT-40 fused; the input gradient of the output layer, zero padding) in
+// the same arithmetic.  A k-step of v_mfma_f32_16x16x32_bf16 takes 8 consecutive k per lane, i.e. 16 bytes of one LDS address: with 3-channel pixels a
+// kernel row's 27 contiguous values start at 6 x bytes -- no alignment --, so
+//   * the patch pads a pixel to FOUR channels (8 bytes per piece; the fourth is zero) and a lane's 8 values are a PAIR of horizontally adjacent taps;
+//     k runs over the 45 groups (kernel row kh, tap pair pr: taps 2 pr, 2 pr + 1; the tenth tap has zero weights) = 12 k-steps of 4 groups (63 % of the
+//     matrix work is useful, against 96 % of the fp32 form's: 72 x 6 x 16 = 1152 cycles per 16 x 16 block against 63 x 32 = 2016);
+//   * every piece plane is stored TWICE, the second copy one pixel further: a pair that starts at an odd column is 16-byte aligned there.  The lane picks
+//     the copy by the parity of its own pixel column (patch width, pair offsets and row offsets are even), the copies lie 7 slots apart modulo 16:
+//     one ds_read_b128 per piece, conflict-free inside a kernel row;
+//   * a group's offset (kh PW + 2 pr) depends on the lane's k group: twelve per-lane address registers, the block row and the piece are immediates;
+//   * the filter as B fragments would be 144 registers: it lives in LDS ([step][piece][lane] x 16 bytes = 36 KB, written once per workgroup), one
+//     ds_read_b128 per piece and k-step shared by the four block rows.  ~150 registers: two workgroups per CU.
+template <int KH, int KW>
+__global__ __launch_bounds__(256, 2) void conv_s16c3x_kernel(ConvArgs a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    char* const lds = reinterpret_cast<char*>(smem);
+    const ConvPlan& p = a.p;
+    constexpr int CIN = 3, COUT = 16;
+    constexpr int PH = kT - 1 + KH, PW = kT - 1 + KW, NPX = PH * PW;
+    static_assert(!(PW & 1), "even patch width: the copy a lane reads is fixed by the parity of its column");
+    constexpr int NPR = (KW + 1) / 2, NG = KH * NPR, KST = (NG + 3) / 4;   // tap pairs per kernel row, groups, k-steps
+    constexpr int PL0 = (((NPX + 2) * 8) + 255) & ~255;                    // one piece plane of one copy
+    constexpr int C1B = 3 * PL0 + 7 * 16;                                  // copy 1 (pixel i at (i + 1) * 8): 7 slots further modulo 16
+    constexpr int FB = (C1B + 3 * PL0 + 255) & ~255;                       // the filter: [KST][3][64 lanes] x 16 bytes
+    constexpr int RB = FB + KST * 3 * 64 * 16;                             // statistics records
+    constexpr int NE = NPX, SX = (NE + 255) / 256;
+    constexpr int REDF = 4 * 3 * 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m16 = lane & 15, kg = lane >> 4;
+    float* const red = reinterpret_cast<float*>(lds + RB);   // [2][REDF]
+    auto fdiv = [](int x, float inv_d) __attribute__((always_inline)) { return (int)(((float)x + 0.5f) * inv_d); };
+    auto uniform_ptr = [](const float* ptr) __attribute__((always_inline)) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    };
+
+    // ---- the filter, once, into LDS: wave w splits the k-steps w, w + 4, ...; lane (channel m16, kg) of step j holds group q = 4 j + kg = (kh, pr):
+    // element e = tap 2 pr + (e >> 2), channel e & 3 (zero for the padded channel, the tenth tap and the groups past the last)
+    for (int j = wave; j < KST; j += 4) {
+        const int q = 4 * j + kg, kh = q / NPR, pr = q - kh * NPR;
+        unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kw = 2 * pr + (e >> 2), ci = e & 3;
+            const float w = (q < NG && kw < KW && ci < 3) ? a.w[((kh * KW + kw) * CIN + ci) * COUT + m16] : 0.f;
+            s16x_split(w, hh[e], mm[e], ll[e]);
+        }
+        uint4* d = reinterpret_cast<uint4*>(lds + FB + (j * 3 * 64 + lane) * 16);
+        d[0] = make_uint4((hh[0] >> 16) | hh[1], (hh[2] >> 16) | hh[3], (hh[4] >> 16) | hh[5], (hh[6] >> 16) | hh[7]);
+        d[64] = make_uint4((mm[0] >> 16) | mm[1], (mm[2] >> 16) | mm[3], (mm[4] >> 16) | mm[5], (mm[6] >> 16) | mm[7]);
+        d[128] = make_uint4((ll[0] >> 16) | (ll[1] & 0xffff0000u), (ll[2] >> 16) | (ll[3] & 0xffff0000u), (ll[4] >> 16) | (ll[5] & 0xffff0000u), (ll[6] >> 16) | (ll[7] & 0xffff0000u));
+    }
+    // ---- A operands: block m of this wave is tile row 4 wave + m; lane (pixel column m16, kg) reads the pixel pair of its group from the copy of its parity
+    const int cp = m16 & 1;
+    int addrA[KST];
+#pragma unroll
+    for (int j = 0; j < KST; ++j) {
+        int q = 4 * j + kg;
+        q = q < NG ? q : NG - 1;
+        const int kh = q / NPR, pr = q - kh * NPR;
+        addrA[j] = cp * C1B + ((4 * wave + kh) * PW + m16 + 2 * pr + cp) * 8;
+    }
+
+    // ---- staging descriptors (tile-invariant): element e = tid + i*256 is patch pixel e (its 3 floats)
+    int pq[SX], pdst[SX];
+    unsigned poffb[SX];
+#pragma unroll
+    for (int i = 0; i < SX; ++i) {
+        const int e = tid + i * 256;
+        pq[i] = -1;
+        pdst[i] = NPX * 8;   // the sink pixel (read by the tenth tap of the last patch row: times a zero weight)
+        poffb[i] = kOOB;
+        if (e < NE) {
+            const int py = fdiv(e, 1.0f / (float)PW), px = e - py * PW;
+            pq[i] = (py << 8) | px;
+            pdst[i] = e * 8;
+            poffb[i] = (unsigned)((py * a.W + px) * CIN) * 4u;
+        }
+    }
+    const unsigned x_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * CIN) * 4u);
+    const bool has_ab3 = a.in_a != nullptr;   // per-channel affine of a 3-channel input
+    const int refl = a.src_mode == SRC_REFLECT ? a.refl : 0;
+
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int total = a.N * tiles;
+    const int GX = (int)gridDim.x;
+    const int my_items = ((int)blockIdx.x < total) ? (total - 1 - (int)blockIdx.x) / GX + 1 : 0;
+    const float inv_tiles = 1.0f / (float)tiles, inv_tx = 1.0f / (float)p.tiles_x;
+    struct Item {
+        int n, ty0, tx0, lin;
+    };
+    auto decode = [&](int it) __attribute__((always_inline)) {
+        Item r;
+        r.lin = (int)blockIdx.x + it * GX;
+        r.n = fdiv(r.lin, inv_tiles);
+        const int tr = r.lin - r.n * tiles;
+        const int tyi = fdiv(tr, inv_tx);
+        r.ty0 = tyi * kT;
+        r.tx0 = (tr - tyi * p.tiles_x) * kT;
+        r.lin = __builtin_amdgcn_readfirstlane(r.lin);
+        r.n = __builtin_amdgcn_readfirstlane(r.n);
+        r.ty0 = __builtin_amdgcn_readfirstlane(r.ty0);
+        r.tx0 = __builtin_amdgcn_readfirstlane(r.tx0);
+        return r;
+    };
+    // TWO tiles of loads in flight (a pixel is 12 bytes: 9 registers per tile): with the sweep at a third of the fp32 form's length one tile of
+    // look-ahead no longer covers the latency of the loads
+    struct Stage {
+        float pv[SX][3];
+        unsigned pok;   // bit i: element i came from inside the image; bit 31: the whole patch did (interior tile)
+        float4 va, vb;
+    };
+    Stage st0, st1;
+    st0.pok = st1.pok = 0;
+    st0.va = st1.va = make_float4(1.f, 1.f, 1.f, 1.f);
+    st0.vb = st1.vb = make_float4(0.f, 0.f, 0.f, 0.f);
+    // live = 0: a tile beyond the list -- every load against an empty buffer (zeros, no traffic), so that the number of loads in flight is the same on every path
+    auto issue = [&](Stage& T, const Item& I, int live) __attribute__((always_inline)) {
+        float (&pv)[SX][3] = T.pv;
+        unsigned& pok = T.pok;
+        float4 &va = T.va, &vb = T.vb;
+        const int vy0 = I.ty0 - a.pad_t, vx0 = I.tx0 - a.pad_l;   // the patch's first pixel in the coordinates of the (mirror-padded) source
+        const float* xn = uniform_ptr(a.x + (size_t)I.n * a.H * a.W * CIN);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, live ? x_bytes : 0u, 0x00020000);
+        const int iy0 = vy0 - refl, ix0 = vx0 - refl;             // ... in the coordinates of the stored image
+        if (iy0 >= 0 && ix0 >= 0 && iy0 + PH <= a.H && ix0 + PW <= a.W) {
+            pok = 0xFFFFFFFFu;
+            const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)((iy0 * a.W + ix0) * CIN) * 4u);
+#pragma unroll
+            for (int i = 0; i < SX; ++i) {
+                const auto t = __builtin_amdgcn_raw_buffer_load_b96(xr, poffb[i], base, 0);
+                __builtin_memcpy(pv[i], &t, 12);
+            }
+        } else {
+            pok = 0;
+#pragma unroll
+            for (int i = 0; i < SX; ++i) {
+                const int vy = vy0 + (pq[i] >> 8), vx = vx0 + (pq[i] & 255);
+                const bool ok = pq[i] >= 0 && (unsigned)vy < (unsigned)(a.H + 2 * refl) && (unsigned)vx < (unsigned)(a.W + 2 * refl);
+                int sy = vy - refl, sx = vx - refl;
+                sy = sy < 0 ? -sy : sy;
+                sx = sx < 0 ? -sx : sx;
+                sy = sy >= a.H ? 2 * (a.H - 1) - sy : sy;
+                sx = sx >= a.W ? 2 * (a.W - 1) - sx : sx;
+                pok |= ok ? (1u << i) : 0u;
+                const auto t = __builtin_amdgcn_raw_buffer_load_b96(xr, ok ? (unsigned)((sy * a.W + sx) * CIN) * 4u : kOOB, 0, 0);
+                __builtin_memcpy(pv[i], &t, 12);
+            }
+        }
+        if (has_ab3) {
+            const float* pa = a.in_a + (size_t)I.n * a.in_nstride;
+            const float* pb = a.in_b + (size_t)I.n * a.in_nstride;
+            va = make_float4(pa[0], pa[1], pa[2], 0.f);
+            vb = make_float4(pb[0], pb[1], pb[2], 0.f);
+        }
+    };
+    auto commit_as = [&](Stage& T, auto MASKED) __attribute__((always_inline)) {
+        constexpr bool masked = decltype(MASKED)::value;
+        float (&pv)[SX][3] = T.pv;
+        const unsigned pok = T.pok;
+        const float4 va = T.va, vb = T.vb;
+#pragma unroll
+        for (int i = 0; i < SX; ++i) {
+            float v[3] = {pv[i][0], pv[i][1], pv[i][2]};
+            if (has_ab3) {   // padding arrives as 0 and must stay 0
+                const unsigned okm = (!masked || ((pok >> i) & 1u)) ? 0xFFFFFFFFu : 0u;
+                v[0] = fmaf(v[0], va.x, __uint_as_float(__float_as_uint(vb.x) & okm));
+                v[1] = fmaf(v[1], va.y, __uint_as_float(__float_as_uint(vb.y) & okm));
+                v[2] = fmaf(v[2], va.z, __uint_as_float(__float_as_uint(vb.z) & okm));
+            }
+            unsigned h[3], m[3], l[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s16x_split(v[c], h[c], m[c], l[c]);
+            const uint2 H = make_uint2((h[0] >> 16) | h[1], h[2] >> 16), M = make_uint2((m[0] >> 16) | m[1], m[2] >> 16),
+                        L = make_uint2((l[0] >> 16) | (l[1] & 0xffff0000u), l[2] >> 16);
+            char* d0 = lds + pdst[i];
+            char* d1 = lds + C1B + 8 + pdst[i];
+            *reinterpret_cast<uint2*>(d0) = H;
+            *reinterpret_cast<uint2*>(d0 + PL0) = M;
+            *reinterpret_cast<uint2*>(d0 + 2 * PL0) = L;
+            *reinterpret_cast<uint2*>(d1) = H;
+            *reinterpret_cast<uint2*>(d1 + PL0) = M;
+            *reinterpret_cast<uint2*>(d1 + 2 * PL0) = L;
+        }
+    };
+    auto commit = [&](Stage& T) __attribute__((always_inline)) {
+        if (T.pok >> 31)
+            commit_as(T, std::false_type{});
+        else
+            commit_as(T, std::true_type{});
+    };
+
+    f32x4 acc[4], acs[4];   // the leading product / the five small ones
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = acs[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+    // one straight line: per k-step the three filter pieces, per (step, block row) the three operand pieces, each read one unit ahead
+    auto sweep = [&]() __attribute__((always_inline)) {
+        s16_bf16x8 av[2][3], bv[2][3];
+        auto rda = [&](int u, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) av[buf][pc] = __builtin_bit_cast(s16_bf16x8, *reinterpret_cast<const uint4*>(lds + addrA[u >> 2] + (u & 3) * PW * 8 + pc * PL0));
+        };
+        auto rdb = [&](int j, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bv[buf][pc] = __builtin_bit_cast(s16_bf16x8, *reinterpret_cast<const uint4*>(lds + FB + ((j * 3 + pc) * 64 + lane) * 16));
+        };
+        rdb(0, 0);
+        rda(0, 0);
+#pragma unroll
+        for (int u = 0; u < KST * 4; ++u) {
+            const int j = u >> 2, m = u & 3, b = u & 1, bb = j & 1;
+            if (u + 1 < KST * 4) rda(u + 1, b ^ 1);
+            if (m == 0 && j + 1 < KST) rdb(j + 1, bb ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acs[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[b][0], bv[bb][2], acs[m], 0, 0, 0);
+            acs[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[b][2], bv[bb][0], acs[m], 0, 0, 0);
+            acs[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[b][1], bv[bb][1], acs[m], 0, 0, 0);
+            acs[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[b][0], bv[bb][1], acs[m], 0, 0, 0);
+            acs[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[b][1], bv[bb][0], acs[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[b][0], bv[bb][0], acc[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] += acs[m];
+    };
+
+    // ---- epilogue of one item: accumulator register r of block m, lane (m16, kg) = pixel (row 4 wave + m, column 4 kg + r), channel m16
+    const unsigned y_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.Ho * a.Wo * COUT) * 4u);
+    auto epilogue = [&](const Item& I, float* rbuf) __attribute__((always_inline)) {
+        const int th_valid = min(kT, a.Ho - I.ty0), tw_valid = min(kT, a.Wo - I.tx0);
+        if (a.stats) {
+            const float cs = __shfl(acc[0][0], m16);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = 4 * wave + m < th_valid && 4 * kg + r < tw_valid;
+                    const float d = ok ? acc[m][r] - cs : 0.f;
+                    s1 += d;
+                    s2 = fmaf(d, d, s2);
+                }
+            s1 += __shfl_xor(s1, 16);
+            s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lane < 16) {
+                rbuf[(wave * 3 + 0) * 16 + lane] = s1;
+                rbuf[(wave * 3 + 1) * 16 + lane] = s2;
+                rbuf[(wave * 3 + 2) * 16 + lane] = cs;
+            }
+        }
+        float* yn = a.y + (size_t)I.n * a.Ho * a.Wo * COUT;
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(yn)), 0, y_bytes, 0x00020000);
+        const int lane_off = ((I.tx0 + 4 * kg) * COUT + m16) * 4;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = 4 * wave + m;
+            const int row_off = (I.ty0 + row) * a.Wo * COUT * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = row < th_valid && 4 * kg + r < tw_valid;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][r]), yr, ok ? (unsigned)(lane_off + row_off + r * COUT * 4) : kOOB, 0, 0);
+            }
+        }
+        zero_acc();
+    };
+    auto finalize = [&](const Item& I, const float* rbuf) __attribute__((always_inline)) {
+        const int th_valid = min(kT, a.Ho - I.ty0), tw_valid = min(kT, a.Wo - I.tx0);
+        float cnt = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int rows = min(4, max(0, th_valid - 4 * w));
+            const float cb = (float)(rows * tw_valid);
+            if (cb > 0.f) {
+                const float S1 = rbuf[(w * 3 + 0) * 16 + tid], S2 = rbuf[(w * 3 + 1) * 16 + tid], sh = rbuf[(w * 3 + 2) * 16 + tid];
+                const float mb = sh + S1 / cb, qb2 = fmaxf(S2 - S1 * S1 / cb, 0.f);
+                const float nn_ = cnt + cb, d = mb - mean, rr = cb / nn_;
+                mean += d * rr;
+                m2 += qb2 + d * d * cnt * rr;
+                cnt = nn_;
+            }
+        }
+        float* st = a.stats + ((size_t)I.lin * 16 + tid) * 3;
+        st[0] = mean;
+        st[1] = m2;
+        st[2] = cnt;
+    };
+
+    if (my_items == 0) return;
+    Item cur = decode(0), prev = cur;
+    issue(st0, cur, 1);
+    commit(st0);
+    __syncthreads();   // (the filter and the first patch)
+    Item nxt = my_items > 1 ? decode(1) : cur;
+    issue(st1, nxt, my_items > 1);
+    // one pipeline step: tile `it` is multiplied; the loads of tile it + 1 (stage C) were issued a step ago, those of tile it + 2 go out now (stage I)
+    auto step = [&](int it, Stage& C, Stage& I2) __attribute__((always_inline)) {
+        if (it > 0 && a.stats && tid < 16) finalize(prev, red + ((it - 1) & 1) * REDF);
+        const int live2 = it + 2 < my_items;
+        const Item nn = live2 ? decode(it + 2) : cur;
+        issue(I2, nn, live2);
+        sweep();
+        FS_LDS_BARRIER();   // A: every wave is done reading the patch
+        if (it + 1 < my_items) commit(C);
+        epilogue(cur, red + (it & 1) * REDF);
+        FS_LDS_BARRIER();   // B: next patch and this tile's statistics records (LDS) visible; the stores drain during the next sweep
+        prev = cur;
+        cur = nxt;
+        nxt = nn;
+    };
+    for (int it = 0; it < my_items; it += 2) {
+        step(it, st1, st0);
+        if (it + 1 < my_items) step(it + 1, st0, st1);
+    }
+    if (a.stats && tid < 16) finalize(prev, red + ((my_items - 1) & 1) * REDF);
+}
+
 // ------------------------------------------------------------------------------------------------------------ host
 // FS_S16_SPLIT (default 1): the folded output layer on the bf16 matrix cores as six exact bf16-piece products (conv_s16x_kernel); 0: fp32 matrix instructions
 static bool s16_split_on() { return tune_int("FS_S16_SPLIT", 1) != 0; }
@@ -719,6 +1043,11 @@ void s16_plan(const ConvArgs& a, ConvPlan* out) {
     p.S = inst == 2 ? 17 : 3;
     const int patch_f = (p.PH * p.PW * p.S + 8 + 3) & ~3;
     p.lds_bytes = 4 * (patch_f + 2 * 4 * 3 * 16);
+    if (inst == 1 && s16_split_on()) {   // conv_s16c3x_kernel: two copies of three piece planes, the filter, the statistics records
+        p.S = 8;
+        const int pl0 = (((p.PH * p.PW + 2) * 8) + 255) & ~255, c1b = 3 * pl0 + 7 * 16, fb = (c1b + 3 * pl0 + 255) & ~255;
+        p.lds_bytes = fb + ((a.KH * ((a.KW + 1) / 2) + 3) / 4) * 3 * 64 * 16 + 4 * (2 * 4 * 3 * 16);
+    }
     if (inst == 2 && s16_split_on()) {   // conv_s16x_kernel: two half planes of (pixels + 1) x 48 bytes, each rounded up to 256 bytes
         p.S = 48;
         p.lds_bytes = 2 * (((p.PH * p.PW + 1) * 48 + 255) & ~255) + 4 * (2 * 4 * 3 * 16);
@@ -733,7 +1062,15 @@ int s16_launch(const ConvArgs& a, hipStream_t s) {
     const int wgs = tune_int("FS_S16_WGS", 512);
     const unsigned grid = (unsigned)(total < wgs ? total : wgs);
     switch (s16_instance(a)) {
-        case 1: hipLaunchKernelGGL((conv_s16_kernel<3, 9, 9, 1>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a); break;
+        case 1:
+            if (p.S == 8) {
+                static BigLds lds_attr;
+                lds_attr.ensure(reinterpret_cast<const void*>(conv_s16c3x_kernel<9, 9>));
+                hipLaunchKernelGGL((conv_s16c3x_kernel<9, 9>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a);
+            } else {
+                hipLaunchKernelGGL((conv_s16_kernel<3, 9, 9, 1>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a);
+            }
+            break;
         case 2:
             if (p.S == 48)
                 hipLaunchKernelGGL((conv_s16x_kernel<9, 5>), dim3(grid), dim3(256), (size_t)p.lds_bytes, s, a);
