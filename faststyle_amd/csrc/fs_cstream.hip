@@ -496,6 +496,326 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvArgs a) {
     fs_fused_in_finalize(a.fin, a.stats, a.N, smem);   // (every workgroup has at least one tile: grid <= tiles)
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the FORWARD residual convs (64 -> 64, 3 x 3, stride 1, VALID; reference im_transf_net.py:201-215) as a DIRECT convolution in six exact
+// bf16-piece products.  The fp32 Winograd F(4x4) kernel executes a quarter of the direct form's products at the fp32 matrix rate and pays an input
+// transform per 8-channel step plus 8-12 k cycles of output transform per item, beside 8 steps of 3.7 k cycles (K = 64 is short); the direct form in
+// split bf16 executes 6 products at 16 x the fp32 rate -- 6/16 x 4 = 1.5 x the Winograd kernel's matrix cycles on paper, and no transforms:
+// 13.8 k cycles of matrix instructions per 8 x 16-pixel tile (the F(4x4) item: 36.9 k per 16 x 16 pixels + ~18 k around them).
+//   * v_mfma_f32_16x16x32_bf16; wave w owns output channels 16 w .. + 15 and keeps ITS filter slice in registers as three pieces (18 k-steps x 12 = 216
+//     registers; a 32-channel block per wave would need 432), every wave multiplies all TH pixel rows of the tile (a block = one tile row of 16 pixels);
+//   * one k-step = half a tap: 32 channels, lane (pixel m16, kg) reads channels 32 (s & 1) + 8 kg .. + 7;
+//   * LDS patch: eight planes of 8 channels, [pixel][piece 3][8 channels] bf16 = 48 bytes per pixel (an odd number of 16-byte slots), every plane a
+//     multiple of 256 bytes: the lanes of a ds_read_b128 group differ in pixel column and in plane only -- conflict-free;
+//   * the pipeline, the on-load affine + ReLU, the per-tile {mean, M2, count} records are conv_stream_kernel's (a wave owns its channels over the whole
+//     tile: the record needs no merge across waves).  One workgroup per CU (~430 registers).
+#ifdef FS_R64X_TRACE
+// debug build only (tools/r64x_trace.py): per-workgroup phase cycle counts of the last launch: [wg][8] = issue, sweep, barrier A, commit, epilogue, barrier B, prologue, tiles
+static __device__ long long g_r64x_trace[4096 * 8];
+extern "C" int fs_debug_r64x_trace(long long* out, int n_wg) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_r64x_trace), sizeof(long long) * 8 * (size_t)n_wg, 0, hipMemcpyDeviceToHost);
+}
+#define FS_R64X_NOW() ((long long)__builtin_readcyclecounter())
+#endif
+typedef float cs_f32x4 __attribute__((ext_vector_type(4)));
+template <int TH>
+__global__ __launch_bounds__(256) void conv_r64x_kernel(ConvArgs a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    char* const lds = reinterpret_cast<char*>(smem);
+    const ConvPlan& p = a.p;
+    constexpr int CIN = 64, COUT = 64, KS = 3;
+    constexpr int PH = TH + KS - 1, PW = kTW + KS - 1, NPX = PH * PW;
+    constexpr int GPB = ((NPX + 1) * 48 + 255) & ~255;   // one 8-channel plane (+ the sink pixel)
+    constexpr int KST = KS * KS * CIN / 32;              // 32-k steps
+    constexpr int SX = (NPX * 16 + 255) / 256;           // 16-byte patch loads per thread and tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m16 = lane & 15, kg = lane >> 4;
+    auto fdiv = [](int x, float inv_d) __attribute__((always_inline)) { return (int)(((float)x + 0.5f) * inv_d); };
+    auto uniform_ptr = [](const float* ptr) __attribute__((always_inline)) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    };
+
+    // ---- the wave's filter slice, once, into registers: lane (channel 16 wave + m16, kg) holds k = 8 kg .. + 7 of step sI = (tap sI / 2, ci 32 (sI & 1) + 8 kg ..)
+    cs_bf16x8 bx[KST][3];
+#pragma unroll
+    for (int sI = 0; sI < KST; ++sI) {
+        unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs_split(a.w[((sI >> 1) * CIN + 32 * (sI & 1) + 8 * kg + e) * COUT + 16 * wave + m16], hh[e], mm[e], ll[e]);
+        bx[sI][0] = __builtin_bit_cast(cs_bf16x8, make_uint4((hh[0] >> 16) | hh[1], (hh[2] >> 16) | hh[3], (hh[4] >> 16) | hh[5], (hh[6] >> 16) | hh[7]));
+        bx[sI][1] = __builtin_bit_cast(cs_bf16x8, make_uint4((mm[0] >> 16) | mm[1], (mm[2] >> 16) | mm[3], (mm[4] >> 16) | mm[5], (mm[6] >> 16) | mm[7]));
+        bx[sI][2] = __builtin_bit_cast(cs_bf16x8, make_uint4((ll[0] >> 16) | (ll[1] & 0xffff0000u), (ll[2] >> 16) | (ll[3] & 0xffff0000u), (ll[4] >> 16) | (ll[5] & 0xffff0000u),
+                                                             (ll[6] >> 16) | (ll[7] & 0xffff0000u)));
+    }
+    const int laneA = kg * GPB + m16 * 48;
+    auto xoff = [](int sI, int b, int pc) __attribute__((always_inline)) {   // compile-time byte offset of step sI, tile row b, piece pc
+        const int tap = sI >> 1, kh = tap / KS, kw = tap % KS;
+        return 4 * (sI & 1) * GPB + ((b + kh) * PW + kw) * 48 + pc * 16;
+    };
+
+    // ---- staging descriptors (tile-invariant): element e = tid + i*256 is channel quad c4 of patch pixel e / 16
+    const int c4 = tid & 15;
+    int pq[SX], pdst[SX];
+    unsigned poffb[SX];
+#pragma unroll
+    for (int i = 0; i < SX; ++i) {
+        const int e = tid + i * 256;
+        pq[i] = -1;
+        pdst[i] = (c4 >> 1) * GPB + NPX * 48 + (c4 & 1) * 8;   // the sink pixel
+        poffb[i] = kOOB;
+        if (e < NPX * 16) {
+            const int pix = e >> 4;
+            const int py = fdiv(pix, 1.0f / (float)PW), px = pix - py * PW;
+            pq[i] = (py << 8) | px;
+            pdst[i] = (c4 >> 1) * GPB + pix * 48 + (c4 & 1) * 8;
+            poffb[i] = (unsigned)((py * a.W + px) * CIN + c4 * 4) * 4u;
+        }
+    }
+    const unsigned x_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * CIN) * 4u);
+    const bool has_ab = a.in_a != nullptr;
+    const bool in_relu = a.in_relu != 0;
+
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int total = a.N * tiles;
+    const int GX = (int)gridDim.x;
+    const int my_items = ((int)blockIdx.x < total) ? (total - 1 - (int)blockIdx.x) / GX + 1 : 0;
+    const float inv_tiles = 1.0f / (float)tiles, inv_tx = 1.0f / (float)p.tiles_x;
+    struct Item {
+        int n, ty0, tx0, lin;
+    };
+    auto decode = [&](int it) __attribute__((always_inline)) {
+        Item r;
+        r.lin = (int)blockIdx.x + it * GX;
+        r.n = fdiv(r.lin, inv_tiles);
+        const int tr = r.lin - r.n * tiles;
+        const int tyi = fdiv(tr, inv_tx);
+        r.ty0 = tyi * TH;
+        r.tx0 = (tr - tyi * p.tiles_x) * kTW;
+        r.lin = __builtin_amdgcn_readfirstlane(r.lin);
+        r.n = __builtin_amdgcn_readfirstlane(r.n);
+        r.ty0 = __builtin_amdgcn_readfirstlane(r.ty0);
+        r.tx0 = __builtin_amdgcn_readfirstlane(r.tx0);
+        return r;
+    };
+    float4 pv[SX];
+    unsigned pok = 0;
+    float4 va = make_float4(1.f, 1.f, 1.f, 1.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto issue = [&](const Item& I) __attribute__((always_inline)) {
+        const int vy0 = I.ty0 - a.pad_t, vx0 = I.tx0 - a.pad_l;
+        const float* xn = uniform_ptr(a.x + (size_t)I.n * a.H * a.W * CIN);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, x_bytes, 0x00020000);
+        if (vy0 >= 0 && vx0 >= 0 && vy0 + PH <= a.H && vx0 + PW <= a.W) {
+            pok = 0xFFFFFFFFu;
+            const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)((vy0 * a.W + vx0) * CIN) * 4u);
+#pragma unroll
+            for (int i = 0; i < SX; ++i) pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, poffb[i], base, 0));
+        } else {
+            pok = 0;
+#pragma unroll
+            for (int i = 0; i < SX; ++i) {
+                const int sy = vy0 + (pq[i] >> 8), sx = vx0 + (pq[i] & 255);
+                const bool ok = pq[i] >= 0 && (unsigned)sy < (unsigned)a.H && (unsigned)sx < (unsigned)a.W;
+                pok |= ok ? (1u << i) : 0u;
+                pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)((sy * a.W + sx) * CIN + c4 * 4) * 4u : kOOB, 0, 0));
+            }
+        }
+        if (has_ab) {
+            va = *reinterpret_cast<const float4*>(a.in_a + (size_t)I.n * a.in_nstride + c4 * 4);
+            vb = *reinterpret_cast<const float4*>(a.in_b + (size_t)I.n * a.in_nstride + c4 * 4);
+        }
+    };
+    auto relu1 = [](float x) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        float r;
+        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+        return r;
+#else
+        return x > 0.f ? x : 0.f;
+#endif
+    };
+    auto commit_as = [&](auto MASKED) __attribute__((always_inline)) {
+        constexpr bool masked = decltype(MASKED)::value;
+#pragma unroll
+        for (int i = 0; i < SX; ++i) {
+            float v[4] = {pv[i].x, pv[i].y, pv[i].z, pv[i].w};
+            if (has_ab) {   // producer instance norm folded into the load; padding arrives as 0 and must stay 0
+                const unsigned okm = (!masked || ((pok >> i) & 1u)) ? 0xFFFFFFFFu : 0u;
+                v[0] = fmaf(v[0], va.x, __uint_as_float(__float_as_uint(vb.x) & okm));
+                v[1] = fmaf(v[1], va.y, __uint_as_float(__float_as_uint(vb.y) & okm));
+                v[2] = fmaf(v[2], va.z, __uint_as_float(__float_as_uint(vb.z) & okm));
+                v[3] = fmaf(v[3], va.w, __uint_as_float(__float_as_uint(vb.w) & okm));
+            }
+            if (in_relu) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = relu1(v[c]);
+            }
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cs_split(v[c], h[c], m[c], l[c]);
+            char* d = lds + pdst[i];
+            *reinterpret_cast<uint2*>(d) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
+            *reinterpret_cast<uint2*>(d + 16) = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
+            *reinterpret_cast<uint2*>(d + 32) = make_uint2((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u));
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+        if (pok >> 31)
+            commit_as(std::false_type{});
+        else
+            commit_as(std::true_type{});
+    };
+
+    cs_f32x4 acc[TH], acs[TH];   // the leading product / the five small ones, per tile row
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < TH; ++b) acc[b] = acs[b] = cs_f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+    // units in PAIRS (two tile rows of one k-step): their matrix instructions alternate, so that an instruction never waits for the result of the one in front
+    // of it (a 16-cycle v_mfma_f32_16x16x32_bf16 that accumulates into the register of its predecessor stalls for the predecessor's latency; with one wave per
+    // SIMD nothing else fills the gap)
+    auto sweep = [&]() __attribute__((always_inline)) {
+        static_assert(!(TH & 1), "tile rows in pairs");
+        cs_bf16x8 av[2][2][3];
+        auto rd = [&](int pr, int buf) __attribute__((always_inline)) {   // pair pr = (step pr / (TH/2), rows 2 (pr % (TH/2)), + 1)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    av[buf][k][pc] = __builtin_bit_cast(cs_bf16x8, *reinterpret_cast<const uint4*>(lds + laneA + xoff(pr / (TH / 2), 2 * (pr % (TH / 2)) + k, pc)));
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int pr = 0; pr < KST * TH / 2; ++pr) {
+            const int sI = pr / (TH / 2), b0 = 2 * (pr % (TH / 2)), b1 = b0 + 1, q = pr & 1;
+            if (pr + 1 < KST * TH / 2) rd(pr + 1, q ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // smallest first: h l, l h, m m, h m, m h into the small accumulators, h h into the leading ones
+            acs[b0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][2], av[q][0][0], acs[b0], 0, 0, 0);
+            acs[b1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][2], av[q][1][0], acs[b1], 0, 0, 0);
+            acs[b0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][0], av[q][0][2], acs[b0], 0, 0, 0);
+            acs[b1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][0], av[q][1][2], acs[b1], 0, 0, 0);
+            acs[b0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][1], av[q][0][1], acs[b0], 0, 0, 0);
+            acs[b1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][1], av[q][1][1], acs[b1], 0, 0, 0);
+            acs[b0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][1], av[q][0][0], acs[b0], 0, 0, 0);
+            acs[b1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][1], av[q][1][0], acs[b1], 0, 0, 0);
+            acs[b0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][0], av[q][0][1], acs[b0], 0, 0, 0);
+            acs[b1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][0], av[q][1][1], acs[b1], 0, 0, 0);
+            acc[b0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][0], av[q][0][0], acc[b0], 0, 0, 0);
+            acc[b1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][0], av[q][1][0], acc[b1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int b = 0; b < TH; ++b) acc[b] += acs[b];
+    };
+
+    // ---- epilogue of one item.  The filter is the matrix instruction's A operand (rows = channels), the pixels its B operand (columns): accumulator
+    // register r of tile row b, lane (m16, kg) = pixel (row b, column m16), channel 16 wave + 4 kg + r -- four consecutive channels of one pixel, ONE 16-byte
+    // store (a quarter of the store instructions of the pixel-major form: the epilogue's stores were issue-bound, and the next tile's loads queue behind them)
+    const unsigned y_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.Ho * a.Wo * COUT) * 4u);
+    auto epilogue = [&](const Item& I) __attribute__((always_inline)) {
+        const int th_valid = min(TH, a.Ho - I.ty0), tw_valid = min(kTW, a.Wo - I.tx0);
+        if (a.stats && !(FS_CS_ABL & 16)) {
+            // the wave owns its 16 channels over the whole tile: sums of (x - c), (x - c)^2 with c = the tile's first pixel, reduced over the 16 pixel columns
+            float cs[4], s1[4], s2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cs[r] = __shfl(acc[0][r], lane & 48);
+                s1[r] = 0.f;
+                s2[r] = 0.f;
+            }
+            const bool colok = m16 < tw_valid;
+#pragma unroll
+            for (int b = 0; b < TH; ++b) {
+                const bool ok = colok && b < th_valid;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d = ok ? acc[b][r] - cs[r] : 0.f;
+                    s1[r] += d;
+                    s2[r] = fmaf(d, d, s2[r]);
+                }
+            }
+#pragma unroll
+            for (int sh = 1; sh < 16; sh <<= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s1[r] += __shfl_xor(s1[r], sh);
+                    s2[r] += __shfl_xor(s2[r], sh);
+                }
+            if (m16 == 0) {
+                const float cb = (float)(th_valid * tw_valid);
+                float* st = a.stats + ((size_t)I.lin * COUT + 16 * wave + 4 * kg) * 3;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[3 * r + 0] = cs[r] + s1[r] / cb;
+                    st[3 * r + 1] = fmaxf(s2[r] - s1[r] * s1[r] / cb, 0.f);
+                    st[3 * r + 2] = cb;
+                }
+            }
+        }
+        float* yn = a.y + (size_t)I.n * a.Ho * a.Wo * COUT;
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(yn)), 0, y_bytes, 0x00020000);
+        const int lane_off = ((I.tx0 + m16) * COUT + 16 * wave + 4 * kg) * 4;
+        const bool colok = m16 < tw_valid;
+#pragma unroll
+        for (int b = 0; b < TH; ++b) {
+            const int row_off = (I.ty0 + b) * a.Wo * COUT * 4;
+            const bool ok = colok && b < th_valid;
+            if (!(FS_CS_ABL & 4) || acc[b][0] == 12345.678f)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fs_u32x4, acc[b]), yr, ok ? (unsigned)(lane_off + row_off) : kOOB, 0, 0);
+        }
+        zero_acc();
+    };
+
+    if (my_items == 0) return;
+#ifdef FS_R64X_TRACE
+    long long tr[7] = {0, 0, 0, 0, 0, 0, 0};
+    long long t0 = FS_R64X_NOW(), t1;
+#define FS_R64X_MARK(i) (t1 = FS_R64X_NOW(), tr[i] += t1 - t0, t0 = t1)
+#else
+#define FS_R64X_MARK(i) ((void)0)
+#endif
+    Item cur = decode(0);
+    issue(cur);
+    commit();
+    FS_TOUCH_F4(va);
+    FS_TOUCH_F4(vb);
+    __syncthreads();
+    FS_R64X_MARK(6);
+    for (int it = 0; it < my_items; ++it) {
+        const bool more = it + 1 < my_items;
+        Item nxt = cur;
+        if (more) {
+            nxt = decode(it + 1);
+            issue(nxt);
+        }
+        FS_R64X_MARK(0);
+        if (!(FS_CS_ABL & 1)) sweep();
+        FS_R64X_MARK(1);
+        FS_LDS_BARRIER();   // A: every wave is done reading the patch
+        FS_R64X_MARK(2);
+        if (more && !(FS_CS_ABL & 2)) commit();
+        FS_TOUCH_F4(va);
+        FS_TOUCH_F4(vb);
+        FS_R64X_MARK(3);
+        epilogue(cur);
+        FS_R64X_MARK(4);
+        FS_LDS_BARRIER();   // B: next patch visible; the stores drain during the next sweep
+        FS_R64X_MARK(5);
+        cur = nxt;
+    }
+#ifdef FS_R64X_TRACE
+    if (tid == 0 && blockIdx.x < 4096) {
+        for (int i = 0; i < 7; ++i) g_r64x_trace[blockIdx.x * 8 + i] = tr[i];
+        g_r64x_trace[blockIdx.x * 8 + 7] = my_items;
+    }
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------------------ host
 namespace {
 struct CsInst {
@@ -523,7 +843,8 @@ bool cstream_eligible(const ConvArgs& a) {
     // bit i enables instance i+1.  Instance 5 (residual convs on small grids) is OFF by default: measured +1 % at batch 4
     // (20 launches 0.68 -> 0.63 ms) for 509 registers, and it would make the kernel choice of the residual convs depend on the
     // batch size (the data-parallel identity grads(batch) = sum grads(sample) then only holds to rounding-order noise)
-    if (!((tune_int("FS_CSTREAM_MASK", 15) >> (inst - 1)) & 1)) return false;
+    const bool r64x = inst == 5 && (a.res_x6 || tune_int("FS_CSTREAM_R64X_ALL", 0)) && cstream_split_on() && !a.add_src && !a.fin.counter;   // the forward residual convs, split-bf16 direct form (conv_r64x_kernel)
+    if (!r64x && !((tune_int("FS_CSTREAM_MASK", 15) >> (inst - 1)) & 1)) return false;
     const bool plain = a.src_mode == SRC_PLAIN && a.dil_x <= 1 && !a.bias && !a.out_relu && !a.mask_src && !a.route_src &&
                        !a.pool_out && a.w_nstride == 0 && !a.w_wino && !a.w_wino2;
     if (!plain) return false;
@@ -553,6 +874,11 @@ void cstream_plan(const ConvArgs& a, ConvPlan* out) {
     p.S = a.Cin + 1;
     p.ksplit = 1;
     int patch_floats = (p.PH * p.PW * p.S + 4 + 3) & ~3;
+    if (inst == 5 && (a.res_x6 || tune_int("FS_CSTREAM_R64X_ALL", 0)) && cstream_split_on() && !a.add_src && !a.fin.counter) {   // conv_r64x_kernel: eight 8-channel planes of (pixels + 1) x 48 bytes, each rounded up to 256
+        p.S = 48;
+        patch_floats = 8 * ((((p.PH * p.PW + 1) * 48) + 255) & ~255) / 4;
+        p.flat = 1;
+    }
     if (inst >= 1 && inst <= 4 && cstream_split_on()) {   // the split-bf16 form (X6): [piece][Cin] bf16 + 16 bytes per pixel, row pitch 32 / 40 pixels, + the sink pixel
         p.S = 3 * a.Cin * 2 + 16;
         const int patch_b = (p.PH * (a.stride == 2 ? 40 : 32) + 1) * p.S;
@@ -581,6 +907,12 @@ int cstream_launch(const ConvArgs& a, hipStream_t s) {
             case 2: cs_launch<16, 1, 2, 32, 2, 1, true>(a, grid, s); break;
             case 3: cs_launch<8, 2, 1, 32, 3, 2, true>(a, grid, s); break;
             case 4: cs_launch<8, 4, 1, 64, 2, 1, true>(a, grid, s); break;
+            case 5: {
+                static BigLds lds_attr;
+                lds_attr.ensure(reinterpret_cast<const void*>(conv_r64x_kernel<8>));
+                hipLaunchKernelGGL((conv_r64x_kernel<8>), dim3(grid), dim3(256), (size_t)a.p.lds_bytes, s, a);
+                break;
+            }
             default: return -4;
         }
         return hipGetLastError() == hipSuccess ? 0 : -3;

@@ -120,6 +120,8 @@ struct ConvArgs {
                              // statistics records and workspace for that tiling), the remainder split in fs_wino2.hip.  Every launch site of fs_tnet.hip sets it
                              // together with prof_tag; the public fs_conv2d_fwd leaves both 0 (round 4 keyed the plan on prof_tag: a launch site that forgot the
                              // "profiler" tag planned another tile count than the layout had allocated for)
+    int res_x6;              // 1: a forward residual conv of the transform net that may take the split-bf16 direct kernel (conv_r64x_kernel, fs_cstream.hip) instead of
+                             // the fp32 Winograd one -- set by the layout (Unit::x6) at plan AND launch time
     FinArgs fin;             // fused instance-norm finalize (with stats; persistent kernels only)
     float* rem_ws;           // optional scratch for the remainder split of fs_wino2 (rem_ws_floats capacity): the items of the last,
     size_t rem_ws_floats;    // partial round of a persistent launch are split over the reduction dimension across ALL workgroups

@@ -32,6 +32,7 @@ struct Unit {
     int tiles;
     int wino;        // forward through a Winograd kernel: 1 wino(2)_conv_kernel (3x3 VALID residual convs on grids that fill the
                      // chip with 64-tile items), 2 wino2h_conv_kernel (half items: smaller grids, batch 4 per GPU), 3 wino4t_conv_kernel (F(4x4,3x3))
+    int x6;          // forward through the split-bf16 direct kernel (conv_r64x_kernel, round 6): the residual convs wherever the launch has enough 8 x 16-pixel tiles
     size_t wino_u;   // its transformed filter ([16][Cin][Cout]; 36 * Cin * Cout floats for 3) in the workspace
     ConvPlan plan;
     WgradPlan wplan;

@@ -106,6 +106,7 @@ static ConvArgs unit_args(const Unit& u, int N) {
     a.shuffle = u.kind == 1;
     a.prof_tag = 1;
     a.tnet_plan = 1;
+    a.res_x6 = u.x6;
     return a;
 }
 
@@ -246,7 +247,24 @@ void tnet_layout(int N, int H, int W, int deconv, TnetLayout* L) {
         // chip (720p / 1080p frames: 240-290 blocks per image); at 256x256 batch 4 they are 100 blocks for 256 CUs and
         // the direct kernel stays.  FS_TNET_WINO=0 disables, =2 forces (tests).
         u.wino = 0;
-        {
+        u.x6 = 0;
+        // (round 6) the residual convs as a direct convolution in six exact bf16-piece products (fs_cstream.hip: conv_r64x_kernel) where the fp32 Winograd
+        // kernel's 16 x 16-pixel items leave most of the chip idle -- batch 4 per GPU: 100 items on 256 CUs against 200 tiles of 8 x 16 pixels; measured
+        // (same lease, profiles/r06_ab_r64x_residual_forward.txt): batch 4 3.22 -> 3.20 ms per step.  Where the items fill the chip the Winograd kernel is
+        // ahead (batch 32: ten forward launches 0.75 against 0.88 ms; 720p 1215 against 1112 fps): per 8 x 16 tile the direct kernel's sweep is 15.7 k
+        // cycles at the full bf16 matrix rate, and issue + commit + epilogue add 10 k that one wave per SIMD cannot overlap (tools/r64x_trace.py).
+        // FS_TNET_RES_X6: 0 never, 1 (default) below FS_TNET_RES_X6_MAX_ITEMS Winograd items (129: less than half of the chip; a 720p frame has 240), 2 wherever the kernel takes the launch.
+        if (u.kind == 0 && i >= 3 && i <= 12 && tune_int("FS_TNET_RES_X6", 1)) {
+            const long w_items = (long)N * cdiv(u.Hc, 16) * cdiv(u.Wc, 16);
+            if (tune_int("FS_TNET_RES_X6", 1) == 2 || w_items < (long)tune_int("FS_TNET_RES_X6_MAX_ITEMS", 129)) {
+                a.res_x6 = 1;
+                a.stats = reinterpret_cast<float*>(16);
+                u.x6 = cstream_eligible(a) ? 1 : 0;
+                a.stats = nullptr;
+                a.res_x6 = u.x6;
+            }
+        }
+        if (!u.x6) {
             const int mode = L->wino_mode;
             a.w_wino = reinterpret_cast<const float*>(16);   // eligibility looks at the shapes only
             a.w_wino2 = a.w_wino;

@@ -26,6 +26,7 @@ CASES = {
     "first9x9_720p": (1, 800, 1360, 3, 16, 9, 1, "VALID"),
     "final9x9_720p": (1, 720, 1280, 16, 3, 9, 1, "SAME"),
     "res_720p": (1, 196, 336, 64, 64, 3, 1, "VALID"),
+    "res_b32": (32, 76, 76, 64, 64, 3, 1, "VALID"),
     # the narrow layers of the transform net at the metric's batch (32 x 256x256)
     "t_first_n32": (32, 344, 344, 3, 16, 9, 1, "VALID"),
     "t_s2a_n32": (32, 336, 336, 16, 32, 3, 2, "SAME"),
@@ -47,7 +48,7 @@ def main():
             w.zero_()
         kw = {"want_stats": True} if os.environ.get("STATS") else {}
         if os.environ.get("WINO"):            # eligible 3x3 convs through the Winograd kernel
-            kw["winograd"] = True
+            kw["winograd"] = {"4t": "4t", "4": 4, "6": 6}.get(os.environ["WINO"], True)
         y = e.conv2d(x, w, s, pad, **kw)
         torch.cuda.synchronize()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
