@@ -295,13 +295,17 @@ static ConvArgs w6_half(const ConvArgs& a, int h) {   // samples [h N/2, (h + 1)
 }
 
 int W6Chains::launch(const ConvArgs& a) {
-    FS_TRY(begin());
+    ConvArgs hb[2];
     for (int h = 0; h < 2; ++h) {
-        ConvArgs b = w6_half(a, h);
-        b.p = conv_plan(b);
-        if (b.p.variant != 12) return -7;
-        FS_TRY(conv_launch(b, h ? aux->side : s));
+        hb[h] = w6_half(a, h);
+        hb[h].p = conv_plan(hb[h]);
     }
+    if (hb[0].p.variant != 12 || hb[1].p.variant != 12) {   // (a half the pipeline does not take -- knobs that disagree: FS_WINO6_CHAIN_MINTILES below FS_WINO6_MINTILES): the whole launch on the caller's stream
+        FS_TRY(end());
+        return conv_launch(a, s);
+    }
+    FS_TRY(begin());
+    for (int h = 0; h < 2; ++h) FS_TRY(conv_launch(hb[h], h ? aux->side : s));
     return 0;
 }
 
