@@ -265,11 +265,11 @@ def fam_table(prof, steps, names):
                 tab[nm]["frac_note"] = "fp32-EQUIVALENT products executed / the fp32 MFMA peak (157.3); the launch issues 6 bf16 products per fp32 one"
                 tab[nm]["bf16_tflops_issued"] = round(6 * tf, 1)
                 tab[nm]["frac_of_bf16_mfma_peak_issued"] = round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4)
-            if nm in ("conv_s16_kernel", "conv_stream_kernel"):   # round 6: the launches of these rows run as split-bf16 kernels unless FS_S16_SPLIT / FS_CSTREAM_SPLIT = 0
-                split = os.environ.get("FS_S16_SPLIT" if nm == "conv_s16_kernel" else "FS_CSTREAM_SPLIT", "1") != "0"
+            if nm in ("conv_s16_kernel", "conv_stream_kernel", "gram_stream_kernel"):   # round 6: the launches of these rows run as split-bf16 kernels unless FS_S16_SPLIT / FS_CSTREAM_SPLIT / FS_GRAM_SPLIT = 0
+                split = os.environ.get({"conv_s16_kernel": "FS_S16_SPLIT", "conv_stream_kernel": "FS_CSTREAM_SPLIT"}.get(nm, "FS_GRAM_SPLIT"), "1") != "0"
                 if split:
                     tab[nm]["frac_note"] = ("fp32-EQUIVALENT FLOPs / the fp32 MFMA peak (157.3): the launches of this row issue their products as six exact bf16 pieces "
-                                            "on the bf16 matrix cores (conv_s16x / conv_s16c3x / conv_stream X6 / conv_r64x; VGG16 conv1_1 in the conv_s16 row stays fp32)")
+                                            "on the bf16 matrix cores (conv_s16x / conv_s16c3x / conv_stream X6 / conv_r64x / gram_streamx; VGG16 conv1_1 in the conv_s16 row and the 64-channel Gram stay fp32)")
     return tab
 
 

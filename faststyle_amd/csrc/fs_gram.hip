@@ -217,6 +217,202 @@ __global__ __launch_bounds__(256, 2) void gram_stream_kernel(GramArgs a) {   // 
     }
 }
 
+// Round 6: the 128-channel tiles in six exact bf16-piece products (the arithmetic of fs_wino6.hip / conv_s16x_kernel).  v_mfma_f32_32x32x16_bf16 takes its 8
+// k values per lane from consecutive PIXELS of one channel, the feature map is pixel-major: the commit TRANSPOSES on the way into LDS -- a thread loads 8
+// consecutive pixels x 4 channels (eight 16-byte loads, the channel quad of a lane is contiguous across lanes), splits the 32 values and writes, per channel
+// and piece, 8 pixels = one 16-byte LDS store into [piece][channel][32 pixels] (row pitch 80 bytes: 5 slots of 16, odd -- the 16 channels of a
+// ds_read_b128 lane group fall on 16 distinct slots).  32-pixel tiles (two k-steps between barriers; 61 KB for both operands: two workgroups per CU), threads
+// 0..127 stage the row group, 128..255 the column group.  The six products of a step accumulate smallest-first in ONE accumulator per block (64 + 60 fragment
+// registers leave no room for a second set under 256).
+typedef __bf16 gs_bf16x8 __attribute__((ext_vector_type(8)));
+__host__ __device__ __forceinline__ void gs_split(float x, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    h = u & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, h);
+    m = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, m);
+    l = __builtin_bit_cast(unsigned, r2);
+}
+__global__ __launch_bounds__(256, 2) void gram_streamx_kernel(GramArgs a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    char* const lds = reinterpret_cast<char*>(smem);
+    constexpr int CG = 128, TP = 32;                       // channels per group, pixels per staged tile
+    constexpr int RB = TP * 2 + 16;                        // bytes per channel row of a piece plane
+    constexpr int PLB = CG * RB;                           // one piece plane: 10240 bytes
+    constexpr int OPB = 3 * PLB;                           // one operand: 30720 bytes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 31, kq = lane >> 5;
+
+    int lin = (int)blockIdx.x;
+    const int split = lin % a.splits;
+    lin /= a.splits;
+    int pair = lin % a.pairs;
+    const int n = lin / a.pairs;
+    int I = 0;
+    while (pair >= a.groups - I) {
+        pair -= a.groups - I;
+        ++I;
+    }
+    const int J = I + pair;
+    const bool diag = I == J;
+    const int p0 = (int)((long long)a.HW * split / a.splits), p1 = (int)((long long)a.HW * (split + 1) / a.splits);
+
+    int ib[4], jb[4], nb;
+    if (!diag) {
+        nb = 4;
+        for (int k = 0; k < 4; ++k) {
+            ib[k] = wave;
+            jb[k] = k;
+        }
+    } else {
+        constexpr unsigned TI = (1u << 8) | (1u << 10) | (1u << 12) | (2u << 14) | (2u << 16) | (3u << 18);
+        constexpr unsigned TJ = (1u << 2) | (2u << 4) | (3u << 6) | (1u << 8) | (2u << 10) | (3u << 12) | (2u << 14) | (3u << 16) | (3u << 18);
+        const int beg = wave == 0 ? 0 : (wave == 1 ? 3 : (wave == 2 ? 6 : 8));
+        nb = wave < 2 ? 3 : 2;
+        for (int k = 0; k < 4; ++k) {
+            const int kk = k < nb ? k : 0;
+            ib[k] = (int)((TI >> (2 * (beg + kk))) & 3u);
+            jb[k] = (int)((TJ >> (2 * (beg + kk))) & 3u);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ib[k] = __builtin_amdgcn_readfirstlane(ib[k]);
+        jb[k] = __builtin_amdgcn_readfirstlane(jb[k]);
+    }
+    nb = __builtin_amdgcn_readfirstlane(nb);
+
+    // ---- staging: thread (operand op = tid >> 7, pixel octet o = (tid >> 5) & 3, channel quad c4 = tid & 31) loads pixels 8 o .. + 7, channels 4 c4 .. + 3
+    const unsigned f_bytes = __builtin_amdgcn_readfirstlane((unsigned)((size_t)a.HW * a.C * 4));
+    const float* Fn = a.F + (size_t)n * a.HW * a.C;
+    {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(Fn);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        Fn = reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    }
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Fn), 0, f_bytes, 0x00020000);
+    const int op = tid >> 7, oct = (tid >> 5) & 3, c4 = tid & 31;
+    const bool stager = op == 0 || !diag;                  // (on the diagonal one staged tile serves both operands)
+    const unsigned colb = (unsigned)(((op ? J : I) * CG + c4 * 4) * 4);
+    const int wdst = op * OPB + (c4 * 4) * RB + oct * 16;   // + e RB (channel) + piece PLB
+    float4 pv[8];
+    auto issue = [&](int pbase) {   // pixels [pbase, pbase + 32) of the range; beyond p1: zeros (out-of-range offset)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int px = pbase + oct * 8 + i;
+            const bool ok = stager && px < p1;
+            pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(fr, ok ? (unsigned)px * (unsigned)a.C * 4u + colb : kOOB, 0, 0));
+        }
+    };
+    auto commit = [&]() {
+        if (!stager) return;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned h[8], m[8], l[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v = e == 0 ? pv[i].x : (e == 1 ? pv[i].y : (e == 2 ? pv[i].z : pv[i].w));
+                gs_split(v, h[i], m[i], l[i]);
+            }
+            char* d = lds + wdst + e * RB;
+            *reinterpret_cast<uint4*>(d) = make_uint4((h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]);
+            *reinterpret_cast<uint4*>(d + PLB) = make_uint4((m[0] >> 16) | m[1], (m[2] >> 16) | m[3], (m[4] >> 16) | m[5], (m[6] >> 16) | m[7]);
+            *reinterpret_cast<uint4*>(d + 2 * PLB) = make_uint4((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u), (l[4] >> 16) | (l[5] & 0xffff0000u),
+                                                                (l[6] >> 16) | (l[7] & 0xffff0000u));
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    const int boff = diag ? 0 : OPB;
+    int oa[4], ob[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        oa[k] = (ib[k] * 32 + lm) * RB + kq * 16;
+        ob[k] = boff + (jb[k] * 32 + lm) * RB + kq * 16;
+    }
+    auto sweep = [&](auto NBKT, auto SHAREA) {
+        constexpr int NBK = decltype(NBKT)::value;
+        constexpr bool shareA = decltype(SHAREA)::value;   // off the diagonal the wave's four blocks have ONE row block: its fragments are read once
+        constexpr int NA = shareA ? 1 : NBK;
+#pragma unroll
+        for (int j = 0; j < TP / 16; ++j) {
+            gs_bf16x8 av[NA][3], bv[NBK][3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+                for (int k = 0; k < NA; ++k) av[k][pc] = __builtin_bit_cast(gs_bf16x8, *reinterpret_cast<const uint4*>(lds + oa[k] + pc * PLB + j * 32));
+#pragma unroll
+                for (int k = 0; k < NBK; ++k) bv[k][pc] = __builtin_bit_cast(gs_bf16x8, *reinterpret_cast<const uint4*>(lds + ob[k] + pc * PLB + j * 32));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the six products, smallest first, block after block inside a product: consecutive matrix instructions never share an accumulator
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+                for (int k = 0; k < NBK; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[shareA ? 0 : k][PA[t]], bv[k][PB[t]], acc[k], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int ntiles = (p1 - p0 + TP - 1) / TP;
+    if (ntiles > 0) {
+        issue(p0);
+        commit();
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            const bool more = t + 1 < ntiles;
+            if (more) issue(p0 + (t + 1) * TP);
+            if (diag)
+                sweep(std::integral_constant<int, 3>{}, std::false_type{});
+            else
+                sweep(std::integral_constant<int, 4>{}, std::true_type{});
+            __syncthreads();   // every wave is done reading the stage
+            if (more) commit();
+            __syncthreads();
+        }
+    }
+    // A 32 x 32 block ON the diagonal holds both of its halves, computed separately -- and in the split arithmetic element (i, j) and element (j, i) add the
+    // same six products in different orders (h l <-> l h, h m <-> m h): equal to rounding, not bit for bit as with ONE fp32 product.  The lower triangle takes
+    // the upper one's values (through LDS, free after the last sweep; every wave of a diagonal tile owns exactly one such block): G stays exactly symmetric.
+    if (diag) {
+        float* const tr = smem + wave * (32 * 33);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nb && ib[k] == jb[k]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * kq) * 33 + lm] = acc[k][r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nb && ib[k] == jb[k]) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * kq;
+                    const float t = tr[lm * 33 + i];
+                    acc[k][r] = i <= lm ? acc[k][r] : t;
+                }
+            }
+    }
+    float* slab = a.slabs + (size_t)blockIdx.x * CG * CG;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k >= nb) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = ib[k] * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+            slab[row * CG + jb[k] * 32 + lm] = acc[k][r];
+        }
+    }
+}
+
 // G[n][(I*CG + r)*C + J*CG + c] = scale * sum over the pixel ranges, and its mirror image.  grid (CG*CG/1024, pairs, N); a thread
 // owns 4 consecutive columns of one row.  On a diagonal tile the blocks below the diagonal were never multiplied: their
 // elements arrive as the mirror of the blocks above.
@@ -790,6 +986,8 @@ static int gram2_stream_impl(const GramArgs& a, int N, int HW, hipStream_t s) {
         static BigLds lds_attr;
         lds_attr.ensure(reinterpret_cast<const void*>(gram_stream_kernel<64>));
         hipLaunchKernelGGL(gram_stream_kernel<64>, dim3((unsigned)(N * a.pairs * a.splits)), dim3(256), lds, s, a);
+    } else if (tune_int("FS_GRAM_SPLIT", 1)) {   // six exact bf16-piece products (gram_streamx_kernel): two operands x three piece planes of 128 channels x 80 bytes
+        hipLaunchKernelGGL(gram_streamx_kernel, dim3((unsigned)(N * a.pairs * a.splits)), dim3(256), (size_t)(2 * 3 * 128 * 80), s, a);
     } else {
         static BigLds lds_attr;
         lds_attr.ensure(reinterpret_cast<const void*>(gram_stream_kernel<128>));
