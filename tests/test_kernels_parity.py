@@ -852,3 +852,28 @@ def test_loss_value_and_gradient_named_exports(eng):
     base = rng.standard_normal(img.shape).astype(np.float32)
     _, g2 = eng.loss_tv_grad(up(eng, img), 1e-4, grad=up(eng, base))          # accumulate: train.py:184's beta * tv on top of an existing gradient
     assert np.abs(down(eng, g2) - (base + 1e-4 * dtv)).max() < 1e-5
+
+
+def test_split_bf16_direct_kernels_are_taken_and_no_less_accurate(eng, knob):
+    """Round 6: the 9x9 image layer (conv_s16c3x_kernel) and the 128-channel Gram tiles (gram_streamx_kernel) multiply on the bf16 matrix cores as six exact
+    products of bf16 pieces (x = h + m + l exactly; fp32 accumulation).  Against the float64 oracle each must stay inside the fp32 kernels' tolerance AND be no
+    less accurate than the fp32 matrix instruction it replaces (measured: 1.8e-7 against 6.6e-7 of the output's magnitude for the conv); the two results differ
+    bit-wise -- the knob really selects another kernel -- and the Gram matrix stays exactly symmetric (diagonal blocks mirror their upper triangle)."""
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, 255, (1, 152, 152, 3)).astype(np.float32)
+    w = (rng.standard_normal((9, 9, 3, 16)) * 0.1).astype(np.float32)
+    want = nnops.conv2d(x.astype(np.float64), w.astype(np.float64), 1, "VALID")
+    f = rng.standard_normal((2, 40, 37, 256)).astype(np.float32)
+    gwant = perceptual.gram(f.astype(np.float64))
+    knob("FS_GRAM2_MIN_TILES", 0)
+    res = {}
+    for split in (1, 0):
+        knob("FS_S16_SPLIT", split)
+        knob("FS_GRAM_SPLIT", split)
+        y = down(eng, eng.conv2d(up(eng, x), up(eng, w), 1, "VALID"))      # 81 tiles of 16 x 16: the streaming 16-channel kernel takes it
+        g = down(eng, eng.gram(up(eng, f)))
+        assert np.array_equal(g, g.transpose(0, 2, 1))
+        res[split] = (y, rel(y, want), g, rel(g, gwant))
+    assert res[1][1] < TOL and res[0][1] < TOL and res[1][3] < TOL and res[0][3] < TOL
+    assert not np.array_equal(res[1][0], res[0][0]) and not np.array_equal(res[1][2], res[0][2])
+    assert res[1][1] <= 1.05 * res[0][1] and res[1][3] <= 1.05 * res[0][3], (res[1][1], res[0][1], res[1][3], res[0][3])
