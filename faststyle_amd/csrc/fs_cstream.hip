@@ -15,6 +15,7 @@
 #include "fs_kernels.h"
 
 #include <type_traits>
+#include <utility>
 
 namespace fs {
 
@@ -816,6 +817,330 @@ __global__ __launch_bounds__(256) void conv_r64x_kernel(ConvArgs a) {
 #endif
 }
 
+// AFF: the producer's instance norm + ReLU on load (a.in_a / a.in_b / a.in_relu all set) -- a template parameter: the sweep that carries the commit is ONE basic block
+// fn(integral_constant<BEG>, ..., integral_constant<BEG + N - 1>)
+template <int BEG, class F, int... J>
+__host__ __device__ __forceinline__ void cs_seq_impl(F& fn, std::integer_sequence<int, J...>) {
+    fn(std::integral_constant<int, BEG + J>{}...);
+}
+template <int BEG, int N, class F>
+__host__ __device__ __forceinline__ void cs_seq(F& fn) {
+    cs_seq_impl<BEG>(fn, std::make_integer_sequence<int, N>{});
+}
+template <int TH, bool AFF>
+__global__ __launch_bounds__(256) void conv_r64p_kernel(ConvArgs a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    char* const lds = reinterpret_cast<char*>(smem);
+    const ConvPlan& p = a.p;
+    constexpr int CIN = 64, COUT = 64, KS = 3;
+    constexpr int PH = TH + KS - 1, PW = kTW + KS - 1, NPX = PH * PW;
+    constexpr int GPB = ((NPX + 1) * 48 + 255) & ~255;   // one 8-channel plane (+ the sink pixel)
+    constexpr int KST = KS * KS * CIN / 32;              // 32-k steps
+    constexpr int SX = (NPX * 16 + 255) / 256;           // 16-byte patch loads per thread and tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m16 = lane & 15, kg = lane >> 4;
+    auto fdiv = [](int x, float inv_d) __attribute__((always_inline)) { return (int)(((float)x + 0.5f) * inv_d); };
+    auto uniform_ptr = [](const float* ptr) __attribute__((always_inline)) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+    };
+
+    // ---- the wave's filter slice, once, into registers: lane (channel 16 wave + m16, kg) holds k = 8 kg .. + 7 of step sI = (tap sI / 2, ci 32 (sI & 1) + 8 kg ..)
+    cs_bf16x8 bx[KST][3];
+#pragma unroll
+    for (int sI = 0; sI < KST; ++sI) {
+        unsigned hh[8], mm[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs_split(a.w[((sI >> 1) * CIN + 32 * (sI & 1) + 8 * kg + e) * COUT + 16 * wave + m16], hh[e], mm[e], ll[e]);
+        bx[sI][0] = __builtin_bit_cast(cs_bf16x8, make_uint4((hh[0] >> 16) | hh[1], (hh[2] >> 16) | hh[3], (hh[4] >> 16) | hh[5], (hh[6] >> 16) | hh[7]));
+        bx[sI][1] = __builtin_bit_cast(cs_bf16x8, make_uint4((mm[0] >> 16) | mm[1], (mm[2] >> 16) | mm[3], (mm[4] >> 16) | mm[5], (mm[6] >> 16) | mm[7]));
+        bx[sI][2] = __builtin_bit_cast(cs_bf16x8, make_uint4((ll[0] >> 16) | (ll[1] & 0xffff0000u), (ll[2] >> 16) | (ll[3] & 0xffff0000u), (ll[4] >> 16) | (ll[5] & 0xffff0000u),
+                                                             (ll[6] >> 16) | (ll[7] & 0xffff0000u)));
+    }
+    const int laneA = kg * GPB + m16 * 48;
+    auto xoff = [](int sI, int b, int pc) __attribute__((always_inline)) {   // compile-time byte offset of step sI, tile row b, piece pc
+        const int tap = sI >> 1, kh = tap / KS, kw = tap % KS;
+        return 4 * (sI & 1) * GPB + ((b + kh) * PW + kw) * 48 + pc * 16;
+    };
+
+    // ---- staging descriptors (tile-invariant): element e = tid + i*256 is channel quad c4 of patch pixel e / 16
+    const int c4 = tid & 15;
+    int pq[SX], pdst[SX];
+    unsigned poffb[SX];
+#pragma unroll
+    for (int i = 0; i < SX; ++i) {
+        const int e = tid + i * 256;
+        pq[i] = -1;
+        pdst[i] = (c4 >> 1) * GPB + NPX * 48 + (c4 & 1) * 8;   // the sink pixel
+        poffb[i] = kOOB;
+        if (e < NPX * 16) {
+            const int pix = e >> 4;
+            const int py = fdiv(pix, 1.0f / (float)PW), px = pix - py * PW;
+            pq[i] = (py << 8) | px;
+            pdst[i] = (c4 >> 1) * GPB + pix * 48 + (c4 & 1) * 8;
+            poffb[i] = (unsigned)((py * a.W + px) * CIN + c4 * 4) * 4u;
+        }
+    }
+    const unsigned x_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.H * a.W * CIN) * 4u);
+    constexpr bool has_ab = AFF, in_relu = AFF;
+
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int total = a.N * tiles;
+    const int GX = (int)gridDim.x;
+    const int my_items = ((int)blockIdx.x < total) ? (total - 1 - (int)blockIdx.x) / GX + 1 : 0;
+    const float inv_tiles = 1.0f / (float)tiles, inv_tx = 1.0f / (float)p.tiles_x;
+    struct Item {
+        int n, ty0, tx0, lin;
+    };
+    auto decode = [&](int it) __attribute__((always_inline)) {
+        Item r;
+        r.lin = (int)blockIdx.x + it * GX;
+        r.n = fdiv(r.lin, inv_tiles);
+        const int tr = r.lin - r.n * tiles;
+        const int tyi = fdiv(tr, inv_tx);
+        r.ty0 = tyi * TH;
+        r.tx0 = (tr - tyi * p.tiles_x) * kTW;
+        r.lin = __builtin_amdgcn_readfirstlane(r.lin);
+        r.n = __builtin_amdgcn_readfirstlane(r.n);
+        r.ty0 = __builtin_amdgcn_readfirstlane(r.ty0);
+        r.tx0 = __builtin_amdgcn_readfirstlane(r.tx0);
+        return r;
+    };
+    // ---- the pipeline (VALID convs only: a patch never needs padding; columns / rows beyond the image read the next row / zeros beyond the sample and only
+    // feed outputs that are neither stored nor counted).  TWO patch buffers: while tile t is multiplied out of buffer t & 1, the loads of tile t + 1 go out
+    // (one per pair of the sweep's first twelve pairs), and their commit -- affine + ReLU, split, three 8-byte stores per 16-byte load -- is threaded between the
+    // matrix instructions of the sweep's second half into the other buffer: a 16-cycle v_mfma_f32_16x16x32_bf16 leaves three issue slots to the SAME wave, and
+    // this kernel has one wave per SIMD (the serial commit was 4.0 k cycles per tile beside 15.7 k of matrix instructions, the issue phase 1.9 k)
+    constexpr int PATCHB = 8 * GPB;
+    float4 pv[SX];
+    float4 va = make_float4(1.f, 1.f, 1.f, 1.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
+    struct Nxt {
+        __amdgpu_buffer_rsrc_t xr;
+        unsigned base;
+        const float *pa, *pb;
+    };
+    auto next_of = [&](const Item& I, int live) __attribute__((always_inline)) {
+        Nxt q;
+        const float* xn = uniform_ptr(a.x + (size_t)I.n * a.H * a.W * CIN);
+        q.xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xn), 0, live ? x_bytes : 0u, 0x00020000);
+        q.base = __builtin_amdgcn_readfirstlane((unsigned)((I.ty0 * a.W + I.tx0) * CIN) * 4u);
+        q.pa = has_ab ? a.in_a + (size_t)I.n * a.in_nstride + c4 * 4 : a.x;
+        q.pb = has_ab ? a.in_b + (size_t)I.n * a.in_nstride + c4 * 4 : a.x;
+        return q;
+    };
+    // (an element past the sample's last byte -- the rows of a ragged bottom tile -- is dropped through the out-of-range offset, as everywhere in this library:
+    // the hardware's range check would return the same zeros, the emulator insists on the marker)
+    auto load_one = [&](const Nxt& q, int i) __attribute__((always_inline)) {
+        const unsigned vo = poffb[i] != kOOB && poffb[i] + q.base + 16u <= x_bytes ? poffb[i] : kOOB;
+        pv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(q.xr, vo, q.base, 0));
+    };
+    auto relu1 = [](float x) __attribute__((always_inline)) {   // ONE v_max_i32 on the bit pattern (negative floats are negative integers); no inline assembly inside the unrolled sweep
+        const int b = __builtin_bit_cast(int, x);
+        return __builtin_bit_cast(float, b > 0 ? b : 0);
+    };
+    // the commit of element i in three steps of <= 12 vector instructions
+    unsigned cw[3];
+    auto commit_a = [&](int i) __attribute__((always_inline)) {
+        float4& v = pv[i];
+        if constexpr (has_ab) {
+            v.x = fmaf(v.x, va.x, vb.x);
+            v.y = fmaf(v.y, va.y, vb.y);
+            v.z = fmaf(v.z, va.z, vb.z);
+            v.w = fmaf(v.w, va.w, vb.w);
+        }
+        if constexpr (in_relu) {
+            v.x = relu1(v.x);
+            v.y = relu1(v.y);
+            v.z = relu1(v.z);
+            v.w = relu1(v.w);
+        }
+    };
+    auto commit_b = [&](int i) __attribute__((always_inline)) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        cs_split(pv[i].x, h0, m0, l0);
+        cs_split(pv[i].y, h1, m1, l1);
+        cw[0] = (h0 >> 16) | h1;
+        cw[1] = (m0 >> 16) | m1;
+        cw[2] = (l0 >> 16) | (l1 & 0xffff0000u);
+    };
+    auto commit_c = [&](int i, int wbuf) __attribute__((always_inline)) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        cs_split(pv[i].z, h0, m0, l0);
+        cs_split(pv[i].w, h1, m1, l1);
+        char* d = lds + wbuf + pdst[i];
+        *reinterpret_cast<uint2*>(d) = make_uint2(cw[0], (h0 >> 16) | h1);
+        *reinterpret_cast<uint2*>(d + 16) = make_uint2(cw[1], (m0 >> 16) | m1);
+        *reinterpret_cast<uint2*>(d + 32) = make_uint2(cw[2], (l0 >> 16) | (l1 & 0xffff0000u));
+    };
+
+    cs_f32x4 acc[TH], acs[TH];   // the leading product / the five small ones, per tile row
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < TH; ++b) acc[b] = acs[b] = cs_f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+    // units in PAIRS (two tile rows of one k-step): their matrix instructions alternate, so that an instruction never waits for the result of the one in front
+    // of it; per pair: its 12 matrix instructions, the 6 operand reads of the NEXT pair, and one piece of the next tile's staging
+    auto sweep = [&](int rbuf, int wbuf, const Nxt& q) __attribute__((always_inline)) {
+        static_assert(!(TH & 1), "tile rows in pairs");
+        constexpr int NP = KST * TH / 2;
+        static_assert(NP >= 36 + 3 * SX && SX <= 12, "the staging pieces fit the sweep");
+        const int ra = laneA + rbuf;
+        cs_bf16x8 av[2][2][3];
+        auto rd = [&](int pr, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    av[buf][k][pc] = __builtin_bit_cast(cs_bf16x8, *reinterpret_cast<const uint4*>(lds + ra + xoff(pr / (TH / 2), 2 * (pr % (TH / 2)) + k, pc)));
+        };
+        rd(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // one pair: the next pair's operand reads, `extra` (a piece of the next tile's staging), the 12 matrix instructions, and the order the scheduler is asked for
+        auto pair = [&](auto PR, auto extra) __attribute__((always_inline)) {
+            constexpr int pr = decltype(PR)::value;
+            constexpr int sI = pr / (TH / 2), b0 = 2 * (pr % (TH / 2)), b1 = b0 + 1, qq = pr & 1;
+            if constexpr (pr + 1 < NP) rd(pr + 1, qq ^ 1);
+            extra();
+            acs[b0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][2], av[qq][0][0], acs[b0], 0, 0, 0);
+            acs[b1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][2], av[qq][1][0], acs[b1], 0, 0, 0);
+            acs[b0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][0], av[qq][0][2], acs[b0], 0, 0, 0);
+            acs[b1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][0], av[qq][1][2], acs[b1], 0, 0, 0);
+            acs[b0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][1], av[qq][0][1], acs[b0], 0, 0, 0);
+            acs[b1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][1], av[qq][1][1], acs[b1], 0, 0, 0);
+            acs[b0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][1], av[qq][0][0], acs[b0], 0, 0, 0);
+            acs[b1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][1], av[qq][1][0], acs[b1], 0, 0, 0);
+            acs[b0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][0], av[qq][0][1], acs[b0], 0, 0, 0);
+            acs[b1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][0], av[qq][1][1], acs[b1], 0, 0, 0);
+            acc[b0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][0], av[qq][0][0], acc[b0], 0, 0, 0);
+            acc[b1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[sI][0], av[qq][1][0], acc[b1], 0, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // one matrix instruction
+                if (g < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // an operand read of the next pair
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);              // a vector-ALU instruction of the commit
+                if (g == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // the pair's global load
+                if (g >= 9) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // an LDS store of the commit
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // (compile-time pair indices through index sequences: a rolled loop over 72 pairs with every staging variant in its body exceeds the full-unroll budget)
+        auto nothing = []() __attribute__((always_inline)) {};
+        auto run_loads = [&](auto... I) __attribute__((always_inline)) { (pair(std::integral_constant<int, decltype(I)::value>{}, [&]() __attribute__((always_inline)) { load_one(q, decltype(I)::value); }), ...); };
+        auto run_plain = [&](auto... I) __attribute__((always_inline)) { (pair(I, nothing), ...); };
+        auto run_commit = [&](auto... I) __attribute__((always_inline)) {
+            (pair(I, [&]() __attribute__((always_inline)) {
+                 constexpr int kk = decltype(I)::value - (NP - 3 * SX), ci = kk / 3, sub = kk % 3;
+                 if constexpr (sub == 0) commit_a(ci);
+                 else if constexpr (sub == 1) commit_b(ci);
+                 else commit_c(ci, wbuf);
+             }),
+             ...);
+        };
+        cs_seq<0, SX>(run_loads);
+        pair(std::integral_constant<int, SX>{}, [&]() __attribute__((always_inline)) {
+            if constexpr (has_ab) va = *reinterpret_cast<const float4*>(q.pa);
+        });
+        pair(std::integral_constant<int, SX + 1>{}, [&]() __attribute__((always_inline)) {
+            if constexpr (has_ab) vb = *reinterpret_cast<const float4*>(q.pb);
+        });
+        cs_seq<SX + 2, NP - 3 * SX - SX - 2>(run_plain);
+        cs_seq<NP - 3 * SX, 3 * SX>(run_commit);
+#pragma unroll
+        for (int b = 0; b < TH; ++b) acc[b] += acs[b];
+    };
+
+    // ---- epilogue of one item.  The filter is the matrix instruction's A operand (rows = channels), the pixels its B operand (columns): accumulator
+    // register r of tile row b, lane (m16, kg) = pixel (row b, column m16), channel 16 wave + 4 kg + r -- four consecutive channels of one pixel, ONE 16-byte
+    // store (a quarter of the store instructions of the pixel-major form: the epilogue's stores were issue-bound, and the next tile's loads queue behind them)
+    const unsigned y_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.Ho * a.Wo * COUT) * 4u);
+    auto epilogue = [&](const Item& I) __attribute__((always_inline)) {
+        const int th_valid = min(TH, a.Ho - I.ty0), tw_valid = min(kTW, a.Wo - I.tx0);
+        if (a.stats) {
+            // the wave owns its 16 channels over the whole tile: sums of (x - c), (x - c)^2 with c = the tile's first pixel, reduced over the 16 pixel columns
+            float cs[4], s1[4], s2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cs[r] = __shfl(acc[0][r], lane & 48);
+                s1[r] = 0.f;
+                s2[r] = 0.f;
+            }
+            const bool colok = m16 < tw_valid;
+#pragma unroll
+            for (int b = 0; b < TH; ++b) {
+                const bool ok = colok && b < th_valid;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d = ok ? acc[b][r] - cs[r] : 0.f;
+                    s1[r] += d;
+                    s2[r] = fmaf(d, d, s2[r]);
+                }
+            }
+#pragma unroll
+            for (int sh = 1; sh < 16; sh <<= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s1[r] += __shfl_xor(s1[r], sh);
+                    s2[r] += __shfl_xor(s2[r], sh);
+                }
+            if (m16 == 0) {
+                const float cb = (float)(th_valid * tw_valid);
+                float* st = a.stats + ((size_t)I.lin * COUT + 16 * wave + 4 * kg) * 3;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[3 * r + 0] = cs[r] + s1[r] / cb;
+                    st[3 * r + 1] = fmaxf(s2[r] - s1[r] * s1[r] / cb, 0.f);
+                    st[3 * r + 2] = cb;
+                }
+            }
+        }
+        float* yn = a.y + (size_t)I.n * a.Ho * a.Wo * COUT;
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(yn)), 0, y_bytes, 0x00020000);
+        const int lane_off = ((I.tx0 + m16) * COUT + 16 * wave + 4 * kg) * 4;
+        const bool colok = m16 < tw_valid;
+#pragma unroll
+        for (int b = 0; b < TH; ++b) {
+            const int row_off = (I.ty0 + b) * a.Wo * COUT * 4;
+            const bool ok = colok && b < th_valid;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(fs_u32x4, acc[b]), yr, ok ? (unsigned)(lane_off + row_off) : kOOB, 0, 0);
+        }
+        zero_acc();
+    };
+
+    if (my_items == 0) return;
+    Item cur = decode(0);
+    {   // the first tile: loads, wait, serial commit into buffer 0
+        const Nxt q0 = next_of(cur, 1);
+#pragma unroll
+        for (int i = 0; i < SX; ++i) load_one(q0, i);
+        if constexpr (has_ab) {
+            va = *reinterpret_cast<const float4*>(q0.pa);
+            vb = *reinterpret_cast<const float4*>(q0.pb);
+        }
+#pragma unroll
+        for (int i = 0; i < SX; ++i) {
+            commit_a(i);
+            commit_b(i);
+            commit_c(i, 0);
+        }
+    }
+    __syncthreads();
+    for (int it = 0; it < my_items; ++it) {
+        const int live = it + 1 < my_items;
+        const Item nxt = live ? decode(it + 1) : cur;
+        const Nxt q = next_of(nxt, live);   // (no next tile: every load against an empty buffer -- zeros, no traffic -- into a patch nobody reads)
+        const int rbuf = (it & 1) * PATCHB;
+        sweep(rbuf, rbuf ^ PATCHB, q);
+        FS_LDS_BARRIER();   // every wave is done reading this tile's patch and writing the next one's
+        epilogue(cur);
+        cur = nxt;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------ host
 namespace {
 struct CsInst {
@@ -878,6 +1203,10 @@ void cstream_plan(const ConvArgs& a, ConvPlan* out) {
         p.S = 48;
         patch_floats = 8 * ((((p.PH * p.PW + 1) * 48) + 255) & ~255) / 4;
         p.flat = 1;
+        if (a.pad_t == 0 && a.pad_l == 0 && tune_int("FS_R64X_PIPE", 1)) {   // VALID: conv_r64p_kernel, the next tile's staging threaded into the sweep over a second patch buffer
+            p.S = 49;
+            patch_floats *= 2;
+        }
     }
     if (inst >= 1 && inst <= 4 && cstream_split_on()) {   // the split-bf16 form (X6): [piece][Cin] bf16 + 16 bytes per pixel, row pitch 32 / 40 pixels, + the sink pixel
         p.S = 3 * a.Cin * 2 + 16;
@@ -908,9 +1237,20 @@ int cstream_launch(const ConvArgs& a, hipStream_t s) {
             case 3: cs_launch<8, 2, 1, 32, 3, 2, true>(a, grid, s); break;
             case 4: cs_launch<8, 4, 1, 64, 2, 1, true>(a, grid, s); break;
             case 5: {
-                static BigLds lds_attr;
-                lds_attr.ensure(reinterpret_cast<const void*>(conv_r64x_kernel<8>));
-                hipLaunchKernelGGL((conv_r64x_kernel<8>), dim3(grid), dim3(256), (size_t)a.p.lds_bytes, s, a);
+                static BigLds lds_attr, lds_attr_p;
+                if (a.p.S == 49 && (a.in_a != nullptr) == (a.in_relu != 0)) {   // the pipelined form (two patch buffers); on-load affine and ReLU come together
+                    static BigLds lds_attr_q;
+                    if (a.in_a) {
+                        lds_attr_p.ensure(reinterpret_cast<const void*>(conv_r64p_kernel<8, true>));
+                        hipLaunchKernelGGL((conv_r64p_kernel<8, true>), dim3(grid), dim3(256), (size_t)a.p.lds_bytes, s, a);
+                    } else {
+                        lds_attr_q.ensure(reinterpret_cast<const void*>(conv_r64p_kernel<8, false>));
+                        hipLaunchKernelGGL((conv_r64p_kernel<8, false>), dim3(grid), dim3(256), (size_t)a.p.lds_bytes, s, a);
+                    }
+                } else {
+                    lds_attr.ensure(reinterpret_cast<const void*>(conv_r64x_kernel<8>));
+                    hipLaunchKernelGGL((conv_r64x_kernel<8>), dim3(grid), dim3(256), (size_t)a.p.lds_bytes, s, a);
+                }
                 break;
             }
             default: return -4;
