@@ -92,3 +92,80 @@ class FrameStylizer(object):
             self._device_pass()
         out = np.array(mem.to_numpy(self._out_u8), copy=True)     # (synchronises; the device buffer is reused next frame)
         return out[0] if single else out
+
+
+class PipelinedStylizer(object):
+    """`depth` FrameStylizer lanes on streams of their own (round 6): frame i + 1 is uploaded and stylized while frame i is still on the device.
+
+    A batch-1 frame is ~45 DEPENDENT launches, 28 of them statistics / residual-add kernels of a few microseconds each: one frame at a time leaves the chip
+    idle between them.  Independent frames need no collective and no shared state (BASELINE: "inference shards independent frames") -- two frame graphs on two
+    streams fill each other's gaps: 720p 1277 -> 1890 frames/s on one MI355X (bench.py: stylize_720p.two_frames_in_flight), for one frame of latency.  Every
+    lane owns its buffers, its workspace (the re-laid-out filters live inside it) and its captured graph; results are bit-identical to FrameStylizer's.
+
+        ps = PipelinedStylizer(eng, variables, H, W)            # same arguments as FrameStylizer, + depth
+        for out in ps.run(frames):                              # any iterable of uint8 [H,W,3] frames, results in order
+            ...
+    or submit(frame) / fetch() by hand (at most `depth` frames between them)."""
+
+    def __init__(self, eng, variables, height, width, depth=2, **kw):
+        if not hasattr(eng.mem, "torch"):
+            raise L.FaststyleError("PipelinedStylizer needs the GPU engine (streams); use FrameStylizer on the emulator")
+        import collections
+        torch = eng.mem.torch
+        self.torch = torch
+        self.depth = int(depth)
+        self.lanes = [FrameStylizer(eng, variables, height, width, **kw) for _ in range(self.depth)]
+        self.streams = [torch.cuda.Stream() for _ in self.lanes]
+        self.events = [torch.cuda.Event() for _ in self.lanes]
+        self.host_in = [torch.empty(ln.shape, dtype=torch.uint8, pin_memory=True) for ln in self.lanes]
+        self.host_out = [torch.empty(ln.out_shape, dtype=torch.uint8, pin_memory=True) for ln in self.lanes]
+        self._pending = collections.deque()
+        self._n = 0
+        self._single = collections.deque()
+
+    def submit(self, frames_u8):
+        if len(self._pending) >= self.depth:
+            raise L.FaststyleError("PipelinedStylizer: %d frames in flight already -- fetch() one first" % self.depth)
+        a = np.asarray(frames_u8)
+        single = a.ndim == 3
+        if single:
+            a = a[np.newaxis]
+        k = self._n % self.depth
+        ln, st, torch = self.lanes[k], self.streams[k], self.torch
+        if a.shape != ln.shape or a.dtype != np.uint8:
+            raise L.FaststyleError("frame shape %s dtype %s, stylizer was built for uint8 %s" % (a.shape, a.dtype, ln.shape))
+        self.host_in[k].copy_(torch.from_numpy(np.ascontiguousarray(a)))       # (host -> pinned host; the lane's previous frame was fetched: its buffers are free)
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            ln._in_u8.copy_(self.host_in[k], non_blocking=True)
+            if ln._use_graph:
+                if ln._graph is None:
+                    ln._capture()
+                ln._graph.replay()
+            else:
+                ln._device_pass()
+            self.host_out[k].copy_(ln._out_u8, non_blocking=True)
+            self.events[k].record(st)
+        self._pending.append(k)
+        self._single.append(single)
+        self._n += 1
+
+    def fetch(self):
+        """The oldest submitted frame's result (host uint8), waiting for its lane only."""
+        k = self._pending.popleft()
+        single = self._single.popleft()
+        self.events[k].synchronize()
+        out = self.host_out[k].numpy().copy()
+        return out[0] if single else out
+
+    def run(self, frames):
+        for f in frames:
+            if len(self._pending) >= self.depth:
+                yield self.fetch()
+            self.submit(f)
+        while self._pending:
+            yield self.fetch()
+
+    def release(self):
+        for ln in self.lanes:
+            ln.release()

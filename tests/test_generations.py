@@ -244,3 +244,29 @@ def test_graph_replayed_720p_frames_equal_the_eager_frames_and_two_stylizers_do_
         assert np.abs(got3 - np.floor(np.clip(want3[0], 0, 255))).max() <= 1.0   # (u8 truncation of the same forward)
     finally:
         stream.FrameStylizer.KEEP_GRAPH = False
+
+
+@pytest.mark.gpu
+def test_pipelined_stylizer_two_frames_in_flight_equals_the_frame_at_a_time_results(knobs):
+    """stream.PipelinedStylizer (round 6): two FrameStylizer lanes on streams of their own, frame i + 1 uploaded and stylized while frame i is still on the
+    device.  Seven different frames (an odd count: the lanes end unevenly) come back in order and byte for byte equal to the one-frame-at-a-time stylizer's;
+    submit() refuses a third frame in flight; a plain same-shape forward on the engine between two submits changes nothing (every lane owns its workspace)."""
+    from faststyle_amd import stream
+    e = get_engine("hip")
+    knobs({})
+    rng = np.random.default_rng(9)
+    f1 = e.mem.from_numpy(e.flatten_params(tnet.init_params(seed=4), scope=""))
+    H, W = 136, 200
+    frames = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(7)]
+    one = stream.FrameStylizer(e, f1, H, W)
+    want = [one(f) for f in frames]
+    ps = stream.PipelinedStylizer(e, f1, H, W)
+    got = list(ps.run(frames))
+    assert len(got) == 7 and all(np.array_equal(g, w) for g, w in zip(got, want))
+    ps.submit(frames[3])
+    e.tnet_forward(f1, e.mem.from_numpy(frames[0].astype(np.float32)[None]))      # the engine's shared workspace, between two submits
+    ps.submit(frames[5])
+    with pytest.raises(Exception):
+        ps.submit(frames[6])
+    assert np.array_equal(ps.fetch(), want[3]) and np.array_equal(ps.fetch(), want[5])
+    assert not np.array_equal(want[3], want[5])
