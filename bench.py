@@ -536,12 +536,12 @@ def main():
             return rep
         fwd["stylize_720p"] = fwd_leg((1, 720, 1280, 3), False, 10, 50, True)
 
-        def two_in_flight(shape, warm, iters, bf16=False):
+        def two_in_flight(shape, warm, iters, bf16=False, depth=int(os.environ.get("FS_BENCH_FRAMES_IN_FLIGHT", "2"))):
             """INFORMATIONAL (round 6; not the metric's number): the same batch-1 frame graph twice -- two frames, two workspaces, two streams -- replayed
             alternately, as a video / webcam pipeline that accepts one frame of latency would run it: the ~45 dependent launches of a frame leave the chip
             idle between them (a 720p frame's 28 statistics / residual-add launches are 5-8 us each for microseconds of work), a second frame fills the gaps."""
             try:
-                streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+                streams = [torch.cuda.Stream() for _ in range(depth)]
                 graphs, keep = [], []
                 for st in streams:
                     x = torch.rand(shape, device="cuda", generator=g) * 255.0
@@ -573,7 +573,7 @@ def main():
                 dt = time.perf_counter() - t0
                 del graphs, keep
                 eng.invalidate_frozen()
-                return {"fps": round(2 * iters * shape[0] / dt, 1), "frames_in_flight": 2,
+                return {"fps": round(depth * iters * shape[0] / dt, 1), "frames_in_flight": depth,
                         "note": "informational: two frame-batch graphs on two streams, alternated; the leg's own fps (one batch at a time) is the configured figure"}
             except Exception as ex:
                 return {"error": "%s: %s" % (type(ex).__name__, ex)}
