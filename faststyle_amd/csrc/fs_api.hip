@@ -125,7 +125,7 @@ int fs_f32_to_u8(fs_ctx* ctx, const float* src, size_t npix, int swap_rb, unsign
 // tests / tuning scripts: re-read the FS_* knobs after changing the environment (not part of the product ABI)
 void fs_debug_reload_env(void) { fs::tune_reload(); }
 const char* fs_last_error(void) { return g_err; }
-const char* fs_version(void) { return "faststyle_hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* fs_version(void) { return "faststyle_hip 0.1 (gfx950, fp32 + split-bf16 MFMA)"; }
 
 int fs_ctx_create(int device, void* hip_stream, fs_ctx** out) {
     if (!out) return fail(-1, "fs_ctx_create: out is null");

@@ -1168,7 +1168,7 @@ bool cstream_eligible(const ConvArgs& a) {
     // bit i enables instance i+1.  Instance 5 (residual convs on small grids) is OFF by default: measured +1 % at batch 4
     // (20 launches 0.68 -> 0.63 ms) for 509 registers, and it would make the kernel choice of the residual convs depend on the
     // batch size (the data-parallel identity grads(batch) = sum grads(sample) then only holds to rounding-order noise)
-    const bool r64x = inst == 5 && (a.res_x6 || tune_int("FS_CSTREAM_R64X_ALL", 0)) && cstream_split_on() && !a.add_src && !a.fin.counter;   // the forward residual convs, split-bf16 direct form (conv_r64x_kernel)
+    const bool r64x = inst == 5 && (a.res_x6 || tune_int("FS_CSTREAM_R64X_ALL", 0)) && cstream_split_on() && !a.add_src && !a.fin.counter && !a.shuffle;   // the forward residual convs, split-bf16 direct form (conv_r64x_kernel)
     if (!r64x && !((tune_int("FS_CSTREAM_MASK", 15) >> (inst - 1)) & 1)) return false;
     const bool plain = a.src_mode == SRC_PLAIN && a.dil_x <= 1 && !a.bias && !a.out_relu && !a.mask_src && !a.route_src &&
                        !a.pool_out && a.w_nstride == 0 && !a.w_wino && !a.w_wino2;
@@ -1199,7 +1199,7 @@ void cstream_plan(const ConvArgs& a, ConvPlan* out) {
     p.S = a.Cin + 1;
     p.ksplit = 1;
     int patch_floats = (p.PH * p.PW * p.S + 4 + 3) & ~3;
-    if (inst == 5 && (a.res_x6 || tune_int("FS_CSTREAM_R64X_ALL", 0)) && cstream_split_on() && !a.add_src && !a.fin.counter) {   // conv_r64x_kernel: eight 8-channel planes of (pixels + 1) x 48 bytes, each rounded up to 256
+    if (inst == 5 && (a.res_x6 || tune_int("FS_CSTREAM_R64X_ALL", 0)) && cstream_split_on() && !a.add_src && !a.fin.counter && !a.shuffle) {   // conv_r64x_kernel: eight 8-channel planes of (pixels + 1) x 48 bytes, each rounded up to 256
         p.S = 48;
         patch_floats = 8 * ((((p.PH * p.PW + 1) * 48) + 255) & ~255) / 4;
         p.flat = 1;
